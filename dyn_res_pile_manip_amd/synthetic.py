@@ -1,0 +1,176 @@
+"""Synthetic stand-ins for what the planner reads from the simulator side.
+
+The reference planner (planners.py:40-45,152-155) reads six things from its
+`env` object: `is_real`, `get_cam_params()`, `get_cam_extrinsics()`,
+`screenHeight`, `screenWidth` and `cvx_region`.  The real `FlexEnv`
+(env/flex_env.py) needs the closed-source FleX simulator, so the hot path is
+driven here by `SyntheticEnv`, which reproduces the demo camera
+(env/flex_env.py:194-200: position (0, 18, 0), pitch -90 deg, fov 45 deg,
+720x720) and the +-5 workspace (env/flex_env.py:454-458).
+
+Also here: seeded synthetic piles, goal fields and nominal pushes with the
+shapes SURVEY.md section 8(d) prescribes.  numpy/scipy only.
+"""
+import numpy as np
+
+SCREEN = 720
+GLOBAL_SCALE = 24.0
+WKSPC_W = 5.0
+
+
+def default_config():
+    """The config keys the hot path reads (config/mpc/config.yaml)."""
+    return {
+        'dataset': {'global_scale': 24, 'wkspc_w': 5.0},
+        'mpc': {
+            'sigma': 0.3,
+            'mppi': {'beta_filter': 0.7, 'reward_weight': 0.1},
+            'gd': {'beta_filter': 0.7, 'lr': 0.05},
+            'n_look_ahead': 1, 'n_sample': 50, 'n_update_iter': 200,
+            'mpc_type': 'MPPI',
+        },
+        'train': {
+            'n_history': 1,
+            'particle': {'nf_effect': 64, 'adj_thresh': 0.08, 'add_delta': False},
+        },
+    }
+
+
+def demo_cam_params():
+    """[fx, fy, cx, cy] of the 45-degree-fov 720x720 demo camera."""
+    f = (SCREEN / 2.0) / np.tan(np.deg2rad(45.0) / 2.0)
+    return [float(f), float(f), SCREEN / 2.0, SCREEN / 2.0]
+
+
+def demo_cam_extrinsics():
+    """OpenGL view matrix of a camera at (0,18,0) looking straight down.
+
+    With it planners.py:192-209 maps world (x,y,z) to camera
+    (x/24, z/24, (18-y)/24): the table plane y=0 sits at z_cam = 0.75.
+    """
+    return np.array([[1.0, 0.0, 0.0, 0.0],
+                     [0.0, 0.0, -1.0, 0.0],
+                     [0.0, 1.0, 0.0, -18.0],
+                     [0.0, 0.0, 0.0, 1.0]], dtype=np.float64)
+
+
+class SyntheticEnv(object):
+    """The six attributes `PlannerGD` reads from `FlexEnv`."""
+
+    def __init__(self, config=None):
+        config = config or default_config()
+        self.is_real = False
+        self.screenHeight = SCREEN
+        self.screenWidth = SCREEN
+        self.wkspc_w = float(config['dataset']['wkspc_w'])
+        self.global_scale = float(config['dataset']['global_scale'])
+        w = self.wkspc_w
+        self.cvx_region = np.array([[-w, w, -w, w]], dtype=np.float64)
+
+    def get_cam_params(self):
+        return demo_cam_params()
+
+    def get_cam_extrinsics(self):
+        return demo_cam_extrinsics()
+
+
+def make_pile(n_particles, n_batch=1, seed=0, kind='uniform'):
+    """Camera-frame pile: jittered (never a lattice, top-k ties are
+    unspecified in the reference), on the table plane z ~= 0.75.
+
+    Returns s_cur [n_batch,N,3] f32, dens [n_batch] f32, attr [n_batch,N] f32.
+    """
+    rng = np.random.default_rng(seed)
+    s = np.empty((n_batch, n_particles, 3), dtype=np.float64)
+    if kind == 'uniform':
+        s[..., 0] = rng.uniform(-0.2, 0.2, (n_batch, n_particles))
+        s[..., 1] = rng.uniform(-0.2, 0.2, (n_batch, n_particles))
+    elif kind == 'blob':
+        r = 0.12 * np.sqrt(rng.uniform(0, 1, (n_batch, n_particles)))
+        th = rng.uniform(0, 2 * np.pi, (n_batch, n_particles))
+        s[..., 0] = r * np.cos(th)
+        s[..., 1] = r * np.sin(th)
+    else:
+        raise ValueError('unknown pile kind: %s' % kind)
+    s[..., 2] = 0.75 - rng.uniform(0, 0.01, (n_batch, n_particles))
+    dens = np.full((n_batch,), n_particles / 0.16, dtype=np.float32)
+    attr = np.zeros((n_batch, n_particles), dtype=np.float32)
+    return s.astype(np.float32), dens, attr
+
+
+def nominal_pushes(n_look_ahead, seed=0):
+    """[H,4] pushes (sx,sy,ex,ey) in world units, in the style of the
+    reference's init_action sets: start near the workspace rim, end inside
+    the +-3.5 clip box."""
+    rng = np.random.default_rng(1000 + seed)
+    acts = np.empty((n_look_ahead, 4), dtype=np.float64)
+    for t in range(n_look_ahead):
+        ang = rng.uniform(0, 2 * np.pi)
+        start = 4.5 * np.array([np.cos(ang), np.sin(ang)])
+        end = rng.uniform(-2.0, 2.0, 2)
+        acts[t, :2] = np.clip(start, -WKSPC_W, WKSPC_W)
+        acts[t, 2:] = np.clip(end, -0.7 * WKSPC_W, 0.7 * WKSPC_W)
+    return acts
+
+
+def sample_pushes(n_sample, n_look_ahead, seed=0):
+    """[n_sample,H,4] pushes: nominal + N(0, 0.6) noise, clipped to the
+    reference's action box (planners.py:151-167)."""
+    rng = np.random.default_rng(2000 + seed)
+    nom = nominal_pushes(n_look_ahead, seed)
+    acts = nom[None] + rng.normal(0, 0.6, (n_sample, n_look_ahead, 4))
+    lo, hi = action_limits()
+    return np.clip(acts, lo, hi).astype(np.float32)
+
+
+def action_limits(wkspc_w=WKSPC_W):
+    """Clip box of planners.py:152-155 for cvx_region [-w,w,-w,w]."""
+    w = wkspc_w
+    d = 2 * w * 0.15
+    lo = np.array([-w, -w, -w + d, -w + d])
+    hi = np.array([w, w, w - d, w - d])
+    return lo, hi
+
+
+def goal_mask(kind='I', size=SCREEN):
+    """0/1 uint8 image, 1 on the goal shape."""
+    m = np.zeros((size, size), dtype=np.uint8)
+    c = size // 2
+    if kind == 'I':
+        m[c - 170:c + 170, c - 22:c + 22] = 1      # stem
+        m[c - 170:c - 135, c - 70:c + 70] = 1      # top serif
+        m[c + 135:c + 170, c - 70:c + 70] = 1      # bottom serif
+    elif kind == 'disc':
+        yy, xx = np.mgrid[0:size, 0:size]
+        m[(yy - c) ** 2 + (xx - c) ** 2 < 75 ** 2] = 1
+    else:
+        raise ValueError('unknown goal kind: %s' % kind)
+    return m
+
+
+def goal_distance_image(mask):
+    """What the reference passes as `obs_goal` (utils.py:566-579): distance
+    of every pixel to the goal shape, 0 on it.  The reference uses OpenCV's
+    5x5-mask approximation; here the exact Euclidean transform."""
+    from scipy import ndimage
+    return np.minimum(ndimage.distance_transform_edt(1 - mask), 1e4).astype(np.float32)
+
+
+def goal_field(obs_goal):
+    """The shifted signed field `G` sampled by the reward
+    (env/flex_rewards.py:172-177), from an `obs_goal` image."""
+    from scipy import ndimage
+    seg = (obs_goal < 0.5)
+    neg = ndimage.distance_transform_edt(seg.astype(np.uint8)).astype(np.float32)
+    g = obs_goal.astype(np.float32) - neg
+    return (g - g.min()).astype(np.float32)
+
+
+def goal_coor_strided(obs_goal, m):
+    """[M,2] (col,row) goal pixels: every k-th goal pixel (a cheap stand-in
+    for the farthest-point subsample of planners.py:620-624)."""
+    rc = np.argwhere(obs_goal < 0.5)
+    cr = rc[:, ::-1].astype(np.float32)
+    m = min(m, cr.shape[0])
+    idx = np.linspace(0, cr.shape[0] - 1, m).astype(np.int64)
+    return np.ascontiguousarray(cr[idx])
