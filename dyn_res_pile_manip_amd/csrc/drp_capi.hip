@@ -1,0 +1,752 @@
+// C ABI of the engine (include/drp.h): context, device workspaces, kernel pipelines.
+// Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+#include "../../include/drp.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "drp_common.h"
+#include "k_aggregate.h"
+#include "k_graph.h"
+#include "k_mlp_valu.h"
+#include "k_mppi.h"
+#include "k_reward.h"
+#ifdef DRP_HAVE_MFMA
+#include "k_mlp_mfma.h"
+#endif
+
+namespace {
+
+std::string g_create_error;
+
+enum KClass { KC_GRAPH = 0, KC_NODE_ENCODE, KC_EDGE_ENCODE, KC_PROJECT, KC_AGGREGATE, KC_UPDATE,
+              KC_PREDICT, KC_REWARD, KC_MPPI, KC_COUNT };
+const char* const kclass_names[KC_COUNT] = {"graph", "node_encode", "edge_encode", "project",
+                                            "aggregate", "update", "predict", "reward", "mppi"};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct drp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int engine = DRP_ENGINE_VALU;
+
+    // model constants
+    bool have_weights = false, have_cam = false, have_goal = false;
+    float adj_thresh = 0.08f, thr = 0.0064f;
+    DevBuf w_raw, w_valu, w_mfma;
+    DrpCam cam{};
+    DevBuf goal_field, goal_coor;
+    int goal_h = 0, goal_w = 0, goal_m = 0;
+
+    // workspaces
+    DevBuf s_in, attr, dens, s_delta, nbr_idx, nbr_cnt, eff, c_node, agg, proj, c_edge, states,
+        actions, rewards, s_out, scratch;
+
+    // MPC state
+    bool mpc_on = false;
+    drp_mpc_params mpc{};
+    DevBuf nominal, noise, partials, gathered, stats;
+    int n_ranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+
+    // last shapes (for debug fetch)
+    int lastB = 0, lastN = 0, lastH = 0;
+
+    // probe
+    int probe_cls = -1;
+    std::vector<hipEvent_t> probe_ev;
+    size_t probe_used = 0;
+};
+
+namespace {
+
+int fail(drp_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                    \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail((c), DRP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define CHK(expr)                  \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != DRP_OK) return rc_; \
+    } while (0)
+
+int ensure(drp_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return DRP_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) return fail(c, DRP_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    b.cap = bytes;
+    return DRP_OK;
+}
+
+template <typename T>
+T* ptr(const DevBuf& b) { return static_cast<T*>(b.p); }
+
+int h2d(drp_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    CHK(ensure(c, b, bytes));
+    HIPCHK(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return DRP_OK;
+}
+
+int d2h(drp_ctx* c, void* dst, const void* src, size_t bytes) {
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return DRP_OK;
+}
+
+// RAII-less probe bracket
+struct ProbeScope {
+    drp_ctx* c;
+    bool on;
+    ProbeScope(drp_ctx* ctx, int cls) : c(ctx), on(ctx->probe_cls == cls) {
+        if (on) rec();
+    }
+    ~ProbeScope() {
+        if (on) rec();
+    }
+    void rec() {
+        if (c->probe_used == c->probe_ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+            c->probe_ev.push_back(e);
+        }
+        (void)hipEventRecord(c->probe_ev[c->probe_used++], c->stream);
+    }
+};
+
+int ensure_step_ws(drp_ctx* c, int B, int N) {
+    const size_t bn = (size_t)B * N;
+    CHK(ensure(c, c->s_delta, bn * 3 * sizeof(float)));
+    CHK(ensure(c, c->nbr_idx, bn * DRP_K * sizeof(int16_t)));
+    CHK(ensure(c, c->nbr_cnt, bn));
+    CHK(ensure(c, c->eff, bn * 64 * sizeof(float)));
+    CHK(ensure(c, c->c_node, bn * 64 * sizeof(float)));
+    CHK(ensure(c, c->agg, bn * 64 * sizeof(float)));
+    CHK(ensure(c, c->proj, bn * 128 * sizeof(float)));
+    CHK(ensure(c, c->c_edge, bn * DRP_K * 64 * sizeof(float)));
+    c->lastB = B;
+    c->lastN = N;
+    return DRP_OK;
+}
+
+struct StepArgs {
+    const float* s_prev; int prev_mod; size_t prev_stride;   // state read by sample b: row b % prev_mod
+    const float* attr; int attr_mod;
+    const float* dens; int dens_mod;
+    const float* actions; size_t act_stride;                  // null: s_delta already in workspace
+    bool build_graph;                                         // false: nbr lists already in workspace
+    float* s_out; size_t out_stride;
+    int B, N;
+};
+
+// One predict_one_step (model/gnn_dyn.py:209-254) [+ gen_s_delta, planners.py:346] for B samples.
+int run_step(drp_ctx* c, const StepArgs& a) {
+    const int B = a.B, N = a.N;
+    hipStream_t st = c->stream;
+    float* s_delta = ptr<float>(c->s_delta);
+    int16_t* nbr_idx = ptr<int16_t>(c->nbr_idx);
+    uint8_t* nbr_cnt = ptr<uint8_t>(c->nbr_cnt);
+    const float* vw = ptr<float>(c->w_valu);
+    if (a.build_graph) {
+        ProbeScope ps(c, KC_GRAPH);
+        hipLaunchKernelGGL(k_graph<256>, dim3(B), dim3(256), 3 * N * sizeof(float), st, a.s_prev,
+                           a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, N, nbr_idx,
+                           nbr_cnt, c->cam, c->thr);
+    }
+#ifdef DRP_HAVE_MFMA
+    if (c->engine == DRP_ENGINE_MFMA) {
+        int rc = run_step_mfma(c, a);
+        if (rc != DRP_OK) return rc;
+        HIPCHK(c, hipGetLastError());
+        return DRP_OK;
+    }
+#endif
+    {
+        ProbeScope ps(c, KC_NODE_ENCODE);
+        hipLaunchKernelGGL(k_node_encode<8>, dim3(B), dim3(256), 0, st, vw, s_delta, a.attr,
+                           a.attr_mod, a.dens, a.dens_mod, N, ptr<float>(c->eff), ptr<float>(c->c_node));
+    }
+    {
+        ProbeScope ps(c, KC_EDGE_ENCODE);
+        hipLaunchKernelGGL(k_edge_encode, dim3(B), dim3(256), (6 * 64 + 3 * 4096) * sizeof(float), st,
+                           vw, a.s_prev, a.prev_mod, a.prev_stride, a.attr, a.attr_mod, a.dens,
+                           a.dens_mod, nbr_idx, nbr_cnt, N, ptr<float>(c->c_edge));
+    }
+    for (int p = 0; p < DRP_PSTEP; ++p) {
+        {
+            ProbeScope ps(c, KC_PROJECT);
+            hipLaunchKernelGGL(k_project<8>, dim3(B), dim3(256), 0, st, vw, ptr<float>(c->eff), N,
+                               ptr<float>(c->proj));
+        }
+        {
+            ProbeScope ps(c, KC_AGGREGATE);
+            hipLaunchKernelGGL(k_aggregate, dim3(B), dim3(256), 0, st, ptr<float>(c->c_edge),
+                               ptr<float>(c->proj), nbr_idx, nbr_cnt, N, ptr<float>(c->agg));
+        }
+        {
+            ProbeScope ps(c, KC_UPDATE);
+            hipLaunchKernelGGL(k_update<8>, dim3(B), dim3(256), 0, st, vw, ptr<float>(c->agg),
+                               ptr<float>(c->c_node), N, ptr<float>(c->eff));
+        }
+    }
+    {
+        ProbeScope ps(c, KC_PREDICT);
+        hipLaunchKernelGGL(k_predict<8>, dim3(B), dim3(256), 0, st, vw, ptr<float>(c->eff), a.s_prev,
+                           a.prev_mod, a.prev_stride, N, a.s_out, a.out_stride);
+    }
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+int run_reward(drp_ctx* c, const float* state, size_t row_stride, int rows, int N, int normalize,
+               float* out) {
+    ProbeScope ps(c, KC_REWARD);
+    hipLaunchKernelGGL(k_reward, dim3(rows), dim3(256), (2 * N + 8) * sizeof(float), c->stream, state,
+                       row_stride, N, ptr<float>(c->goal_field), c->goal_h, c->goal_w,
+                       ptr<float>(c->goal_coor), c->goal_m, c->cam, normalize, out);
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+// H-step rollout over device-resident s0/attr/dens (in s_in/attr/dens, nb rows) and actions.
+int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool reward_last) {
+    CHK(ensure_step_ws(c, B, N));
+    CHK(ensure(c, c->states, (size_t)B * H * N * 3 * sizeof(float)));
+    CHK(ensure(c, c->rewards, (size_t)B * H * sizeof(float)));
+    c->lastH = H;
+    float* states = ptr<float>(c->states);
+    const size_t hstride = (size_t)H * N * 3;
+    for (int t = 0; t < H; ++t) {
+        StepArgs a{};
+        if (t == 0) {
+            a.s_prev = ptr<float>(c->s_in); a.prev_mod = nb; a.prev_stride = (size_t)N * 3;
+        } else {
+            a.s_prev = states + (size_t)(t - 1) * N * 3; a.prev_mod = B; a.prev_stride = hstride;
+        }
+        a.attr = ptr<float>(c->attr); a.attr_mod = nb;
+        a.dens = ptr<float>(c->dens); a.dens_mod = nb;
+        a.actions = ptr<float>(c->actions) + (size_t)t * 4; a.act_stride = (size_t)H * 4;
+        a.build_graph = true;
+        a.s_out = states + (size_t)t * N * 3; a.out_stride = hstride;
+        a.B = B; a.N = N;
+        CHK(run_step(c, a));
+    }
+    if (reward_all) {
+        // rows = B*H consecutive [N,3] blocks
+        CHK(run_reward(c, states, (size_t)N * 3, B * H, N, 1, ptr<float>(c->rewards)));
+    } else if (reward_last) {
+        // only the last step's state of every sample; written at rewards[b*H + H-1]
+        CHK(ensure(c, c->scratch, (size_t)B * sizeof(float)));
+        CHK(run_reward(c, states + (size_t)(H - 1) * N * 3, hstride, B, N, 1, ptr<float>(c->scratch)));
+        HIPCHK(c, hipMemcpy2DAsync(ptr<float>(c->rewards) + (H - 1), H * sizeof(float), c->scratch.p,
+                                   sizeof(float), sizeof(float), B, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return DRP_OK;
+}
+
+void pack_valu(const float* w, std::vector<float>& v) {
+    v.assign(V_TOTAL, 0.0f);
+    auto T = [&](int dst, int src, int out, int in, int ld, int col0) {
+        // dst[k][o] = w[src + o*ld + col0 + k]
+        for (int o = 0; o < out; ++o)
+            for (int k = 0; k < in; ++k) v[dst + k * 64 + o] = w[src + o * ld + col0 + k];
+    };
+    auto C = [&](int dst, int src, int n) { for (int i = 0; i < n; ++i) v[dst + i] = w[src + i]; };
+    T(V_PE0_T, W_PE0_W, 64, 5, 5, 0);   C(V_PE0_B, W_PE0_B, 64);
+    T(V_PE2_T, W_PE2_W, 64, 64, 64, 0); C(V_PE2_B, W_PE2_B, 64);
+    T(V_PPE_T, W_PP_W, 64, 64, 129, 0);
+    for (int o = 0; o < 64; ++o) v[V_PP_WD + o] = w[W_PP_W + o * 129 + 128];
+    C(V_PP_B, W_PP_B, 64);
+    T(V_AGG_T, W_PP_W, 64, 64, 129, 64);
+    T(V_RE0_T, W_RE0_W, 64, 6, 6, 0);   C(V_RE0_B, W_RE0_B, 64);
+    T(V_RE2_T, W_RE2_W, 64, 64, 64, 0); C(V_RE2_B, W_RE2_B, 64);
+    T(V_RE4_T, W_RE4_W, 64, 64, 64, 0); C(V_RE4_B, W_RE4_B, 64);
+    T(V_RPE_T, W_RP_W, 64, 64, 193, 0);
+    for (int o = 0; o < 64; ++o) v[V_RP_WD + o] = w[W_RP_W + o * 193 + 192];
+    C(V_RP_B, W_RP_B, 64);
+    T(V_RPR_T, W_RP_W, 64, 64, 193, 64);
+    T(V_RPS_T, W_RP_W, 64, 64, 193, 128);
+    T(V_PR0_T, W_PR0_W, 64, 64, 64, 0); C(V_PR0_B, W_PR0_B, 64);
+    C(V_PR1_W, W_PR1_W, 192);
+    C(V_PR1_B, W_PR1_B, 3);
+}
+
+int need(drp_ctx* c, bool weights, bool cam, bool goal) {
+    if (!c) return DRP_EINVAL;
+    if (weights && !c->have_weights) return fail(c, DRP_ESTATE, "weights not loaded (drp_load_weights)");
+    if (cam && !c->have_cam) return fail(c, DRP_ESTATE, "camera not set (drp_set_camera)");
+    if (goal && !c->have_goal) return fail(c, DRP_ESTATE, "goal not set (drp_set_goal)");
+    return DRP_OK;
+}
+
+int check_bn(drp_ctx* c, int B, int N) {
+    if (B <= 0 || N <= 0 || N > 16384) return fail(c, DRP_EINVAL, "bad shape B=%d N=%d", B, N);
+    return DRP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int drp_create(int device, drp_ctx** out) {
+    if (!out) return fail(nullptr, DRP_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, DRP_EHIP, "no HIP device available: %s", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, DRP_EINVAL, "device %d out of range (%d)", device, n);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, DRP_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+    drp_ctx* c = new drp_ctx();
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(nullptr, DRP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return DRP_OK;
+}
+
+void drp_destroy(drp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    DevBuf* bufs[] = {&c->w_raw, &c->w_valu, &c->w_mfma, &c->goal_field, &c->goal_coor, &c->s_in,
+                      &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
+                      &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
+                      &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (hipEvent_t ev : c->probe_ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* drp_last_error(const drp_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int drp_sync(drp_ctx* c) {
+    if (!c) return DRP_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DRP_OK;
+}
+
+int drp_set_engine(drp_ctx* c, int engine) {
+    if (!c) return DRP_EINVAL;
+    if (engine == DRP_ENGINE_VALU) { c->engine = engine; return DRP_OK; }
+#ifdef DRP_HAVE_MFMA
+    if (engine == DRP_ENGINE_MFMA) { c->engine = engine; return DRP_OK; }
+#endif
+    return fail(c, DRP_EINVAL, "engine %d not available in this build", engine);
+}
+
+int drp_device_info(drp_ctx* c, char* name, size_t name_len, int* n_cu, size_t* hbm_bytes) {
+    if (!c) return DRP_EINVAL;
+    hipDeviceProp_t p;
+    HIPCHK(c, hipGetDeviceProperties(&p, c->device));
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (n_cu) *n_cu = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+    return DRP_OK;
+}
+
+int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_thresh) {
+    if (!c || !blob) return DRP_EINVAL;
+    if (n_floats != (size_t)W_TOTAL)
+        return fail(c, DRP_EINVAL, "weight blob has %zu floats, expected %d", n_floats, (int)W_TOTAL);
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<float> v;
+    pack_valu(blob, v);
+    CHK(h2d(c, c->w_raw, blob, n_floats * sizeof(float)));
+    CHK(h2d(c, c->w_valu, v.data(), v.size() * sizeof(float)));
+#ifdef DRP_HAVE_MFMA
+    {
+        std::vector<float> m;
+        pack_mfma(blob, m);
+        CHK(h2d(c, c->w_mfma, m.data(), m.size() * sizeof(float)));
+    }
+#endif
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->adj_thresh = adj_thresh;
+    // threshold = adj_thresh * adj_thresh in Python doubles, then an fp32 scalar
+    // (model/gnn_dyn.py:229,236)
+    c->thr = (float)((double)adj_thresh * (double)adj_thresh);
+    c->have_weights = true;
+    return DRP_OK;
+}
+
+int drp_set_camera(drp_ctx* c, const float m34[12], float global_scale, const float intr[4]) {
+    if (!c || !m34 || !intr) return DRP_EINVAL;
+    memcpy(c->cam.m, m34, 12 * sizeof(float));
+    c->cam.gs = global_scale;
+    c->cam.fx = intr[0]; c->cam.fy = intr[1]; c->cam.cx = intr[2]; c->cam.cy = intr[3];
+    c->have_cam = true;
+    return DRP_OK;
+}
+
+int drp_set_goal(drp_ctx* c, const float* field, int h, int w, const float* goal_coor, int m) {
+    if (!c || !field || !goal_coor || h <= 0 || w <= 0 || m <= 0) return fail(c, DRP_EINVAL, "bad goal");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(h2d(c, c->goal_field, field, (size_t)h * w * sizeof(float)));
+    CHK(h2d(c, c->goal_coor, goal_coor, (size_t)m * 2 * sizeof(float)));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->goal_h = h; c->goal_w = w; c->goal_m = m;
+    c->have_goal = true;
+    return DRP_OK;
+}
+
+int drp_gen_s_delta(drp_ctx* c, const float* s_cur, const float* action, int B, int N, float* out) {
+    CHK(need(c, false, true, false));
+    CHK(check_bn(c, B, N));
+    if (!s_cur || !action || !out) return fail(c, DRP_EINVAL, "null buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(h2d(c, c->s_in, s_cur, (size_t)B * N * 3 * sizeof(float)));
+    CHK(h2d(c, c->actions, action, (size_t)B * 4 * sizeof(float)));
+    CHK(ensure(c, c->s_delta, (size_t)B * N * 3 * sizeof(float)));
+    hipLaunchKernelGGL(k_sdelta, dim3(B), dim3(256), 0, c->stream, ptr<float>(c->s_in),
+                       ptr<float>(c->actions), N, ptr<float>(c->s_delta), c->cam);
+    HIPCHK(c, hipGetLastError());
+    CHK(d2h(c, out, c->s_delta.p, (size_t)B * N * 3 * sizeof(float)));
+    return drp_sync(c);
+}
+
+int drp_build_graph(drp_ctx* c, const float* s_cur, const float* s_delta, int B, int N,
+                    int16_t* nbr_idx_out, uint8_t* nbr_cnt_out) {
+    CHK(need(c, true, false, false));
+    CHK(check_bn(c, B, N));
+    if (!s_cur || !s_delta || !nbr_idx_out || !nbr_cnt_out) return fail(c, DRP_EINVAL, "null buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_step_ws(c, B, N));
+    CHK(h2d(c, c->s_in, s_cur, (size_t)B * N * 3 * sizeof(float)));
+    CHK(h2d(c, c->s_delta, s_delta, (size_t)B * N * 3 * sizeof(float)));
+    hipLaunchKernelGGL(k_graph<256>, dim3(B), dim3(256), 3 * N * sizeof(float), c->stream,
+                       ptr<float>(c->s_in), B, (size_t)N * 3, (const float*)nullptr, (size_t)0,
+                       ptr<float>(c->s_delta), N, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt),
+                       c->cam, c->thr);
+    HIPCHK(c, hipGetLastError());
+    CHK(d2h(c, nbr_idx_out, c->nbr_idx.p, (size_t)B * N * DRP_K * sizeof(int16_t)));
+    CHK(d2h(c, nbr_cnt_out, c->nbr_cnt.p, (size_t)B * N));
+    return drp_sync(c);
+}
+
+static int step_common(drp_ctx* c, const float* a_cur, const float* s_cur, const float* s_delta,
+                       const float* dens, const int16_t* nbr_idx, const uint8_t* nbr_cnt, int B, int N,
+                       float* s_pred_out) {
+    CHK(need(c, true, false, false));
+    CHK(check_bn(c, B, N));
+    if (!a_cur || !s_cur || !s_delta || !dens || !s_pred_out) return fail(c, DRP_EINVAL, "null buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_step_ws(c, B, N));
+    const size_t bn = (size_t)B * N;
+    CHK(h2d(c, c->s_in, s_cur, bn * 3 * sizeof(float)));
+    CHK(h2d(c, c->s_delta, s_delta, bn * 3 * sizeof(float)));
+    CHK(h2d(c, c->attr, a_cur, bn * sizeof(float)));
+    CHK(h2d(c, c->dens, dens, (size_t)B * sizeof(float)));
+    CHK(ensure(c, c->s_out, bn * 3 * sizeof(float)));
+    if (nbr_idx) {
+        CHK(h2d(c, c->nbr_idx, nbr_idx, bn * DRP_K * sizeof(int16_t)));
+        CHK(h2d(c, c->nbr_cnt, nbr_cnt, bn));
+    }
+    StepArgs a{};
+    a.s_prev = ptr<float>(c->s_in); a.prev_mod = B; a.prev_stride = (size_t)N * 3;
+    a.attr = ptr<float>(c->attr); a.attr_mod = B;
+    a.dens = ptr<float>(c->dens); a.dens_mod = B;
+    a.actions = nullptr; a.act_stride = 0;
+    a.build_graph = (nbr_idx == nullptr);
+    a.s_out = ptr<float>(c->s_out); a.out_stride = (size_t)N * 3;
+    a.B = B; a.N = N;
+    CHK(run_step(c, a));
+    CHK(d2h(c, s_pred_out, c->s_out.p, bn * 3 * sizeof(float)));
+    return drp_sync(c);
+}
+
+int drp_step(drp_ctx* c, const float* a_cur, const float* s_cur, const float* s_delta,
+             const float* dens, int B, int N, float* s_pred_out) {
+    return step_common(c, a_cur, s_cur, s_delta, dens, nullptr, nullptr, B, N, s_pred_out);
+}
+
+int drp_forward(drp_ctx* c, const float* a_cur, const float* s_cur, const float* s_delta,
+                const float* dens, const int16_t* nbr_idx, const uint8_t* nbr_cnt, int B, int N,
+                float* s_pred_out) {
+    if (!nbr_idx || !nbr_cnt) return fail(c, DRP_EINVAL, "null neighbour lists");
+    return step_common(c, a_cur, s_cur, s_delta, dens, nbr_idx, nbr_cnt, B, N, s_pred_out);
+}
+
+int drp_rollout(drp_ctx* c, const float* s0, const float* attr, const float* dens, int nb, int N,
+                const float* actions, int B, int H, float* states_out, float* reward_out) {
+    CHK(need(c, true, true, reward_out != nullptr));
+    CHK(check_bn(c, B, N));
+    if (!s0 || !attr || !dens || !actions) return fail(c, DRP_EINVAL, "null buffer");
+    if (nb <= 0 || H <= 0 || B % nb != 0)
+        return fail(c, DRP_EINVAL, "bad rollout shape nb=%d B=%d H=%d (B must be a multiple of nb)", nb, B, H);
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
+    CHK(h2d(c, c->attr, attr, (size_t)nb * N * sizeof(float)));
+    CHK(h2d(c, c->dens, dens, (size_t)nb * sizeof(float)));
+    CHK(h2d(c, c->actions, actions, (size_t)B * H * 4 * sizeof(float)));
+    CHK(run_rollout(c, nb, N, B, H, reward_out != nullptr, false));
+    if (states_out) CHK(d2h(c, states_out, c->states.p, (size_t)B * H * N * 3 * sizeof(float)));
+    if (reward_out) CHK(d2h(c, reward_out, c->rewards.p, (size_t)B * H * sizeof(float)));
+    return drp_sync(c);
+}
+
+int drp_reward(drp_ctx* c, const float* state, int Bp, int N, int normalize, float* reward_out) {
+    CHK(need(c, false, true, true));
+    CHK(check_bn(c, Bp, N));
+    if (!state || !reward_out) return fail(c, DRP_EINVAL, "null buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(h2d(c, c->s_out, state, (size_t)Bp * N * 3 * sizeof(float)));
+    CHK(ensure(c, c->scratch, (size_t)Bp * sizeof(float)));
+    CHK(run_reward(c, ptr<float>(c->s_out), (size_t)N * 3, Bp, N, normalize, ptr<float>(c->scratch)));
+    CHK(d2h(c, reward_out, c->scratch.p, (size_t)Bp * sizeof(float)));
+    return drp_sync(c);
+}
+
+// ---- sampling MPC -------------------------------------------------------------------------
+int drp_mpc_begin(drp_ctx* c, const drp_mpc_params* p, const float* s0, const float* attr,
+                  const float* dens, const double* nominal) {
+    CHK(need(c, true, true, true));
+    if (!p || !s0 || !attr || !dens || !nominal) return fail(c, DRP_EINVAL, "null argument");
+    if (p->n_batch <= 0 || p->n_sample <= 0 || p->n_look_ahead <= 0 || p->n_look_ahead > 64)
+        return fail(c, DRP_EINVAL, "bad mpc shape");
+    const int nb = p->n_batch, N = p->n_particles, H = p->n_look_ahead, B = p->n_sample * nb;
+    CHK(check_bn(c, B, N));
+    HIPCHK(c, hipSetDevice(c->device));
+    c->mpc = *p;
+    CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
+    CHK(h2d(c, c->attr, attr, (size_t)nb * N * sizeof(float)));
+    CHK(h2d(c, c->dens, dens, (size_t)nb * sizeof(float)));
+    CHK(h2d(c, c->nominal, nominal, (size_t)H * 4 * sizeof(double)));
+    CHK(ensure(c, c->actions, (size_t)B * H * 4 * sizeof(float)));
+    CHK(ensure(c, c->partials, (size_t)(6 + 4 * H) * sizeof(double)));
+    CHK(ensure(c, c->gathered, (size_t)(6 + 4 * H) * sizeof(double) * (size_t)(c->n_ranks > 0 ? c->n_ranks : 1)));
+    CHK(ensure(c, c->stats, 8 * sizeof(double)));
+    CHK(ensure_step_ws(c, B, N));
+    CHK(ensure(c, c->states, (size_t)B * H * N * 3 * sizeof(float)));
+    CHK(ensure(c, c->rewards, (size_t)B * H * sizeof(float)));
+    CHK(ensure(c, c->scratch, (size_t)B * sizeof(float)));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->mpc_on = true;
+    return DRP_OK;
+}
+
+int drp_mpc_sample(drp_ctx* c, const float* noise, uint64_t iteration) {
+    if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    const drp_mpc_params& p = c->mpc;
+    const float* dnoise = nullptr;
+    if (noise) {
+        CHK(h2d(c, c->noise, noise, (size_t)p.n_sample * p.n_look_ahead * 4 * sizeof(float)));
+        dnoise = ptr<float>(c->noise);
+    }
+    ProbeScope ps(c, KC_MPPI);
+    hipLaunchKernelGGL(k_mppi_sample, dim3((p.n_sample + 127) / 128), dim3(128), 0, c->stream,
+                       ptr<double>(c->nominal), dnoise, p.n_sample, p.n_batch, p.n_look_ahead, p.sigma,
+                       p.beta_filter, make_float4(p.act_lo[0], p.act_lo[1], p.act_lo[2], p.act_lo[3]),
+                       make_float4(p.act_hi[0], p.act_hi[1], p.act_hi[2], p.act_hi[3]), p.seed,
+                       p.sample_offset, iteration, ptr<float>(c->actions));
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+int drp_mpc_set_actions(drp_ctx* c, const float* actions) {
+    if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    if (!actions) return fail(c, DRP_EINVAL, "null actions");
+    const drp_mpc_params& p = c->mpc;
+    CHK(h2d(c, c->actions, actions, (size_t)p.n_sample * p.n_batch * p.n_look_ahead * 4 * sizeof(float)));
+    return DRP_OK;
+}
+
+int drp_mpc_rollout(drp_ctx* c, int reward_all_steps) {
+    if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    const drp_mpc_params& p = c->mpc;
+    return run_rollout(c, p.n_batch, p.n_particles, p.n_sample * p.n_batch, p.n_look_ahead,
+                       reward_all_steps != 0, reward_all_steps == 0);
+}
+
+static int launch_partials(drp_ctx* c) {
+    const drp_mpc_params& p = c->mpc;
+    const int H = p.n_look_ahead;
+    ProbeScope ps(c, KC_MPPI);
+    hipLaunchKernelGGL(k_mppi_partials, dim3(4 * H + 1), dim3(256), 0, c->stream,
+                       ptr<float>(c->rewards) + (H - 1), H, ptr<float>(c->actions), p.n_sample, p.n_batch,
+                       H, p.reward_weight, p.sample_offset, ptr<double>(c->partials));
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+int drp_mpc_partials(drp_ctx* c, double* out) {
+    if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    CHK(launch_partials(c));
+    if (out) {
+        CHK(d2h(c, out, c->partials.p, (size_t)(6 + 4 * c->mpc.n_look_ahead) * sizeof(double)));
+        return drp_sync(c);
+    }
+    return DRP_OK;
+}
+
+static int launch_update(drp_ctx* c, const double* dev_partials, int n_ranks) {
+    const drp_mpc_params& p = c->mpc;
+    ProbeScope ps(c, KC_MPPI);
+    hipLaunchKernelGGL(k_mppi_update, dim3(1), dim3(128), 0, c->stream, dev_partials, n_ranks,
+                       p.n_look_ahead, (double)p.n_sample * (double)n_ranks, ptr<double>(c->nominal),
+                       ptr<double>(c->stats));
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+int drp_mpc_update(drp_ctx* c, const double* partials, int n_ranks, double* nominal_out) {
+    if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    if (!partials || n_ranks <= 0) return fail(c, DRP_EINVAL, "bad partials");
+    const size_t rec = (size_t)(6 + 4 * c->mpc.n_look_ahead) * sizeof(double);
+    CHK(h2d(c, c->gathered, partials, rec * n_ranks));
+    CHK(launch_update(c, ptr<double>(c->gathered), n_ranks));
+    if (nominal_out) {
+        CHK(d2h(c, nominal_out, c->nominal.p, (size_t)c->mpc.n_look_ahead * 4 * sizeof(double)));
+        return drp_sync(c);
+    }
+    return DRP_OK;
+}
+
+int drp_mpc_update_device(drp_ctx* c) {
+    if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    CHK(launch_partials(c));
+    const int rec = 6 + 4 * c->mpc.n_look_ahead;
+    if (c->comm && c->n_ranks > 1) {
+        CHK(ensure(c, c->gathered, (size_t)rec * sizeof(double) * c->n_ranks));
+        ncclResult_t r = ncclAllGather(c->partials.p, c->gathered.p, rec, ncclDouble, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", ncclGetErrorString(r));
+        return launch_update(c, ptr<double>(c->gathered), c->n_ranks);
+    }
+    return launch_update(c, ptr<double>(c->partials), 1);
+}
+
+int drp_mpc_get(drp_ctx* c, float* actions, float* rewards, float* rewards_all, float* states,
+                double* nominal) {
+    if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    const drp_mpc_params& p = c->mpc;
+    const int H = p.n_look_ahead, B = p.n_sample * p.n_batch, N = p.n_particles;
+    if (actions) CHK(d2h(c, actions, c->actions.p, (size_t)B * H * 4 * sizeof(float)));
+    if (rewards)
+        HIPCHK(c, hipMemcpy2DAsync(rewards, sizeof(float), ptr<float>(c->rewards) + (H - 1),
+                                   H * sizeof(float), sizeof(float), B, hipMemcpyDeviceToHost, c->stream));
+    if (rewards_all) CHK(d2h(c, rewards_all, c->rewards.p, (size_t)B * H * sizeof(float)));
+    if (states) CHK(d2h(c, states, c->states.p, (size_t)B * H * N * 3 * sizeof(float)));
+    if (nominal) CHK(d2h(c, nominal, c->nominal.p, (size_t)H * 4 * sizeof(double)));
+    return drp_sync(c);
+}
+
+// ---- RCCL -------------------------------------------------------------------------------------
+int drp_comm_unique_id(char* id128) {
+    if (!id128) return DRP_EINVAL;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, DRP_ECOMM, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    memcpy(id128, &id, 128);
+    return DRP_OK;
+}
+
+int drp_comm_init(drp_ctx* c, const char* id128, int rank, int n_ranks) {
+    if (!c || !id128 || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(c, DRP_EINVAL, "bad comm args");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, id, rank);
+    if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    return DRP_OK;
+}
+
+int drp_comm_destroy(drp_ctx* c) {
+    if (!c) return DRP_EINVAL;
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    c->n_ranks = 1;
+    c->rank = 0;
+    return DRP_OK;
+}
+
+// ---- measurement / debugging -----------------------------------------------------------------
+int drp_probe_begin(drp_ctx* c, const char* kernel_class) {
+    if (!c) return DRP_EINVAL;
+    c->probe_cls = -1;
+    c->probe_used = 0;
+    if (!kernel_class || !*kernel_class) return DRP_OK;
+    for (int i = 0; i < KC_COUNT; ++i)
+        if (strcmp(kernel_class, kclass_names[i]) == 0) { c->probe_cls = i; return DRP_OK; }
+    return fail(c, DRP_EINVAL, "unknown kernel class '%s'", kernel_class);
+}
+
+int drp_probe_read(drp_ctx* c, double* total_ms, long* launches) {
+    if (!c) return DRP_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    long n = 0;
+    for (size_t i = 0; i + 1 < c->probe_used; i += 2) {
+        float ms = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->probe_ev[i], c->probe_ev[i + 1]));
+        tot += ms;
+        ++n;
+    }
+    c->probe_used = 0;
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return DRP_OK;
+}
+
+long drp_debug_fetch(drp_ctx* c, const char* name, void* out, size_t out_bytes) {
+    if (!c || !name || !out) return DRP_EINVAL;
+    const size_t bn = (size_t)c->lastB * c->lastN;
+    const DevBuf* b = nullptr;
+    size_t bytes = 0;
+    if (!strcmp(name, "s_delta")) { b = &c->s_delta; bytes = bn * 3 * 4; }
+    else if (!strcmp(name, "nbr_idx")) { b = &c->nbr_idx; bytes = bn * DRP_K * 2; }
+    else if (!strcmp(name, "nbr_cnt")) { b = &c->nbr_cnt; bytes = bn; }
+    else if (!strcmp(name, "effect")) { b = &c->eff; bytes = bn * 64 * 4; }
+    else if (!strcmp(name, "c_node")) { b = &c->c_node; bytes = bn * 64 * 4; }
+    else if (!strcmp(name, "c_edge")) { b = &c->c_edge; bytes = bn * DRP_K * 64 * 4; }
+    else if (!strcmp(name, "proj")) { b = &c->proj; bytes = bn * 128 * 4; }
+    else if (!strcmp(name, "agg")) { b = &c->agg; bytes = bn * 64 * 4; }
+    else if (!strcmp(name, "stats")) { b = &c->stats; bytes = 8 * sizeof(double); }
+    else return fail(c, DRP_EINVAL, "unknown buffer '%s'", name);
+    if (!b->p || bytes == 0 || bytes > b->cap) return fail(c, DRP_ESTATE, "buffer '%s' not populated", name);
+    if (out_bytes < bytes) return fail(c, DRP_EINVAL, "buffer '%s' needs %zu bytes", name, bytes);
+    if (hipMemcpyAsync(out, b->p, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return fail(c, DRP_EHIP, "debug fetch failed");
+    return (long)bytes;
+}
+
+}  // extern "C"

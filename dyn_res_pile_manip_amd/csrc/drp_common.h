@@ -1,0 +1,83 @@
+// Shared definitions for the gfx950 kernels of the particle-GNN rollout engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DRP_K 10
+#define DRP_F 64
+#define DRP_PSTEP 3              // model/gnn_dyn.py:160
+#define DRP_DENS_SCALE 5000.0f   // model/gnn_dyn.py:158
+#define DRP_PUSHER_W (0.8f / 24.0f)   // planners.py:228
+#define DRP_SOFT_SCALE 0.01f     // planners.py:251
+
+// camera constants, passed by value to kernels (planners.py:192-209,
+// env/flex_rewards.py:189-193)
+struct DrpCam {
+    float m[12];     // 3x4 affine world->camera (before the division by gs)
+    float gs;        // global_scale
+    float fx, fy, cx, cy;
+};
+
+// Offsets (in floats) into the state_dict blob, torch Linear layout [out,in]
+// (module order of model/gnn_dyn.py:125-145).
+enum {
+    W_PE0_W = 0,                    // [64,5]
+    W_PE0_B = W_PE0_W + 64 * 5,     // [64]
+    W_PE2_W = W_PE0_B + 64,         // [64,64]
+    W_PE2_B = W_PE2_W + 64 * 64,
+    W_RE0_W = W_PE2_B + 64,         // [64,6]
+    W_RE0_B = W_RE0_W + 64 * 6,
+    W_RE2_W = W_RE0_B + 64,         // [64,64]
+    W_RE2_B = W_RE2_W + 64 * 64,
+    W_RE4_W = W_RE2_B + 64,         // [64,64]
+    W_RE4_B = W_RE4_W + 64 * 64,
+    W_PP_W = W_RE4_B + 64,          // [64,129] = [W_pe | W_agg | w_d]
+    W_PP_B = W_PP_W + 64 * 129,
+    W_RP_W = W_PP_B + 64,           // [64,193] = [W_e | W_r | W_s | w_d]
+    W_RP_B = W_RP_W + 64 * 193,
+    W_PR0_W = W_RP_B + 64,          // [64,64]
+    W_PR0_B = W_PR0_W + 64 * 64,
+    W_PR1_W = W_PR0_B + 64,         // [3,64]
+    W_PR1_B = W_PR1_W + 3 * 64,
+    W_TOTAL = W_PR1_B + 3           // 38403
+};
+static_assert(W_TOTAL == 38403, "state_dict size");
+
+// Device-side weight pack for the VALU engine: every matrix transposed to
+// [in][64] so lane = output feature reads consecutive floats.
+enum {
+    V_PE0_T = 0,                    // [5][64]
+    V_PE0_B = V_PE0_T + 5 * 64,
+    V_PE2_T = V_PE0_B + 64,         // [64][64]
+    V_PE2_B = V_PE2_T + 4096,
+    V_PPE_T = V_PE2_B + 64,         // W_pe^T  [64][64]   (particle propagator, encode part)
+    V_PP_WD = V_PPE_T + 4096,       // w_d     [64]
+    V_PP_B = V_PP_WD + 64,          // bias    [64]
+    V_AGG_T = V_PP_B + 64,          // W_agg^T [64][64]
+    V_RE0_T = V_AGG_T + 4096,       // [6][64]
+    V_RE0_B = V_RE0_T + 6 * 64,
+    V_RE2_T = V_RE0_B + 64,
+    V_RE2_B = V_RE2_T + 4096,
+    V_RE4_T = V_RE2_B + 64,
+    V_RE4_B = V_RE4_T + 4096,
+    V_RPE_T = V_RE4_B + 64,         // W_e^T [64][64]   (relation propagator, encode part)
+    V_RP_WD = V_RPE_T + 4096,
+    V_RP_B = V_RP_WD + 64,
+    V_RPR_T = V_RP_B + 64,          // W_r^T [64][64]
+    V_RPS_T = V_RPR_T + 4096,       // W_s^T [64][64]
+    V_PR0_T = V_RPS_T + 4096,
+    V_PR0_B = V_PR0_T + 4096,
+    V_PR1_W = V_PR0_B + 64,         // [3][64] (row-major as in torch: dot per output)
+    V_PR1_B = V_PR1_W + 192,
+    V_TOTAL = V_PR1_B + 4
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float bcast_lane(float v, int lane_const) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
+}

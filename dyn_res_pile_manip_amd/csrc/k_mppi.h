@@ -1,0 +1,190 @@
+// Sampling-MPC bookkeeping on the device: action sampling and the softmax-weighted
+// update, written so the sample axis can be sharded over GPUs.
+//
+//   sample_action_sequences   planners.py:69-190  (noise_type 'normal')
+//   optimize_action           planners.py:549-561
+//
+// Both are dead code in the reference (nothing calls them; the live planner is gradient
+// descent) -- they are implemented from their definitions.
+#pragma once
+#include "drp_common.h"
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32(uint32_t (&c)[4], uint64_t key) {
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u1 = ((float)a + 1.0f) * 2.3283064365386963e-10f;   // (0,1]
+    const float u2 = (float)b * 2.3283064365386963e-10f;
+    const float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.283185307179586f * u2, &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+
+// One thread per sample: temporally filtered Gaussian residual added to the nominal
+// sequence, clipped to the action box; written to all n_batch rows of the sample
+// (row = sample * n_batch + batch, planners.py:661-662).
+//   noise: null -> Philox normals keyed by (seed; global sample, t, iteration),
+//          else [n_sample,H,4] standard normal draws from the host.
+__global__ void k_mppi_sample(const double* __restrict__ nominal, const float* __restrict__ noise,
+                              int n_sample, int n_batch, int H, float sigma, float beta, float4 lo,
+                              float4 hi, uint64_t seed, uint64_t sample_offset, uint64_t iteration,
+                              float* __restrict__ actions) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sample) return;
+    const float lo_[4] = {lo.x, lo.y, lo.z, lo.w}, hi_[4] = {hi.x, hi.y, hi.z, hi.w};
+    double resid[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < H; ++t) {
+        float n[4];
+        if (noise != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) n[c] = noise[((size_t)s * H + t) * 4 + c];
+        } else {
+            const uint64_t gs = sample_offset + (uint64_t)s;
+            uint32_t ctr[4] = {(uint32_t)gs, (uint32_t)(gs >> 32), (uint32_t)t, (uint32_t)iteration};
+            philox4x32(ctr, seed);
+            box_muller(ctr[0], ctr[1], n[0], n[1]);
+            box_muller(ctr[2], ctr[3], n[2], n[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            resid[c] = (double)beta * ((double)sigma * (double)n[c]) + resid[c] * (1.0 - (double)beta);
+            double a = nominal[t * 4 + c] + resid[c];
+            a = fmin(fmax(a, (double)lo_[c]), (double)hi_[c]);
+            for (int j = 0; j < n_batch; ++j)
+                actions[(((size_t)s * n_batch + j) * H + t) * 4 + c] = (float)a;
+        }
+    }
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
+}
+
+__device__ __forceinline__ double block_max_d(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, red[w]);
+    return t;
+}
+
+// Per-rank partial record of the softmax-weighted mean (layout documented in drp.h):
+//   [0] m = max_s lambda r_s   [1] Z = sum_s exp(lambda r_s - m)   [2..2+4H) A = sum_s w_s act_s
+//   [2+4H] sum r   [3+4H] sum r^2   [4+4H] max r   [5+4H] argmax (global sample index)
+// r_s = mean over the n_batch columns of the sample's final-step reward.
+// grid = 4H + 1 blocks of 256 threads; block j < 4H reduces A[j], the last block the rest.
+__global__ void __launch_bounds__(256)
+k_mppi_partials(const float* __restrict__ reward, int reward_stride, const float* __restrict__ actions,
+                int n_sample, int n_batch, int H, float lambda, uint64_t sample_offset,
+                double* __restrict__ out) {
+    __shared__ double red[4];
+    const int j = blockIdx.x;
+    const int HJ = 4 * H;
+    double mloc = -__builtin_inf();
+    for (int s = threadIdx.x; s < n_sample; s += blockDim.x) {
+        double r = 0.0;
+        for (int c = 0; c < n_batch; ++c) r += (double)reward[((size_t)s * n_batch + c) * reward_stride];
+        r /= (double)n_batch;
+        mloc = fmax(mloc, (double)lambda * r);
+    }
+    const double m = block_max_d(mloc, red);
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    double rmax = -__builtin_inf();
+    int amax = 0;
+    for (int s = threadIdx.x; s < n_sample; s += blockDim.x) {
+        double r = 0.0;
+        for (int c = 0; c < n_batch; ++c) r += (double)reward[((size_t)s * n_batch + c) * reward_stride];
+        r /= (double)n_batch;
+        const double w = exp((double)lambda * r - m);
+        if (j < HJ) {
+            acc0 += w * (double)actions[((size_t)s * n_batch) * HJ + j];
+        } else {
+            acc0 += w;
+            acc1 += r;
+            acc2 += r * r;
+            if (r > rmax) { rmax = r; amax = s; }
+        }
+    }
+    const double t0 = block_sum_d(acc0, red);
+    if (j < HJ) {
+        if (threadIdx.x == 0) out[2 + j] = t0;
+        return;
+    }
+    const double t1 = block_sum_d(acc1, red);
+    const double t2 = block_sum_d(acc2, red);
+    const double gmax = block_max_d(rmax, red);
+    // lowest sample index attaining the max (deterministic)
+    double cand = (rmax == gmax) ? (double)amax : 1e300;
+    cand = -block_max_d(-cand, red);
+    if (threadIdx.x == 0) {
+        out[0] = m;
+        out[1] = t0;
+        out[2 + HJ] = t1;
+        out[3 + HJ] = t2;
+        out[4 + HJ] = gmax;
+        out[5 + HJ] = cand + (double)sample_offset;
+    }
+}
+
+// Combine n_ranks partial records into the new nominal sequence (and global stats).
+//   stats_out: [0] mean r  [1] unbiased std r  [2] max r  [3] argmax  [4] Z  [5] m
+__global__ void k_mppi_update(const double* __restrict__ partials, int n_ranks, int H,
+                              double n_sample_total, double* __restrict__ nominal,
+                              double* __restrict__ stats_out) {
+    const int HJ = 4 * H, REC = 6 + HJ;
+    double m = -__builtin_inf();
+    for (int g = 0; g < n_ranks; ++g) m = fmax(m, partials[(size_t)g * REC]);
+    double Z = 0.0;
+    for (int g = 0; g < n_ranks; ++g) Z += partials[(size_t)g * REC + 1] * exp(partials[(size_t)g * REC] - m);
+    for (int j = threadIdx.x; j < HJ; j += blockDim.x) {
+        double a = 0.0;
+        for (int g = 0; g < n_ranks; ++g)
+            a += partials[(size_t)g * REC + 2 + j] * exp(partials[(size_t)g * REC] - m);
+        nominal[j] = a / Z;
+    }
+    if (threadIdx.x == 0) {
+        double s1 = 0.0, s2 = 0.0, rmax = -__builtin_inf(), arg = 0.0;
+        for (int g = 0; g < n_ranks; ++g) {
+            const double* p = partials + (size_t)g * REC;
+            s1 += p[2 + HJ];
+            s2 += p[3 + HJ];
+            if (p[4 + HJ] > rmax) { rmax = p[4 + HJ]; arg = p[5 + HJ]; }
+        }
+        const double mean = s1 / n_sample_total;
+        const double var = (n_sample_total > 1.0) ? fmax((s2 - s1 * mean) / (n_sample_total - 1.0), 0.0) : 0.0;
+        stats_out[0] = mean;
+        stats_out[1] = sqrt(var);
+        stats_out[2] = rmax;
+        stats_out[3] = arg;
+        stats_out[4] = Z;
+        stats_out[5] = m;
+    }
+}

@@ -1,0 +1,231 @@
+"""numpy-facing wrapper of one C-ABI context (one GPU, one HIP stream)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(L.c_float_p)
+
+
+def _dp(a):
+    return a.ctypes.data_as(L.c_double_p)
+
+
+class Engine(object):
+    """Owns a `drp_ctx`.  Every method takes/returns numpy arrays (fp32)."""
+
+    def __init__(self, device=0, engine=None):
+        self.lib = L.load()
+        h = ctypes.c_void_p()
+        rc = self.lib.drp_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise L.DrpError('drp_create(device=%d) failed (%d): %s' %
+                             (device, rc, self.lib.drp_last_error(None).decode()))
+        self.h = h
+        self.device = int(device)
+        self.H = 0
+        if engine is not None:
+            self.set_engine(engine)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.drp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise L.DrpError('drp error %d: %s' % (rc, self.lib.drp_last_error(self.h).decode()))
+        return rc
+
+    # ---- constants ----------------------------------------------------------------
+    def set_engine(self, engine):
+        self._ck(self.lib.drp_set_engine(self.h, int(engine)))
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        ncu = ctypes.c_int()
+        mem = ctypes.c_size_t()
+        self._ck(self.lib.drp_device_info(self.h, name, 256, ctypes.byref(ncu), ctypes.byref(mem)))
+        return {'name': name.value.decode(), 'n_cu': ncu.value, 'hbm_bytes': mem.value}
+
+    def load_weights(self, blob, adj_thresh=0.08):
+        blob = _f32(blob).ravel()
+        self._ck(self.lib.drp_load_weights(self.h, _fp(blob), blob.size, float(adj_thresh)))
+
+    def set_camera(self, m34, global_scale, intr):
+        m34 = _f32(m34).ravel()
+        intr = _f32(intr).ravel()
+        assert m34.size == 12 and intr.size == 4
+        self._ck(self.lib.drp_set_camera(self.h, _fp(m34), float(global_scale), _fp(intr)))
+
+    def set_goal(self, field, goal_coor):
+        field = _f32(field)
+        goal_coor = _f32(goal_coor)
+        assert field.ndim == 2 and goal_coor.ndim == 2 and goal_coor.shape[1] == 2
+        self._ck(self.lib.drp_set_goal(self.h, _fp(field), field.shape[0], field.shape[1],
+                                       _fp(goal_coor), goal_coor.shape[0]))
+
+    # ---- single operations --------------------------------------------------------
+    def gen_s_delta(self, s_cur, action):
+        s_cur, action = _f32(s_cur), _f32(action)
+        B, N, _ = s_cur.shape
+        assert action.shape == (B, 4)
+        out = np.empty((B, N, 3), dtype=np.float32)
+        self._ck(self.lib.drp_gen_s_delta(self.h, _fp(s_cur), _fp(action), B, N, _fp(out)))
+        return out
+
+    def build_graph(self, s_cur, s_delta):
+        s_cur, s_delta = _f32(s_cur), _f32(s_delta)
+        B, N, _ = s_cur.shape
+        idx = np.empty((B, N, L.DRP_K), dtype=np.int16)
+        cnt = np.empty((B, N), dtype=np.uint8)
+        self._ck(self.lib.drp_build_graph(self.h, _fp(s_cur), _fp(s_delta), B, N,
+                                          idx.ctypes.data_as(L.c_int16_p),
+                                          cnt.ctypes.data_as(L.c_uint8_p)))
+        return idx, cnt
+
+    def step(self, a_cur, s_cur, s_delta, dens):
+        a_cur, s_cur, s_delta, dens = _f32(a_cur), _f32(s_cur), _f32(s_delta), _f32(dens)
+        B, N, _ = s_cur.shape
+        assert a_cur.shape == (B, N) and s_delta.shape == (B, N, 3) and dens.shape == (B,)
+        out = np.empty((B, N, 3), dtype=np.float32)
+        self._ck(self.lib.drp_step(self.h, _fp(a_cur), _fp(s_cur), _fp(s_delta), _fp(dens), B, N,
+                                   _fp(out)))
+        return out
+
+    def forward(self, a_cur, s_cur, s_delta, dens, nbr_idx, nbr_cnt):
+        a_cur, s_cur, s_delta, dens = _f32(a_cur), _f32(s_cur), _f32(s_delta), _f32(dens)
+        nbr_idx = np.ascontiguousarray(nbr_idx, dtype=np.int16)
+        nbr_cnt = np.ascontiguousarray(nbr_cnt, dtype=np.uint8)
+        B, N, _ = s_cur.shape
+        assert nbr_idx.shape == (B, N, L.DRP_K) and nbr_cnt.shape == (B, N)
+        out = np.empty((B, N, 3), dtype=np.float32)
+        self._ck(self.lib.drp_forward(self.h, _fp(a_cur), _fp(s_cur), _fp(s_delta), _fp(dens),
+                                      nbr_idx.ctypes.data_as(L.c_int16_p),
+                                      nbr_cnt.ctypes.data_as(L.c_uint8_p), B, N, _fp(out)))
+        return out
+
+    def rollout(self, s0, attr, dens, actions, want_states=True, want_reward=False):
+        s0, attr, dens, actions = _f32(s0), _f32(attr), _f32(dens), _f32(actions)
+        nb, N, _ = s0.shape
+        B, H, _ = actions.shape
+        states = np.empty((B, H, N, 3), dtype=np.float32) if want_states else None
+        rew = np.empty((B, H), dtype=np.float32) if want_reward else None
+        self._ck(self.lib.drp_rollout(self.h, _fp(s0), _fp(attr), _fp(dens), nb, N, _fp(actions), B, H,
+                                      _fp(states) if want_states else None,
+                                      _fp(rew) if want_reward else None))
+        return states, rew
+
+    def reward(self, state, normalize=True):
+        state = _f32(state)
+        Bp, N, _ = state.shape
+        out = np.empty((Bp,), dtype=np.float32)
+        self._ck(self.lib.drp_reward(self.h, _fp(state), Bp, N, int(bool(normalize)), _fp(out)))
+        return out
+
+    # ---- device-resident MPPI -----------------------------------------------------
+    def mpc_begin(self, s0, attr, dens, nominal, n_sample, sigma, beta_filter, reward_weight,
+                  act_lo, act_hi, seed=0, sample_offset=0):
+        s0, attr, dens = _f32(s0), _f32(attr), _f32(dens)
+        nominal = np.ascontiguousarray(nominal, dtype=np.float64)
+        nb, N, _ = s0.shape
+        H = nominal.shape[0]
+        p = L.MpcParams()
+        p.n_batch, p.n_particles, p.n_sample, p.n_look_ahead = nb, N, int(n_sample), H
+        p.sigma, p.beta_filter, p.reward_weight = float(sigma), float(beta_filter), float(reward_weight)
+        for i in range(4):
+            p.act_lo[i] = float(act_lo[i])
+            p.act_hi[i] = float(act_hi[i])
+        p.seed, p.sample_offset = int(seed), int(sample_offset)
+        self._ck(self.lib.drp_mpc_begin(self.h, ctypes.byref(p), _fp(s0), _fp(attr), _fp(dens),
+                                        _dp(nominal)))
+        self.H, self.nb, self.N, self.ns = H, nb, N, int(n_sample)
+
+    def mpc_sample(self, iteration, noise=None):
+        if noise is not None:
+            noise = _f32(noise)
+            assert noise.shape == (self.ns, self.H, 4)
+        self._ck(self.lib.drp_mpc_sample(self.h, _fp(noise) if noise is not None else None,
+                                         int(iteration)))
+
+    def mpc_set_actions(self, actions):
+        actions = _f32(actions)
+        assert actions.shape == (self.ns * self.nb, self.H, 4)
+        self._ck(self.lib.drp_mpc_set_actions(self.h, _fp(actions)))
+
+    def mpc_rollout(self, reward_all_steps=False):
+        self._ck(self.lib.drp_mpc_rollout(self.h, int(bool(reward_all_steps))))
+
+    def mpc_partials(self, fetch=True):
+        out = np.empty((6 + 4 * self.H,), dtype=np.float64) if fetch else None
+        self._ck(self.lib.drp_mpc_partials(self.h, _dp(out) if fetch else None))
+        return out
+
+    def mpc_update(self, partials):
+        partials = np.ascontiguousarray(partials, dtype=np.float64).reshape(-1, 6 + 4 * self.H)
+        nominal = np.empty((self.H, 4), dtype=np.float64)
+        self._ck(self.lib.drp_mpc_update(self.h, _dp(partials), partials.shape[0], _dp(nominal)))
+        return nominal
+
+    def mpc_update_device(self):
+        self._ck(self.lib.drp_mpc_update_device(self.h))
+
+    def mpc_get(self, actions=False, rewards=False, rewards_all=False, states=False, nominal=False):
+        B = self.ns * self.nb
+        a = np.empty((B, self.H, 4), np.float32) if actions else None
+        r = np.empty((B,), np.float32) if rewards else None
+        ra = np.empty((B, self.H), np.float32) if rewards_all else None
+        s = np.empty((B, self.H, self.N, 3), np.float32) if states else None
+        n = np.empty((self.H, 4), np.float64) if nominal else None
+        self._ck(self.lib.drp_mpc_get(self.h, _fp(a) if actions else None, _fp(r) if rewards else None,
+                                      _fp(ra) if rewards_all else None, _fp(s) if states else None,
+                                      _dp(n) if nominal else None))
+        return {'actions': a, 'rewards': r, 'rewards_all': ra, 'states': s, 'nominal': n}
+
+    def mpc_stats(self):
+        out = np.empty((8,), dtype=np.float64)
+        self._ck(self.lib.drp_debug_fetch(self.h, b'stats', out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+        return {'mean': out[0], 'std': out[1], 'max': out[2], 'argmax': int(out[3]), 'Z': out[4], 'm': out[5]}
+
+    # ---- multi-GPU ------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        rc = self.lib.drp_comm_unique_id(buf)
+        if rc != 0:
+            raise L.DrpError('drp_comm_unique_id failed: %s' % self.lib.drp_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, uid, rank, n_ranks):
+        self._ck(self.lib.drp_comm_init(self.h, uid, int(rank), int(n_ranks)))
+
+    # ---- measurement ------------------------------------------------------------------
+    def sync(self):
+        self._ck(self.lib.drp_sync(self.h))
+
+    def probe_begin(self, kernel_class):
+        self._ck(self.lib.drp_probe_begin(self.h, kernel_class.encode() if kernel_class else None))
+
+    def probe_read(self):
+        ms = ctypes.c_double()
+        n = ctypes.c_long()
+        self._ck(self.lib.drp_probe_read(self.h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def debug_fetch(self, name, shape, dtype=np.float32):
+        out = np.empty(shape, dtype=dtype)
+        self._ck(self.lib.drp_debug_fetch(self.h, name.encode(), out.ctypes.data_as(ctypes.c_void_p),
+                                          out.nbytes))
+        return out

@@ -1,0 +1,164 @@
+/*
+ * drp.h -- C ABI of the MI355X-native particle-GNN rollout + sampling-MPC engine.
+ *
+ * The reference (WangYixuan12/dyn-res-pile-manip) has no FFI for this path: its
+ * boundary is a Python call surface.  This header is the
+ * C-ABI a Python/ctypes (or any other) host binds to get the same operations;
+ * every entry point cites the reference function it replaces (paths relative to
+ * the reference repo).  Plain pointers and sizes only; all float data is fp32
+ * row-major; host buffers are caller-owned; device workspaces are owned by the
+ * context and re-used while the shapes fit.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DRP_E* code otherwise, and
+ *     never throws; drp_last_error() gives the message of the last failure.
+ *   - one context per GPU, one HIP stream per context.  Functions taking host
+ *     buffers synchronise before returning; the drp_mpc_* family only enqueues
+ *     work on the context's stream (drp_sync() waits).
+ *   - B = n_sample * n_batch rows; row = sample * n_batch + batch
+ *     (planners.py:336-339).  K = 10 in-edges per receiver at most
+ *     (model/gnn_dyn.py:231).  F = 64 features (nf_effect).
+ */
+#ifndef DRP_H
+#define DRP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRP_K 10
+#define DRP_F 64
+#define DRP_N_WEIGHTS 38403   /* floats in the state_dict, SURVEY.md 8 a16 */
+
+enum {
+    DRP_OK = 0,
+    DRP_EINVAL = -1,    /* bad argument / shape */
+    DRP_ESTATE = -2,    /* call order: weights / camera / goal / state not set */
+    DRP_EHIP = -3,      /* HIP runtime error */
+    DRP_ENOMEM = -4,
+    DRP_ECOMM = -5      /* RCCL error */
+};
+
+/* which kernels compute the MLPs */
+enum {
+    DRP_ENGINE_VALU = 0,  /* fp32 VALU reference kernels */
+    DRP_ENGINE_MFMA = 1   /* fp32 MFMA (v_mfma_f32_32x32x2_f32) kernels */
+};
+
+typedef struct drp_ctx drp_ctx;
+
+/* ---- life cycle ------------------------------------------------------------------ */
+int drp_create(int device, drp_ctx** out);
+void drp_destroy(drp_ctx* ctx);
+const char* drp_last_error(const drp_ctx* ctx);     /* ctx may be NULL: last create error */
+int drp_sync(drp_ctx* ctx);
+int drp_set_engine(drp_ctx* ctx, int engine);
+int drp_device_info(drp_ctx* ctx, char* name, size_t name_len, int* n_cu, size_t* hbm_bytes);
+
+/* ---- model constants ----------------------------------------------------------- */
+/* PropNetDiffDenModel.load_state_dict (visualize_mpc.py:36-41): the 38 403 floats of
+ * the state_dict, concatenated in its own key order, torch Linear
+ * layout [out,in].  adj_thresh = config train.particle.adj_thresh
+ * (model/gnn_dyn.py:206). */
+int drp_load_weights(drp_ctx* ctx, const float* blob, size_t n_floats, float adj_thresh);
+
+/* PlannerGD.world2cam (planners.py:192-209): m34 = first three rows of
+ * inv(inv(cam_extrinsic) diag(1,-1,-1,1)) in fp32, global_scale from the config;
+ * intr = env.get_cam_params() = [fx,fy,cx,cy] (env/flex_env.py:1135-1142). */
+int drp_set_camera(drp_ctx* ctx, const float m34[12], float global_scale, const float intr[4]);
+
+/* config_reward_ptcl's constants (env/flex_rewards.py:172-177, planners.py:620-624):
+ * field = goal - distanceTransform(goal < 0.5), shifted to min 0, [h,w];
+ * goal_coor [m,2] = (col,row) goal pixels. */
+int drp_set_goal(drp_ctx* ctx, const float* field, int h, int w, const float* goal_coor, int m);
+
+/* ---- single operations on host buffers (unit parity with the reference) -------- */
+/* PlannerGD.gen_s_delta (planners.py:211-257). s_cur [B,N,3], action [B,4] -> [B,N,3] */
+int drp_gen_s_delta(drp_ctx* ctx, const float* s_cur, const float* action, int B, int N,
+                    float* s_delta_out);
+
+/* The graph of predict_one_step (model/gnn_dyn.py:223-251) as receiver-major lists:
+ * nbr_idx [B,N,10] int16 (ascending sender, -1 padded), nbr_cnt [B,N] uint8. */
+int drp_build_graph(drp_ctx* ctx, const float* s_cur, const float* s_delta, int B, int N,
+                    int16_t* nbr_idx_out, uint8_t* nbr_cnt_out);
+
+/* PropNetDiffDenModel.predict_one_step (model/gnn_dyn.py:209-254).
+ * a_cur [B,N], s_cur/s_delta [B,N,3], dens [B] -> s_pred [B,N,3] */
+int drp_step(drp_ctx* ctx, const float* a_cur, const float* s_cur, const float* s_delta,
+             const float* dens, int B, int N, float* s_pred_out);
+
+/* PropModuleDiffDen.forward (model/gnn_dyn.py:147-198) with the relations given as
+ * lists instead of dense one-hot Rr/Rs. */
+int drp_forward(drp_ctx* ctx, const float* a_cur, const float* s_cur, const float* s_delta,
+                const float* dens, const int16_t* nbr_idx, const uint8_t* nbr_cnt, int B, int N,
+                float* s_pred_out);
+
+/* PlannerGD.ptcl_model_rollout (planners.py:302-370): s0 [nb,N,3], attr [nb,N],
+ * dens [nb], actions [B,H,4] -> states_out [B,H,N,3] (nullable).  If reward_out is
+ * not NULL it receives config_reward_ptcl of every step, [B,H] (what
+ * ptcl_evaluate_traj computes, planners.py:414-422); needs drp_set_goal. */
+int drp_rollout(drp_ctx* ctx, const float* s0, const float* attr, const float* dens, int nb,
+                int N, const float* actions, int B, int H, float* states_out, float* reward_out);
+
+/* config_reward_ptcl (env/flex_rewards.py:156-214) downstream of the distance
+ * transform.  state [Bp,N,3] -> reward [Bp]. */
+int drp_reward(drp_ctx* ctx, const float* state, int Bp, int N, int normalize, float* reward_out);
+
+/* ---- device-resident sampling MPC (MPPI) ------------------------------------------
+ * One iteration = sample_action_sequences (planners.py:69-190) -> ptcl_model_rollout
+ * -> final-step reward -> optimize_action (planners.py:549-561), all on the stream.
+ * The sample axis may be sharded over ranks: each rank runs n_sample_local samples
+ * and the softmax-weighted mean is combined from per-rank partials. */
+typedef struct drp_mpc_params {
+    int n_batch;          /* initial-state columns (particle re-samplings) */
+    int n_particles;
+    int n_sample;         /* samples on THIS rank */
+    int n_look_ahead;     /* H */
+    float sigma;          /* mpc.sigma * global_scale / 12 (planners.py:116) */
+    float beta_filter;    /* mpc.mppi.beta_filter (planners.py:93) */
+    float reward_weight;  /* mpc.mppi.reward_weight (planners.py:553) */
+    float act_lo[4];      /* clip box (planners.py:152-155) */
+    float act_hi[4];
+    uint64_t seed;        /* Philox key */
+    uint64_t sample_offset; /* first global sample index of this rank (Philox counter) */
+} drp_mpc_params;
+
+int drp_mpc_begin(drp_ctx* ctx, const drp_mpc_params* p, const float* s0, const float* attr,
+                  const float* dens, const double* nominal /* [H,4] */);
+/* noise: NULL -> device Philox normals; else host [B,H,4] standard-normal draws. */
+int drp_mpc_sample(drp_ctx* ctx, const float* noise, uint64_t iteration);
+int drp_mpc_set_actions(drp_ctx* ctx, const float* actions /* [B,H,4] */);
+int drp_mpc_rollout(drp_ctx* ctx, int reward_all_steps);
+/* per-rank partials of the softmax mean over column `col`'s samples:
+ * out[0]=m, out[1]=Z, out[2..2+4H)=A, then sum r, sum r^2, max r, argmax (as double). */
+int drp_mpc_partials(drp_ctx* ctx, double* out /* [6+4H], nullable */);
+/* combine `n_ranks` partial records (as returned above, concatenated) into the new
+ * nominal sequence; uploads it as the next iteration's nominal. */
+int drp_mpc_update(drp_ctx* ctx, const double* partials, int n_ranks, double* nominal_out);
+/* partials -> (RCCL all-gather if a communicator is attached) -> update, no host hop */
+int drp_mpc_update_device(drp_ctx* ctx);
+int drp_mpc_get(drp_ctx* ctx, float* actions /*[B,H,4]*/, float* rewards /*[B] final*/,
+                float* rewards_all /*[B,H]*/, float* states /*[B,H,N,3]*/, double* nominal);
+
+/* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------ */
+int drp_comm_unique_id(char* id128);                       /* ncclGetUniqueId */
+int drp_comm_init(drp_ctx* ctx, const char* id128, int rank, int n_ranks);
+int drp_comm_destroy(drp_ctx* ctx);
+
+/* ---- measurement / debugging ----------------------------------------------------- */
+/* HIP-event timing of one kernel class on the context's stream.  name: "graph",
+ * "node_encode", "edge_encode", "project", "aggregate", "update", "predict", "reward",
+ * "mppi".  drp_probe_read returns total ms and launches since drp_probe_begin. */
+int drp_probe_begin(drp_ctx* ctx, const char* kernel_class);
+int drp_probe_read(drp_ctx* ctx, double* total_ms, long* launches);
+/* copy an intermediate device buffer to the host: "s_delta","nbr_idx","nbr_cnt",
+ * "particle_encode"(eff0),"c_node","c_edge","proj","agg","effect". returns bytes. */
+long drp_debug_fetch(drp_ctx* ctx, const char* name, void* out, size_t out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRP_H */
