@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one "step" = one sampling-MPC iteration on the device
+  sample pushes (MPPI) -> H-step GNN rollout (graph rebuild + impulse + PropNet each step)
+  -> final-step reward -> softmax-weighted update [-> RCCL all-gather when sharded].
+
+Metric (BASELINE.json): particle-steps/s = samples x particles x steps / wall time.
+Workload at N=1: BASELINE.json configs[1] -- 300-particle pile, 1024 MPPI samples,
+10-step horizon (inputs resident in HBM).  With --gpus N the sample axis is sharded,
+1024 samples per GPU (weak scaling, configs[2] at N=8).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_F32_TFLOPS = 157.3      # dense fp32 (vector == f32-input MFMA rate)
+KERNEL_CLASSES = ['graph', 'node_encode', 'edge_encode', 'project', 'aggregate', 'update',
+                  'predict', 'reward', 'mppi']
+# algorithmic work of one LAUNCH of each class, per particle (node) or per edge
+FLOP_PER_EDGE_ENCODE = 2 * (6 * 64 + 3 * 64 * 64)
+FLOP_PER_NODE = {'node_encode': 2 * (5 * 64 + 2 * 64 * 64), 'project': 2 * 2 * 64 * 64,
+                 'update': 2 * 64 * 64, 'predict': 2 * (64 * 64 + 3 * 64)}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--particles', type=int, default=300)
+    ap.add_argument('--samples', type=int, default=1024, help='MPPI samples per GPU')
+    ap.add_argument('--horizon', type=int, default=10)
+    ap.add_argument('--engine', default=os.environ.get('DRP_ENGINE', 'auto'))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-samples', type=int, default=64)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam):
+    """The oracle (dense-formulation PyTorch, the reference's algorithmic shape) on this
+    box's host cores, on a bounded sample of the same workload."""
+    import torch
+    from oracle import propnet_dense as od
+    from dyn_res_pile_manip_amd import synthetic as syn
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    W = od.load_weights(sd)
+    ns, H, N = args.cpu_samples, args.horizon, args.particles
+    acts = syn.sample_pushes(ns, H, seed=1)
+    ext = syn.demo_cam_extrinsics()
+    with torch.no_grad():
+        od.rollout(W, s0, dens, attr, acts[:4, :1], ext, 24)          # warm-up
+        t0 = time.perf_counter()
+        st = od.rollout(W, s0, dens, attr, acts, ext, 24)
+        r = od.config_reward_ptcl(st[:, -1], G, cam, goal_coor)
+        od.optimize_action(acts, r.numpy(), 0.1)
+        dt = time.perf_counter() - t0
+    return {'value': ns * N * H / dt, 'unit': 'particle-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d samples x %d particles x %d steps, oracle/propnet_dense.py (dense '
+                      'Rr/Rs PyTorch fp32, %d threads), %.1f s' % (ns, N, H, cores, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    import torch
+    import torch.distributed as dist
+    from dyn_res_pile_manip_amd import synthetic as syn, weights, _lib
+    from dyn_res_pile_manip_amd.engine import Engine
+    from dyn_res_pile_manip_amd.planners import world2cam_affine
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    N, ns, H = args.particles, args.samples, args.horizon
+    eng = Engine(local_rank)
+    engine = args.engine
+    if engine == 'auto':
+        try:
+            eng.set_engine(_lib.ENGINE_MFMA)
+            engine = 'mfma'
+        except _lib.DrpError:
+            eng.set_engine(_lib.ENGINE_VALU)
+            engine = 'valu'
+    else:
+        eng.set_engine({'valu': _lib.ENGINE_VALU, 'mfma': _lib.ENGINE_MFMA}[engine])
+    sd = weights.random_state_dict(seed=0)
+    eng.load_weights(weights.blob_from_state_dict(sd), 0.08)
+    M34 = world2cam_affine(syn.demo_cam_extrinsics())
+    cam = syn.demo_cam_params()
+    eng.set_camera(M34, 24.0, cam)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    G = syn.goal_field(obs_goal)
+    goal_coor = syn.goal_coor_strided(obs_goal, 5 * N)
+    eng.set_goal(G, goal_coor)
+    s0, dens, attr = syn.make_pile(N, 1, seed=0)
+    lo, hi = syn.action_limits()
+    nominal = syn.nominal_pushes(H, seed=0)
+    eng.mpc_begin(s0, attr, dens, nominal, n_sample=ns, sigma=0.3 * 24 / 12.0, beta_filter=0.7,
+                  reward_weight=0.1, act_lo=lo, act_hi=hi, seed=1234, sample_offset=rank * ns)
+    if world > 1:
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0], rank, world)
+
+    it = [0]
+
+    def step():
+        eng.mpc_sample(it[0])
+        eng.mpc_rollout(False)
+        eng.mpc_update_device()
+        it[0] += 1
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # untimed calibration: one iteration per kernel class with the HIP-event probe on
+    per_class = {}
+    for kc in KERNEL_CLASSES:
+        eng.probe_begin(kc)
+        step()
+        ms, n = eng.probe_read()
+        per_class[kc] = (ms, n)
+    dominant = max(per_class, key=lambda k: per_class[k][0])
+    kbar = float(eng.debug_fetch('nbr_cnt', (ns, N), np.uint8).mean())
+    eng.probe_begin(dominant)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    dom_ms, dom_n = eng.probe_read()
+    eng.probe_begin(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total = world * ns * N * H * args.steps
+        avg_s = dom_ms / max(dom_n, 1) * 1e-3
+        B = ns
+        if dominant == 'aggregate':
+            work = B * N * (2 * kbar + 2) * 256.0
+            roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+        elif dominant == 'edge_encode':
+            work = B * N * kbar * FLOP_PER_EDGE_ENCODE
+            roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s'}
+        elif dominant in FLOP_PER_NODE:
+            work = B * N * FLOP_PER_NODE[dominant]
+            roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s'}
+        else:
+            roof = {'bound': 'hbm', 'achieved': 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+        roof['frac'] = roof['achieved'] / roof['peak']
+        roof['kernel'] = dominant
+        roof['avg_launch_ms'] = avg_s * 1e3
+        roof['launches'] = dom_n
+        roof['traffic'] = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                roof['traffic'] = tj.get(engine, {}).get(dominant)
+            except Exception:
+                pass
+        out = {
+            'metric': 'MPC rollout-steps/sec (samples x particles x steps/sec)',
+            'value': total / dt, 'unit': 'particle-steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%d-particle pile, %d MPPI samples per GPU, %d-step horizon '
+                                   '(BASELINE configs[%d])' % (N, ns, H, 1 if world == 1 else 2),
+                       'n_particles': N, 'n_sample_per_gpu': ns, 'n_look_ahead': H, 'engine': engine,
+                       'mean_in_degree': kbar, 'parallelism': 'samples sharded x%d' % world},
+            'roofline': roof,
+            'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

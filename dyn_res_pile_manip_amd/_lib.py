@@ -26,8 +26,8 @@ class MpcParams(ctypes.Structure):
     """struct drp_mpc_params (include/drp.h)."""
     _fields_ = [('n_batch', ctypes.c_int), ('n_particles', ctypes.c_int),
                 ('n_sample', ctypes.c_int), ('n_look_ahead', ctypes.c_int),
-                ('sigma', ctypes.c_float), ('beta_filter', ctypes.c_float),
-                ('reward_weight', ctypes.c_float),
+                ('sigma', ctypes.c_double), ('beta_filter', ctypes.c_double),
+                ('reward_weight', ctypes.c_double),
                 ('act_lo', ctypes.c_float * 4), ('act_hi', ctypes.c_float * 4),
                 ('seed', ctypes.c_uint64), ('sample_offset', ctypes.c_uint64)]
 

@@ -44,7 +44,7 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
 //   noise: null -> Philox normals keyed by (seed; global sample, t, iteration),
 //          else [n_sample,H,4] standard normal draws from the host.
 __global__ void k_mppi_sample(const double* __restrict__ nominal, const float* __restrict__ noise,
-                              int n_sample, int n_batch, int H, float sigma, float beta, float4 lo,
+                              int n_sample, int n_batch, int H, double sigma, double beta, float4 lo,
                               float4 hi, uint64_t seed, uint64_t sample_offset, uint64_t iteration,
                               float* __restrict__ actions) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -65,7 +65,7 @@ __global__ void k_mppi_sample(const double* __restrict__ nominal, const float* _
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            resid[c] = (double)beta * ((double)sigma * (double)n[c]) + resid[c] * (1.0 - (double)beta);
+            resid[c] = beta * (sigma * (double)n[c]) + resid[c] * (1.0 - beta);
             double a = nominal[t * 4 + c] + resid[c];
             a = fmin(fmax(a, (double)lo_[c]), (double)hi_[c]);
             for (int j = 0; j < n_batch; ++j)
@@ -103,7 +103,7 @@ __device__ __forceinline__ double block_max_d(double v, double* red) {
 // grid = 4H + 1 blocks of 256 threads; block j < 4H reduces A[j], the last block the rest.
 __global__ void __launch_bounds__(256)
 k_mppi_partials(const float* __restrict__ reward, int reward_stride, const float* __restrict__ actions,
-                int n_sample, int n_batch, int H, float lambda, uint64_t sample_offset,
+                int n_sample, int n_batch, int H, double lambda, uint64_t sample_offset,
                 double* __restrict__ out) {
     __shared__ double red[4];
     const int j = blockIdx.x;
@@ -113,7 +113,7 @@ k_mppi_partials(const float* __restrict__ reward, int reward_stride, const float
         double r = 0.0;
         for (int c = 0; c < n_batch; ++c) r += (double)reward[((size_t)s * n_batch + c) * reward_stride];
         r /= (double)n_batch;
-        mloc = fmax(mloc, (double)lambda * r);
+        mloc = fmax(mloc, lambda * r);
     }
     const double m = block_max_d(mloc, red);
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
@@ -123,7 +123,7 @@ k_mppi_partials(const float* __restrict__ reward, int reward_stride, const float
         double r = 0.0;
         for (int c = 0; c < n_batch; ++c) r += (double)reward[((size_t)s * n_batch + c) * reward_stride];
         r /= (double)n_batch;
-        const double w = exp((double)lambda * r - m);
+        const double w = exp(lambda * r - m);
         if (j < HJ) {
             acc0 += w * (double)actions[((size_t)s * n_batch) * HJ + j];
         } else {

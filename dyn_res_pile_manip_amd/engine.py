@@ -69,7 +69,13 @@ class Engine(object):
         m34 = _f32(m34).ravel()
         intr = _f32(intr).ravel()
         assert m34.size == 12 and intr.size == 4
+        self._cam = (m34.copy(), float(global_scale))
         self._ck(self.lib.drp_set_camera(self.h, _fp(m34), float(global_scale), _fp(intr)))
+
+    def set_camera_intrinsics(self, intr):
+        """Change [fx,fy,cx,cy] only (the reward's projection), keeping the extrinsic map."""
+        m34, gs = getattr(self, '_cam', (np.eye(3, 4, dtype=np.float32).ravel(), 1.0))
+        self.set_camera(m34, gs, intr)
 
     def set_goal(self, field, goal_coor):
         field = _f32(field)

@@ -1,0 +1,123 @@
+"""Host-side mirror of the reference's `model/gnn_dyn.py` call surface, backed by the
+HIP engine through the C ABI.
+
+  PropNetDiffDenModel(config, use_gpu)                       model/gnn_dyn.py:200-207
+    .load_state_dict(state_dict, strict=False)               visualize_mpc.py:36-41
+    .predict_one_step(a_cur, s_cur, s_delta, particle_dens, particle_nums=None)   :209-254
+    .model.forward(a_cur, s_cur, s_delta, Rr, Rs, particle_dens)                  :147-198
+
+Arguments may be torch tensors (any device) or numpy arrays; the result comes back in
+the same kind.  No computation happens on the host: a missing GPU or a missing
+libdrp.so raises.
+"""
+import numpy as np
+
+from . import weights as _weights
+from .engine import Engine
+
+
+def _to_np(x):
+    if hasattr(x, 'detach'):
+        return x.detach().cpu().numpy().astype(np.float32, copy=False), x
+    return np.asarray(x, dtype=np.float32), None
+
+
+def _like(out, proto):
+    if proto is None:
+        return out
+    import torch
+    return torch.from_numpy(out).to(device=proto.device, dtype=proto.dtype)
+
+
+def relations_to_lists(Rr, Rs):
+    """Dense one-hot Rr/Rs [B,E,N] (model/gnn_dyn.py:248-251) -> receiver-major lists
+    nbr_idx [B,N,10] int16, nbr_cnt [B,N] uint8 (edge order preserved per receiver)."""
+    Rr, _ = _to_np(Rr)
+    Rs, _ = _to_np(Rs)
+    B, E, N = Rr.shape
+    idx = -np.ones((B, N, 10), dtype=np.int16)
+    cnt = np.zeros((B, N), dtype=np.uint8)
+    bs, es = np.nonzero(Rr.sum(2) > 0.5)
+    recv = Rr[bs, es].argmax(1)
+    send = Rs[bs, es].argmax(1)
+    for b, i, j in zip(bs, recv, send):
+        k = cnt[b, i]
+        if k >= 10:
+            raise ValueError('receiver %d of sample %d has more than 10 in-edges' % (i, b))
+        idx[b, i, k] = j
+        cnt[b, i] = k + 1
+    return idx, cnt
+
+
+class PropModuleDiffDen(object):
+    """`model.model` of the reference: forward() with explicit relations."""
+
+    def __init__(self, owner):
+        self._owner = owner
+        self.nf_effect = owner.config['train']['particle']['nf_effect']
+
+    def forward(self, a_cur, s_cur, s_delta, Rr, Rs, particle_dens, verbose=False):
+        a, proto = _to_np(a_cur)
+        s, _ = _to_np(s_cur)
+        sd, _ = _to_np(s_delta)
+        d, _ = _to_np(particle_dens)
+        idx, cnt = relations_to_lists(Rr, Rs)
+        return _like(self._owner.engine.forward(a, s, sd, d, idx, cnt), proto)
+
+    __call__ = forward
+
+
+class PropNetDiffDenModel(object):
+    def __init__(self, config, use_gpu=True, device=0, engine=None):
+        if config['train']['particle']['nf_effect'] != 64:
+            raise NotImplementedError('the HIP kernels are built for nf_effect = 64')
+        self.config = config
+        self.adj_thresh = config['train']['particle']['adj_thresh']
+        self.engine = engine if engine is not None else Engine(device)
+        self.model = PropModuleDiffDen(self)
+        self._blob = None
+
+    # nn.Module look-alikes used by the reference's scripts
+    def cuda(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._blob = _weights.blob_from_state_dict(state_dict, strict=strict)
+        self.engine.load_weights(self._blob, self.adj_thresh)
+        return self
+
+    def state_dict(self):
+        if self._blob is None:
+            raise RuntimeError('no weights loaded')
+        return _weights.state_dict_from_blob(self._blob)
+
+    def predict_one_step(self, a_cur, s_cur, s_delta, particle_dens, particle_nums=None):
+        a, proto = _to_np(a_cur)
+        s, _ = _to_np(s_cur)
+        sd, _ = _to_np(s_delta)
+        d, _ = _to_np(particle_dens)
+        assert a.shape == s.shape[:2]            # model/gnn_dyn.py:218-219
+        assert s.shape == sd.shape
+        if particle_nums is not None:
+            # model/gnn_dyn.py:238-241: rows/columns beyond particle_nums[b] leave the graph.
+            # Unused by the MPC path and by training: build the lists on the
+            # device, mask them on the host, run forward with explicit relations.
+            idx, cnt = self.engine.build_graph(s, sd)
+            for b in range(s.shape[0]):
+                n = int(particle_nums[b])
+                keep = idx[b] < n
+                keep[n:] = False
+                keep &= idx[b] >= 0
+                for i in range(s.shape[1]):
+                    js = idx[b, i][keep[i]]
+                    idx[b, i] = -1
+                    idx[b, i, :len(js)] = js
+                    cnt[b, i] = len(js)
+            return _like(self.engine.forward(a, s, sd, d, idx, cnt), proto)
+        return _like(self.engine.step(a, s, sd, d), proto)

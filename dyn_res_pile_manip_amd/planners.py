@@ -1,0 +1,344 @@
+"""Host-side mirror of the reference's `planners.py` call surface (PlannerGD), driving
+the HIP engine through the C ABI.
+
+Same method names, argument orders and return structures as the reference
+(SURVEY.md 8b); tensors may be torch tensors or numpy arrays.  The optimiser inside
+`trajectory_optimization_ptcl_multi_traj` is the sampling planner (MPPI) built from
+the reference's own `sample_action_sequences` / `optimize_action` definitions
+(planners.py:69-190, :549-561): forward-only, which is what shards over GPUs.  The
+reference's live gradient-descent loop (planners.py:674-764) needs reverse-mode
+kernels and is the next scope row.
+"""
+import time
+
+import numpy as np
+
+from .gnn_dyn import PropNetDiffDenModel, _like, _to_np
+
+DEBUG = False
+
+
+def particle_num_to_iter_time(particle_num):
+    """planners.py:25-28: the reference's fitted ms per GD iteration at batch 300 on its
+    (unstated) GPU.  Kept for callers; the planner below measures its own iteration time."""
+    t = (2969.3971 - 69.923244 * particle_num + 1.8509846 * particle_num ** 2) / 200.
+    return max(int(t), 1)
+
+
+def world2cam_affine(cam_extrinsic):
+    """planners.py:197-203: rows 0..2 of inv(inv(cam_ext) diag(1,-1,-1,1)), built in
+    float64 and cast to fp32 as the reference does."""
+    gl = np.diag([1.0, -1.0, -1.0, 1.0])
+    m = np.linalg.inv(np.matmul(np.linalg.inv(np.asarray(cam_extrinsic, dtype=np.float64)), gl))
+    return np.ascontiguousarray(m[:3, :4], dtype=np.float32)
+
+
+class Planner(object):
+    def __init__(self, config, env):
+        self.config = config
+        self.action_dim = 4
+        self.global_scale = config['dataset']['global_scale']
+        self.img_ch = 1
+        self.n_his = config['train']['n_history']
+        self.env = env
+        self.cam_params = self.env.get_cam_params()
+        self.is_real = self.env.is_real
+        if not self.is_real:
+            self.cam_extrinsic = self.env.get_cam_extrinsics()
+        else:
+            raise NotImplementedError('real-robot path (gen_s_delta_irl) is out of scope')
+        self.screenHeight = self.env.screenHeight
+        self.screenWidth = self.env.screenWidth
+
+    def trajectory_optimization(self, state_cur, obs_goal, model_dy, act_seq, n_sample,
+                                n_look_ahead, n_update_iter, action_lower_lim, action_upper_lim,
+                                use_gpu):
+        pass   # empty in the reference too (planners.py:55-62)
+
+
+class PlannerGD(Planner):
+    def __init__(self, config, env):
+        super(PlannerGD, self).__init__(config, env)
+        self._m34 = world2cam_affine(self.cam_extrinsic)
+        self._goal_key = None
+
+    # ---- engine plumbing -----------------------------------------------------------
+    def _bind(self, model_dy):
+        if not isinstance(model_dy, PropNetDiffDenModel):
+            raise NotImplementedError      # planners.py:355
+        eng = model_dy.engine
+        eng.set_camera(self._m34, float(self.global_scale), self.cam_params)
+        return eng
+
+    def _set_goal(self, eng, obs_goal, goal_coor):
+        from . import flex_rewards
+        g, _ = _to_np(obs_goal)
+        gc, _ = _to_np(goal_coor)
+        key = (id(eng), g.shape, float(g.sum()), gc.shape, float(gc.sum()))
+        if key != self._goal_key:
+            eng.set_goal(flex_rewards.goal_field(g), gc)
+            self._goal_key = key
+
+    def _clip_box(self):
+        """planners.py:151-167 for cvx region 0."""
+        r = self.env.cvx_region
+        xd, yd = r[0, 1] - r[0, 0], r[0, 3] - r[0, 2]
+        lo = np.array([r[0, 0], r[0, 2], r[0, 0] + xd * 0.15, r[0, 2] + yd * 0.15])
+        hi = np.array([r[0, 1], r[0, 3], r[0, 1] - xd * 0.15, r[0, 3] - yd * 0.15])
+        return lo, hi
+
+    # ---- planners.py:69-190 ---------------------------------------------------------
+    def sample_action_sequences(self, init_act_seq, init_act_label_seq, n_sample, action_lower_lim,
+                                action_upper_lim, noise_type='normal'):
+        """Host (numpy, global np.random) version with the reference's semantics; the MPC
+        loop uses the device sampler (Philox) with the same filter and clip."""
+        beta = self.config['mpc']['mppi']['beta_filter']
+        init_act_seq = np.asarray(init_act_seq, dtype=np.float64)
+        dim3 = init_act_seq.ndim == 3
+        act_seqs = np.stack([init_act_seq] * n_sample)
+        resid = np.zeros((n_sample,) + init_act_seq.shape[1:])
+        lo, hi = self._clip_box()
+        for i in range(self.n_his - 1, init_act_seq.shape[0]):
+            if noise_type == 'normal':
+                sigma = self.config['mpc']['sigma'] * self.global_scale / 12.0
+                noise = np.random.normal(0, sigma, resid.shape)
+            elif noise_type == 'uniform':
+                sigma = 2.0 * self.global_scale / 12.0
+                noise = np.random.uniform(-sigma, sigma, resid.shape)
+            elif noise_type == 'total_rand':
+                noise = np.zeros(resid.shape)
+            else:
+                raise ValueError('unknown noise type: %s' % noise_type)
+            resid = beta * noise + resid * (1. - beta)
+            act_seqs[:, i] += resid
+            if dim3:
+                act_seqs[:, i, 0] = np.clip(act_seqs[:, i, 0], lo, hi)
+            else:
+                act_seqs[:, i] = np.clip(act_seqs[:, i], lo, hi)
+            if noise_type == 'total_rand':
+                act_seqs[:, i, 0] = np.random.uniform(lo, hi, (n_sample, self.action_dim))
+        return act_seqs
+
+    # ---- planners.py:192-209 --------------------------------------------------------
+    def world2cam(self, world_pts):
+        p, proto = _to_np(world_pts)
+        hom = np.concatenate([p, np.ones((p.shape[0], 1), np.float32)], 1)
+        cam = (hom @ self._m34.T) / np.float32(self.global_scale)
+        return _like(cam.astype(np.float32), proto)
+
+    # ---- planners.py:211-257 --------------------------------------------------------
+    def gen_s_delta(self, s_cur, action, model_dy=None):
+        s, proto = _to_np(s_cur)
+        a, _ = _to_np(action)
+        assert s.shape[0] == a.shape[0]
+        eng = self._engine(model_dy)
+        return _like(eng.gen_s_delta(s, a), proto)
+
+    def _engine(self, model_dy=None):
+        if model_dy is not None:
+            self._eng = self._bind(model_dy)
+        if getattr(self, '_eng', None) is None:
+            raise RuntimeError('no engine bound yet: pass model_dy once')
+        return self._eng
+
+    # ---- planners.py:302-370 --------------------------------------------------------
+    def ptcl_model_rollout(self, s_cur_tensor, s_param_tensor, a_cur_tensor, model_dy, act_seqs,
+                           enable_grad=True):
+        s, proto = _to_np(s_cur_tensor)
+        d, _ = _to_np(s_param_tensor)
+        a, _ = _to_np(a_cur_tensor)
+        acts, _ = _to_np(act_seqs)
+        assert s.shape[2] == 3 and a.shape[1] == s.shape[1]
+        self.particle_num = s.shape[1]
+        eng = self._engine(model_dy)
+        t0 = time.perf_counter()
+        states, _ = eng.rollout(s, a, d, acts, want_states=True, want_reward=False)
+        ms = (time.perf_counter() - t0) * 1e3
+        return {'model_rollout': {'state_pred': _like(states, proto)}, 'rollout_time': ms}
+
+    # ---- planners.py:372-452 --------------------------------------------------------
+    def ptcl_evaluate_traj(self, obs_seqs, obs_goal, obs_goal_coor_tensor, debug=False,
+                           funnel_dist=None, distractor_df_fn=None, act_seqs_tensor=None,
+                           normalize_rew=True):
+        if distractor_df_fn is not None:
+            raise NotImplementedError('distractor rewards are unused on the live path')
+        obs, proto = _to_np(obs_seqs)
+        assert obs.ndim == 5 and obs.shape[4] == 3
+        g, _ = _to_np(obs_goal)
+        assert g.shape == (self.screenHeight, self.screenWidth)
+        ns, H, cvx, N, _ = obs.shape
+        eng = self._engine()
+        self._set_goal(eng, g, obs_goal_coor_tensor)
+        r = eng.reward(obs.reshape(ns * H * cvx, N, 3), normalize=normalize_rew)
+        next_r = r.reshape(ns, H, cvx)
+        reward_seqs = next_r[:, -1].copy()
+        return _like(reward_seqs, proto), _like(next_r, proto)
+
+    # ---- planners.py:549-561 --------------------------------------------------------
+    def optimize_action(self, act_seqs, reward_seqs):
+        lam = self.config['mpc']['mppi']['reward_weight']
+        act_seqs = np.asarray(act_seqs, dtype=np.float64)
+        reward_seqs = np.asarray(reward_seqs, dtype=np.float64)
+        assert act_seqs.ndim == 4
+        ns, H, cvx, ad = act_seqs.shape
+        out = np.zeros((H, cvx, ad))
+        for i in range(cvx):
+            z = lam * reward_seqs[:, i]
+            w = np.exp(z - z.max())
+            w /= w.sum()
+            out[:, i, :] = (w.reshape(-1, 1, 1) * act_seqs[:, :, i, :]).sum(0)
+        return out
+
+    # ---- planners.py:563-871 --------------------------------------------------------
+    def trajectory_optimization_ptcl_multi_traj(self, state_cur_np, state_param, attr_cur_np,
+                                                obs_goal, model_dy, act_seq, act_label_seq, n_sample,
+                                                n_look_ahead, n_update_iter, action_lower_lim,
+                                                action_upper_lim, use_gpu=True,
+                                                rollout_best_action_sequence=True, reward_params=None,
+                                                funnel_dist=None, distractor_df_fn=None, gd_loop=1,
+                                                time_lim=float('inf'), goal_coor=None, seed=None,
+                                                comm=None):
+        """Same contract as the reference (returned dict keys, shapes, voting rule); the
+        inner optimiser is MPPI.  `act_seq` [n_look_ahead, traj_num, 4] seeds iteration 0:
+        its traj_num candidates are scored and the best becomes the nominal sequence that
+        the following iterations perturb with `n_sample` filtered-noise samples.
+        Extra keyword arguments (not in the reference): goal_coor to skip the host-side
+        farthest-point subsample, seed for the device sampler, comm=(rank, n_ranks, uid)
+        to shard samples over GPUs."""
+        assert type(state_cur_np) == np.ndarray and state_cur_np.ndim == 3
+        assert state_cur_np.shape[0] == state_param.shape[0] and state_cur_np.shape[2] == 3
+        assert type(obs_goal) == np.ndarray and obs_goal.ndim == 2
+        assert type(act_seq) == np.ndarray and act_seq.ndim == 3
+        assert act_seq.shape[0] == act_label_seq.shape[0] and act_label_seq.ndim == 1
+        assert act_seq.shape[0] == n_look_ahead
+        if distractor_df_fn is not None:
+            raise NotImplementedError('distractor rewards are unused on the live path')
+        start = time.time()
+        self.particle_num = N = state_cur_np.shape[1]
+        n_batch = state_cur_np.shape[0]
+        H = n_look_ahead
+        traj_num = int(act_seq.shape[1])
+        eng = self._bind(model_dy)
+        self._eng = eng
+
+        obs_goal = obs_goal.astype(np.float32)
+        if goal_coor is None:
+            # planners.py:620-624: goal pixels (col,row), farthest-point subsample to 5N
+            rc = np.argwhere(obs_goal < 0.5)
+            cr = rc[:, ::-1].astype(np.float32)
+            goal_coor = fps_np(cr, min(N * 5, cr.shape[0]), 0)[0]
+        self._set_goal(eng, obs_goal, goal_coor)
+
+        lo, hi = self._clip_box()
+        cfg = self.config['mpc']
+        sigma = cfg['sigma'] * self.global_scale / 12.0
+        rank, n_ranks = 0, 1
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+
+        max_reward = -np.inf * np.ones(n_batch, dtype=np.float32)
+        max_reward_traj_idx = np.zeros(n_batch, dtype=np.int64)
+        best_actions_of_samples = np.zeros((n_batch, H, self.action_dim), dtype=np.float32)
+        n_iter = int(n_update_iter) * int(gd_loop)
+        rew_mean = np.zeros((1, n_iter), dtype=np.float32)
+        rew_std = np.zeros((1, n_iter), dtype=np.float32)
+        rollout_time = 0.0
+        optim_time = 0.0
+        time_lim_s = time_lim / 1000.0
+
+        def aggregate(rewards, actions, ns):
+            # planners.py:721-727: per-column running max / argmax / best action
+            r = rewards.reshape(ns, n_batch)
+            cur_max = r.max(0)
+            idx = r.argmax(0)
+            for j in range(n_batch):
+                if cur_max[j] > max_reward[j]:
+                    max_reward[j] = cur_max[j]
+                    max_reward_traj_idx[j] = idx[j]
+                    best_actions_of_samples[j] = actions[idx[j] * n_batch + j]
+            return r
+
+        # iteration 0: score the traj_num candidates
+        cand = np.repeat(act_seq.transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)  # [traj*nb,H,4]
+        eng.mpc_begin(state_cur_np, attr_cur_np, state_param, act_seq[:, 0, :], n_sample=traj_num,
+                      sigma=sigma, beta_filter=cfg['mppi']['beta_filter'],
+                      reward_weight=cfg['mppi']['reward_weight'], act_lo=lo, act_hi=hi, seed=seed)
+        eng.mpc_set_actions(cand)
+        t0 = time.perf_counter()
+        eng.mpc_rollout(False)
+        got = eng.mpc_get(rewards=True)
+        rollout_time += (time.perf_counter() - t0) * 1e3
+        r0 = aggregate(got['rewards'], cand, traj_num)
+        reward_seqs = got['rewards'].copy()
+        act_seqs_last = cand
+        nominal = act_seq[:, int(np.argmax(r0.mean(1))), :].astype(np.float64)
+        i = 0
+        if n_iter > 0:
+            rew_mean[0, 0] = r0[:, 0].mean()
+            rew_std[0, 0] = r0[:, 0].std(ddof=1) if traj_num > 1 else 0.0
+        if n_iter > 1:
+            eng.mpc_begin(state_cur_np, attr_cur_np, state_param, nominal, n_sample=n_sample,
+                          sigma=sigma, beta_filter=cfg['mppi']['beta_filter'],
+                          reward_weight=cfg['mppi']['reward_weight'], act_lo=lo, act_hi=hi, seed=seed)
+        for i in range(1, n_iter):
+            t0 = time.perf_counter()
+            eng.mpc_sample(i)
+            eng.mpc_rollout(False)
+            t1 = time.perf_counter()
+            eng.mpc_update_device()
+            got = eng.mpc_get(rewards=True, actions=True)
+            t2 = time.perf_counter()
+            rollout_time += (t1 - t0) * 1e3
+            optim_time += (t2 - t1) * 1e3
+            r = aggregate(got['rewards'], got['actions'], n_sample)
+            reward_seqs, act_seqs_last = got['rewards'], got['actions']
+            rew_mean[0, i] = r[:, 0].mean()
+            rew_std[0, i] = r[:, 0].std(ddof=1) if n_sample > 1 else 0.0
+            if (time.time() - start) > time_lim_s:
+                break
+
+        # planners.py:773-781: vote = most frequent best-trajectory index over the columns,
+        # ties -> the column with the highest reward
+        counts = np.bincount(max_reward_traj_idx)
+        idx_best_act = int(np.argmax(counts))
+        idx_best_sample, best_r = -1, -np.inf
+        for j in range(n_batch):
+            if idx_best_act == max_reward_traj_idx[j] and max_reward[j] > best_r:
+                idx_best_sample, best_r = j, max_reward[j]
+        best_seq = best_actions_of_samples[idx_best_sample][None]       # [1,H,4]
+
+        obs_seq_best, reward_best, next_r = None, None, None
+        if rollout_best_action_sequence:
+            # planners.py:821-851: B=1 re-rollout of the winner on column 0 + all-step reward
+            states, rew = eng.rollout(state_cur_np[0:1], attr_cur_np[0:1], state_param[0:1], best_seq,
+                                      want_states=True, want_reward=True)
+            obs_seq_best = states[0]
+            next_r = rew[0][:, None]                                    # [H,1]
+            reward_best = rew[0, -1:].copy()                            # [1]
+        ns_last = reward_seqs.shape[0] // n_batch
+        return {'action_sequence': best_seq[0],
+                'action_full': act_seqs_last[:, 0, :],
+                'reward_full': reward_seqs.reshape(ns_last, n_batch)[:, 0],
+                'observation_sequence': obs_seq_best,
+                'observation_distractor_sequence': None,
+                'reward': reward_best,
+                'next_r': next_r,
+                'rew_mean': rew_mean,
+                'rew_std': rew_std,
+                'nominal_sequence': eng.mpc_get(nominal=True)['nominal'] if n_iter > 1 else nominal,
+                'times': {'total_time': time.time() - start, 'rollout_time': rollout_time,
+                          'optim_time': optim_time},
+                'iter_num': i}
+
+
+def fps_np(pcd, particle_num, init_idx=-1):
+    """utils.py:451-466: farthest-point subsample (host, once per planner call)."""
+    pcd = np.asarray(pcd)
+    idx = np.random.randint(pcd.shape[0]) if init_idx == -1 else init_idx
+    chosen = [idx]
+    dist = np.linalg.norm(pcd - pcd[idx], axis=1)
+    while len(chosen) < particle_num:
+        idx = int(dist.argmax())
+        chosen.append(idx)
+        dist = np.minimum(dist, np.linalg.norm(pcd - pcd[idx], axis=1))
+    return pcd[chosen], dist.max()

@@ -117,9 +117,9 @@ typedef struct drp_mpc_params {
     int n_particles;
     int n_sample;         /* samples on THIS rank */
     int n_look_ahead;     /* H */
-    float sigma;          /* mpc.sigma * global_scale / 12 (planners.py:116) */
-    float beta_filter;    /* mpc.mppi.beta_filter (planners.py:93) */
-    float reward_weight;  /* mpc.mppi.reward_weight (planners.py:553) */
+    double sigma;         /* mpc.sigma * global_scale / 12 (planners.py:116) */
+    double beta_filter;   /* mpc.mppi.beta_filter (planners.py:93) */
+    double reward_weight; /* mpc.mppi.reward_weight (planners.py:553) */
     float act_lo[4];      /* clip box (planners.py:152-155) */
     float act_hi[4];
     uint64_t seed;        /* Philox key */

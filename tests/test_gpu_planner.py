@@ -1,0 +1,131 @@
+"""GPU: the reference's Python call surface (model/gnn_dyn.py, planners.py,
+env/flex_rewards.py) served by the HIP engine -- written like the reference's own
+call sites (visualize_mpc.py:36-84, env/flex_env.py:1048-1065)."""
+import numpy as np
+import pytest
+import torch
+
+from dyn_res_pile_manip_amd import synthetic as syn
+from dyn_res_pile_manip_amd.gnn_dyn import PropNetDiffDenModel
+from dyn_res_pile_manip_amd.planners import PlannerGD
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def stack(golden):
+    config = syn.default_config()
+    env = syn.SyntheticEnv(config)
+    model = PropNetDiffDenModel(config, True)
+    sd = {k[2:]: torch.from_numpy(golden.weights_seed0[k]) for k in golden.weights_seed0.files
+          if k.startswith('w/')}
+    model.load_state_dict(sd, strict=False)
+    model.cuda().eval()
+    planner = PlannerGD(config, env)
+    yield config, env, model, planner
+    model.engine.close()
+
+
+def test_predict_one_step_torch_in_torch_out(stack, golden):
+    _, _, model, _ = stack
+    g = golden.one_step
+    args = [torch.from_numpy(g['n64/' + k]) for k in ('attr', 's_cur', 's_delta', 'dens')]
+    out = model.predict_one_step(*args)
+    assert isinstance(out, torch.Tensor) and out.dtype == torch.float32
+    assert np.abs(out.numpy() - g['n64/s_pred']).max() < 2e-6
+    with pytest.raises(AssertionError):
+        model.predict_one_step(args[0][:, :10], args[1], args[2], args[3])
+
+
+def test_forward_with_dense_onehot_relations(stack, golden):
+    _, _, model, _ = stack
+    g = golden.one_step
+    idx, cnt = g['n8/nbr_idx'], g['n8/nbr_cnt']
+    B, N = cnt.shape
+    E = int(cnt.reshape(B, -1).sum(1).max())
+    Rr = np.zeros((B, E, N), np.float32)
+    Rs = np.zeros((B, E, N), np.float32)
+    for b in range(B):
+        e = 0
+        for i in range(N):
+            for k in range(cnt[b, i]):
+                Rr[b, e, i] = 1
+                Rs[b, e, idx[b, i, k]] = 1
+                e += 1
+    out = model.model.forward(g['n8/attr'], g['n8/s_cur'], g['n8/s_delta'], Rr, Rs, g['n8/dens'])
+    assert np.abs(out - g['n8/s_pred']).max() < 2e-6
+
+
+def test_particle_nums_masks_padded_particles(stack, golden):
+    _, _, model, _ = stack
+    g = golden.one_step
+    a, s, sd, d = (g['n64/' + k] for k in ('attr', 's_cur', 's_delta', 'dens'))
+    nums = np.array([64, 40, 64, 10])
+    out = model.predict_one_step(a, s, sd, d, particle_nums=nums)
+    from oracle import propnet_dense as od
+    W = od.load_weights(golden.weights_seed0)
+    adj, _ = od.adjacency(torch.from_numpy(s), torch.from_numpy(sd), 0.08)
+    for b in range(4):                                   # model/gnn_dyn.py:238-241
+        adj[b, nums[b]:, :] = 0
+        adj[b, :, nums[b]:] = 0
+    Rr, Rs = od.onehot_relations(adj)
+    ref = od.forward_dense(W, torch.from_numpy(a), torch.from_numpy(s), torch.from_numpy(sd), Rr, Rs,
+                           torch.from_numpy(d)).numpy()
+    assert np.abs(out - ref).max() < 2e-6
+
+
+def test_rollout_and_evaluate_like_the_planner_does(stack, golden):
+    _, _, model, planner = stack
+    g = golden.rollout
+    out = planner.ptcl_model_rollout(torch.from_numpy(g['c1_nb2/s_cur']), torch.from_numpy(g['c1_nb2/dens']),
+                                     torch.from_numpy(g['c1_nb2/attr']), model,
+                                     torch.from_numpy(g['c1_nb2/act_seqs']))
+    sp = out['model_rollout']['state_pred']
+    assert sp.shape == (16, 5, 64, 3) and out['rollout_time'] > 0
+    assert np.abs(sp.numpy() - g['c1_nb2/state_pred']).max() < 5e-6
+    r = golden.reward
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    planner.particle_num = 64
+    planner.ptcl_model_rollout(g['c1/s_cur'], g['c1/dens'], g['c1/attr'], model, g['c1/act_seqs'])
+    obs = torch.from_numpy(g['c1/state_pred']).reshape(16, 5, 1, 64, 3)
+    rs, nr = planner.ptcl_evaluate_traj(obs, torch.from_numpy(obs_goal), torch.from_numpy(r['I/goal_coor']))
+    assert rs.shape == (16, 1) and nr.shape == (16, 5, 1)
+    np.testing.assert_allclose(rs.numpy(), r['I/eval_reward_seqs'], rtol=2e-5)
+    np.testing.assert_allclose(nr.numpy(), r['I/eval_next_r'], rtol=2e-5)
+    sd = planner.gen_s_delta(golden.s_delta['s_cur'], golden.s_delta['action'])
+    np.testing.assert_allclose(sd, golden.s_delta['s_delta'], atol=3e-7)
+    w2c = planner.world2cam(golden.s_delta['world2cam_in'])
+    np.testing.assert_allclose(w2c, golden.s_delta['world2cam_out'], atol=1e-7)
+
+
+def test_trajectory_optimization_contract(stack, golden):
+    """Same call as env/flex_env.py:1048-1065; same dict as planners.py:858-871."""
+    _, env, model, planner = stack
+    g = golden.gd_planner
+    s, dens, attr, act_seq = g['s_cur'], g['dens'], g['attr'], g['act_seq']
+    nb, N, _ = s.shape
+    traj = act_seq.shape[1]
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    np.random.seed(0)
+    res = planner.trajectory_optimization_ptcl_multi_traj(
+        s, dens, attr, obs_goal, model, act_seq, np.zeros(1), n_sample=64, n_look_ahead=1,
+        n_update_iter=6, action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=1e9)
+    for k in ('action_sequence', 'action_full', 'reward_full', 'observation_sequence', 'reward',
+              'next_r', 'rew_mean', 'rew_std', 'times', 'iter_num'):
+        assert k in res, k
+    assert res['action_sequence'].shape == g['out/action_sequence'].shape == (1, 4)
+    assert res['observation_sequence'].shape == g['out/observation_sequence'].shape
+    assert res['reward'].shape == g['out/reward'].shape
+    assert res['next_r'].shape == g['out/next_r'].shape
+    assert res['rew_mean'].shape == (1, 6) and res['rew_std'].shape == (1, 6)
+    assert res['action_full'].shape == (64 * nb, 4) and res['reward_full'].shape == (64,)
+    lo_, hi_ = planner._clip_box()
+    assert (res['action_sequence'] >= lo_ - 1e-5).all() and (res['action_sequence'] <= hi_ + 1e-5).all()
+    # iteration 0 scores exactly the reference's candidate set: same mean reward as the
+    # reference's first GD iteration (before any Adam step), column 0
+    np.testing.assert_allclose(res['rew_mean'][0, 0], g['out/rew_mean'][0, 0], rtol=2e-5)
+    np.testing.assert_allclose(res['rew_std'][0, 0], g['out/rew_std'][0, 0], rtol=2e-4)
+    # the planner must not do worse than the best initial candidate
+    cand_best = res['rew_mean'][0, 0]
+    assert res['reward'][0] >= cand_best - 1e-3
