@@ -43,6 +43,7 @@ struct drp_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int engine = DRP_ENGINE_VALU;
+    int n_cu = 256;
 
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
@@ -167,6 +168,54 @@ struct StepArgs {
     float* s_out; size_t out_stride;
     int B, N;
 };
+
+#ifdef DRP_HAVE_MFMA
+int mfma_grid(drp_ctx* c, long ntiles) {
+    long blocks = (ntiles + MFMA_WAVES - 1) / MFMA_WAVES;
+    long cap = (long)c->n_cu;
+    return (int)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap);
+}
+
+// MLP stages of one step on the fp32 MFMA kernels (graph already built, s_delta in workspace)
+int run_step_mfma(drp_ctx* c, const StepArgs& a) {
+    const int B = a.B, N = a.N;
+    hipStream_t st = c->stream;
+    const float* mw = ptr<float>(c->w_mfma);
+    const dim3 blk(64 * MFMA_WAVES);
+    const long node_tiles = (long)B * ((N + 31) / 32);
+    const long edge_tiles = (long)B * ((N * DRP_K + 31) / 32);
+    {
+        ProbeScope ps(c, KC_NODE_ENCODE);
+        hipLaunchKernelGGL(km_node_encode, dim3(mfma_grid(c, node_tiles)), blk, KM_NODE_LDS, st, mw,
+                           ptr<float>(c->s_delta), a.attr, a.attr_mod, a.dens, a.dens_mod, N, B,
+                           ptr<float>(c->eff), ptr<float>(c->c_node), ptr<float>(c->proj));
+    }
+    {
+        ProbeScope ps(c, KC_EDGE_ENCODE);
+        hipLaunchKernelGGL(km_edge_encode, dim3(mfma_grid(c, edge_tiles)), blk, KM_EDGE_LDS, st, mw,
+                           a.s_prev, a.prev_mod, a.prev_stride, a.attr, a.attr_mod, a.dens, a.dens_mod,
+                           ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N, B, ptr<float>(c->c_edge));
+    }
+    for (int p = 0; p < DRP_PSTEP; ++p) {
+        {
+            ProbeScope ps(c, KC_AGGREGATE);
+            hipLaunchKernelGGL(k_aggregate, dim3(B), dim3(256), 0, st, ptr<float>(c->c_edge),
+                               ptr<float>(c->proj), ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N,
+                               ptr<float>(c->agg));
+        }
+        ProbeScope ps(c, p + 1 < DRP_PSTEP ? KC_UPDATE : KC_PREDICT);
+        if (p + 1 < DRP_PSTEP)
+            hipLaunchKernelGGL(km_update<false>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
+                               ptr<float>(c->agg), ptr<float>(c->c_node), ptr<float>(c->eff), N, B,
+                               ptr<float>(c->proj), a.s_prev, a.prev_mod, a.prev_stride, a.s_out, a.out_stride);
+        else
+            hipLaunchKernelGGL(km_update<true>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
+                               ptr<float>(c->agg), ptr<float>(c->c_node), ptr<float>(c->eff), N, B,
+                               ptr<float>(c->proj), a.s_prev, a.prev_mod, a.prev_stride, a.s_out, a.out_stride);
+    }
+    return DRP_OK;
+}
+#endif
 
 // One predict_one_step (model/gnn_dyn.py:209-254) [+ gen_s_delta, planners.py:346] for B samples.
 int run_step(drp_ctx* c, const StepArgs& a) {
@@ -334,6 +383,21 @@ int drp_create(int device, drp_ctx** out) {
         delete c;
         return fail(nullptr, DRP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        c->n_cu = prop.multiProcessorCount;
+#ifdef DRP_HAVE_MFMA
+    // the MFMA kernels keep packed weights + per-wave transposition tiles in LDS (> 64 KiB)
+    if (hipFuncSetAttribute((const void*)km_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_node_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(nullptr, DRP_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    }
+    c->engine = DRP_ENGINE_MFMA;
+#endif
     *out = c;
     return DRP_OK;
 }

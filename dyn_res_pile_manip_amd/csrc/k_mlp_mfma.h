@@ -1,0 +1,441 @@
+// fp32 MFMA engine for the PropNet MLPs (model/gnn_dyn.py:147-198), factored form.
+//
+// Every dense layer is computed TRANSPOSED with v_mfma_f32_32x32x2_f32:
+//     D[out feature][item] = sum_k W[out][k] * X[k][item]
+// weights are the A operand (32 output features per block), activations the B operand
+// (32 items = edge slots or particles, one per lane column).  The C/D layout of this
+// instruction puts an item on a lane column and 16 output features per register block:
+//     reg r of lane l  <->  D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+// and the B operand wants   lane l  ->  X[k = l>>5][col = l&31]   per 2-deep k-step.
+// So register r of output block ob IS the B operand of k-step s = 16*ob + r of the next
+// layer, provided the weights of that layer are packed with the matching k order
+//     kidx(s, h) = 32*(s>>4) + (s&3) + 8*((s&15)>>2) + 4*h.
+// A whole MLP chain (3-4 layers) therefore runs in registers: no LDS or HBM round trip
+// for activations, one ds_read_b128 of packed weights per four MFMAs, ReLU applied as
+// the operand is consumed.  fp32 in, fp32 accumulate: bit-for-bit an fma chain.
+//
+// A wave works on tiles of 32 items; tiles move between row-major HBM ([item][64]) and
+// the fragment layout through a per-wave padded LDS tile (stride 68 floats: the b128
+// transposing accesses are bank-conflict free).
+#pragma once
+#include <vector>
+
+#include "drp_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TILE_LD 68
+#define TILE_FLOATS (32 * TILE_LD)
+#define MFMA_WAVES 8
+
+// ---- packed weights (floats).  64x64 matrix: [ob 2][s4 8][lane 64][c 4]; 64x8: [ob 2][lane 64][c 4]
+enum {
+    M_RE0 = 0,                  // relation encoder layer 0, K padded to 8 (bias in column 6)
+    M_RE2 = M_RE0 + 512,
+    M_RE4 = M_RE2 + 4096,
+    M_RPE = M_RE4 + 4096,       // W_e
+    M_PE0 = M_RPE + 4096,       // particle encoder layer 0, K padded to 8 (bias in column 5)
+    M_PE2 = M_PE0 + 512,
+    M_PPE = M_PE2 + 4096,       // W_pe
+    M_RPR = M_PPE + 4096,       // W_r
+    M_RPS = M_RPR + 4096,       // W_s
+    M_AGG = M_RPS + 4096,       // W_agg
+    M_PR0 = M_AGG + 4096,       // predictor layer 0
+    // plain 64-float rows (natural feature order)
+    R_RE2_B = M_PR0 + 4096,
+    R_RE4_B = R_RE2_B + 64,
+    R_RP_B = R_RE4_B + 64,
+    R_RP_WD = R_RP_B + 64,
+    R_PE2_B = R_RP_WD + 64,
+    R_PP_B = R_PE2_B + 64,
+    R_PP_WD = R_PP_B + 64,
+    R_PR0_B = R_PP_WD + 64,
+    R_PR1_W = R_PR0_B + 64,     // [3][64]
+    R_PR1_B = R_PR1_W + 192,    // [4]
+    M_TOTAL = R_PR1_B + 4
+};
+
+inline int mfma_kidx(int s, int h) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; }
+
+// host: state_dict blob -> packed fragments
+inline void pack_mfma(const float* w, std::vector<float>& m) {
+    m.assign(M_TOTAL, 0.0f);
+    auto P64 = [&](int dst, int src, int ld, int col0) {
+        for (int ob = 0; ob < 2; ++ob)
+            for (int s = 0; s < 32; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, h = lane >> 5;
+                    m[dst + ((ob * 8 + (s >> 2)) * 64 + lane) * 4 + (s & 3)] =
+                        w[src + (32 * ob + i) * ld + col0 + mfma_kidx(s, h)];
+                }
+    };
+    auto P8 = [&](int dst, int src_w, int src_b, int in) {
+        for (int ob = 0; ob < 2; ++ob)
+            for (int s = 0; s < 4; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, h = lane >> 5, k = 2 * s + h, o = 32 * ob + i;
+                    float v = 0.0f;
+                    if (k < in) v = w[src_w + o * in + k];
+                    else if (k == in) v = w[src_b + o];          // bias rides on a constant-1 input
+                    m[dst + (ob * 64 + lane) * 4 + s] = v;
+                }
+    };
+    auto C = [&](int dst, int src, int n) { for (int i = 0; i < n; ++i) m[dst + i] = w[src + i]; };
+    P8(M_RE0, W_RE0_W, W_RE0_B, 6);
+    P64(M_RE2, W_RE2_W, 64, 0);
+    P64(M_RE4, W_RE4_W, 64, 0);
+    P64(M_RPE, W_RP_W, 193, 0);
+    P8(M_PE0, W_PE0_W, W_PE0_B, 5);
+    P64(M_PE2, W_PE2_W, 64, 0);
+    P64(M_PPE, W_PP_W, 129, 0);
+    P64(M_RPR, W_RP_W, 193, 64);
+    P64(M_RPS, W_RP_W, 193, 128);
+    P64(M_AGG, W_PP_W, 129, 64);
+    P64(M_PR0, W_PR0_W, 64, 0);
+    C(R_RE2_B, W_RE2_B, 64);
+    C(R_RE4_B, W_RE4_B, 64);
+    C(R_RP_B, W_RP_B, 64);
+    for (int o = 0; o < 64; ++o) m[R_RP_WD + o] = w[W_RP_W + o * 193 + 192];
+    C(R_PE2_B, W_PE2_B, 64);
+    C(R_PP_B, W_PP_B, 64);
+    for (int o = 0; o < 64; ++o) m[R_PP_WD + o] = w[W_PP_W + o * 129 + 128];
+    C(R_PR0_B, W_PR0_B, 64);
+    C(R_PR1_W, W_PR1_W, 192);
+    C(R_PR1_B, W_PR1_B, 3);
+}
+
+// ---- fragments ------------------------------------------------------------------------------
+struct Frag {
+    f32x16 v[2];     // v[ob][r] = feature 32*ob + (r&3) + 8*(r>>2) + 4*h of item (lane & 31)
+};
+
+__device__ __forceinline__ void frag_zero(Frag& f) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { f.v[0][r] = 0.0f; f.v[1][r] = 0.0f; }
+}
+
+// 64 floats in natural feature order (LDS or global, 16-B aligned) -> this lane's 32 features
+__device__ __forceinline__ void frag_from_row(const float* row, int h, Frag& f) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = *reinterpret_cast<const float4*>(row + 32 * ob + 8 * g + 4 * h);
+            f.v[ob][4 * g + 0] = t.x; f.v[ob][4 * g + 1] = t.y;
+            f.v[ob][4 * g + 2] = t.z; f.v[ob][4 * g + 3] = t.w;
+        }
+}
+
+__device__ __forceinline__ void frag_to_row(float* row, int h, const Frag& f) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(row + 32 * ob + 8 * g + 4 * h) =
+                make_float4(f.v[ob][4 * g + 0], f.v[ob][4 * g + 1], f.v[ob][4 * g + 2], f.v[ob][4 * g + 3]);
+}
+
+__device__ __forceinline__ void frag_relu(Frag& f) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { f.v[0][r] = fmaxf(f.v[0][r], 0.0f); f.v[1][r] = fmaxf(f.v[1][r], 0.0f); }
+}
+
+// LDS accesses of one wave complete in order; this only stops the compiler from moving them.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// row-major global tile [rows<=32][64 floats, row stride ld] <-> padded LDS tile; each wave
+// instruction moves 1 KiB of four consecutive rows.
+__device__ __forceinline__ void tile_g2l(const float* __restrict__ g, int ld, int rows, float* tile, int lane) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int f = q * 64 + lane, row = f >> 4, c4 = f & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows) v = *reinterpret_cast<const float4*>(g + (size_t)row * ld + c4 * 4);
+        *reinterpret_cast<float4*>(tile + row * TILE_LD + c4 * 4) = v;
+    }
+}
+
+__device__ __forceinline__ void tile_l2g(float* __restrict__ g, int ld, int rows, const float* tile, int lane) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int f = q * 64 + lane, row = f >> 4, c4 = f & 15;
+        if (row < rows)
+            *reinterpret_cast<float4*>(g + (size_t)row * ld + c4 * 4) =
+                *reinterpret_cast<const float4*>(tile + row * TILE_LD + c4 * 4);
+    }
+}
+
+// fragment -> row-major global tile through the wave's LDS tile
+__device__ __forceinline__ void frag_store_tile(const Frag& f, float* __restrict__ g, int ld, int rows,
+                                                float* tile, int lane) {
+    wave_lds_fence();
+    frag_to_row(tile + (lane & 31) * TILE_LD, lane >> 5, f);
+    wave_lds_fence();
+    tile_l2g(g, ld, rows, tile, lane);
+}
+
+__device__ __forceinline__ void frag_load_tile(Frag& f, const float* __restrict__ g, int ld, int rows,
+                                               float* tile, int lane) {
+    wave_lds_fence();
+    tile_g2l(g, ld, rows, tile, lane);
+    wave_lds_fence();
+    frag_from_row(tile + (lane & 31) * TILE_LD, lane >> 5, f);
+}
+
+// acc += W x   for a 64x64 layer; wp = packed weights in LDS as float4[(ob*8+s4)*64 + lane]
+template <bool RELU_IN>
+__device__ __forceinline__ void mfma_layer64(const float4* __restrict__ wp, const Frag& in, Frag& acc, int lane) {
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+        const float4 a0 = wp[s4 * 64 + lane];
+        const float4 a1 = wp[(8 + s4) * 64 + lane];
+        const float a0c[4] = {a0.x, a0.y, a0.z, a0.w};
+        const float a1c[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float b = in.v[s4 >> 2][4 * (s4 & 3) + c];
+            if (RELU_IN) b = fmaxf(b, 0.0f);
+            acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c[c], b, acc.v[0], 0, 0, 0);
+            acc.v[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c[c], b, acc.v[1], 0, 0, 0);
+        }
+    }
+}
+
+// first layers: K = 8 (inputs + constant 1 for the bias); x[s] = this lane's input 2s + h
+__device__ __forceinline__ void mfma_layer8(const float4* __restrict__ wp, const float (&x)[4], Frag& acc, int lane) {
+    const float4 a0 = wp[lane];
+    const float4 a1 = wp[64 + lane];
+    const float a0c[4] = {a0.x, a0.y, a0.z, a0.w};
+    const float a1c[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c[s], x[s], acc.v[0], 0, 0, 0);
+        acc.v[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c[s], x[s], acc.v[1], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ src, int n) {
+    for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
+        *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+}
+
+// bias row + d * w_d row, as this lane's fragment
+__device__ __forceinline__ void frag_bias_dens(const float* b_row, const float* wd_row, float d, int h, Frag& f) {
+    Frag w;
+    frag_from_row(b_row, h, f);
+    frag_from_row(wd_row, h, w);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        f.v[0][r] = fmaf(d, w.v[0][r], f.v[0][r]);
+        f.v[1][r] = fmaf(d, w.v[1][r], f.v[1][r]);
+    }
+}
+
+// ---- relation encoder + edge constant (gnn_dyn.py:166-171,179-180 and the constant part of
+//      :186-187):  c_edge[slot] = W_e relu(L3 relu(L2 relu(L1 x))) + w_d d + b
+// items = edge slots (receiver i, k) in [b][i][k] order, 32 consecutive slots per tile.
+// grid-stride over all B * ceil(10N/32) tiles, 8 waves per workgroup.
+__global__ void __launch_bounds__(64 * MFMA_WAVES)
+km_edge_encode(const float* __restrict__ mw, const float* __restrict__ s_cur, int s_mod, size_t s_stride,
+               const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+               const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt, int N, int B,
+               float* __restrict__ c_edge) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w1 = lds;                 // 512
+    float* w2 = w1 + 512;            // 4096
+    float* w4 = w2 + 4096;
+    float* we = w4 + 4096;
+    float* rows = we + 4096;         // b2, b4, b_rp, wd_rp : 4 x 64
+    float* tiles = rows + 256;
+    lds_fill(w1, mw + M_RE0, 512);
+    lds_fill(w2, mw + M_RE2, 4096);
+    lds_fill(w4, mw + M_RE4, 4096);
+    lds_fill(we, mw + M_RPE, 4096);
+    lds_fill(rows, mw + R_RE2_B, 256);      // R_RE2_B, R_RE4_B, R_RP_B, R_RP_WD are consecutive
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    float* tile = tiles + wave * TILE_FLOATS;
+    const int nslots = N * DRP_K;
+    const int tps = (nslots + 31) >> 5;
+    const long ntiles = (long)B * tps;
+    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
+        const int slot = min(t * 32 + j, nslots - 1);
+        const int i = slot / DRP_K, k = slot - i * DRP_K;
+        const int cnt = nbr_cnt[(size_t)b * N + i];
+        const int jn = (k < cnt) ? (int)nbr_idx[((size_t)b * N + i) * DRP_K + k] : i;
+        const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
+        const float* at = attr + (size_t)(b % attr_mod) * N;
+        const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+        // inputs [a_r, a_s, dx, dy, dz, d, 1, 0]; this lane supplies index 2s + h
+        float x[4];
+        if (h == 0) {
+            x[0] = at[i];
+            x[1] = s[i * 3 + 0] - s[jn * 3 + 0];
+            x[2] = s[i * 3 + 2] - s[jn * 3 + 2];
+            x[3] = 1.0f;
+        } else {
+            x[0] = at[jn];
+            x[1] = s[i * 3 + 1] - s[jn * 3 + 1];
+            x[2] = d;
+            x[3] = 0.0f;
+        }
+        Frag a, c;
+        frag_zero(a);
+        mfma_layer8(reinterpret_cast<const float4*>(w1), x, a, lane);
+        frag_from_row(rows + 0, h, c);
+        mfma_layer64<true>(reinterpret_cast<const float4*>(w2), a, c, lane);
+        frag_from_row(rows + 64, h, a);
+        mfma_layer64<true>(reinterpret_cast<const float4*>(w4), c, a, lane);
+        frag_bias_dens(rows + 128, rows + 192, d, h, c);
+        mfma_layer64<true>(reinterpret_cast<const float4*>(we), a, c, lane);
+        const int rows_valid = min(32, nslots - t * 32);
+        frag_store_tile(c, c_edge + ((size_t)b * nslots + (size_t)t * 32) * 64, 64, rows_valid, tile, lane);
+    }
+}
+
+// ---- particle encoder, node constant and the first projections -------------------------------
+//   pe = relu(L2 relu(L1 [s_delta, a, d]))   eff0 = pe                 gnn_dyn.py:174-176
+//   c_node = W_pe pe + w_d d + b             (constant part of :191-193)
+//   proj = [W_r pe | W_s pe]                 (first propagation step's node terms)
+__global__ void __launch_bounds__(64 * MFMA_WAVES)
+km_node_encode(const float* __restrict__ mw, const float* __restrict__ s_delta,
+               const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+               int N, int B, float* __restrict__ eff, float* __restrict__ c_node, float* __restrict__ proj) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w1 = lds;                 // 512
+    float* w2 = w1 + 512;
+    float* wpe = w2 + 4096;
+    float* wr = wpe + 4096;
+    float* ws = wr + 4096;
+    float* rows = ws + 4096;         // b_pe2, b_pp, wd_pp : 3 x 64
+    float* tiles = rows + 192;
+    lds_fill(w1, mw + M_PE0, 512);
+    lds_fill(w2, mw + M_PE2, 4096);
+    lds_fill(wpe, mw + M_PPE, 4096);
+    lds_fill(wr, mw + M_RPR, 4096);
+    lds_fill(ws, mw + M_RPS, 4096);
+    lds_fill(rows, mw + R_PE2_B, 192);      // R_PE2_B, R_PP_B, R_PP_WD consecutive
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    float* tile = tiles + wave * TILE_FLOATS;
+    const int tps = (N + 31) >> 5;
+    const long ntiles = (long)B * tps;
+    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
+        const int i = min(t * 32 + j, N - 1);
+        const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+        const float* sd = s_delta + ((size_t)b * N + i) * 3;
+        // inputs [sdx, sdy, sdz, a, d, 1, 0, 0]; this lane supplies index 2s + h
+        float x[4];
+        if (h == 0) { x[0] = sd[0]; x[1] = sd[2]; x[2] = d; x[3] = 0.0f; }
+        else { x[0] = sd[1]; x[1] = attr[(size_t)(b % attr_mod) * N + i]; x[2] = 1.0f; x[3] = 0.0f; }
+        const int rows_valid = min(32, N - t * 32);
+        const size_t row0 = (size_t)b * N + (size_t)t * 32;
+        Frag a, pe, c;
+        frag_zero(a);
+        mfma_layer8(reinterpret_cast<const float4*>(w1), x, a, lane);
+        frag_from_row(rows + 0, h, pe);
+        mfma_layer64<true>(reinterpret_cast<const float4*>(w2), a, pe, lane);
+        frag_relu(pe);
+        frag_store_tile(pe, eff + row0 * 64, 64, rows_valid, tile, lane);
+        frag_bias_dens(rows + 64, rows + 128, d, h, c);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(wpe), pe, c, lane);
+        frag_store_tile(c, c_node + row0 * 64, 64, rows_valid, tile, lane);
+        frag_zero(c);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(wr), pe, c, lane);
+        frag_store_tile(c, proj + row0 * 128, 128, rows_valid, tile, lane);
+        frag_zero(c);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(ws), pe, c, lane);
+        frag_store_tile(c, proj + row0 * 128 + 64, 128, rows_valid, tile, lane);
+    }
+}
+
+// ---- node update fused with what consumes it ---------------------------------------------------
+//   eff = relu(c_node + W_agg agg + eff)                         gnn_dyn.py:191-193,:82-85
+//   LAST == false:  proj = [W_r eff | W_s eff]                   next step's :183-187 node terms
+//   LAST == true :  s_pred = W1 relu(W0 eff + b0) + b1 + s_cur   gnn_dyn.py:196-198
+template <bool LAST>
+__global__ void __launch_bounds__(64 * MFMA_WAVES)
+km_update(const float* __restrict__ mw, const float* __restrict__ agg, const float* __restrict__ c_node,
+          float* __restrict__ eff, int N, int B, float* __restrict__ proj,
+          const float* __restrict__ s_cur, int s_mod, size_t s_stride, float* __restrict__ s_out,
+          size_t out_stride) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wa = lds;                 // W_agg
+    float* wx = wa + 4096;           // W_r | predictor layer 0
+    float* wy = wx + 4096;           // W_s (unused when LAST)
+    float* rows = wy + 4096;         // b_pr0, w_pr1[3], b_pr1 : 64 + 192 + 4
+    float* tiles = rows + 264;
+    lds_fill(wa, mw + M_AGG, 4096);
+    if (LAST) {
+        lds_fill(wx, mw + M_PR0, 4096);
+        lds_fill(rows, mw + R_PR0_B, 260);   // R_PR0_B, R_PR1_W, R_PR1_B consecutive
+    } else {
+        lds_fill(wx, mw + M_RPR, 4096);
+        lds_fill(wy, mw + M_RPS, 4096);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    float* tile = tiles + wave * TILE_FLOATS;
+    const int tps = (N + 31) >> 5;
+    const long ntiles = (long)B * tps;
+    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
+        const int rows_valid = min(32, N - t * 32);
+        const size_t row0 = (size_t)b * N + (size_t)t * 32;
+        Frag g, e, c;
+        frag_load_tile(g, agg + row0 * 64, 64, rows_valid, tile, lane);
+        frag_load_tile(e, eff + row0 * 64, 64, rows_valid, tile, lane);
+        frag_load_tile(c, c_node + row0 * 64, 64, rows_valid, tile, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { e.v[0][r] += c.v[0][r]; e.v[1][r] += c.v[1][r]; }
+        mfma_layer64<false>(reinterpret_cast<const float4*>(wa), g, e, lane);
+        frag_relu(e);
+        if (!LAST) {
+            frag_store_tile(e, eff + row0 * 64, 64, rows_valid, tile, lane);
+            frag_zero(c);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(wx), e, c, lane);
+            frag_store_tile(c, proj + row0 * 128, 128, rows_valid, tile, lane);
+            frag_zero(c);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(wy), e, c, lane);
+            frag_store_tile(c, proj + row0 * 128 + 64, 128, rows_valid, tile, lane);
+        } else {
+            frag_store_tile(e, eff + row0 * 64, 64, rows_valid, tile, lane);   // kept for debug taps
+            frag_from_row(rows + 0, h, c);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(wx), e, c, lane);
+            frag_relu(c);
+            // 64 -> 3: each lane dots its 32 hidden features, the two halves are added
+            float out[3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                Frag w;
+                frag_from_row(rows + 64 + 64 * o, h, w);
+                float p = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p = fmaf(c.v[0][r], w.v[0][r], p);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p = fmaf(c.v[1][r], w.v[1][r], p);
+                out[o] = p + __shfl_xor(p, 32, 64);
+            }
+            const int i = t * 32 + j;
+            if (h == 0 && i < N) {
+                const float* s = s_cur + (size_t)(b % s_mod) * s_stride + (size_t)i * 3;
+                float* so = s_out + (size_t)b * out_stride + (size_t)i * 3;
+#pragma unroll
+                for (int o = 0; o < 3; ++o) so[o] = (out[o] + rows[64 + 192 + o]) + s[o];
+            }
+        }
+    }
+}
+
+#define KM_EDGE_LDS ((512 + 3 * 4096 + 256 + MFMA_WAVES * TILE_FLOATS) * sizeof(float))
+#define KM_NODE_LDS ((512 + 4 * 4096 + 192 + MFMA_WAVES * TILE_FLOATS) * sizeof(float))
+#define KM_UPD_LDS ((3 * 4096 + 264 + MFMA_WAVES * TILE_FLOATS) * sizeof(float))

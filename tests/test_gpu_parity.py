@@ -11,7 +11,7 @@ from oracle import propnet_sparse as osp
 pytestmark = pytest.mark.gpu
 
 ONE_STEP = ['n64', 'n50', 'n150', 'n300', 'n600', 'n8', 'blob150']
-ENGINES = ['valu']
+ENGINES = ['valu', 'mfma']
 
 
 def disp_rel(out, ref, s_cur):
