@@ -198,12 +198,14 @@ def main():
         roof['kernel'] = dominant
         roof['avg_launch_ms'] = avg_s * 1e3
         roof['launches'] = dom_n
+        roof['algorithmic_per_launch'] = work if dominant in ('aggregate', 'edge_encode') or dominant in FLOP_PER_NODE else None
+        # HBM-side bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 +
+        # WRITE_SIZE, profiles/summarize_pmc.py); collected on this same workload
         roof['traffic'] = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (N, ns) == (300, 1024):
             try:
-                tj = json.load(open(tpath))
-                roof['traffic'] = tj.get(engine, {}).get(dominant)
+                roof['traffic'] = json.load(open(tpath))[engine][dominant]['hbm_bytes_per_launch']
             except Exception:
                 pass
         out = {

@@ -1,0 +1,78 @@
+"""Sample-axis sharding of the sampling planner over ranks (one process per GPU).
+
+Samples never interact inside rollout or reward (planners.py:336-359,
+env/flex_rewards.py:164-214 are batched per row), so each rank rolls out its own
+contiguous block of samples with no data-path collective.  The one exchange is the
+softmax-weighted update (planners.py:549-561): every rank contributes the record
+    [m, Z, A[H*4], sum r, sum r^2, max r, argmax]          (6 + 4H doubles)
+and the combined mean is  sum_g A_g e^(m_g - M) / sum_g Z_g e^(m_g - M),  M = max_g m_g.
+
+Two transports for that record:
+  * on the device: drp_mpc_update_device() all-gathers it with RCCL (xGMI) and runs the
+    combine kernel -- no host hop (bench.py, one fused collective per iteration);
+  * through torch.distributed (`allgather_records`): any backend, used by the planner when
+    it is handed a process group, and by the gloo tests on CPU.
+`combine_records` is the host mirror of the combine kernel (k_mppi_update).
+"""
+import numpy as np
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous block [lo, hi) of the n_total samples owned by `rank`."""
+    base, rem = divmod(int(n_total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def record_size(H):
+    return 6 + 4 * H
+
+
+def make_record(reward_weight, rewards, act_seqs, sample_offset=0):
+    """Host version of one rank's record (what k_mppi_partials computes on the device).
+    rewards [ns] (already averaged over the batch columns), act_seqs [ns,H,4]."""
+    r = np.asarray(rewards, dtype=np.float64)
+    a = np.asarray(act_seqs, dtype=np.float64)
+    z = float(reward_weight) * r
+    m = z.max()
+    w = np.exp(z - m)
+    H = a.shape[1]
+    rec = np.empty(record_size(H), dtype=np.float64)
+    rec[0], rec[1] = m, w.sum()
+    rec[2:2 + 4 * H] = (w[:, None, None] * a).sum(0).ravel()
+    rec[2 + 4 * H], rec[3 + 4 * H] = r.sum(), (r * r).sum()
+    rec[4 + 4 * H], rec[5 + 4 * H] = r.max(), float(np.argmax(r) + sample_offset)
+    return rec
+
+
+def combine_records(records, n_sample_total):
+    """[n_ranks, 6+4H] -> (nominal [H,4], stats dict)."""
+    rec = np.asarray(records, dtype=np.float64)
+    rec = rec.reshape(-1, rec.shape[-1])
+    H = (rec.shape[1] - 6) // 4
+    M = rec[:, 0].max()
+    scale = np.exp(rec[:, 0] - M)
+    Z = (rec[:, 1] * scale).sum()
+    A = (rec[:, 2:2 + 4 * H] * scale[:, None]).sum(0)
+    s1, s2 = rec[:, 2 + 4 * H].sum(), rec[:, 3 + 4 * H].sum()
+    n = float(n_sample_total)
+    mean = s1 / n
+    var = max((s2 - s1 * mean) / (n - 1.0), 0.0) if n > 1 else 0.0
+    g = int(np.argmax(rec[:, 4 + 4 * H]))
+    stats = {'mean': mean, 'std': float(np.sqrt(var)), 'max': rec[g, 4 + 4 * H],
+             'argmax': int(rec[g, 5 + 4 * H]), 'Z': Z, 'm': M}
+    return (A / Z).reshape(H, 4), stats
+
+
+def allgather_records(record, group=None):
+    """All-gather one rank's record over a torch.distributed process group (any backend).
+    Returns [world, 6+4H] float64."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    t = torch.from_numpy(np.ascontiguousarray(record, dtype=np.float64)).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return torch.stack(out).cpu().numpy()

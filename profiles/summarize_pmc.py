@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection.csv (two separate passes)
+-> per-kernel HBM-side bytes per launch, written to profiles/traffic.json.
+
+Corrections, from /opt/skills/guides/MI355X_MICROARCH.md (section HBM): both counters are
+in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a 16-B-per-lane coalesced
+read, WRITE_SIZE is exact for 16-B-per-lane stores.  Calibrated on this code's own access
+pattern: km_update reads three [B*N,64] fp32 buffers with float4 loads = 230 400 KiB per
+launch at 1024 x 300 and FETCH_SIZE reports 115 461 KiB (x0.501).
+
+usage: summarize_pmc.py <engine> <fetch_counter_collection.csv> <write_counter_collection.csv>
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+CLASS = {'k_graph': 'graph', 'k_node_encode': 'node_encode', 'k_edge_encode': 'edge_encode',
+         'k_project': 'project', 'k_aggregate': 'aggregate', 'k_update': 'update',
+         'k_predict': 'predict', 'km_node_encode': 'node_encode', 'km_edge_encode': 'edge_encode',
+         'km_update<false>': 'update', 'km_update<true>': 'predict', 'k_reward': 'reward',
+         'km_prop<false>': 'update', 'km_prop<true>': 'predict'}
+
+
+def per_kernel(path, counter):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        name = r['Kernel_Name'].split('(')[0].replace('void ', '').strip()
+        d[name].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in d.items()}, {k: len(v) for k, v in d.items()}
+
+
+def main():
+    engine, fpath, wpath = sys.argv[1:4]
+    fetch, nf = per_kernel(fpath, 'FETCH_SIZE')
+    write, _ = per_kernel(wpath, 'WRITE_SIZE')
+    out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'traffic.json')
+    out = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    rows = {}
+    for k in sorted(fetch):
+        base = k.split('<')[0] if k not in CLASS else k
+        cls = CLASS.get(k, CLASS.get(base))
+        if cls is None:
+            continue
+        fb = 2.0 * fetch[k] * 1024.0
+        wb = write.get(k, 0.0) * 1024.0
+        rows[cls] = {'kernel': k, 'launches_sampled': nf[k], 'fetch_bytes_raw_counter': fetch[k] * 1024.0,
+                     'fetch_bytes': fb, 'write_bytes': wb, 'hbm_bytes_per_launch': fb + wb}
+        print('%-22s %-20s fetch %8.1f MB (raw %8.1f)  write %8.1f MB' %
+              (cls, k, fb / 1e6, fetch[k] * 1024 / 1e6, wb / 1e6))
+    out[engine] = rows
+    json.dump(out, open(out_path, 'w'), indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -203,3 +203,37 @@ def test_mppi_sampler(ctx, golden):
     ctx.mpc_sample(2)
     b = ctx.mpc_get(actions=True)['actions'].reshape(ns, 2, H, 4)[:, 0]
     assert np.abs(b - a).max() > 0.1                        # a new iteration draws new noise
+
+
+def test_mppi_two_shards_combine_on_device(ctx, golden):
+    """Two ranks' records (sample_offset 0 and 32) combined by the device kernel == one rank
+    with all 64 samples == the host mirror in sharding.py."""
+    from dyn_res_pile_manip_amd import sharding
+    g = golden.mppi
+    acts = g['opt_act_seqs'][:, :, 0, :].astype(np.float32)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('disc'))
+    N = 16
+    ctx.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+    s0, dens, attr = syn.make_pile(N, 1, seed=1)
+    lo, hi = syn.action_limits()
+    kw = dict(sigma=0.6, beta_filter=0.7, reward_weight=0.1, act_lo=lo, act_hi=hi)
+    ctx.mpc_begin(s0, attr, dens, g['nominal'], n_sample=64, **kw)
+    ctx.mpc_set_actions(acts)
+    ctx.mpc_rollout()
+    full = ctx.mpc_partials()
+    r_full = ctx.mpc_get(rewards=True)['rewards']
+    want = ctx.mpc_update(full)
+    recs = []
+    for rank in range(2):
+        ctx.mpc_begin(s0, attr, dens, g['nominal'], n_sample=32, sample_offset=32 * rank, **kw)
+        ctx.mpc_set_actions(acts[32 * rank:32 * rank + 32])
+        ctx.mpc_rollout()
+        rec = ctx.mpc_partials()
+        host = sharding.make_record(0.1, r_full[32 * rank:32 * rank + 32], acts[32 * rank:32 * rank + 32], 32 * rank)
+        np.testing.assert_allclose(rec, host, rtol=1e-9, atol=1e-9)
+        recs.append(rec)
+    got = ctx.mpc_update(np.stack(recs))
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10)
+    nominal, stats = sharding.combine_records(np.stack(recs), 64)
+    np.testing.assert_allclose(nominal, want, rtol=1e-10, atol=1e-10)
+    assert stats['argmax'] == int(np.argmax(r_full))

@@ -1,0 +1,80 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the sampling planner -- contiguous sample
+shards, one all-gather of the per-rank records, combine == the unsharded
+optimize_action (planners.py:549-561).  The rollout/reward on each rank is played by the
+oracle here (no GPU in this container); on the GPU box the same records come from
+k_mppi_partials and travel over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dyn_res_pile_manip_amd import sharding, synthetic as syn, weights
+    from oracle import propnet_sparse as osp
+    N, H, ns_total = 24, 3, 10          # 10 samples over 2 ranks: 5 + 5; and 3 ranks would be 4+3+3
+    sd = weights.random_state_dict(seed=0)
+    W = osp.weights_np(sd)
+    M34 = osp.world2cam_affine(syn.demo_cam_extrinsics(), 24)
+    s0, dens, attr = syn.make_pile(N, 1, seed=3)
+    acts = syn.sample_pushes(ns_total, H, seed=3)             # every rank can rebuild the global set
+    obs_goal = syn.goal_distance_image(syn.goal_mask('disc'))
+    G = syn.goal_field(obs_goal)
+    gc = syn.goal_coor_strided(obs_goal, 5 * N)
+    lo, hi = sharding.shard_range(ns_total, rank, world)
+    st = osp.rollout(W, s0, dens, attr, acts[lo:hi], M34, 24.0)
+    r = osp.reward(st[:, -1], G, syn.demo_cam_params(), gc)
+    rec = sharding.make_record(0.1, r, acts[lo:hi], sample_offset=lo)
+    allrec = sharding.allgather_records(rec)
+    nominal, stats = sharding.combine_records(allrec, ns_total)
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), nominal=nominal, r=r, lo=lo, hi=hi,
+             mean=stats['mean'], std=stats['std'], argmax=stats['argmax'])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_mppi_update_equals_single_rank(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from dyn_res_pile_manip_amd import synthetic as syn
+    from oracle import propnet_dense as od
+    got = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(world)]
+    np.testing.assert_array_equal(got[0]['nominal'], got[1]['nominal'])     # every rank agrees
+    assert (int(got[0]['lo']), int(got[0]['hi']), int(got[1]['lo']), int(got[1]['hi'])) == (0, 5, 5, 10)
+    r_all = np.concatenate([got[0]['r'], got[1]['r']])
+    acts = syn.sample_pushes(10, 3, seed=3)
+    expect = od.optimize_action(acts, r_all, 0.1)
+    np.testing.assert_allclose(got[0]['nominal'], expect, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got[0]['mean'], r_all.astype(np.float64).mean(), rtol=1e-12)
+    np.testing.assert_allclose(got[0]['std'], r_all.astype(np.float64).std(ddof=1), rtol=1e-9)
+    assert int(got[0]['argmax']) == int(np.argmax(r_all))
+
+
+def test_shard_range_covers_everything():
+    from dyn_res_pile_manip_amd.sharding import shard_range
+    for n, w in [(10, 3), (1024, 8), (7, 8), (8192, 8)]:
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
