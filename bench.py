@@ -118,7 +118,7 @@ def main():
             eng.set_engine(_lib.ENGINE_VALU)
             engine = 'valu'
     else:
-        eng.set_engine({'valu': _lib.ENGINE_VALU, 'mfma': _lib.ENGINE_MFMA}[engine])
+        eng.set_engine(_lib.ENGINES[engine])
     sd = weights.random_state_dict(seed=0)
     eng.load_weights(weights.blob_from_state_dict(sd), 0.08)
     M34 = world2cam_affine(syn.demo_cam_extrinsics())

@@ -15,6 +15,8 @@ DRP_F = 64
 DRP_N_WEIGHTS = 38403
 ENGINE_VALU = 0
 ENGINE_MFMA = 1
+ENGINE_SPLIT = 2
+ENGINES = {'valu': ENGINE_VALU, 'mfma': ENGINE_MFMA, 'split': ENGINE_SPLIT}
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_double_p = ctypes.POINTER(ctypes.c_double)

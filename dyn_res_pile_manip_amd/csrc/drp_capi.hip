@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,6 +21,7 @@
 #include "k_reward.h"
 #ifdef DRP_HAVE_MFMA
 #include "k_mlp_mfma.h"
+#include "k_mlp_split.h"
 #endif
 
 namespace {
@@ -44,11 +46,12 @@ struct drp_ctx {
     std::string err;
     int engine = DRP_ENGINE_VALU;
     int n_cu = 256;
+    bool agg_global_only = false;   // DRP_AGG_GLOBAL=1: always gather sender rows from L2/HBM
 
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
     float adj_thresh = 0.08f, thr = 0.0064f;
-    DevBuf w_raw, w_valu, w_mfma;
+    DevBuf w_raw, w_valu, w_mfma, w_split;
     DrpCam cam{};
     DevBuf goal_field, goal_coor;
     int goal_h = 0, goal_w = 0, goal_m = 0;
@@ -169,6 +172,20 @@ struct StepArgs {
     int B, N;
 };
 
+int graph_block(int N) { int t = ((N + 63) / 64) * 64; return t > 1024 ? 1024 : t; }
+
+void launch_aggregate(drp_ctx* c, int B, int N) {
+    ProbeScope ps(c, KC_AGGREGATE);
+    if (N <= K_AGG_LDS_MAX_N && !c->agg_global_only)
+        hipLaunchKernelGGL(k_aggregate_lds, dim3(B), dim3(512), (size_t)N * 256, c->stream,
+                           ptr<float>(c->c_edge), ptr<float>(c->proj), ptr<int16_t>(c->nbr_idx),
+                           ptr<uint8_t>(c->nbr_cnt), N, ptr<float>(c->agg));
+    else
+        hipLaunchKernelGGL(k_aggregate, dim3(B), dim3(256), 0, c->stream, ptr<float>(c->c_edge),
+                           ptr<float>(c->proj), ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N,
+                           ptr<float>(c->agg));
+}
+
 #ifdef DRP_HAVE_MFMA
 int mfma_grid(drp_ctx* c, long ntiles) {
     long blocks = (ntiles + MFMA_WAVES - 1) / MFMA_WAVES;
@@ -192,17 +209,18 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     }
     {
         ProbeScope ps(c, KC_EDGE_ENCODE);
-        hipLaunchKernelGGL(km_edge_encode, dim3(mfma_grid(c, edge_tiles)), blk, KM_EDGE_LDS, st, mw,
-                           a.s_prev, a.prev_mod, a.prev_stride, a.attr, a.attr_mod, a.dens, a.dens_mod,
-                           ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N, B, ptr<float>(c->c_edge));
+        if (c->engine == DRP_ENGINE_SPLIT)
+            hipLaunchKernelGGL(km_edge_encode_split, dim3(mfma_grid(c, edge_tiles)), blk, KM_EDGE_SPLIT_LDS, st,
+                               ptr<uint16_t>(c->w_split), mw, a.s_prev, a.prev_mod, a.prev_stride, a.attr,
+                               a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx),
+                               ptr<uint8_t>(c->nbr_cnt), N, B, ptr<float>(c->c_edge));
+        else
+            hipLaunchKernelGGL(km_edge_encode, dim3(mfma_grid(c, edge_tiles)), blk, KM_EDGE_LDS, st, mw,
+                               a.s_prev, a.prev_mod, a.prev_stride, a.attr, a.attr_mod, a.dens, a.dens_mod,
+                               ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N, B, ptr<float>(c->c_edge));
     }
     for (int p = 0; p < DRP_PSTEP; ++p) {
-        {
-            ProbeScope ps(c, KC_AGGREGATE);
-            hipLaunchKernelGGL(k_aggregate, dim3(B), dim3(256), 0, st, ptr<float>(c->c_edge),
-                               ptr<float>(c->proj), ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N,
-                               ptr<float>(c->agg));
-        }
+        launch_aggregate(c, B, N);
         ProbeScope ps(c, p + 1 < DRP_PSTEP ? KC_UPDATE : KC_PREDICT);
         if (p + 1 < DRP_PSTEP)
             hipLaunchKernelGGL(km_update<false>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
@@ -227,12 +245,12 @@ int run_step(drp_ctx* c, const StepArgs& a) {
     const float* vw = ptr<float>(c->w_valu);
     if (a.build_graph) {
         ProbeScope ps(c, KC_GRAPH);
-        hipLaunchKernelGGL(k_graph<256>, dim3(B), dim3(256), 3 * N * sizeof(float), st, a.s_prev,
+        hipLaunchKernelGGL(k_graph, dim3(B), dim3(graph_block(N)), 3 * N * sizeof(float), st, a.s_prev,
                            a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, N, nbr_idx,
                            nbr_cnt, c->cam, c->thr);
     }
 #ifdef DRP_HAVE_MFMA
-    if (c->engine == DRP_ENGINE_MFMA) {
+    if (c->engine == DRP_ENGINE_MFMA || c->engine == DRP_ENGINE_SPLIT) {
         int rc = run_step_mfma(c, a);
         if (rc != DRP_OK) return rc;
         HIPCHK(c, hipGetLastError());
@@ -256,11 +274,7 @@ int run_step(drp_ctx* c, const StepArgs& a) {
             hipLaunchKernelGGL(k_project<8>, dim3(B), dim3(256), 0, st, vw, ptr<float>(c->eff), N,
                                ptr<float>(c->proj));
         }
-        {
-            ProbeScope ps(c, KC_AGGREGATE);
-            hipLaunchKernelGGL(k_aggregate, dim3(B), dim3(256), 0, st, ptr<float>(c->c_edge),
-                               ptr<float>(c->proj), nbr_idx, nbr_cnt, N, ptr<float>(c->agg));
-        }
+        launch_aggregate(c, B, N);
         {
             ProbeScope ps(c, KC_UPDATE);
             hipLaunchKernelGGL(k_update<8>, dim3(B), dim3(256), 0, st, vw, ptr<float>(c->agg),
@@ -386,10 +400,18 @@ int drp_create(int device, drp_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
+    c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
+    if (hipFuncSetAttribute((const void*)k_aggregate_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            K_AGG_LDS_MAX_N * 256) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(nullptr, DRP_EHIP, "hipFuncSetAttribute(k_aggregate_lds) failed");
+    }
 #ifdef DRP_HAVE_MFMA
     // the MFMA kernels keep packed weights + per-wave transposition tiles in LDS (> 64 KiB)
     if (hipFuncSetAttribute((const void*)km_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_node_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_edge_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_SPLIT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
@@ -407,7 +429,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    DevBuf* bufs[] = {&c->w_raw, &c->w_valu, &c->w_mfma, &c->goal_field, &c->goal_coor, &c->s_in,
+    DevBuf* bufs[] = {&c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
                       &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats};
@@ -430,7 +452,7 @@ int drp_set_engine(drp_ctx* c, int engine) {
     if (!c) return DRP_EINVAL;
     if (engine == DRP_ENGINE_VALU) { c->engine = engine; return DRP_OK; }
 #ifdef DRP_HAVE_MFMA
-    if (engine == DRP_ENGINE_MFMA) { c->engine = engine; return DRP_OK; }
+    if (engine == DRP_ENGINE_MFMA || engine == DRP_ENGINE_SPLIT) { c->engine = engine; return DRP_OK; }
 #endif
     return fail(c, DRP_EINVAL, "engine %d not available in this build", engine);
 }
@@ -459,6 +481,10 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
         std::vector<float> m;
         pack_mfma(blob, m);
         CHK(h2d(c, c->w_mfma, m.data(), m.size() * sizeof(float)));
+        std::vector<uint16_t> sp;
+        pack_split(blob, sp);
+        CHK(h2d(c, c->w_split, sp.data(), sp.size() * sizeof(uint16_t)));
+        HIPCHK(c, hipStreamSynchronize(c->stream));     // m, sp are about to go out of scope
     }
 #endif
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -514,7 +540,7 @@ int drp_build_graph(drp_ctx* c, const float* s_cur, const float* s_delta, int B,
     CHK(ensure_step_ws(c, B, N));
     CHK(h2d(c, c->s_in, s_cur, (size_t)B * N * 3 * sizeof(float)));
     CHK(h2d(c, c->s_delta, s_delta, (size_t)B * N * 3 * sizeof(float)));
-    hipLaunchKernelGGL(k_graph<256>, dim3(B), dim3(256), 3 * N * sizeof(float), c->stream,
+    hipLaunchKernelGGL(k_graph, dim3(B), dim3(graph_block(N)), 3 * N * sizeof(float), c->stream,
                        ptr<float>(c->s_in), B, (size_t)N * 3, (const float*)nullptr, (size_t)0,
                        ptr<float>(c->s_delta), N, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt),
                        c->cam, c->thr);

@@ -49,3 +49,49 @@ k_aggregate(const float* __restrict__ c_edge, const float* __restrict__ proj,
         out[(size_t)i * 16 + q] = acc;
     }
 }
+
+// Variant for samples whose sender rows fit in LDS (N <= 600): the workgroup first copies
+// the sample's [N][64] W_s eff rows into LDS (one compulsory read), then every gather is a
+// conflict-free ds_read_b128 (a row is 256 B = all 64 banks, 16 lanes read it whole), so
+// HBM sees only the compulsory bytes: c_edge stream + proj once + agg write.
+// grid = B, block = 512 threads (32 receivers per pass), dynamic LDS = N * 256 bytes.
+__global__ void __launch_bounds__(512)
+k_aggregate_lds(const float* __restrict__ c_edge, const float* __restrict__ proj,
+                const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt, int N,
+                float* __restrict__ agg) {
+    extern __shared__ __attribute__((aligned(16))) float4 ps[];      // [N][16]
+    const int b = blockIdx.x;
+    const int q = threadIdx.x & 15;
+    const int g = threadIdx.x >> 4;          // 0..31
+    const float4* ce = reinterpret_cast<const float4*>(c_edge) + (size_t)b * N * DRP_K * 16;
+    const float4* pj = reinterpret_cast<const float4*>(proj) + (size_t)b * N * 32;
+    float4* out = reinterpret_cast<float4*>(agg) + (size_t)b * N * 16;
+    const int16_t* nb = nbr_idx + (size_t)b * N * DRP_K;
+    const uint8_t* nc = nbr_cnt + (size_t)b * N;
+    for (int idx = threadIdx.x; idx < N * 16; idx += 512)
+        ps[idx] = pj[(size_t)(idx >> 4) * 32 + 16 + (idx & 15)];
+    __syncthreads();
+    for (int i = g; i < N; i += 32) {
+        const int cnt = nc[i];
+        const float4 pr = pj[(size_t)i * 32 + q];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int js[DRP_K];
+#pragma unroll
+        for (int k = 0; k < DRP_K; ++k) js[k] = (k < cnt) ? (int)nb[i * DRP_K + k] : i;
+        float4 c[DRP_K];
+#pragma unroll
+        for (int k = 0; k < DRP_K; ++k) c[k] = ce[((size_t)i * DRP_K + k) * 16 + q];
+#pragma unroll
+        for (int k = 0; k < DRP_K; ++k) {
+            const float4 s = ps[js[k] * 16 + q];
+            if (k < cnt) {
+                acc.x += fmaxf((c[k].x + pr.x) + s.x, 0.0f);
+                acc.y += fmaxf((c[k].y + pr.y) + s.y, 0.0f);
+                acc.z += fmaxf((c[k].z + pr.z) + s.z, 0.0f);
+                acc.w += fmaxf((c[k].w + pr.w) + s.w, 0.0f);
+            }
+        }
+        out[(size_t)i * 16 + q] = acc;
+    }
+}
+#define K_AGG_LDS_MAX_N 600

@@ -80,12 +80,12 @@ __device__ __forceinline__ float pair_dis(float xi, float yi, float zi, float xj
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
-// grid = B, block = BLOCK threads, dynamic LDS = 3*N floats.
+// grid = B, block = min(1024, N rounded up to a wave) threads (one receiver per thread in a
+// single pass whenever N <= 1024), dynamic LDS = 3*N floats.
 //   s_prev  : sample b reads row (b % prev_mod) at stride prev_stride floats
 //   actions : if not null, s_delta is generated from actions[b*act_stride ..+4] and
 //             written to s_delta; otherwise s_delta is read.
-template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(1024)
 k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
         const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
         int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr) {
@@ -94,6 +94,7 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
     float* py = lds + N;
     float* pz = lds + 2 * N;
     const int b = blockIdx.x;
+    const int BLOCK = blockDim.x;
     const float* s = s_prev + (size_t)(b % prev_mod) * prev_stride;
     float* sd = s_delta + (size_t)b * N * 3;
 

@@ -45,7 +45,8 @@ enum {
 /* which kernels compute the MLPs */
 enum {
     DRP_ENGINE_VALU = 0,  /* fp32 VALU reference kernels */
-    DRP_ENGINE_MFMA = 1   /* fp32 MFMA (v_mfma_f32_32x32x2_f32) kernels */
+    DRP_ENGINE_MFMA = 1,  /* fp32 MFMA (v_mfma_f32_32x32x2_f32) kernels */
+    DRP_ENGINE_SPLIT = 2  /* as MFMA, relation encoder on split-bf16 (3-pass) MFMA, fp32 accumulate */
 };
 
 typedef struct drp_ctx drp_ctx;

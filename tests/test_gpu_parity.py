@@ -11,7 +11,7 @@ from oracle import propnet_sparse as osp
 pytestmark = pytest.mark.gpu
 
 ONE_STEP = ['n64', 'n50', 'n150', 'n300', 'n600', 'n8', 'blob150']
-ENGINES = ['valu', 'mfma']
+ENGINES = ['valu', 'mfma', 'split']
 
 
 def disp_rel(out, ref, s_cur):
@@ -34,7 +34,7 @@ def ctx(golden):
 
 def set_engine(ctx, name):
     from dyn_res_pile_manip_amd import _lib
-    ctx.set_engine({'valu': _lib.ENGINE_VALU, 'mfma': _lib.ENGINE_MFMA}[name])
+    ctx.set_engine(_lib.ENGINES[name])
 
 
 def test_gen_s_delta(ctx, golden):
