@@ -111,14 +111,8 @@ def main():
     eng = Engine(local_rank)
     engine = args.engine
     if engine == 'auto':
-        try:
-            eng.set_engine(_lib.ENGINE_MFMA)
-            engine = 'mfma'
-        except _lib.DrpError:
-            eng.set_engine(_lib.ENGINE_VALU)
-            engine = 'valu'
-    else:
-        eng.set_engine(_lib.ENGINES[engine])
+        engine = 'fused'
+    eng.set_engine(_lib.ENGINES[engine])
     sd = weights.random_state_dict(seed=0)
     eng.load_weights(weights.blob_from_state_dict(sd), 0.08)
     M34 = world2cam_affine(syn.demo_cam_extrinsics())

@@ -16,7 +16,8 @@ DRP_N_WEIGHTS = 38403
 ENGINE_VALU = 0
 ENGINE_MFMA = 1
 ENGINE_SPLIT = 2
-ENGINES = {'valu': ENGINE_VALU, 'mfma': ENGINE_MFMA, 'split': ENGINE_SPLIT}
+ENGINE_FUSED = 3
+ENGINES = {'valu': ENGINE_VALU, 'mfma': ENGINE_MFMA, 'split': ENGINE_SPLIT, 'fused': ENGINE_FUSED}
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_double_p = ctypes.POINTER(ctypes.c_double)

@@ -207,9 +207,13 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                            ptr<float>(c->s_delta), a.attr, a.attr_mod, a.dens, a.dens_mod, N, B,
                            ptr<float>(c->eff), ptr<float>(c->c_node), ptr<float>(c->proj));
     }
-    {
+    // split engine, small enough samples: the relation encoder is recomputed inside the
+    // aggregate of every propagation step and c_edge is never materialised
+    const bool fused = (c->engine == DRP_ENGINE_FUSED) && N <= KM_FUSED_MAX_N;
+    const bool split = fused || c->engine == DRP_ENGINE_SPLIT || c->engine == DRP_ENGINE_FUSED;
+    if (!fused) {
         ProbeScope ps(c, KC_EDGE_ENCODE);
-        if (c->engine == DRP_ENGINE_SPLIT)
+        if (split)
             hipLaunchKernelGGL(km_edge_encode_split, dim3(mfma_grid(c, edge_tiles)), blk, KM_EDGE_SPLIT_LDS, st,
                                ptr<uint16_t>(c->w_split), mw, a.s_prev, a.prev_mod, a.prev_stride, a.attr,
                                a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx),
@@ -220,7 +224,15 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                                ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N, B, ptr<float>(c->c_edge));
     }
     for (int p = 0; p < DRP_PSTEP; ++p) {
-        launch_aggregate(c, B, N);
+        if (fused) {
+            ProbeScope ps(c, KC_AGGREGATE);
+            hipLaunchKernelGGL(km_edge_agg_split, dim3(B < c->n_cu ? B : c->n_cu), blk, KM_FUSED_LDS(N), st,
+                               ptr<uint16_t>(c->w_split), mw, a.s_prev, a.prev_mod, a.prev_stride, a.attr,
+                               a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx),
+                               ptr<uint8_t>(c->nbr_cnt), ptr<float>(c->proj), N, B, ptr<float>(c->agg));
+        } else {
+            launch_aggregate(c, B, N);
+        }
         ProbeScope ps(c, p + 1 < DRP_PSTEP ? KC_UPDATE : KC_PREDICT);
         if (p + 1 < DRP_PSTEP)
             hipLaunchKernelGGL(km_update<false>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
@@ -250,7 +262,7 @@ int run_step(drp_ctx* c, const StepArgs& a) {
                            nbr_cnt, c->cam, c->thr);
     }
 #ifdef DRP_HAVE_MFMA
-    if (c->engine == DRP_ENGINE_MFMA || c->engine == DRP_ENGINE_SPLIT) {
+    if (c->engine != DRP_ENGINE_VALU) {
         int rc = run_step_mfma(c, a);
         if (rc != DRP_OK) return rc;
         HIPCHK(c, hipGetLastError());
@@ -412,13 +424,14 @@ int drp_create(int device, drp_ctx** out) {
     if (hipFuncSetAttribute((const void*)km_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_node_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_edge_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_SPLIT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_edge_agg_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_FUSED_LDS(KM_FUSED_MAX_N)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         delete c;
         return fail(nullptr, DRP_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     }
-    c->engine = DRP_ENGINE_MFMA;
+    c->engine = DRP_ENGINE_FUSED;
 #endif
     *out = c;
     return DRP_OK;
@@ -452,7 +465,10 @@ int drp_set_engine(drp_ctx* c, int engine) {
     if (!c) return DRP_EINVAL;
     if (engine == DRP_ENGINE_VALU) { c->engine = engine; return DRP_OK; }
 #ifdef DRP_HAVE_MFMA
-    if (engine == DRP_ENGINE_MFMA || engine == DRP_ENGINE_SPLIT) { c->engine = engine; return DRP_OK; }
+    if (engine == DRP_ENGINE_MFMA || engine == DRP_ENGINE_SPLIT || engine == DRP_ENGINE_FUSED) {
+        c->engine = engine;
+        return DRP_OK;
+    }
 #endif
     return fail(c, DRP_EINVAL, "engine %d not available in this build", engine);
 }

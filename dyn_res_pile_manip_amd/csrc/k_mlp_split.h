@@ -209,3 +209,108 @@ km_edge_encode_split(const uint16_t* __restrict__ sw, const float* __restrict__ 
 }
 
 #define KM_EDGE_SPLIT_LDS ((S_TOTAL * 4 + 256 + MFMA_WAVES * TILE_FLOATS) * sizeof(float))
+
+// ---- fused: relation encoder recomputed per propagation step + segmented aggregate -----------
+// With the split chain the encoder is cheap enough to recompute in each of the three
+// propagation steps, so the [B,N,10,64] edge-constant buffer (786 MB at 1024 x 300, written
+// once and read three times per rollout step: 55 % of all HBM traffic of the unfused
+// pipeline) never exists.  One workgroup per sample: the sample's W_s eff rows and particle
+// positions are staged in LDS once, then a wave owns a tile of 32 receivers, loops over
+// the 10 slots, runs the chain for the 32 edges (slot k of each receiver) and accumulates
+//     agg[i] += relu(c_edge + (W_r eff)[i] + (W_s eff)[send])      gnn_dyn.py:183-189
+// in the accumulator layout (receiver on the lane, 32 features in registers).  The sender
+// rows are gathered from LDS with ds_read_b128 (row stride 68 floats spreads the rows over
+// the banks).  HBM traffic per launch: proj once (157 MB) + agg (79 MB).
+// Needs N*272 + 60 KB of LDS: N <= KM_FUSED_MAX_N.
+#define KM_FUSED_MAX_N 368
+#define PS_LD 68
+
+__global__ void __launch_bounds__(64 * MFMA_WAVES)
+km_edge_agg_split(const uint16_t* __restrict__ sw, const float* __restrict__ mw,
+                  const float* __restrict__ s_cur, int s_mod, size_t s_stride,
+                  const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+                  const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
+                  const float* __restrict__ proj, int N, int B, float* __restrict__ agg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wsp_f = lds;                          // S_TOTAL * 4 floats
+    float* rows = wsp_f + S_TOTAL * 4;           // b2, b4, b_rp, wd_rp
+    float* pos = rows + 256;                     // [N][4] = x, y, z, attr
+    float* ps = pos + ((N * 4 + 3) & ~3);        // [N][PS_LD]
+    lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
+    lds_fill(rows, mw + R_RE2_B, 256);
+    const bf16x8* wsp = reinterpret_cast<const bf16x8*>(wsp_f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tps = (N + 31) >> 5;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();                         // previous sample's readers are done
+        const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
+        const float* at = attr + (size_t)(b % attr_mod) * N;
+        const float4* pj = reinterpret_cast<const float4*>(proj) + (size_t)b * N * 32;
+        for (int i = threadIdx.x; i < N; i += blockDim.x)
+            *reinterpret_cast<float4*>(pos + i * 4) = make_float4(s[i * 3], s[i * 3 + 1], s[i * 3 + 2], at[i]);
+        for (int idx = threadIdx.x; idx < N * 16; idx += blockDim.x)
+            *reinterpret_cast<float4*>(ps + (idx >> 4) * PS_LD + (idx & 15) * 4) = pj[(size_t)(idx >> 4) * 32 + 16 + (idx & 15)];
+        __syncthreads();
+        const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+        for (int t = wave; t < tps; t += MFMA_WAVES) {
+            const int i = min(t * 32 + j, N - 1);
+            const int cnt = nbr_cnt[(size_t)b * N + i];
+            const int16_t* nb = nbr_idx + ((size_t)b * N + i) * DRP_K;
+            // bpr = b + d w_d + (W_r eff)[i]: the receiver's share of every in-edge, used as the
+            // initial accumulator of the chain's last layer
+            Frag bpr, acc;
+            {
+                Frag pr;
+                frag_bias_dens(rows + 128, rows + 192, d, h, bpr);
+                frag_from_row(proj + ((size_t)b * N + i) * 128, h, pr);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
+            }
+            frag_zero(acc);
+            const float4 pi = *reinterpret_cast<const float4*>(pos + i * 4);
+            int jn = (0 < cnt) ? (int)nb[0] : i;
+#pragma unroll 1
+            for (int k = 0; k < DRP_K; ++k) {
+                // keep the (loop-invariant) packed-weight reads inside the loop: hoisted, they
+                // would occupy several hundred VGPRs
+                asm volatile("" ::: "memory");
+                const int jcur = jn;
+                if (k + 1 < DRP_K) jn = (k + 1 < cnt) ? (int)nb[k + 1] : i;    // prefetch next index
+                const float4 pn = *reinterpret_cast<const float4*>(pos + jcur * 4);
+                float x[8];
+                x[0] = pi.w; x[1] = pn.w;
+                x[2] = pi.x - pn.x; x[3] = pi.y - pn.y; x[4] = pi.z - pn.z;
+                x[5] = d; x[6] = 1.0f; x[7] = 0.0f;
+                Frag a, c;
+                FragB fb;
+                frag_zero(a);
+                mfma_layer8_split(wsp + S_RE0, x, h, a, lane);
+                split_frag<true>(a, fb);
+                frag_from_row(rows + 0, h, c);
+                mfma_layer64_split(wsp + S_RE2, fb, c, lane);
+                split_frag<true>(c, fb);
+                frag_from_row(rows + 64, h, a);
+                mfma_layer64_split(wsp + S_RE4, fb, a, lane);
+                split_frag<true>(a, fb);
+                c = bpr;
+                mfma_layer64_split(wsp + S_RPE, fb, c, lane);
+                const float keep = (k < cnt) ? 1.0f : 0.0f;
+                const float* srow = ps + jcur * PS_LD + 4 * h;
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 sv = *reinterpret_cast<const float4*>(srow + 32 * ob + 8 * g);
+                        acc.v[ob][4 * g + 0] += keep * fmaxf(c.v[ob][4 * g + 0] + sv.x, 0.0f);
+                        acc.v[ob][4 * g + 1] += keep * fmaxf(c.v[ob][4 * g + 1] + sv.y, 0.0f);
+                        acc.v[ob][4 * g + 2] += keep * fmaxf(c.v[ob][4 * g + 2] + sv.z, 0.0f);
+                        acc.v[ob][4 * g + 3] += keep * fmaxf(c.v[ob][4 * g + 3] + sv.w, 0.0f);
+                    }
+            }
+            if (t * 32 + j < N) frag_to_row(agg + ((size_t)b * N + i) * 64, h, acc);
+        }
+    }
+}
+
+#define KM_FUSED_LDS(N) ((size_t)(S_TOTAL * 4 + 256 + (((N) * 4 + 3) & ~3) + (N) * PS_LD) * sizeof(float))
