@@ -46,19 +46,20 @@ struct drp_ctx {
     std::string err;
     int engine = DRP_ENGINE_VALU;
     int n_cu = 256;
+    bool fused_agg_only = false;    // DRP_FUSED_AGG_ONLY=1: fused engine keeps km_update separate
     bool agg_global_only = false;   // DRP_AGG_GLOBAL=1: always gather sender rows from L2/HBM
 
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
     float adj_thresh = 0.08f, thr = 0.0064f;
-    DevBuf w_raw, w_valu, w_mfma, w_split;
+    DevBuf w_raw, w_valu, w_mfma, w_split, w_split6;
     DrpCam cam{};
     DevBuf goal_field, goal_coor;
     int goal_h = 0, goal_w = 0, goal_m = 0;
 
     // workspaces
     DevBuf s_in, attr, dens, s_delta, nbr_idx, nbr_cnt, eff, c_node, agg, proj, c_edge, states,
-        actions, rewards, s_out, scratch;
+        actions, rewards, s_out, scratch, proj2;
 
     // MPC state
     bool mpc_on = false;
@@ -156,6 +157,7 @@ int ensure_step_ws(drp_ctx* c, int B, int N) {
     CHK(ensure(c, c->c_node, bn * 64 * sizeof(float)));
     CHK(ensure(c, c->agg, bn * 64 * sizeof(float)));
     CHK(ensure(c, c->proj, bn * 128 * sizeof(float)));
+    CHK(ensure(c, c->proj2, bn * 128 * sizeof(float)));
     CHK(ensure(c, c->c_edge, bn * DRP_K * 64 * sizeof(float)));
     c->lastB = B;
     c->lastN = N;
@@ -209,7 +211,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     }
     // split engine, small enough samples: the relation encoder is recomputed inside the
     // aggregate of every propagation step and c_edge is never materialised
-    const bool fused = (c->engine == DRP_ENGINE_FUSED) && N <= KM_FUSED_MAX_N;
+    const bool fused = (c->engine == DRP_ENGINE_FUSED);
     const bool split = fused || c->engine == DRP_ENGINE_SPLIT || c->engine == DRP_ENGINE_FUSED;
     if (!fused) {
         ProbeScope ps(c, KC_EDGE_ENCODE);
@@ -223,10 +225,33 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                                a.s_prev, a.prev_mod, a.prev_stride, a.attr, a.attr_mod, a.dens, a.dens_mod,
                                ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N, B, ptr<float>(c->c_edge));
     }
+    if (fused && !c->fused_agg_only) {
+        // graph -> node_encode -> 3 x km_prop: the whole propagation step in one launch each
+        float* pa = ptr<float>(c->proj);
+        float* pb = ptr<float>(c->proj2);
+        for (int p = 0; p < DRP_PSTEP; ++p) {
+            const bool last = (p + 1 == DRP_PSTEP);
+            ProbeScope ps(c, last ? KC_PREDICT : KC_AGGREGATE);
+            if (!last)
+                hipLaunchKernelGGL(km_prop<false>, dim3(mfma_grid(c, node_tiles)), blk, KM_PROP_LDS(false), st,
+                                   ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod,
+                                   a.prev_stride, a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx),
+                                   ptr<uint8_t>(c->nbr_cnt), pa, ptr<float>(c->c_node), ptr<float>(c->eff), N, B,
+                                   pb, a.s_out, a.out_stride);
+            else
+                hipLaunchKernelGGL(km_prop<true>, dim3(mfma_grid(c, node_tiles)), blk, KM_PROP_LDS(true), st,
+                                   ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod,
+                                   a.prev_stride, a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx),
+                                   ptr<uint8_t>(c->nbr_cnt), pa, ptr<float>(c->c_node), ptr<float>(c->eff), N, B,
+                                   pb, a.s_out, a.out_stride);
+            float* tmp = pa; pa = pb; pb = tmp;
+        }
+        return DRP_OK;
+    }
     for (int p = 0; p < DRP_PSTEP; ++p) {
         if (fused) {
             ProbeScope ps(c, KC_AGGREGATE);
-            hipLaunchKernelGGL(km_edge_agg_split, dim3(B < c->n_cu ? B : c->n_cu), blk, KM_FUSED_LDS(N), st,
+            hipLaunchKernelGGL(km_edge_agg_split_flat, dim3(mfma_grid(c, node_tiles)), blk, KM_FLAT_LDS, st,
                                ptr<uint16_t>(c->w_split), mw, a.s_prev, a.prev_mod, a.prev_stride, a.attr,
                                a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx),
                                ptr<uint8_t>(c->nbr_cnt), ptr<float>(c->proj), N, B, ptr<float>(c->agg));
@@ -413,6 +438,7 @@ int drp_create(int device, drp_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
     c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
+    c->fused_agg_only = getenv("DRP_FUSED_AGG_ONLY") != nullptr;
     if (hipFuncSetAttribute((const void*)k_aggregate_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                             K_AGG_LDS_MAX_N * 256) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
@@ -424,7 +450,8 @@ int drp_create(int device, drp_ctx** out) {
     if (hipFuncSetAttribute((const void*)km_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_node_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_edge_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_SPLIT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_edge_agg_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_FUSED_LDS(KM_FUSED_MAX_N)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
@@ -442,7 +469,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    DevBuf* bufs[] = {&c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->goal_field, &c->goal_coor, &c->s_in,
+    DevBuf* bufs[] = {&c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
                       &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats};
@@ -500,6 +527,10 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
         std::vector<uint16_t> sp;
         pack_split(blob, sp);
         CHK(h2d(c, c->w_split, sp.data(), sp.size() * sizeof(uint16_t)));
+        std::vector<uint16_t> sp6;
+        pack_split6(blob, sp6);
+        CHK(h2d(c, c->w_split6, sp6.data(), sp6.size() * sizeof(uint16_t)));
+        HIPCHK(c, hipStreamSynchronize(c->stream));     // sp6 too
         HIPCHK(c, hipStreamSynchronize(c->stream));     // m, sp are about to go out of scope
     }
 #endif

@@ -214,103 +214,293 @@ km_edge_encode_split(const uint16_t* __restrict__ sw, const float* __restrict__ 
 // With the split chain the encoder is cheap enough to recompute in each of the three
 // propagation steps, so the [B,N,10,64] edge-constant buffer (786 MB at 1024 x 300, written
 // once and read three times per rollout step: 55 % of all HBM traffic of the unfused
-// pipeline) never exists.  One workgroup per sample: the sample's W_s eff rows and particle
-// positions are staged in LDS once, then a wave owns a tile of 32 receivers, loops over
-// the 10 slots, runs the chain for the 32 edges (slot k of each receiver) and accumulates
+// pipeline) never exists.  A wave owns a tile of 32 receivers, loops over the 10 slots,
+// runs the chain for the 32 edges (slot k of each receiver) and accumulates
 //     agg[i] += relu(c_edge + (W_r eff)[i] + (W_s eff)[send])      gnn_dyn.py:183-189
-// in the accumulator layout (receiver on the lane, 32 features in registers).  The sender
-// rows are gathered from LDS with ds_read_b128 (row stride 68 floats spreads the rows over
-// the banks).  HBM traffic per launch: proj once (157 MB) + agg (79 MB).
-// Needs N*272 + 60 KB of LDS: N <= KM_FUSED_MAX_N.
-#define KM_FUSED_MAX_N 368
-#define PS_LD 68
-
+// in the accumulator layout (receiver on the lane, 32 features in registers); the sender
+// rows are gathered from L2 early in the iteration and consumed after the chain.
+// No per-sample state in LDS, so receiver tiles of all samples are dealt to the waves of
+// the whole grid (perfect balance, any N).
 __global__ void __launch_bounds__(64 * MFMA_WAVES)
-km_edge_agg_split(const uint16_t* __restrict__ sw, const float* __restrict__ mw,
-                  const float* __restrict__ s_cur, int s_mod, size_t s_stride,
-                  const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
-                  const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
-                  const float* __restrict__ proj, int N, int B, float* __restrict__ agg) {
+km_edge_agg_split_flat(const uint16_t* __restrict__ sw, const float* __restrict__ mw,
+                       const float* __restrict__ s_cur, int s_mod, size_t s_stride,
+                       const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+                       const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
+                       const float* __restrict__ proj, int N, int B, float* __restrict__ agg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wsp_f = lds;                          // S_TOTAL * 4 floats
-    float* rows = wsp_f + S_TOTAL * 4;           // b2, b4, b_rp, wd_rp
-    float* pos = rows + 256;                     // [N][4] = x, y, z, attr
-    float* ps = pos + ((N * 4 + 3) & ~3);        // [N][PS_LD]
+    float* wsp_f = lds;
+    float* rows = wsp_f + S_TOTAL * 4;
     lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
     lds_fill(rows, mw + R_RE2_B, 256);
+    __syncthreads();
     const bf16x8* wsp = reinterpret_cast<const bf16x8*>(wsp_f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tps = (N + 31) >> 5;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        __syncthreads();                         // previous sample's readers are done
+    const long ntiles = (long)B * tps;
+    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
         const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
         const float* at = attr + (size_t)(b % attr_mod) * N;
-        const float4* pj = reinterpret_cast<const float4*>(proj) + (size_t)b * N * 32;
-        for (int i = threadIdx.x; i < N; i += blockDim.x)
-            *reinterpret_cast<float4*>(pos + i * 4) = make_float4(s[i * 3], s[i * 3 + 1], s[i * 3 + 2], at[i]);
-        for (int idx = threadIdx.x; idx < N * 16; idx += blockDim.x)
-            *reinterpret_cast<float4*>(ps + (idx >> 4) * PS_LD + (idx & 15) * 4) = pj[(size_t)(idx >> 4) * 32 + 16 + (idx & 15)];
-        __syncthreads();
+        const float* pj = proj + (size_t)b * N * 128;
         const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
-        for (int t = wave; t < tps; t += MFMA_WAVES) {
-            const int i = min(t * 32 + j, N - 1);
-            const int cnt = nbr_cnt[(size_t)b * N + i];
-            const int16_t* nb = nbr_idx + ((size_t)b * N + i) * DRP_K;
-            // bpr = b + d w_d + (W_r eff)[i]: the receiver's share of every in-edge, used as the
-            // initial accumulator of the chain's last layer
-            Frag bpr, acc;
-            {
-                Frag pr;
-                frag_bias_dens(rows + 128, rows + 192, d, h, bpr);
-                frag_from_row(proj + ((size_t)b * N + i) * 128, h, pr);
+        const int i = min(t * 32 + j, N - 1);
+        const int cnt = nbr_cnt[(size_t)b * N + i];
+        const int16_t* nb = nbr_idx + ((size_t)b * N + i) * DRP_K;
+        Frag bpr, acc;
+        {
+            Frag pr;
+            frag_bias_dens(rows + 128, rows + 192, d, h, bpr);
+            frag_from_row(pj + (size_t)i * 128, h, pr);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
-            }
-            frag_zero(acc);
-            const float4 pi = *reinterpret_cast<const float4*>(pos + i * 4);
-            int jn = (0 < cnt) ? (int)nb[0] : i;
+            for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
+        }
+        frag_zero(acc);
+        const float pix = s[i * 3 + 0], piy = s[i * 3 + 1], piz = s[i * 3 + 2], pia = at[i];
+        int jn = (0 < cnt) ? (int)nb[0] : i;
 #pragma unroll 1
-            for (int k = 0; k < DRP_K; ++k) {
-                // keep the (loop-invariant) packed-weight reads inside the loop: hoisted, they
-                // would occupy several hundred VGPRs
-                asm volatile("" ::: "memory");
-                const int jcur = jn;
-                if (k + 1 < DRP_K) jn = (k + 1 < cnt) ? (int)nb[k + 1] : i;    // prefetch next index
-                const float4 pn = *reinterpret_cast<const float4*>(pos + jcur * 4);
-                float x[8];
-                x[0] = pi.w; x[1] = pn.w;
-                x[2] = pi.x - pn.x; x[3] = pi.y - pn.y; x[4] = pi.z - pn.z;
-                x[5] = d; x[6] = 1.0f; x[7] = 0.0f;
-                Frag a, c;
-                FragB fb;
-                frag_zero(a);
-                mfma_layer8_split(wsp + S_RE0, x, h, a, lane);
-                split_frag<true>(a, fb);
-                frag_from_row(rows + 0, h, c);
-                mfma_layer64_split(wsp + S_RE2, fb, c, lane);
-                split_frag<true>(c, fb);
-                frag_from_row(rows + 64, h, a);
-                mfma_layer64_split(wsp + S_RE4, fb, a, lane);
-                split_frag<true>(a, fb);
-                c = bpr;
-                mfma_layer64_split(wsp + S_RPE, fb, c, lane);
-                const float keep = (k < cnt) ? 1.0f : 0.0f;
-                const float* srow = ps + jcur * PS_LD + 4 * h;
+        for (int k = 0; k < DRP_K; ++k) {
+            asm volatile("" ::: "memory");
+            const int jcur = jn;
+            if (k + 1 < DRP_K) jn = (k + 1 < cnt) ? (int)nb[k + 1] : i;
+            float x[8];
+            x[0] = pia; x[1] = at[jcur];
+            x[2] = pix - s[jcur * 3 + 0]; x[3] = piy - s[jcur * 3 + 1]; x[4] = piz - s[jcur * 3 + 2];
+            x[5] = d; x[6] = 1.0f; x[7] = 0.0f;
+            Frag sv;                                        // issued now, consumed after the chain
+            frag_from_row(pj + (size_t)jcur * 128 + 64, h, sv);
+            Frag a, c;
+            FragB fb;
+            frag_zero(a);
+            mfma_layer8_split(wsp + S_RE0, x, h, a, lane);
+            split_frag<true>(a, fb);
+            frag_from_row(rows + 0, h, c);
+            mfma_layer64_split(wsp + S_RE2, fb, c, lane);
+            split_frag<true>(c, fb);
+            frag_from_row(rows + 64, h, a);
+            mfma_layer64_split(wsp + S_RE4, fb, a, lane);
+            split_frag<true>(a, fb);
+            c = bpr;
+            mfma_layer64_split(wsp + S_RPE, fb, c, lane);
+            const float keep = (k < cnt) ? 1.0f : 0.0f;
 #pragma unroll
-                for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 sv = *reinterpret_cast<const float4*>(srow + 32 * ob + 8 * g);
-                        acc.v[ob][4 * g + 0] += keep * fmaxf(c.v[ob][4 * g + 0] + sv.x, 0.0f);
-                        acc.v[ob][4 * g + 1] += keep * fmaxf(c.v[ob][4 * g + 1] + sv.y, 0.0f);
-                        acc.v[ob][4 * g + 2] += keep * fmaxf(c.v[ob][4 * g + 2] + sv.z, 0.0f);
-                        acc.v[ob][4 * g + 3] += keep * fmaxf(c.v[ob][4 * g + 3] + sv.w, 0.0f);
-                    }
+            for (int r = 0; r < 16; ++r) {
+                acc.v[0][r] += keep * fmaxf(c.v[0][r] + sv.v[0][r], 0.0f);
+                acc.v[1][r] += keep * fmaxf(c.v[1][r] + sv.v[1][r], 0.0f);
             }
-            if (t * 32 + j < N) frag_to_row(agg + ((size_t)b * N + i) * 64, h, acc);
+        }
+        if (t * 32 + j < N) frag_to_row(agg + ((size_t)b * N + i) * 64, h, acc);
+    }
+}
+#define KM_FLAT_LDS ((size_t)(S_TOTAL * 4 + 256) * sizeof(float))
+
+// ---- whole propagation step in one kernel -----------------------------------------------------
+// km_prop<LAST>: per tile of 32 receivers
+//     agg  = sum_k relu(c_edge_k + (W_r eff)[i] + (W_s eff)[send_k])   (chain recomputed, above)
+//     eff  = relu(c_node + W_agg agg + eff)                             gnn_dyn.py:191-193
+//     !LAST: proj_next = [W_r eff | W_s eff]    (next step's node terms; ping-pong buffer, other
+//                                                tiles still gather this step's rows)
+//     LAST : s_pred = W1 relu(W0 eff + b0) + b1 + s_cur                 gnn_dyn.py:196-198
+// agg never leaves the registers: the accumulator layout of the segmented sum is the
+// B-operand layout of the next MFMA.  The node layers use a three-way bf16 split with six
+// products (W_hi x_hi, W_hi x_mid, W_mid x_hi, W_mid x_mid, W_hi x_lo, W_lo x_hi): error
+// <= 2^-24 relative per product, indistinguishable from the fp32 chain (measured 6.4e-7 vs
+// 5.9e-7 on the displacement), at 6/16 of the fp32 MFMA time.
+enum {                        // units of bf16x8; 64x64: [part 3][ob 2][s 4][lane 64]
+    S6_AGG = 0,
+    S6_RPR = S6_AGG + 1536,
+    S6_RPS = S6_RPR + 1536,
+    S6_PR0 = S6_RPS + 1536,
+    S6_TOTAL = S6_PR0 + 1536
+};
+
+inline void pack_split6(const float* w, std::vector<uint16_t>& out) {
+    out.assign((size_t)S6_TOTAL * 8, 0);
+    auto P = [&](int dst, int src, int ld, int col0) {
+        for (int ob = 0; ob < 2; ++ob)
+            for (int s = 0; s < 4; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int i = lane & 31, h = lane >> 5;
+                        float v = w[src + (32 * ob + i) * ld + col0 + split_feature(s, h, jj)];
+                        for (int part = 0; part < 3; ++part) {
+                            const uint16_t q = host_bf16_rne(v);
+                            out[((size_t)dst + ((part * 2 + ob) * 4 + s) * 64 + lane) * 8 + jj] = q;
+                            v -= host_bf16_to_f32(q);
+                        }
+                    }
+    };
+    P(S6_AGG, W_PP_W, 129, 64);
+    P(S6_RPR, W_RP_W, 193, 64);
+    P(S6_RPS, W_RP_W, 193, 128);
+    P(S6_PR0, W_PR0_W, 64, 0);
+}
+
+struct FragB6 {
+    bf16x8 p[3][4];          // [part][k-step]
+};
+
+__device__ __forceinline__ void split_frag6(const Frag& in, FragB6& o) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float x = in.v[s >> 1][8 * (s & 1) + jj];
+            const __bf16 hi = (__bf16)x;
+            const float r1 = x - (float)hi;
+            const __bf16 mid = (__bf16)r1;
+            o.p[0][s][jj] = hi;
+            o.p[1][s][jj] = mid;
+            o.p[2][s][jj] = (__bf16)(r1 - (float)mid);
+        }
+}
+
+__device__ __forceinline__ void mfma_layer64_split6(const bf16x8* __restrict__ wp, const FragB6& b, Frag& acc, int lane) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            const bf16x8 w0 = wp[((0 * 2 + ob) * 4 + s) * 64 + lane];
+            const bf16x8 w1 = wp[((1 * 2 + ob) * 4 + s) * 64 + lane];
+            const bf16x8 w2 = wp[((2 * 2 + ob) * 4 + s) * 64 + lane];
+            acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b.p[0][s], acc.v[ob], 0, 0, 0);
+            acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b.p[2][s], acc.v[ob], 0, 0, 0);
+            acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b.p[1][s], acc.v[ob], 0, 0, 0);
+            acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b.p[0][s], acc.v[ob], 0, 0, 0);
+            acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b.p[1][s], acc.v[ob], 0, 0, 0);
+            acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b.p[0][s], acc.v[ob], 0, 0, 0);
         }
     }
 }
 
-#define KM_FUSED_LDS(N) ((size_t)(S_TOTAL * 4 + 256 + (((N) * 4 + 3) & ~3) + (N) * PS_LD) * sizeof(float))
+template <bool LAST>
+__global__ void __launch_bounds__(64 * MFMA_WAVES)
+km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
+        const float* __restrict__ s_cur, int s_mod, size_t s_stride,
+        const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+        const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
+        const float* __restrict__ proj, const float* __restrict__ c_node, float* __restrict__ eff,
+        int N, int B, float* __restrict__ proj_next, float* __restrict__ s_out, size_t out_stride) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wsp_f = lds;                              // edge chain, S_TOTAL units
+    float* w6_f = wsp_f + S_TOTAL * 4;               // node layers: AGG | (RPR RPS) or (PR0)
+    float* rows = w6_f + (LAST ? 2 : 3) * 1536 * 4;  // b2,b4,b_rp,wd_rp | b_pr0, w_pr1[3], b_pr1
+    lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
+    lds_fill(w6_f, reinterpret_cast<const float*>(sw6) + S6_AGG * 4, 1536 * 4);
+    if (LAST) {
+        lds_fill(w6_f + 1536 * 4, reinterpret_cast<const float*>(sw6) + S6_PR0 * 4, 1536 * 4);
+        lds_fill(rows + 256, mw + R_PR0_B, 260);
+    } else {
+        lds_fill(w6_f + 1536 * 4, reinterpret_cast<const float*>(sw6) + S6_RPR * 4, 2 * 1536 * 4);
+    }
+    lds_fill(rows, mw + R_RE2_B, 256);
+    __syncthreads();
+    const bf16x8* wsp = reinterpret_cast<const bf16x8*>(wsp_f);
+    const bf16x8* w6 = reinterpret_cast<const bf16x8*>(w6_f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tps = (N + 31) >> 5;
+    const long ntiles = (long)B * tps;
+    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
+        const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
+        const float* at = attr + (size_t)(b % attr_mod) * N;
+        const float* pj = proj + (size_t)b * N * 128;
+        const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+        const int i = min(t * 32 + j, N - 1);
+        const bool live = (t * 32 + j) < N;
+        const size_t row = (size_t)b * N + i;
+        const int cnt = nbr_cnt[row];
+        const int16_t* nb = nbr_idx + row * DRP_K;
+        Frag bpr, acc;
+        {
+            Frag pr;
+            frag_bias_dens(rows + 128, rows + 192, d, h, bpr);
+            frag_from_row(pj + (size_t)i * 128, h, pr);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
+        }
+        frag_zero(acc);
+        const float pix = s[i * 3 + 0], piy = s[i * 3 + 1], piz = s[i * 3 + 2], pia = at[i];
+        int jn = (0 < cnt) ? (int)nb[0] : i;
+#pragma unroll 1
+        for (int k = 0; k < DRP_K; ++k) {
+            asm volatile("" ::: "memory");          // keep the packed-weight reads inside the loop
+            const int jcur = jn;
+            if (k + 1 < DRP_K) jn = (k + 1 < cnt) ? (int)nb[k + 1] : i;
+            float x[8];
+            x[0] = pia; x[1] = at[jcur];
+            x[2] = pix - s[jcur * 3 + 0]; x[3] = piy - s[jcur * 3 + 1]; x[4] = piz - s[jcur * 3 + 2];
+            x[5] = d; x[6] = 1.0f; x[7] = 0.0f;
+            Frag sv;                                 // issued now, consumed after the chain
+            frag_from_row(pj + (size_t)jcur * 128 + 64, h, sv);
+            Frag a, c;
+            FragB fb;
+            frag_zero(a);
+            mfma_layer8_split(wsp + S_RE0, x, h, a, lane);
+            split_frag<true>(a, fb);
+            frag_from_row(rows + 0, h, c);
+            mfma_layer64_split(wsp + S_RE2, fb, c, lane);
+            split_frag<true>(c, fb);
+            frag_from_row(rows + 64, h, a);
+            mfma_layer64_split(wsp + S_RE4, fb, a, lane);
+            split_frag<true>(a, fb);
+            c = bpr;
+            mfma_layer64_split(wsp + S_RPE, fb, c, lane);
+            const float keep = (k < cnt) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc.v[0][r] += keep * fmaxf(c.v[0][r] + sv.v[0][r], 0.0f);
+                acc.v[1][r] += keep * fmaxf(c.v[1][r] + sv.v[1][r], 0.0f);
+            }
+        }
+        // ---- node update on the aggregate still in registers
+        asm volatile("" ::: "memory");
+        Frag e;
+        {
+            Frag cn;
+            frag_from_row(eff + row * 64, h, e);
+            frag_from_row(c_node + row * 64, h, cn);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { e.v[0][r] += cn.v[0][r]; e.v[1][r] += cn.v[1][r]; }
+        }
+        FragB6 f6;
+        split_frag6(acc, f6);
+        mfma_layer64_split6(w6, f6, e, lane);
+        frag_relu(e);
+        if (live) frag_to_row(eff + row * 64, h, e);
+        split_frag6(e, f6);
+        if (!LAST) {
+            Frag p;
+            frag_zero(p);
+            mfma_layer64_split6(w6 + 1536, f6, p, lane);
+            if (live) frag_to_row(proj_next + row * 128, h, p);
+            frag_zero(p);
+            mfma_layer64_split6(w6 + 2 * 1536, f6, p, lane);
+            if (live) frag_to_row(proj_next + row * 128 + 64, h, p);
+        } else {
+            Frag hd;
+            frag_from_row(rows + 256, h, hd);
+            mfma_layer64_split6(w6 + 1536, f6, hd, lane);
+            frag_relu(hd);
+            float out[3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                Frag w;
+                frag_from_row(rows + 256 + 64 + 64 * o, h, w);
+                float p = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p = fmaf(hd.v[0][r], w.v[0][r], p);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p = fmaf(hd.v[1][r], w.v[1][r], p);
+                out[o] = p + __shfl_xor(p, 32, 64);
+            }
+            if (h == 0 && live) {
+                float* so = s_out + (size_t)b * out_stride + (size_t)i * 3;
+#pragma unroll
+                for (int o = 0; o < 3; ++o) so[o] = (out[o] + rows[256 + 64 + 192 + o]) + s[i * 3 + o];
+            }
+        }
+    }
+}
+#define KM_PROP_LDS(LAST) ((size_t)(S_TOTAL * 4 + ((LAST) ? 2 : 3) * 1536 * 4 + 256 + 260 + 4) * sizeof(float))

@@ -47,8 +47,8 @@ enum {
     DRP_ENGINE_VALU = 0,  /* fp32 VALU reference kernels */
     DRP_ENGINE_MFMA = 1,  /* fp32 MFMA (v_mfma_f32_32x32x2_f32) kernels */
     DRP_ENGINE_SPLIT = 2, /* as MFMA, relation encoder on split-bf16 (3-pass) MFMA, fp32 accumulate */
-    DRP_ENGINE_FUSED = 3  /* as SPLIT, encoder recomputed inside each aggregate (no edge-constant
-                             buffer) when N <= 368; larger N run as SPLIT */
+    DRP_ENGINE_FUSED = 3  /* as SPLIT, encoder recomputed inside each aggregate: the edge-constant
+                             buffer is never materialised */
 };
 
 typedef struct drp_ctx drp_ctx;

@@ -71,12 +71,12 @@ def test_one_step(ctx, golden, case, engine):
     np.testing.assert_allclose(eff, taps['particle_effect_2'], rtol=0, atol=1e-5)
     c_node = ctx.debug_fetch('c_node', (B, N, 64))
     np.testing.assert_allclose(c_node, taps['c_node'], rtol=0, atol=5e-6)
-    if not (engine == 'fused' and N <= 368):          # the fused engine never materialises c_edge
+    if engine != 'fused':          # the fused engine never materialises c_edge
         c_edge = ctx.debug_fetch('c_edge', (B, N, 10, 64))
         valid = np.arange(10)[None, None, :] < taps['nbr_cnt'][:, :, None]
         np.testing.assert_allclose(c_edge[valid], taps['c_edge'][valid], rtol=0, atol=5e-6)
-    agg = ctx.debug_fetch('agg', (B, N, 64))
-    np.testing.assert_allclose(agg, taps['effect_rel_2'].sum(2), rtol=0, atol=2e-5)
+        agg = ctx.debug_fetch('agg', (B, N, 64))     # (in the fused engine agg stays in registers)
+        np.testing.assert_allclose(agg, taps['effect_rel_2'].sum(2), rtol=0, atol=2e-5)
 
 
 @pytest.mark.parametrize('engine', ENGINES)
