@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdrp.so')
+# DRP_LIB: alternative build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get('DRP_LIB') or os.path.join(_HERE, 'libdrp.so')
 
 DRP_K = 10
 DRP_F = 64

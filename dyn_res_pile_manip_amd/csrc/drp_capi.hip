@@ -232,18 +232,14 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
         for (int p = 0; p < DRP_PSTEP; ++p) {
             const bool last = (p + 1 == DRP_PSTEP);
             ProbeScope ps(c, last ? KC_PREDICT : KC_AGGREGATE);
-            if (!last)
-                hipLaunchKernelGGL(km_prop<false>, dim3(mfma_grid(c, node_tiles)), blk, KM_PROP_LDS(false), st,
-                                   ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod,
-                                   a.prev_stride, a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx),
-                                   ptr<uint8_t>(c->nbr_cnt), pa, ptr<float>(c->c_node), ptr<float>(c->eff), N, B,
-                                   pb, a.s_out, a.out_stride);
-            else
-                hipLaunchKernelGGL(km_prop<true>, dim3(mfma_grid(c, node_tiles)), blk, KM_PROP_LDS(true), st,
-                                   ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod,
-                                   a.prev_stride, a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx),
-                                   ptr<uint8_t>(c->nbr_cnt), pa, ptr<float>(c->c_node), ptr<float>(c->eff), N, B,
-                                   pb, a.s_out, a.out_stride);
+            long pb_ = (node_tiles + PROP_WAVES - 1) / PROP_WAVES;
+            const dim3 grid((unsigned)(pb_ < c->n_cu ? pb_ : c->n_cu)), pblk(64 * PROP_WAVES);
+#define PROP_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
+                  a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, \
+                  ptr<float>(c->c_node), ptr<float>(c->eff), N, B, pb, a.s_out, a.out_stride
+            if (!last) hipLaunchKernelGGL(km_prop<false>, grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS);
+            else hipLaunchKernelGGL(km_prop<true>, grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS);
+#undef PROP_ARGS
             float* tmp = pa; pa = pb; pb = tmp;
         }
         return DRP_OK;

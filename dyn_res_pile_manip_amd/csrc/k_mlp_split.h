@@ -96,6 +96,17 @@ struct FragB {
 
 template <bool RELU>
 __device__ __forceinline__ void split_frag(const Frag& in, FragB& o) {
+#ifdef DRP_ABLATE_NOSPLIT      // timing experiment: dependent, but no vector work (wrong results)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 t = {in.v[s >> 1][8 * (s & 1)], in.v[s >> 1][8 * (s & 1) + 1], in.v[s >> 1][8 * (s & 1) + 2], in.v[s >> 1][8 * (s & 1) + 3]};
+        f32x4 u = {in.v[s >> 1][8 * (s & 1) + 4], in.v[s >> 1][8 * (s & 1) + 5], in.v[s >> 1][8 * (s & 1) + 6], in.v[s >> 1][8 * (s & 1) + 7]};
+        o.hi[s] = __builtin_bit_cast(bf16x8, t);
+        o.lo[s] = __builtin_bit_cast(bf16x8, u);
+    }
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -109,18 +120,53 @@ __device__ __forceinline__ void split_frag(const Frag& in, FragB& o) {
 }
 
 // acc += W x, W packed as bf16x8[(part*2 + ob)*4 + s][lane]
+// Packed-weight operands of one MFMA group (3 MFMAs: one k-step of one output block).
+struct WOp {
+    bf16x8 hi, lo;
+};
+
+__device__ __forceinline__ WOp wop_load(const bf16x8* __restrict__ wp, int s, int ob, int lane) {
+    WOp w;
+    w.hi = wp[((0 * 2 + ob) * 4 + s) * 64 + lane];
+    w.lo = wp[((1 * 2 + ob) * 4 + s) * 64 + lane];
+    return w;
+}
+
+__device__ __forceinline__ void mfma_group(const WOp& w, const FragB& b, Frag& acc, int s, int ob) {
+    acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, b.hi[s], acc.v[ob], 0, 0, 0);
+    acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, b.lo[s], acc.v[ob], 0, 0, 0);
+    acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, b.hi[s], acc.v[ob], 0, 0, 0);
+}
+
+// acc += W x.  24 MFMAs in 8 groups; the LDS reads of group g+1 are issued before the MFMAs
+// of group g (an un-prefetched ds_read_b128 pair costs more than the 96 cycles its three
+// MFMAs take), `first` holds group 0 (loaded by the caller while the previous layer's
+// output was being split) and `next` receives group 0 of the following layer.
+// Group order: k-steps 0,1 for both output blocks (they need only the first half of the
+// previous layer's split), then k-steps 2,3 of block 0, then of block 1.
+__device__ __forceinline__ void mfma_layer64_split(const bf16x8* __restrict__ wp, const FragB& b, Frag& acc, int lane,
+                                                   const WOp& first, const bf16x8* __restrict__ wp_next, WOp& next) {
+    WOp w1 = wop_load(wp, 0, 1, lane);
+    mfma_group(first, b, acc, 0, 0);
+    WOp w2 = wop_load(wp, 1, 0, lane);
+    mfma_group(w1, b, acc, 0, 1);
+    w1 = wop_load(wp, 1, 1, lane);
+    mfma_group(w2, b, acc, 1, 0);
+    w2 = wop_load(wp, 2, 0, lane);
+    mfma_group(w1, b, acc, 1, 1);
+    w1 = wop_load(wp, 3, 0, lane);
+    mfma_group(w2, b, acc, 2, 0);
+    w2 = wop_load(wp, 2, 1, lane);
+    mfma_group(w1, b, acc, 3, 0);
+    w1 = wop_load(wp, 3, 1, lane);
+    mfma_group(w2, b, acc, 2, 1);
+    if (wp_next != nullptr) next = wop_load(wp_next, 0, 0, lane);
+    mfma_group(w1, b, acc, 3, 1);
+}
+
 __device__ __forceinline__ void mfma_layer64_split(const bf16x8* __restrict__ wp, const FragB& b, Frag& acc, int lane) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
-            const bf16x8 a_hi = wp[((0 * 2 + ob) * 4 + s) * 64 + lane];
-            const bf16x8 a_lo = wp[((1 * 2 + ob) * 4 + s) * 64 + lane];
-            acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b.hi[s], acc.v[ob], 0, 0, 0);
-            acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b.lo[s], acc.v[ob], 0, 0, 0);
-            acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b.hi[s], acc.v[ob], 0, 0, 0);
-        }
-    }
+    WOp first = wop_load(wp, 0, 0, lane), next;
+    mfma_layer64_split(wp, b, acc, lane, first, nullptr, next);
 }
 
 // first layer: one k-step over [a_r, a_s, dx, dy, dz, d, 1, 0] (lanes of half 1 supply zeros)
@@ -373,8 +419,9 @@ __device__ __forceinline__ void mfma_layer64_split6(const bf16x8* __restrict__ w
     }
 }
 
+#define PROP_WAVES 8
 template <bool LAST>
-__global__ void __launch_bounds__(64 * MFMA_WAVES)
+__global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
         const float* __restrict__ s_cur, int s_mod, size_t s_stride,
         const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
@@ -401,7 +448,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     const int j = lane & 31, h = lane >> 5;
     const int tps = (N + 31) >> 5;
     const long ntiles = (long)B * tps;
-    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+    for (long gt = (long)blockIdx.x * PROP_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * PROP_WAVES) {
         const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
         const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
         const float* at = attr + (size_t)(b % attr_mod) * N;
@@ -422,37 +469,63 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         }
         frag_zero(acc);
         const float pix = s[i * 3 + 0], piy = s[i * 3 + 1], piz = s[i * 3 + 2], pia = at[i];
-        int jn = (0 < cnt) ? (int)nb[0] : i;
+        // two-deep software pipeline on the dependent loads (index -> sender position): the
+        // position of slot k+1 and the index of slot k+2 are requested while slot k computes
+        int j0 = (0 < cnt) ? (int)nb[0] : i;
+        int j1 = (1 < cnt) ? (int)nb[1] : i;
+        float p0x = s[j0 * 3 + 0], p0y = s[j0 * 3 + 1], p0z = s[j0 * 3 + 2], p0a = at[j0];
 #pragma unroll 1
         for (int k = 0; k < DRP_K; ++k) {
             asm volatile("" ::: "memory");          // keep the packed-weight reads inside the loop
-            const int jcur = jn;
-            if (k + 1 < DRP_K) jn = (k + 1 < cnt) ? (int)nb[k + 1] : i;
+            const int jcur = j0;
+            const float p1x = s[j1 * 3 + 0], p1y = s[j1 * 3 + 1], p1z = s[j1 * 3 + 2], p1a = at[j1];
+            const int j2 = (k + 2 < cnt) ? (int)nb[min(k + 2, DRP_K - 1)] : i;
             float x[8];
-            x[0] = pia; x[1] = at[jcur];
-            x[2] = pix - s[jcur * 3 + 0]; x[3] = piy - s[jcur * 3 + 1]; x[4] = piz - s[jcur * 3 + 2];
+            x[0] = pia; x[1] = p0a;
+            x[2] = pix - p0x; x[3] = piy - p0y; x[4] = piz - p0z;
             x[5] = d; x[6] = 1.0f; x[7] = 0.0f;
             Frag sv;                                 // issued now, consumed after the chain
+#ifdef DRP_ABLATE_NOGATHER
+            frag_from_row(rows + 0, h, sv);
+#else
             frag_from_row(pj + (size_t)jcur * 128 + 64, h, sv);
+#endif
             Frag a, c;
             FragB fb;
             frag_zero(a);
             mfma_layer8_split(wsp + S_RE0, x, h, a, lane);
+            WOp w0 = wop_load(wsp + S_RE2, 0, 0, lane), wn;
             split_frag<true>(a, fb);
             frag_from_row(rows + 0, h, c);
-            mfma_layer64_split(wsp + S_RE2, fb, c, lane);
+            mfma_layer64_split(wsp + S_RE2, fb, c, lane, w0, wsp + S_RE4, wn);
             split_frag<true>(c, fb);
             frag_from_row(rows + 64, h, a);
-            mfma_layer64_split(wsp + S_RE4, fb, a, lane);
+            mfma_layer64_split(wsp + S_RE4, fb, a, lane, wn, wsp + S_RPE, w0);
             split_frag<true>(a, fb);
             c = bpr;
-            mfma_layer64_split(wsp + S_RPE, fb, c, lane);
+            mfma_layer64_split(wsp + S_RPE, fb, c, lane, w0, nullptr, wn);
             const float keep = (k < cnt) ? 1.0f : 0.0f;
+#ifdef DRP_ABLATE_NOEPI
+            acc.v[0][0] += keep * (c.v[0][0] + sv.v[0][0]);
+            acc.v[1][15] += keep * (c.v[1][15] + sv.v[1][15]);
+#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc.v[0][r] += keep * fmaxf(c.v[0][r] + sv.v[0][r], 0.0f);
                 acc.v[1][r] += keep * fmaxf(c.v[1][r] + sv.v[1][r], 0.0f);
             }
+#endif
+            j0 = j1; j1 = j2;
+            p0x = p1x; p0y = p1y; p0z = p1z; p0a = p1a;
+#ifdef DRP_SCHED_PIPE
+            // scheduling pipeline for this loop body: one MFMA, then the vector work that fits
+            // under it (78 MFMAs, ~600 VALU per iteration)
+#pragma unroll
+            for (int q = 0; q < 78; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, DRP_SCHED_PIPE, 0);
+            }
+#endif
         }
         // ---- node update on the aggregate still in registers
         asm volatile("" ::: "memory");
