@@ -25,8 +25,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3      # dense fp32 (vector == f32-input MFMA rate)
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA
 KERNEL_CLASSES = ['graph', 'node_encode', 'edge_encode', 'project', 'aggregate', 'update',
-                  'predict', 'reward', 'mppi']
+                  'predict', 'reward', 'mppi', 'prop']
 # algorithmic work of one LAUNCH of each class, per particle (node) or per edge
 FLOP_PER_EDGE_ENCODE = 2 * (6 * 64 + 3 * 64 * 64)
 FLOP_PER_NODE = {'node_encode': 2 * (5 * 64 + 2 * 64 * 64), 'project': 2 * 2 * 64 * 64,
@@ -177,7 +178,18 @@ def main():
         total = world * ns * N * H * args.steps
         avg_s = dom_ms / max(dom_n, 1) * 1e-3
         B = ns
-        if dominant == 'aggregate':
+        tiles = B * ((N + 31) // 32)
+        if dominant == 'prop':
+            # km_prop: per 32-receiver tile, 10 slots x 78 bf16 MFMAs (the
+            # 3-term split relation-encoder chain) + the 6-term split node layers (144 MFMAs, 96 in
+            # the last step); roofline on the bf16 FLOPs actually EXECUTED, 2*32*32*16 per MFMA
+            mfmas = tiles * (10 * 78 + (2 * 144 + 96) / 3.0)
+            work = mfmas * 32768.0
+            alg = B * N * (kbar * FLOP_PER_EDGE_ENCODE + 2 * 64 * 64 * (1 + 2 * 2 / 3.0 + 1 / 3.0))
+            roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                    'mfma_dtype': 'bf16 operands (fp32 values split in 2 or 3 bf16 terms), fp32 accumulate',
+                    'algorithmic_f32_tflops': alg / avg_s / 1e12}
+        elif dominant == 'aggregate':
             work = B * N * (2 * kbar + 2) * 256.0
             roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
         elif dominant == 'edge_encode':
@@ -192,7 +204,7 @@ def main():
         roof['kernel'] = dominant
         roof['avg_launch_ms'] = avg_s * 1e3
         roof['launches'] = dom_n
-        roof['algorithmic_per_launch'] = work if dominant in ('aggregate', 'edge_encode') or dominant in FLOP_PER_NODE else None
+        roof['work_per_launch'] = work if dominant in ('prop', 'aggregate', 'edge_encode') or dominant in FLOP_PER_NODE else None
         # HBM-side bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 +
         # WRITE_SIZE, profiles/summarize_pmc.py); collected on this same workload
         roof['traffic'] = None
@@ -206,7 +218,9 @@ def main():
             'metric': 'MPC rollout-steps/sec (samples x particles x steps/sec)',
             'value': total / dt, 'unit': 'particle-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if engine in ('valu', 'mfma') else 'f32 (MLP products as split-bf16 MFMA terms, fp32 accumulate)',
+            'data': 'synthetic',
             'config': {'workload': '%d-particle pile, %d MPPI samples per GPU, %d-step horizon '
                                    '(BASELINE configs[%d])' % (N, ns, H, 1 if world == 1 else 2),
                        'n_particles': N, 'n_sample_per_gpu': ns, 'n_look_ahead': H, 'engine': engine,

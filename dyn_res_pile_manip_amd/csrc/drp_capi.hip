@@ -29,9 +29,9 @@ namespace {
 std::string g_create_error;
 
 enum KClass { KC_GRAPH = 0, KC_NODE_ENCODE, KC_EDGE_ENCODE, KC_PROJECT, KC_AGGREGATE, KC_UPDATE,
-              KC_PREDICT, KC_REWARD, KC_MPPI, KC_COUNT };
+              KC_PREDICT, KC_REWARD, KC_MPPI, KC_PROP, KC_COUNT };
 const char* const kclass_names[KC_COUNT] = {"graph", "node_encode", "edge_encode", "project",
-                                            "aggregate", "update", "predict", "reward", "mppi"};
+                                            "aggregate", "update", "predict", "reward", "mppi", "prop"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -174,7 +174,8 @@ struct StepArgs {
     int B, N;
 };
 
-int graph_block(int N) { int t = ((N + 63) / 64) * 64; return t > 1024 ? 1024 : t; }
+int graph_chunks(int N) { return (N + GRAPH_THREADS - 1) / GRAPH_THREADS; }
+size_t graph_lds(int N) { return (size_t)4 * N * sizeof(float) + (size_t)GRAPH_THREADS * GRAPH_CAP * sizeof(int16_t); }
 
 void launch_aggregate(drp_ctx* c, int B, int N) {
     ProbeScope ps(c, KC_AGGREGATE);
@@ -231,7 +232,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
         float* pb = ptr<float>(c->proj2);
         for (int p = 0; p < DRP_PSTEP; ++p) {
             const bool last = (p + 1 == DRP_PSTEP);
-            ProbeScope ps(c, last ? KC_PREDICT : KC_AGGREGATE);
+            ProbeScope ps(c, KC_PROP);
             long pb_ = (node_tiles + PROP_WAVES - 1) / PROP_WAVES;
             const dim3 grid((unsigned)(pb_ < c->n_cu ? pb_ : c->n_cu)), pblk(64 * PROP_WAVES);
 #define PROP_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
@@ -278,9 +279,9 @@ int run_step(drp_ctx* c, const StepArgs& a) {
     const float* vw = ptr<float>(c->w_valu);
     if (a.build_graph) {
         ProbeScope ps(c, KC_GRAPH);
-        hipLaunchKernelGGL(k_graph, dim3(B), dim3(graph_block(N)), 3 * N * sizeof(float), st, a.s_prev,
+        hipLaunchKernelGGL(k_graph, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), graph_lds(N), st, a.s_prev,
                            a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, N, nbr_idx,
-                           nbr_cnt, c->cam, c->thr);
+                           nbr_cnt, c->cam, c->thr, graph_chunks(N));
     }
 #ifdef DRP_HAVE_MFMA
     if (c->engine != DRP_ENGINE_VALU) {
@@ -405,7 +406,7 @@ int need(drp_ctx* c, bool weights, bool cam, bool goal) {
 }
 
 int check_bn(drp_ctx* c, int B, int N) {
-    if (B <= 0 || N <= 0 || N > 16384) return fail(c, DRP_EINVAL, "bad shape B=%d N=%d", B, N);
+    if (B <= 0 || N <= 0 || N > 4096) return fail(c, DRP_EINVAL, "bad shape B=%d N=%d (N <= 4096)", B, N);
     return DRP_OK;
 }
 
@@ -435,7 +436,8 @@ int drp_create(int device, drp_ctx** out) {
         c->n_cu = prop.multiProcessorCount;
     c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
     c->fused_agg_only = getenv("DRP_FUSED_AGG_ONLY") != nullptr;
-    if (hipFuncSetAttribute((const void*)k_aggregate_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_aggregate_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                             K_AGG_LDS_MAX_N * 256) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         delete c;
@@ -583,10 +585,10 @@ int drp_build_graph(drp_ctx* c, const float* s_cur, const float* s_delta, int B,
     CHK(ensure_step_ws(c, B, N));
     CHK(h2d(c, c->s_in, s_cur, (size_t)B * N * 3 * sizeof(float)));
     CHK(h2d(c, c->s_delta, s_delta, (size_t)B * N * 3 * sizeof(float)));
-    hipLaunchKernelGGL(k_graph, dim3(B), dim3(graph_block(N)), 3 * N * sizeof(float), c->stream,
+    hipLaunchKernelGGL(k_graph, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), graph_lds(N), c->stream,
                        ptr<float>(c->s_in), B, (size_t)N * 3, (const float*)nullptr, (size_t)0,
                        ptr<float>(c->s_delta), N, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt),
-                       c->cam, c->thr);
+                       c->cam, c->thr, graph_chunks(N));
     HIPCHK(c, hipGetLastError());
     CHK(d2h(c, nbr_idx_out, c->nbr_idx.p, (size_t)B * N * DRP_K * sizeof(int16_t)));
     CHK(d2h(c, nbr_cnt_out, c->nbr_cnt.p, (size_t)B * N));
@@ -696,6 +698,7 @@ int drp_mpc_begin(drp_ctx* c, const drp_mpc_params* p, const float* s0, const fl
 
 int drp_mpc_sample(drp_ctx* c, const float* noise, uint64_t iteration) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    HIPCHK(c, hipSetDevice(c->device));
     const drp_mpc_params& p = c->mpc;
     const float* dnoise = nullptr;
     if (noise) {
@@ -714,6 +717,7 @@ int drp_mpc_sample(drp_ctx* c, const float* noise, uint64_t iteration) {
 
 int drp_mpc_set_actions(drp_ctx* c, const float* actions) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    HIPCHK(c, hipSetDevice(c->device));
     if (!actions) return fail(c, DRP_EINVAL, "null actions");
     const drp_mpc_params& p = c->mpc;
     CHK(h2d(c, c->actions, actions, (size_t)p.n_sample * p.n_batch * p.n_look_ahead * 4 * sizeof(float)));
@@ -722,6 +726,7 @@ int drp_mpc_set_actions(drp_ctx* c, const float* actions) {
 
 int drp_mpc_rollout(drp_ctx* c, int reward_all_steps) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    HIPCHK(c, hipSetDevice(c->device));
     const drp_mpc_params& p = c->mpc;
     return run_rollout(c, p.n_batch, p.n_particles, p.n_sample * p.n_batch, p.n_look_ahead,
                        reward_all_steps != 0, reward_all_steps == 0);
@@ -740,6 +745,7 @@ static int launch_partials(drp_ctx* c) {
 
 int drp_mpc_partials(drp_ctx* c, double* out) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    HIPCHK(c, hipSetDevice(c->device));
     CHK(launch_partials(c));
     if (out) {
         CHK(d2h(c, out, c->partials.p, (size_t)(6 + 4 * c->mpc.n_look_ahead) * sizeof(double)));
@@ -760,6 +766,7 @@ static int launch_update(drp_ctx* c, const double* dev_partials, int n_ranks) {
 
 int drp_mpc_update(drp_ctx* c, const double* partials, int n_ranks, double* nominal_out) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    HIPCHK(c, hipSetDevice(c->device));
     if (!partials || n_ranks <= 0) return fail(c, DRP_EINVAL, "bad partials");
     const size_t rec = (size_t)(6 + 4 * c->mpc.n_look_ahead) * sizeof(double);
     CHK(h2d(c, c->gathered, partials, rec * n_ranks));
@@ -773,6 +780,7 @@ int drp_mpc_update(drp_ctx* c, const double* partials, int n_ranks, double* nomi
 
 int drp_mpc_update_device(drp_ctx* c) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    HIPCHK(c, hipSetDevice(c->device));
     CHK(launch_partials(c));
     const int rec = 6 + 4 * c->mpc.n_look_ahead;
     if (c->comm && c->n_ranks > 1) {
@@ -787,6 +795,7 @@ int drp_mpc_update_device(drp_ctx* c) {
 int drp_mpc_get(drp_ctx* c, float* actions, float* rewards, float* rewards_all, float* states,
                 double* nominal) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    HIPCHK(c, hipSetDevice(c->device));
     const drp_mpc_params& p = c->mpc;
     const int H = p.n_look_ahead, B = p.n_sample * p.n_batch, N = p.n_particles;
     if (actions) CHK(d2h(c, actions, c->actions.p, (size_t)B * H * 4 * sizeof(float)));

@@ -419,7 +419,11 @@ __device__ __forceinline__ void mfma_layer64_split6(const bf16x8* __restrict__ w
     }
 }
 
+#ifndef PROP_WAVES
 #define PROP_WAVES 8
+#endif
+// PROP_LOWREG: rebuild the receiver term each slot and gather the sender row after the chain
+// (64 fewer live registers, for three waves per SIMD)
 template <bool LAST>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
@@ -459,7 +463,9 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         const size_t row = (size_t)b * N + i;
         const int cnt = nbr_cnt[row];
         const int16_t* nb = nbr_idx + row * DRP_K;
-        Frag bpr, acc;
+        Frag acc;
+#ifndef PROP_LOWREG
+        Frag bpr;
         {
             Frag pr;
             frag_bias_dens(rows + 128, rows + 192, d, h, bpr);
@@ -467,6 +473,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
         }
+#endif
         frag_zero(acc);
         const float pix = s[i * 3 + 0], piy = s[i * 3 + 1], piz = s[i * 3 + 2], pia = at[i];
         // two-deep software pipeline on the dependent loads (index -> sender position): the
@@ -485,10 +492,12 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
             x[2] = pix - p0x; x[3] = piy - p0y; x[4] = piz - p0z;
             x[5] = d; x[6] = 1.0f; x[7] = 0.0f;
             Frag sv;                                 // issued now, consumed after the chain
+#ifndef PROP_LOWREG
 #ifdef DRP_ABLATE_NOGATHER
             frag_from_row(rows + 0, h, sv);
 #else
             frag_from_row(pj + (size_t)jcur * 128 + 64, h, sv);
+#endif
 #endif
             Frag a, c;
             FragB fb;
@@ -502,8 +511,21 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
             frag_from_row(rows + 64, h, a);
             mfma_layer64_split(wsp + S_RE4, fb, a, lane, wn, wsp + S_RPE, w0);
             split_frag<true>(a, fb);
+#ifdef PROP_LOWREG
+            {
+                Frag pr;
+                frag_bias_dens(rows + 128, rows + 192, d, h, c);
+                frag_from_row(pj + (size_t)i * 128, h, pr);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { c.v[0][r] += pr.v[0][r]; c.v[1][r] += pr.v[1][r]; }
+            }
+#else
             c = bpr;
+#endif
             mfma_layer64_split(wsp + S_RPE, fb, c, lane, w0, nullptr, wn);
+#ifdef PROP_LOWREG
+            frag_from_row(pj + (size_t)jcur * 128 + 64, h, sv);
+#endif
             const float keep = (k < cnt) ? 1.0f : 0.0f;
 #ifdef DRP_ABLATE_NOEPI
             acc.v[0][0] += keep * (c.v[0][0] + sv.v[0][0]);

@@ -154,7 +154,7 @@ int drp_comm_destroy(drp_ctx* ctx);
 /* ---- measurement / debugging ----------------------------------------------------- */
 /* HIP-event timing of one kernel class on the context's stream.  name: "graph",
  * "node_encode", "edge_encode", "project", "aggregate", "update", "predict", "reward",
- * "mppi".  drp_probe_read returns total ms and launches since drp_probe_begin. */
+ * "mppi", "prop" (the fused propagation-step kernel of DRP_ENGINE_FUSED).  drp_probe_read returns total ms and launches since drp_probe_begin. */
 int drp_probe_begin(drp_ctx* ctx, const char* kernel_class);
 int drp_probe_read(drp_ctx* ctx, double* total_ms, long* launches);
 /* copy an intermediate device buffer to the host: "s_delta","nbr_idx","nbr_cnt",

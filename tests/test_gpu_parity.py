@@ -240,3 +240,34 @@ def test_mppi_two_shards_combine_on_device(ctx, golden):
     nominal, stats = sharding.combine_records(np.stack(recs), 64)
     np.testing.assert_allclose(nominal, want, rtol=1e-10, atol=1e-10)
     assert stats['argmax'] == int(np.argmax(r_full))
+
+
+def test_rccl_communicator_single_rank(ctx, golden):
+    """RCCL path with a one-rank communicator: unique id, init, the all-gather inside
+    drp_mpc_update_device and the combine -- same answer as the communicator-free path."""
+    g = golden.mppi
+    acts = g['opt_act_seqs'][:, :, 0, :].astype(np.float32)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('disc'))
+    N = 16
+    ctx.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+    s0, dens, attr = syn.make_pile(N, 1, seed=1)
+    lo, hi = syn.action_limits()
+    ctx.mpc_begin(s0, attr, dens, g['nominal'], n_sample=64, sigma=0.6, beta_filter=0.7,
+                  reward_weight=0.1, act_lo=lo, act_hi=hi)
+    ctx.mpc_set_actions(acts)
+    ctx.mpc_rollout()
+    ctx.mpc_update_device()
+    want = ctx.mpc_get(nominal=True)['nominal']
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 0, 1)
+    try:
+        ctx.mpc_begin(s0, attr, dens, g['nominal'], n_sample=64, sigma=0.6, beta_filter=0.7,
+                      reward_weight=0.1, act_lo=lo, act_hi=hi)
+        ctx.mpc_set_actions(acts)
+        ctx.mpc_rollout()
+        ctx.mpc_update_device()
+        got = ctx.mpc_get(nominal=True)['nominal']
+    finally:
+        ctx._ck(ctx.lib.drp_comm_destroy(ctx.h))
+    np.testing.assert_array_equal(got, want)
