@@ -175,7 +175,7 @@ struct StepArgs {
 };
 
 int graph_chunks(int N) { return (N + GRAPH_THREADS - 1) / GRAPH_THREADS; }
-size_t graph_lds(int N) { return (size_t)4 * N * sizeof(float) + (size_t)GRAPH_THREADS * GRAPH_CAP * sizeof(int16_t); }
+size_t graph_lds(int N) { return (size_t)4 * N * sizeof(float); }
 
 void launch_aggregate(drp_ctx* c, int B, int N) {
     ProbeScope ps(c, KC_AGGREGATE);
@@ -585,10 +585,13 @@ int drp_build_graph(drp_ctx* c, const float* s_cur, const float* s_delta, int B,
     CHK(ensure_step_ws(c, B, N));
     CHK(h2d(c, c->s_in, s_cur, (size_t)B * N * 3 * sizeof(float)));
     CHK(h2d(c, c->s_delta, s_delta, (size_t)B * N * 3 * sizeof(float)));
+    {
+    ProbeScope ps(c, KC_GRAPH);
     hipLaunchKernelGGL(k_graph, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), graph_lds(N), c->stream,
                        ptr<float>(c->s_in), B, (size_t)N * 3, (const float*)nullptr, (size_t)0,
                        ptr<float>(c->s_delta), N, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt),
                        c->cam, c->thr, graph_chunks(N));
+    }
     HIPCHK(c, hipGetLastError());
     CHK(d2h(c, nbr_idx_out, c->nbr_idx.p, (size_t)B * N * DRP_K * sizeof(int16_t)));
     CHK(d2h(c, nbr_cnt_out, c->nbr_cnt.p, (size_t)B * N));

@@ -80,29 +80,21 @@ __device__ __forceinline__ float pair_dis(float xi, float yi, float zi, float xj
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
-// Neighbour lists, two phases per receiver (one thread each):
-//   1. sweep all senders (one ds_read_b128 broadcast per sender), append the index of every
-//      sender inside the radius to the thread's own candidate list in LDS.  Only in-radius
-//      senders can become edges: adj = (dis - thr < 0) * topk, so the edge set is "the up to
-//      10 nearest among the in-radius senders" -- the candidates (38 of 300 on average on the
-//      0.4 x 0.4 workspace) are all that the top-k selection has to look at.
-//   2. sorted insertion of the candidates' (distance, index) pairs into ten registers, then
-//      a small sorting network puts the survivors in ascending sender index.
-// A thread whose candidate list overflows (very dense piles) falls back to the exact
-// two-sweep selection over all senders.  Distances are recomputed with the same
-// expression in both phases, so the selection is bit-identical to the one-phase form.
-// grid = B * ceil(N / GRAPH_THREADS): a workgroup owns GRAPH_THREADS consecutive receivers of one
-// sample (small workgroups, 21 KB of LDS at N = 300: seven per CU, no occupancy tail);
-// every workgroup stages all N displaced positions, the first one of a sample writes s_delta.
-// dynamic LDS = 4*N floats + GRAPH_THREADS * GRAPH_CAP int16.
-#define GRAPH_CAP 64
+// Neighbour lists, one thread per receiver, two sweeps over the sample's senders (positions
+// broadcast from LDS, one ds_read_b128 each):
+//   1. the ten smallest in-radius distances, kept ascending in ten registers.  Inserting d
+//      into an ascending list is new[q] = clamp(d, old[q-1], old[q]) = v_med3_f32: ten
+//      instructions per sender, no branch, no divergence.  The list starts at thr, so
+//      senders outside the radius (which can never be edges: adj = (dis - thr < 0) * topk)
+//      leave it unchanged and list[9] ends as min(thr, 10th smallest in-radius distance).
+//   2. senders in ascending index with d <= list[9] and d - thr < 0 are the edges (at most
+//      ten; ties at the cut go to the lower index).
+// Both sweeps evaluate the distance with the same expression, so the result is exactly
+// the reference's radius AND top-10 mask.
+// grid = B * ceil(N / GRAPH_THREADS): a workgroup owns GRAPH_THREADS consecutive receivers of
+// one sample and stages all N displaced positions (16 B each) in LDS; the first workgroup
+// of a sample writes s_delta.  dynamic LDS = 4*N floats.
 #define GRAPH_THREADS 128
-
-__device__ __forceinline__ void cswap_idx(int& a, int& b) {
-    const int lo = min(a, b), hi = max(a, b);
-    a = lo;
-    b = hi;
-}
 
 __global__ void __launch_bounds__(GRAPH_THREADS)
 k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
@@ -110,15 +102,13 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
         int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* p4 = reinterpret_cast<float4*>(lds);                       // [N] displaced positions
-    int16_t* cand = reinterpret_cast<int16_t*>(lds + 4 * N);           // [GRAPH_CAP][blockDim]
     const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
-    const int BLOCK = GRAPH_THREADS;
     const float* s = s_prev + (size_t)(b % prev_mod) * prev_stride;
     float* sd = s_delta + (size_t)b * N * 3;
 
     if (actions != nullptr) {
         const PushFrame f = push_frame(cam, actions + (size_t)b * act_stride);
-        for (int i = threadIdx.x; i < N; i += BLOCK) {
+        for (int i = threadIdx.x; i < N; i += GRAPH_THREADS) {
             float x = s[i * 3 + 0], y = s[i * 3 + 1], z = s[i * 3 + 2];
             float ox, oy, oz;
             push_delta(f, x, y, z, ox, oy, oz);
@@ -130,101 +120,53 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
             p4[i] = make_float4(__fadd_rn(x, ox), __fadd_rn(y, oy), __fadd_rn(z, oz), 0.0f);  // gnn_dyn.py:224
         }
     } else {
-        for (int i = threadIdx.x; i < N; i += BLOCK)
+        for (int i = threadIdx.x; i < N; i += GRAPH_THREADS)
             p4[i] = make_float4(__fadd_rn(s[i * 3 + 0], sd[i * 3 + 0]), __fadd_rn(s[i * 3 + 1], sd[i * 3 + 1]),
                                 __fadd_rn(s[i * 3 + 2], sd[i * 3 + 2]), 0.0f);
     }
     __syncthreads();
 
-    {
-        const int i = chunk * GRAPH_THREADS + threadIdx.x;
-        if (i >= N) return;
-        const float4 pi = p4[i];
-        // phase 1: candidates inside the radius (four senders per trip: the LDS reads are issued
-        // together, the appends stay in ascending order)
-        int nc = 0;
-        int j = 0;
-        for (; j + 4 <= N; j += 4) {
-            const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
-            const float d0 = pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z);
-            const float d1 = pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z);
-            const float d2 = pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z);
-            const float d3 = pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z);
-            if (__fsub_rn(d0, thr) < 0.0f) { if (nc < GRAPH_CAP) cand[nc * BLOCK + threadIdx.x] = (int16_t)j; ++nc; }
-            if (__fsub_rn(d1, thr) < 0.0f) { if (nc < GRAPH_CAP) cand[nc * BLOCK + threadIdx.x] = (int16_t)(j + 1); ++nc; }
-            if (__fsub_rn(d2, thr) < 0.0f) { if (nc < GRAPH_CAP) cand[nc * BLOCK + threadIdx.x] = (int16_t)(j + 2); ++nc; }
-            if (__fsub_rn(d3, thr) < 0.0f) { if (nc < GRAPH_CAP) cand[nc * BLOCK + threadIdx.x] = (int16_t)(j + 3); ++nc; }
+    const int i = chunk * GRAPH_THREADS + threadIdx.x;
+    if (i >= N) return;
+    const float4 pi = p4[i];
+    float best[DRP_K];
+#pragma unroll
+    for (int q = 0; q < DRP_K; ++q) best[q] = thr;
+    int j = 0;
+    for (; j + 4 <= N; j += 4) {
+        const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
+        const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
+                             pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int q = DRP_K - 1; q > 0; --q) best[q] = __builtin_amdgcn_fmed3f(d4[u], best[q - 1], best[q]);
+            best[0] = fminf(best[0], d4[u]);
         }
-        for (; j < N; ++j) {
-            const float4 pj = p4[j];
-            const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
-            if (__fsub_rn(d, thr) < 0.0f) {
-                if (nc < GRAPH_CAP) cand[nc * BLOCK + threadIdx.x] = (int16_t)j;
-                ++nc;
-            }
-        }
-        float bd[DRP_K];
-        int bj[DRP_K];
-#pragma unroll
-        for (int q = 0; q < DRP_K; ++q) { bd[q] = __builtin_inff(); bj[q] = 0x7fff; }
-        if (nc <= GRAPH_CAP) {
-            // phase 2: ten nearest candidates, ties to the lower index (candidates come in ascending j)
-            for (int c = 0; c < nc; ++c) {
-                const int j = cand[c * BLOCK + threadIdx.x];
-                const float4 pj = p4[j];
-                const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
-                if (d < bd[DRP_K - 1]) {
-#pragma unroll
-                    for (int q = DRP_K - 1; q > 0; --q) {
-                        const bool up = d < bd[q - 1];            // everything from q-1 on shifts up
-                        const bool here = !up && d < bd[q];
-                        bj[q] = up ? bj[q - 1] : (here ? j : bj[q]);
-                        bd[q] = up ? bd[q - 1] : (here ? d : bd[q]);
-                    }
-                    if (d < bd[0]) { bd[0] = d; bj[0] = j; }
-                }
-            }
-        } else {
-            // exact fallback: 10 smallest in-radius distances, then ascending index sweep
-            for (int j = 0; j < N; ++j) {
-                const float4 pj = p4[j];
-                const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
-                if (__fsub_rn(d, thr) < 0.0f && d < bd[DRP_K - 1]) {
-#pragma unroll
-                    for (int q = DRP_K - 1; q > 0; --q) bd[q] = (d < bd[q - 1]) ? bd[q - 1] : fminf(bd[q], d);
-                    bd[0] = fminf(bd[0], d);
-                }
-            }
-            const float kth = bd[DRP_K - 1];
-            int cnt2 = 0;
-            for (int j = 0; j < N; ++j) {
-                const float4 pj = p4[j];
-                const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
-                if (d <= kth && __fsub_rn(d, thr) < 0.0f && cnt2 < DRP_K) {
-#pragma unroll
-                    for (int q = 0; q < DRP_K; ++q)
-                        if (q == cnt2) bj[q] = j;
-                    ++cnt2;
-                }
-            }
-        }
-        const int cnt = min(nc, DRP_K);
-        // ascending sender index (empty slots hold 0x7fff and sink to the end): 10-input network
-        cswap_idx(bj[0], bj[1]); cswap_idx(bj[2], bj[3]); cswap_idx(bj[4], bj[5]); cswap_idx(bj[6], bj[7]); cswap_idx(bj[8], bj[9]);
-        cswap_idx(bj[0], bj[2]); cswap_idx(bj[1], bj[3]); cswap_idx(bj[4], bj[6]); cswap_idx(bj[5], bj[7]);
-        cswap_idx(bj[1], bj[2]); cswap_idx(bj[5], bj[6]); cswap_idx(bj[0], bj[4]); cswap_idx(bj[3], bj[7]);
-        cswap_idx(bj[1], bj[5]); cswap_idx(bj[2], bj[6]);
-        cswap_idx(bj[1], bj[4]); cswap_idx(bj[3], bj[6]);
-        cswap_idx(bj[2], bj[4]); cswap_idx(bj[3], bj[5]);
-        cswap_idx(bj[3], bj[4]);
-        // bj[0..7] sorted; merge the sorted pair (8,9) in by insertion
-#pragma unroll
-        for (int e = 8; e < DRP_K; ++e)
-#pragma unroll
-            for (int q = e; q > 0; --q) cswap_idx(bj[q - 1], bj[q]);
-        int16_t* out = nbr_idx + ((size_t)b * N + i) * DRP_K;
-#pragma unroll
-        for (int q = 0; q < DRP_K; ++q) out[q] = (q < cnt) ? (int16_t)bj[q] : (int16_t)-1;
-        nbr_cnt[(size_t)b * N + i] = (uint8_t)cnt;
     }
+    for (; j < N; ++j) {
+        const float4 pj = p4[j];
+        const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
+#pragma unroll
+        for (int q = DRP_K - 1; q > 0; --q) best[q] = __builtin_amdgcn_fmed3f(d, best[q - 1], best[q]);
+        best[0] = fminf(best[0], d);
+    }
+    const float kth = best[DRP_K - 1];
+    int16_t* out = nbr_idx + ((size_t)b * N + i) * DRP_K;
+    int cnt = 0;
+    for (j = 0; j + 4 <= N; j += 4) {
+        const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
+        const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
+                             pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (d4[u] <= kth && __fsub_rn(d4[u], thr) < 0.0f && cnt < DRP_K) out[cnt++] = (int16_t)(j + u);
+    }
+    for (; j < N; ++j) {
+        const float4 pj = p4[j];
+        const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
+        if (d <= kth && __fsub_rn(d, thr) < 0.0f && cnt < DRP_K) out[cnt++] = (int16_t)j;
+    }
+    nbr_cnt[(size_t)b * N + i] = (uint8_t)cnt;
+    for (int q = cnt; q < DRP_K; ++q) out[q] = -1;
 }
