@@ -206,9 +206,14 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     const long edge_tiles = (long)B * ((N * DRP_K + 31) / 32);
     {
         ProbeScope ps(c, KC_NODE_ENCODE);
-        hipLaunchKernelGGL(km_node_encode, dim3(mfma_grid(c, node_tiles)), blk, KM_NODE_LDS, st, mw,
-                           ptr<float>(c->s_delta), a.attr, a.attr_mod, a.dens, a.dens_mod, N, B,
-                           ptr<float>(c->eff), ptr<float>(c->c_node), ptr<float>(c->proj));
+        if (c->engine == DRP_ENGINE_FUSED)
+            hipLaunchKernelGGL(km_node_encode_split, dim3(mfma_grid(c, node_tiles)), blk, KM_NODE_SPLIT_LDS, st,
+                               ptr<uint16_t>(c->w_split6), mw, ptr<float>(c->s_delta), a.attr, a.attr_mod, a.dens,
+                               a.dens_mod, N, B, ptr<float>(c->eff), ptr<float>(c->c_node), ptr<float>(c->proj));
+        else
+            hipLaunchKernelGGL(km_node_encode, dim3(mfma_grid(c, node_tiles)), blk, KM_NODE_LDS, st, mw,
+                               ptr<float>(c->s_delta), a.attr, a.attr_mod, a.dens, a.dens_mod, N, B,
+                               ptr<float>(c->eff), ptr<float>(c->c_node), ptr<float>(c->proj));
     }
     // split engine, small enough samples: the relation encoder is recomputed inside the
     // aggregate of every propagation step and c_edge is never materialised
@@ -448,6 +453,7 @@ int drp_create(int device, drp_ctx** out) {
     if (hipFuncSetAttribute((const void*)km_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_node_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_edge_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_SPLIT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_node_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_SPLIT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||

@@ -357,7 +357,10 @@ enum {                        // units of bf16x8; 64x64: [part 3][ob 2][s 4][lan
     S6_RPR = S6_AGG + 1536,
     S6_RPS = S6_RPR + 1536,
     S6_PR0 = S6_RPS + 1536,
-    S6_TOTAL = S6_PR0 + 1536
+    S6_PE2 = S6_PR0 + 1536,
+    S6_PPE = S6_PE2 + 1536,
+    S6_PE0 = S6_PPE + 1536,      // first layer, one k-step: [part 3][ob 2][lane 64]
+    S6_TOTAL = S6_PE0 + 384
 };
 
 inline void pack_split6(const float* w, std::vector<uint16_t>& out) {
@@ -380,6 +383,22 @@ inline void pack_split6(const float* w, std::vector<uint16_t>& out) {
     P(S6_RPR, W_RP_W, 193, 64);
     P(S6_RPS, W_RP_W, 193, 128);
     P(S6_PR0, W_PR0_W, 64, 0);
+    P(S6_PE2, W_PE2_W, 64, 0);
+    P(S6_PPE, W_PP_W, 129, 0);
+    // particle encoder layer 0: inputs [sdx, sdy, sdz, a, d, 1(bias), 0, 0], k = 8h + jj, h = 1 unused
+    for (int ob = 0; ob < 2; ++ob)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int jj = 0; jj < 8; ++jj) {
+                const int i = lane & 31, h = lane >> 5, o = 32 * ob + i;
+                float v = 0.0f;
+                if (h == 0 && jj < 5) v = w[W_PE0_W + o * 5 + jj];
+                else if (h == 0 && jj == 5) v = w[W_PE0_B + o];
+                for (int part = 0; part < 3; ++part) {
+                    const uint16_t q = host_bf16_rne(v);
+                    out[((size_t)S6_PE0 + (part * 2 + ob) * 64 + lane) * 8 + jj] = q;
+                    v -= host_bf16_to_f32(q);
+                }
+            }
 }
 
 struct FragB6 {
@@ -599,3 +618,84 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     }
 }
 #define KM_PROP_LDS(LAST) ((size_t)(S_TOTAL * 4 + ((LAST) ? 2 : 3) * 1536 * 4 + 256 + 260 + 4) * sizeof(float))
+
+
+// ---- particle encoder, node constant and first projections on the 6-term split --------------
+// Same contract as km_node_encode (k_mlp_mfma.h); outputs go straight from the accumulator
+// layout to their rows (no LDS transposition tiles: LDS holds the 126 KB of packed weights).
+__device__ __forceinline__ void mfma_layer8_split6(const bf16x8* __restrict__ wp, const float (&x)[8], int h, Frag& acc, int lane) {
+    bf16x8 b0, b1, b2;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const float v = (h == 0) ? x[jj] : 0.0f;
+        const __bf16 hi = (__bf16)v;
+        const float r1 = v - (float)hi;
+        const __bf16 mid = (__bf16)r1;
+        b0[jj] = hi;
+        b1[jj] = mid;
+        b2[jj] = (__bf16)(r1 - (float)mid);
+    }
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+        const bf16x8 w0 = wp[(0 * 2 + ob) * 64 + lane];
+        const bf16x8 w1 = wp[(1 * 2 + ob) * 64 + lane];
+        const bf16x8 w2 = wp[(2 * 2 + ob) * 64 + lane];
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b0, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b2, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b1, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b0, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b1, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b0, acc.v[ob], 0, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(64 * MFMA_WAVES)
+km_node_encode_split(const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
+                     const float* __restrict__ s_delta, const float* __restrict__ attr, int attr_mod,
+                     const float* __restrict__ dens, int dens_mod, int N, int B,
+                     float* __restrict__ eff, float* __restrict__ c_node, float* __restrict__ proj) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w6_f = lds;                         // PE2 | PPE | RPR | RPS (4 x 1536 units) | PE0 (384)
+    float* rows = w6_f + (4 * 1536 + 384) * 4; // b_pe2, b_pp, wd_pp
+    lds_fill(w6_f, reinterpret_cast<const float*>(sw6) + S6_PE2 * 4, 2 * 1536 * 4);
+    lds_fill(w6_f + 2 * 1536 * 4, reinterpret_cast<const float*>(sw6) + S6_RPR * 4, 2 * 1536 * 4);
+    lds_fill(w6_f + 4 * 1536 * 4, reinterpret_cast<const float*>(sw6) + S6_PE0 * 4, 384 * 4);
+    lds_fill(rows, mw + R_PE2_B, 192);
+    __syncthreads();
+    const bf16x8* w6 = reinterpret_cast<const bf16x8*>(w6_f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tps = (N + 31) >> 5;
+    const long ntiles = (long)B * tps;
+    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+        asm volatile("" ::: "memory");      // keep the packed-weight reads inside the loop (see km_prop)
+        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
+        const int i = min(t * 32 + j, N - 1);
+        const bool live = (t * 32 + j) < N;
+        const size_t row = (size_t)b * N + i;
+        const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+        const float* sd = s_delta + row * 3;
+        float x[8] = {sd[0], sd[1], sd[2], attr[(size_t)(b % attr_mod) * N + i], d, 1.0f, 0.0f, 0.0f};
+        Frag a, pe, c;
+        FragB6 f6;
+        frag_zero(a);
+        mfma_layer8_split6(w6 + 4 * 1536, x, h, a, lane);
+        frag_relu(a);
+        split_frag6(a, f6);
+        frag_from_row(rows + 0, h, pe);
+        mfma_layer64_split6(w6, f6, pe, lane);
+        frag_relu(pe);
+        if (live) frag_to_row(eff + row * 64, h, pe);
+        split_frag6(pe, f6);
+        frag_bias_dens(rows + 64, rows + 128, d, h, c);
+        mfma_layer64_split6(w6 + 1536, f6, c, lane);
+        if (live) frag_to_row(c_node + row * 64, h, c);
+        frag_zero(c);
+        mfma_layer64_split6(w6 + 2 * 1536, f6, c, lane);
+        if (live) frag_to_row(proj + row * 128, h, c);
+        frag_zero(c);
+        mfma_layer64_split6(w6 + 3 * 1536, f6, c, lane);
+        if (live) frag_to_row(proj + row * 128 + 64, h, c);
+    }
+}
+#define KM_NODE_SPLIT_LDS ((size_t)((4 * 1536 + 384) * 4 + 192) * sizeof(float))
