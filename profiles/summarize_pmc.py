@@ -18,7 +18,7 @@ import sys
 
 CLASS = {'k_graph': 'graph', 'k_node_encode': 'node_encode', 'k_edge_encode': 'edge_encode',
          'k_project': 'project', 'k_aggregate': 'aggregate', 'k_update': 'update',
-         'k_predict': 'predict', 'km_node_encode': 'node_encode', 'km_edge_encode': 'edge_encode',
+         'k_predict': 'predict', 'km_node_encode': 'node_encode', 'km_node_encode_split': 'node_encode', 'km_edge_encode': 'edge_encode',
          'km_update<false>': 'update', 'km_update<true>': 'predict', 'k_reward': 'reward',
          'km_prop<false>': 'prop', 'km_prop<true>': 'prop_last'}
 
