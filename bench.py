@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--engine', default=os.environ.get('DRP_ENGINE', 'auto'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=64)
+    ap.add_argument('--no-alt', action='store_true', help='skip the fp32-MFMA engine comparison run')
     return ap.parse_args()
 
 
@@ -174,6 +175,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the same K steps on the pure-fp32 MFMA engine (bit-for-bit an fp32 fma chain), for reference
+    alt = None
+    if engine != 'mfma' and not args.no_alt:
+        eng.set_engine(_lib.ENGINES['mfma'])
+        for _ in range(2):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dta = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dta], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dta = float(t.item())
+        alt = {'engine': 'mfma', 'dtype': 'f32', 'value': world * ns * N * H * args.steps / dta,
+               'ms_per_step': dta / args.steps * 1e3}
+        eng.set_engine(_lib.ENGINES[engine])
     if rank == 0:
         total = world * ns * N * H * args.steps
         avg_s = dom_ms / max(dom_n, 1) * 1e-3
@@ -228,6 +248,7 @@ def main():
             'roofline': roof,
             'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items()},
         }
+        out['alt_engine'] = alt
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam)
         else:
