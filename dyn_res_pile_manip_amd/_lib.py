@@ -72,6 +72,11 @@ SIGNATURES = {
     'drp_mpc_update_device': (ctypes.c_int, [ctypes.c_void_p]),
     'drp_mpc_get': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                    c_double_p]),
+    'drp_gd_begin': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
+                                    c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_float_p, c_float_p]),
+    'drp_gd_grad': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p]),
+    'drp_gd_step': (ctypes.c_int, [ctypes.c_void_p, c_float_p]),
+    'drp_gd_get': (ctypes.c_int, [ctypes.c_void_p, c_float_p]),
     'drp_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'drp_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'drp_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),

@@ -19,6 +19,7 @@
 #include "k_mlp_valu.h"
 #include "k_mppi.h"
 #include "k_reward.h"
+#include "k_backward.h"
 #ifdef DRP_HAVE_MFMA
 #include "k_mlp_mfma.h"
 #include "k_mlp_split.h"
@@ -67,6 +68,13 @@ struct drp_ctx {
     DevBuf nominal, noise, partials, gathered, stats;
     int n_ranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+
+    // gradient-descent planner state
+    bool gd_on = false;
+    int gd_nb = 0, gd_N = 0, gd_B = 0, gd_H = 0, gd_iter = 0;
+    double gd_lr = 0.05;
+    float gd_lo[4] = {0, 0, 0, 0}, gd_hi[4] = {0, 0, 0, 0};
+    DevBuf eff_hist, proj_hist, g_eff, g_cnode, g_agg, g_proj, g_state, g_sdelta, g_act, adam_m, adam_v;
 
     // last shapes (for debug fetch)
     int lastB = 0, lastN = 0, lastH = 0;
@@ -172,6 +180,8 @@ struct StepArgs {
     bool build_graph;                                         // false: nbr lists already in workspace
     float* s_out; size_t out_stride;
     int B, N;
+    float* eff_hist = nullptr;      // [4][B*N*64]: effect after the encoder and after every propagation step
+    float* proj_hist = nullptr;     // [3][B*N*128]: node projections used by every propagation step
 };
 
 int graph_chunks(int N) { return (N + GRAPH_THREADS - 1) / GRAPH_THREADS; }
@@ -215,6 +225,17 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                                ptr<float>(c->s_delta), a.attr, a.attr_mod, a.dens, a.dens_mod, N, B,
                                ptr<float>(c->eff), ptr<float>(c->c_node), ptr<float>(c->proj));
     }
+    const size_t bn64 = (size_t)B * N * 64;
+    auto save_hist = [&](int slot) -> int {
+        if (a.eff_hist)
+            HIPCHK(c, hipMemcpyAsync(a.eff_hist + (size_t)slot * bn64, c->eff.p, bn64 * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st));
+        if (a.proj_hist && slot < DRP_PSTEP)
+            HIPCHK(c, hipMemcpyAsync(a.proj_hist + (size_t)slot * bn64 * 2, c->proj.p, bn64 * 2 * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st));
+        return DRP_OK;
+    };
+    CHK(save_hist(0));
     // split engine, small enough samples: the relation encoder is recomputed inside the
     // aggregate of every propagation step and c_edge is never materialised
     const bool fused = (c->engine == DRP_ENGINE_FUSED);
@@ -269,6 +290,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             hipLaunchKernelGGL(km_update<true>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
                                ptr<float>(c->agg), ptr<float>(c->c_node), ptr<float>(c->eff), N, B,
                                ptr<float>(c->proj), a.s_prev, a.prev_mod, a.prev_stride, a.s_out, a.out_stride);
+        CHK(save_hist(p + 1));
     }
     return DRP_OK;
 }
@@ -473,7 +495,8 @@ void drp_destroy(drp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    DevBuf* bufs[] = {&c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
+    DevBuf* bufs[] = {&c->eff_hist, &c->proj_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
+                      &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
                       &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats};
@@ -814,6 +837,141 @@ int drp_mpc_get(drp_ctx* c, float* actions, float* rewards, float* rewards_all, 
     if (rewards_all) CHK(d2h(c, rewards_all, c->rewards.p, (size_t)B * H * sizeof(float)));
     if (states) CHK(d2h(c, states, c->states.p, (size_t)B * H * N * 3 * sizeof(float)));
     if (nominal) CHK(d2h(c, nominal, c->nominal.p, (size_t)H * 4 * sizeof(double)));
+    return drp_sync(c);
+}
+
+// ---- gradient-descent planner (row f1), horizon 1 -------------------------------------------
+namespace {
+int gd_forward_backward(drp_ctx* c) {
+    const int nb = c->gd_nb, N = c->gd_N, B = c->gd_B;
+    const size_t bn = (size_t)B * N;
+    hipStream_t st = c->stream;
+    // forward on the fp32 MFMA pipeline, keeping what the backward pass needs
+    const int saved_engine = c->engine;
+    c->engine = DRP_ENGINE_MFMA;
+    StepArgs a{};
+    a.s_prev = ptr<float>(c->s_in); a.prev_mod = nb; a.prev_stride = (size_t)N * 3;
+    a.attr = ptr<float>(c->attr); a.attr_mod = nb;
+    a.dens = ptr<float>(c->dens); a.dens_mod = nb;
+    a.actions = ptr<float>(c->actions); a.act_stride = 4;
+    a.build_graph = true;
+    a.s_out = ptr<float>(c->states); a.out_stride = (size_t)N * 3;
+    a.B = B; a.N = N;
+    a.eff_hist = ptr<float>(c->eff_hist);
+    a.proj_hist = ptr<float>(c->proj_hist);
+    int rc = run_step(c, a);
+    c->engine = saved_engine;
+    CHK(rc);
+    CHK(run_reward(c, ptr<float>(c->states), (size_t)N * 3, B, N, 1, ptr<float>(c->rewards)));
+    // backward
+    const float* vw = ptr<float>(c->w_valu);
+    const float* wraw = ptr<float>(c->w_raw);
+    float* eh = ptr<float>(c->eff_hist);
+    float* ph = ptr<float>(c->proj_hist);
+    hipLaunchKernelGGL(kb_reward, dim3(B), dim3(256), 4 * N * sizeof(float), st, ptr<float>(c->states), (size_t)N * 3,
+                       N, ptr<float>(c->goal_field), c->goal_h, c->goal_w, ptr<float>(c->goal_coor), c->goal_m, c->cam,
+                       1, ptr<float>(c->g_state), (size_t)N * 3);
+    hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eh + 3 * bn * 64, ptr<float>(c->g_state),
+                       (size_t)N * 3, N, ptr<float>(c->g_eff));
+    for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+        hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eh + (size_t)(p + 1) * bn * 64,
+                           ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N,
+                           ptr<float>(c->g_agg));
+        HIPCHK(c, hipMemsetAsync(c->g_proj.p, 0, bn * 128 * sizeof(float), st));
+        hipLaunchKernelGGL(kb_edges, dim3(B), dim3(256), 0, st, ptr<float>(c->c_edge), ph + (size_t)p * bn * 128,
+                           ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), ptr<float>(c->g_agg), N,
+                           ptr<float>(c->g_proj));
+        hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff));
+    }
+    hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw, ptr<float>(c->s_delta), ptr<float>(c->attr),
+                       nb, ptr<float>(c->dens), nb, eh, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N,
+                       ptr<float>(c->g_sdelta));
+    hipLaunchKernelGGL(kb_sdelta, dim3(B), dim3(256), 0, st, ptr<float>(c->s_in), nb, (size_t)N * 3,
+                       ptr<float>(c->actions), (size_t)4, ptr<float>(c->g_sdelta), N, c->cam, ptr<float>(c->g_act),
+                       (size_t)4);
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+}  // namespace
+
+int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* dens, int nb, int N,
+                 const float* actions, int B, int H, double lr, const float act_lo[4], const float act_hi[4]) {
+    CHK(need(c, true, true, true));
+    CHK(check_bn(c, B, N));
+    if (!s0 || !attr || !dens || !actions || !act_lo || !act_hi) return fail(c, DRP_EINVAL, "null argument");
+    if (H != 1)
+        return fail(c, DRP_EINVAL, "the reverse-mode kernels cover horizon 1 (the reference's demo setting); H=%d", H);
+    if (nb <= 0 || B % nb != 0) return fail(c, DRP_EINVAL, "B must be a multiple of n_batch");
+#ifndef DRP_HAVE_MFMA
+    return fail(c, DRP_ESTATE, "built without the MFMA engine");
+#endif
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bn = (size_t)B * N;
+    CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
+    CHK(h2d(c, c->attr, attr, (size_t)nb * N * sizeof(float)));
+    CHK(h2d(c, c->dens, dens, (size_t)nb * sizeof(float)));
+    CHK(h2d(c, c->actions, actions, (size_t)B * 4 * sizeof(float)));
+    CHK(ensure_step_ws(c, B, N));
+    CHK(ensure(c, c->states, bn * 3 * sizeof(float)));
+    CHK(ensure(c, c->rewards, (size_t)B * sizeof(float)));
+    CHK(ensure(c, c->eff_hist, 4 * bn * 64 * sizeof(float)));
+    CHK(ensure(c, c->proj_hist, 3 * bn * 128 * sizeof(float)));
+    CHK(ensure(c, c->g_eff, bn * 64 * sizeof(float)));
+    CHK(ensure(c, c->g_cnode, bn * 64 * sizeof(float)));
+    CHK(ensure(c, c->g_agg, bn * 64 * sizeof(float)));
+    CHK(ensure(c, c->g_proj, bn * 128 * sizeof(float)));
+    CHK(ensure(c, c->g_state, bn * 3 * sizeof(float)));
+    CHK(ensure(c, c->g_sdelta, bn * 3 * sizeof(float)));
+    CHK(ensure(c, c->g_act, (size_t)B * 4 * sizeof(float)));
+    CHK(ensure(c, c->adam_m, (size_t)B * 4 * sizeof(float)));
+    CHK(ensure(c, c->adam_v, (size_t)B * 4 * sizeof(float)));
+    HIPCHK(c, hipMemsetAsync(c->adam_m.p, 0, (size_t)B * 4 * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->adam_v.p, 0, (size_t)B * 4 * sizeof(float), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->gd_nb = nb; c->gd_N = N; c->gd_B = B; c->gd_H = H; c->gd_iter = 0; c->gd_lr = lr;
+    memcpy(c->gd_lo, act_lo, 4 * sizeof(float));
+    memcpy(c->gd_hi, act_hi, 4 * sizeof(float));
+    c->lastH = 1;
+    c->gd_on = true;
+    c->mpc_on = false;
+    return DRP_OK;
+}
+
+int drp_gd_grad(drp_ctx* c, float* rewards_out, float* grad_act_out, float* grad_state_out) {
+    if (!c || !c->gd_on) return fail(c, DRP_ESTATE, "drp_gd_begin not called");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(gd_forward_backward(c));
+    const size_t bn = (size_t)c->gd_B * c->gd_N;
+    if (rewards_out) CHK(d2h(c, rewards_out, c->rewards.p, (size_t)c->gd_B * sizeof(float)));
+    if (grad_act_out) CHK(d2h(c, grad_act_out, c->g_act.p, (size_t)c->gd_B * 4 * sizeof(float)));
+    if (grad_state_out) CHK(d2h(c, grad_state_out, c->g_state.p, bn * 3 * sizeof(float)));
+    return drp_sync(c);
+}
+
+int drp_gd_step(drp_ctx* c, float* rewards_out) {
+    if (!c || !c->gd_on) return fail(c, DRP_ESTATE, "drp_gd_begin not called");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(gd_forward_backward(c));
+    c->gd_iter += 1;
+    // torch.optim.Adam: step_size = lr / (1 - beta1^t), denom = sqrt(v) / sqrt(1 - beta2^t) + eps
+    const double bc1 = 1.0 - pow(0.9, (double)c->gd_iter), bc2 = 1.0 - pow(0.999, (double)c->gd_iter);
+    const int n = c->gd_B * 4;
+    hipLaunchKernelGGL(k_adam, dim3((n + 255) / 256), dim3(256), 0, c->stream, ptr<float>(c->actions),
+                       ptr<float>(c->g_act), ptr<float>(c->adam_m), ptr<float>(c->adam_v), n, (float)(c->gd_lr / bc1),
+                       (float)sqrt(bc2), make_float4(c->gd_lo[0], c->gd_lo[1], c->gd_lo[2], c->gd_lo[3]),
+                       make_float4(c->gd_hi[0], c->gd_hi[1], c->gd_hi[2], c->gd_hi[3]));
+    HIPCHK(c, hipGetLastError());
+    if (rewards_out) {
+        CHK(d2h(c, rewards_out, c->rewards.p, (size_t)c->gd_B * sizeof(float)));
+        return drp_sync(c);
+    }
+    return DRP_OK;
+}
+
+int drp_gd_get(drp_ctx* c, float* actions_out) {
+    if (!c || !c->gd_on) return fail(c, DRP_ESTATE, "drp_gd_begin not called");
+    if (!actions_out) return fail(c, DRP_EINVAL, "null buffer");
+    CHK(d2h(c, actions_out, c->actions.p, (size_t)c->gd_B * 4 * sizeof(float)));
     return drp_sync(c);
 }
 

@@ -1,0 +1,384 @@
+// Reverse mode of the path for the gradient-descent planner:
+//   loss = -sum_b reward_b    planners.py:743   ->   d loss / d pushes
+// through config_reward_ptcl (env/flex_rewards.py:189-214), PropModuleDiffDen.forward
+// (model/gnn_dyn.py:147-198; the graph masks are constants: autograd gives zero through
+// topk / the radius test) and gen_s_delta (planners.py:211-257; the hard mask is constant,
+// the soft mask and the projections are differentiated, the direction depends on the push).
+//
+// This round: horizon 1 (the reference's demo setting, config/mpc/config.yaml:38), so the
+// particle positions are constants and only the impulse path s_delta -> particle encoder ->
+// propagation -> predictor carries gradient.  Correctness-first fp32 VALU kernels over the
+// activations the fp32 MFMA engine saved in HBM (eff after every step, proj per step, c_edge,
+// c_node); ReLU masks are recomputed from them.  The one scatter of the backward pass
+// (gradient of the gathered sender rows) uses fp32 global atomics, 256 B per wave
+// instruction segment.
+#pragma once
+#include "drp_common.h"
+#include "k_graph.h"
+#include "k_mlp_valu.h"
+
+// acc[r] += sum_k x[r][k] * W[k*ld + col0 + lane]   (W in torch [out][in] layout read as [k][lane]:
+// the transposed product g_in = W^T g_out)
+template <int IN, int R>
+__device__ __forceinline__ void dense_bcast_ld(const float* __restrict__ W, int ld, int col0, const float (&x)[R],
+                                               float (&acc)[R], int lane) {
+#pragma unroll 8
+    for (int k = 0; k < IN; ++k) {
+        const float w = W[k * ld + col0 + lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = fmaf(bcast_lane(x[r], k), w, acc[r]);
+    }
+}
+
+#define KB_R 4
+
+// ---- reward backward: g_state[b,n,:] = d(-reward_b... ) see below ------------------------------
+// loss = -sum_b reward_b, reward_b = -(r1 + r2)/N  =>  d loss / d r1 = d loss / d r2 = 1/N.
+//   r1 = sum_n bilinear(G, pix_n)      -> grid_sample's gradient w.r.t. the grid (zero where the
+//                                          border clamp is active, as torch does)
+//   r2 = sum_m min_n |g_m - pix_n|     -> -(g_m - pix_n*) / dist to the arg-min particle n*
+//   pix = (x fx / z + cx, y fy / z + cy)
+// one workgroup per state row; gradient accumulated in LDS, then written.
+__global__ void __launch_bounds__(256)
+kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float* __restrict__ G, int Hh, int Ww,
+          const float* __restrict__ goal_coor, int M, DrpCam cam, int normalize, float* __restrict__ g_state,
+          size_t g_stride) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* px = lds;
+    float* py = lds + N;
+    float* gx = lds + 2 * N;     // d loss / d pixel x
+    float* gy = lds + 3 * N;
+    const float* s = state + (size_t)blockIdx.x * row_stride;
+    const float scale = normalize ? 1.0f / (float)N : 1.0f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float x = s[n * 3 + 0], y = s[n * 3 + 1], z = s[n * 3 + 2];
+        const float u = x * cam.fx / z + cam.cx, v = y * cam.fy / z + cam.cy;
+        px[n] = u;
+        py[n] = v;
+        // bilinear sample gradient (align_corners = False, padding 'border')
+        const float nx = u / (float)Hh * 2.0f - 1.0f, ny = v / (float)Hh * 2.0f - 1.0f;
+        float ix = ((nx + 1.0f) * (float)Ww - 1.0f) / 2.0f, iy = ((ny + 1.0f) * (float)Hh - 1.0f) / 2.0f;
+        // clip_coordinates_set_grad: gradient multiplier 0 outside [0, size-1]
+        float mx = (float)Ww / (float)Hh, my = 1.0f;     // d ix / d u, d iy / d v
+        if (ix <= 0.0f) { ix = 0.0f; mx = 0.0f; } else if (ix >= (float)(Ww - 1)) { ix = (float)(Ww - 1); mx = 0.0f; }
+        if (iy <= 0.0f) { iy = 0.0f; my = 0.0f; } else if (iy >= (float)(Hh - 1)) { iy = (float)(Hh - 1); my = 0.0f; }
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float tx = ix - x0f, ty = iy - y0f;
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const float g00 = G[(size_t)y0 * Ww + x0];
+        const float g01 = (x1 < Ww) ? G[(size_t)y0 * Ww + x1] : 0.0f;
+        const float g10 = (y1 < Hh) ? G[(size_t)y1 * Ww + x0] : 0.0f;
+        const float g11 = (x1 < Ww && y1 < Hh) ? G[(size_t)y1 * Ww + x1] : 0.0f;
+        const float dgx = (g01 - g00) * (1.0f - ty) + (g11 - g10) * ty;
+        const float dgy = (g10 - g00) * (1.0f - tx) + (g11 - g01) * tx;
+        gx[n] = scale * dgx * mx;
+        gy[n] = scale * dgy * my;
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        const float qx = goal_coor[m * 2 + 0], qy = goal_coor[m * 2 + 1];
+        float best = __builtin_inff();
+        int arg = 0;
+        for (int n = 0; n < N; ++n) {
+            const float dx = qx - px[n], dy = qy - py[n];
+            const float d2 = dx * dx + dy * dy;
+            if (d2 < best) { best = d2; arg = n; }       // first minimum, as torch.min
+        }
+        const float dist = sqrtf(best);
+        // d |q - p| / d p = -(q - p) / dist
+        atomicAdd(&gx[arg], -scale * (qx - px[arg]) / dist);
+        atomicAdd(&gy[arg], -scale * (qy - py[arg]) / dist);
+    }
+    __syncthreads();
+    float* g = g_state + (size_t)blockIdx.x * g_stride;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float x = s[n * 3 + 0], y = s[n * 3 + 1], z = s[n * 3 + 2];
+        g[n * 3 + 0] = gx[n] * cam.fx / z;
+        g[n * 3 + 1] = gy[n] * cam.fy / z;
+        g[n * 3 + 2] = -(gx[n] * x * cam.fx + gy[n] * y * cam.fy) / (z * z);
+    }
+}
+
+// ---- predictor backward: g_eff = W0^T ((W1^T g_out) . [W0 eff + b0 > 0]) ------------------------
+__global__ void __launch_bounds__(256)
+kb_predict(const float* __restrict__ vw, const float* __restrict__ wraw, const float* __restrict__ eff,
+           const float* __restrict__ g_out, size_t g_stride, int N, float* __restrict__ g_eff) {
+    __shared__ float w0t[4096], w0[4096];
+    lds_copy(w0t, vw + V_PR0_T, 4096);
+    lds_copy(w0, wraw + W_PR0_W, 4096);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const float b0 = vw[V_PR0_B + lane];
+    const float w1x = vw[V_PR1_W + lane], w1y = vw[V_PR1_W + 64 + lane], w1z = vw[V_PR1_W + 128 + lane];
+    const float* go = g_out + (size_t)b * g_stride;
+    for (int base = wave * KB_R; base < N; base += nwave * KB_R) {
+        float x[KB_R], h[KB_R], gh[KB_R], ge[KB_R];
+#pragma unroll
+        for (int r = 0; r < KB_R; ++r) {
+            x[r] = eff[((size_t)b * N + min(base + r, N - 1)) * 64 + lane];
+            h[r] = b0;
+        }
+        dense_bcast<64, KB_R>(w0t, x, h, lane);
+#pragma unroll
+        for (int r = 0; r < KB_R; ++r) {
+            const int i = min(base + r, N - 1);
+            const float g = w1x * go[i * 3 + 0] + w1y * go[i * 3 + 1] + w1z * go[i * 3 + 2];
+            gh[r] = (h[r] > 0.0f) ? g : 0.0f;
+            ge[r] = 0.0f;
+        }
+        dense_bcast_ld<64, KB_R>(w0, 64, 0, gh, ge, lane);
+#pragma unroll
+        for (int r = 0; r < KB_R; ++r)
+            if (base + r < N) g_eff[((size_t)b * N + base + r) * 64 + lane] = ge[r];
+    }
+}
+
+// ---- node update backward: g_z = g_eff . [eff_next > 0]; g_cnode += g_z; g_agg = W_agg^T g_z;
+//      g_eff <- g_z (the residual's share of the gradient w.r.t. the previous effect)
+__global__ void __launch_bounds__(256)
+kb_update(const float* __restrict__ wraw, const float* __restrict__ eff_next, float* __restrict__ g_eff,
+          float* __restrict__ g_cnode, int first, int N, float* __restrict__ g_agg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const float* wpp = wraw + W_PP_W;
+    for (int base = wave * KB_R; base < N; base += nwave * KB_R) {
+        float gz[KB_R], ga[KB_R];
+#pragma unroll
+        for (int r = 0; r < KB_R; ++r) {
+            const size_t row = (size_t)b * N + min(base + r, N - 1);
+            const float g = g_eff[row * 64 + lane];
+            gz[r] = (eff_next[row * 64 + lane] > 0.0f) ? g : 0.0f;
+            ga[r] = 0.0f;
+        }
+        dense_bcast_ld<64, KB_R>(wpp, 129, 64, gz, ga, lane);
+#pragma unroll
+        for (int r = 0; r < KB_R; ++r) {
+            if (base + r >= N) continue;
+            const size_t row = (size_t)b * N + base + r;
+            g_eff[row * 64 + lane] = gz[r];
+            g_cnode[row * 64 + lane] = first ? gz[r] : g_cnode[row * 64 + lane] + gz[r];
+            g_agg[row * 64 + lane] = ga[r];
+        }
+    }
+}
+
+// ---- aggregate backward: g_u = g_agg[i] . [c_edge + P_r[i] + P_s[j] > 0];
+//      g_proj[i][0:64] = sum_k g_u (receiver term), g_proj[j][64:128] += g_u (sender term, atomics)
+// same 16-lanes-per-receiver layout as k_aggregate; g_proj must be zeroed before the launch.
+__global__ void __launch_bounds__(256)
+kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const int16_t* __restrict__ nbr_idx,
+         const uint8_t* __restrict__ nbr_cnt, const float* __restrict__ g_agg, int N, float* __restrict__ g_proj) {
+    const int b = blockIdx.x;
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const float4* ce = reinterpret_cast<const float4*>(c_edge) + (size_t)b * N * DRP_K * 16;
+    const float4* pj = reinterpret_cast<const float4*>(proj) + (size_t)b * N * 32;
+    const float4* ga = reinterpret_cast<const float4*>(g_agg) + (size_t)b * N * 16;
+    float* gp = g_proj + (size_t)b * N * 128;
+    const int16_t* nb = nbr_idx + (size_t)b * N * DRP_K;
+    const uint8_t* nc = nbr_cnt + (size_t)b * N;
+    for (int i = g; i < N; i += 16) {
+        const int cnt = nc[i];
+        const float4 pr = pj[(size_t)i * 32 + q];
+        const float4 gi = ga[(size_t)i * 16 + q];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < cnt; ++k) {
+            const int j = nb[i * DRP_K + k];
+            const float4 c = ce[((size_t)i * DRP_K + k) * 16 + q];
+            const float4 ps = pj[(size_t)j * 32 + 16 + q];
+            float4 gu;
+            gu.x = ((c.x + pr.x) + ps.x > 0.0f) ? gi.x : 0.0f;
+            gu.y = ((c.y + pr.y) + ps.y > 0.0f) ? gi.y : 0.0f;
+            gu.z = ((c.z + pr.z) + ps.z > 0.0f) ? gi.z : 0.0f;
+            gu.w = ((c.w + pr.w) + ps.w > 0.0f) ? gi.w : 0.0f;
+            acc.x += gu.x; acc.y += gu.y; acc.z += gu.z; acc.w += gu.w;
+            float* dst = gp + (size_t)j * 128 + 64 + q * 4;
+            atomicAdd(dst + 0, gu.x);
+            atomicAdd(dst + 1, gu.y);
+            atomicAdd(dst + 2, gu.z);
+            atomicAdd(dst + 3, gu.w);
+        }
+        *reinterpret_cast<float4*>(gp + (size_t)i * 128 + q * 4) = acc;
+    }
+}
+
+// ---- projection backward: g_eff += W_r^T g_proj[:, 0:64] + W_s^T g_proj[:, 64:128] -------------
+__global__ void __launch_bounds__(256)
+kb_project(const float* __restrict__ wraw, const float* __restrict__ g_proj, int N, float* __restrict__ g_eff) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const float* wrp = wraw + W_RP_W;
+    for (int base = wave * KB_R; base < N; base += nwave * KB_R) {
+        float gr[KB_R], gs[KB_R], ge[KB_R];
+#pragma unroll
+        for (int r = 0; r < KB_R; ++r) {
+            const size_t row = (size_t)b * N + min(base + r, N - 1);
+            gr[r] = g_proj[row * 128 + lane];
+            gs[r] = g_proj[row * 128 + 64 + lane];
+            ge[r] = g_eff[row * 64 + lane];
+        }
+        dense_bcast_ld<64, KB_R>(wrp, 193, 64, gr, ge, lane);
+        dense_bcast_ld<64, KB_R>(wrp, 193, 128, gs, ge, lane);
+#pragma unroll
+        for (int r = 0; r < KB_R; ++r)
+            if (base + r < N) g_eff[((size_t)b * N + base + r) * 64 + lane] = ge[r];
+    }
+}
+
+// ---- particle encoder backward: g_pe = g_eff0 + W_pe^T g_cnode; through relu(W2 relu(W1 x + b1) + b2)
+//      to the three impulse inputs: g_s_delta[b,n,0:3]
+__global__ void __launch_bounds__(256)
+kb_node_encode(const float* __restrict__ vw, const float* __restrict__ wraw, const float* __restrict__ s_delta,
+               const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+               const float* __restrict__ pe, const float* __restrict__ g_eff0, const float* __restrict__ g_cnode,
+               int N, float* __restrict__ g_sdelta) {
+    __shared__ float w0t[5 * 64];
+    lds_copy(w0t, vw + V_PE0_T, 5 * 64);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+    const float b0 = vw[V_PE0_B + lane];
+    const float* sd = s_delta + (size_t)b * N * 3;
+    const float* at = attr + (size_t)(b % attr_mod) * N;
+    const float w1x = wraw[W_PE0_W + lane * 5 + 0], w1y = wraw[W_PE0_W + lane * 5 + 1], w1z = wraw[W_PE0_W + lane * 5 + 2];
+    for (int base = wave * KB_R; base < N; base += nwave * KB_R) {
+        float x[KB_R], h1[KB_R], gc[KB_R], gpe[KB_R], gh[KB_R];
+#pragma unroll
+        for (int r = 0; r < KB_R; ++r) {
+            const int i = min(base + r, N - 1);
+            const size_t row = (size_t)b * N + i;
+            float v = 0.0f;
+            if (lane < 3) v = sd[i * 3 + lane];
+            else if (lane == 3) v = at[i];
+            else if (lane == 4) v = d;
+            x[r] = v;
+            h1[r] = b0;
+            gc[r] = g_cnode[row * 64 + lane];
+            gpe[r] = g_eff0[row * 64 + lane];
+        }
+        dense_bcast<5, KB_R>(w0t, x, h1, lane);                      // h1 pre-activation
+        dense_bcast_ld<64, KB_R>(wraw + W_PP_W, 129, 0, gc, gpe, lane);   // + W_pe^T g_cnode
+#pragma unroll
+        for (int r = 0; r < KB_R; ++r) {
+            const size_t row = (size_t)b * N + min(base + r, N - 1);
+            gpe[r] = (pe[row * 64 + lane] > 0.0f) ? gpe[r] : 0.0f;  // through the encoder's output ReLU
+            gh[r] = 0.0f;
+        }
+        dense_bcast_ld<64, KB_R>(wraw + W_PE2_W, 64, 0, gpe, gh, lane);   // W2^T
+#pragma unroll
+        for (int r = 0; r < KB_R; ++r) {
+            const float g = (h1[r] > 0.0f) ? gh[r] : 0.0f;
+            const float ox = wave_sum(g * w1x), oy = wave_sum(g * w1y), oz = wave_sum(g * w1z);
+            const int i = base + r;
+            if (i < N && lane < 3) g_sdelta[((size_t)b * N + i) * 3 + lane] = (lane == 0) ? ox : (lane == 1) ? oy : oz;
+        }
+    }
+}
+
+// ---- gen_s_delta backward: g_action[b, 0:4] = sum_n J_n^T g_s_delta[n], forward-mode over the four
+//      push parameters (sx, sy, ex, ey); the hard mask is a constant (planners.py:248)
+struct Dual4 {
+    float v, d[4];
+};
+__device__ __forceinline__ Dual4 dconst(float v) { return Dual4{v, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ Dual4 operator+(const Dual4& a, const Dual4& b) {
+    return Dual4{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2], a.d[3] + b.d[3]}};
+}
+__device__ __forceinline__ Dual4 operator-(const Dual4& a, const Dual4& b) {
+    return Dual4{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2], a.d[3] - b.d[3]}};
+}
+__device__ __forceinline__ Dual4 operator*(const Dual4& a, const Dual4& b) {
+    return Dual4{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2],
+                             a.d[3] * b.v + a.v * b.d[3]}};
+}
+__device__ __forceinline__ Dual4 operator/(const Dual4& a, const Dual4& b) {
+    const float q = a.v / b.v, ib = 1.0f / b.v;
+    return Dual4{q, {(a.d[0] - q * b.d[0]) * ib, (a.d[1] - q * b.d[1]) * ib, (a.d[2] - q * b.d[2]) * ib,
+                     (a.d[3] - q * b.d[3]) * ib}};
+}
+__device__ __forceinline__ Dual4 dsqrt(const Dual4& a) {
+    const float r = sqrtf(a.v), k = 0.5f / r;
+    return Dual4{r, {a.d[0] * k, a.d[1] * k, a.d[2] * k, a.d[3] * k}};
+}
+__device__ __forceinline__ Dual4 dscale(const Dual4& a, float s) {
+    return Dual4{a.v * s, {a.d[0] * s, a.d[1] * s, a.d[2] * s, a.d[3] * s}};
+}
+
+__global__ void __launch_bounds__(256)
+kb_sdelta(const float* __restrict__ s_cur, int s_mod, size_t s_stride, const float* __restrict__ actions,
+          size_t act_stride, const float* __restrict__ g_sdelta, int N, DrpCam cam, float* __restrict__ g_action,
+          size_t gact_stride) {
+    __shared__ float red[4][4];
+    const int b = blockIdx.x;
+    const float* act = actions + (size_t)b * act_stride;
+    const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
+    const float* gs = g_sdelta + (size_t)b * N * 3;
+    // camera-frame start / end as duals of (sx, sy, ex, ey): s3 = (sx, 0, -sy), e3 = (ex, 0, -ey)
+    Dual4 sc[3], ec[3];
+    const float igs = 1.0f / cam.gs;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float m0 = cam.m[r * 4 + 0], m2 = cam.m[r * 4 + 2], m3 = cam.m[r * 4 + 3];
+        sc[r] = Dual4{(m0 * act[0] - m2 * act[1] + m3) * igs, {m0 * igs, -m2 * igs, 0.f, 0.f}};
+        ec[r] = Dual4{(m0 * act[2] - m2 * act[3] + m3) * igs, {0.f, 0.f, m0 * igs, -m2 * igs}};
+    }
+    const Dual4 vx = ec[0] - sc[0], vy = ec[1] - sc[1], vz = ec[2] - sc[2];
+    const Dual4 len = dsqrt(vx * vx + vy * vy + vz * vz);
+    const Dual4 dx = vx / len, dy = vy / len, dz = vz / len;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float px = s[n * 3 + 0], py = s[n * 3 + 1], pz = s[n * 3 + 2];
+        const Dual4 rx = dconst(px) - sc[0], ry = dconst(py) - sc[1], rz = dconst(pz) - sc[2];
+        const Dual4 v = ry * dx - rx * dy;                                  // (p - s) . ortho, ortho = (-dy, dx, 0)
+        const Dual4 u = rx * dx + ry * dy + rz * dz;
+        if (!(u.v < len.v && u.v > 0.0f)) continue;                          // hard mask (constant)
+        // soft = exp(-max(relu(-w - v), relu(v - w)) / 0.01)
+        Dual4 pen = dconst(0.0f);
+        const float lo = -DRP_PUSHER_W - v.v, hi = v.v - DRP_PUSHER_W;
+        if (lo > 0.0f && lo >= hi) pen = dconst(-DRP_PUSHER_W) - v;
+        else if (hi > 0.0f) pen = v - dconst(DRP_PUSHER_W);
+        const float e = expf(-pen.v / DRP_SOFT_SCALE);
+        const Dual4 soft = Dual4{e, {-e * pen.d[0] / DRP_SOFT_SCALE, -e * pen.d[1] / DRP_SOFT_SCALE,
+                                     -e * pen.d[2] / DRP_SOFT_SCALE, -e * pen.d[3] / DRP_SOFT_SCALE}};
+        const Dual4 te = (ec[0] - dconst(px)) * dx + (ec[1] - dconst(py)) * dy + (ec[2] - dconst(pz)) * dz;
+        const Dual4 base = te * soft;
+        const Dual4 ox = base * dx, oy = base * dy, oz = base * dz;
+        const float g0 = gs[n * 3 + 0], g1 = gs[n * 3 + 1], g2 = gs[n * 3 + 2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += g0 * ox.d[c] + g1 * oy.d[c] + g2 * oz.d[c];
+    }
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float t = wave_sum(acc[c]);
+        if ((threadIdx.x & 63) == 0) red[wave][c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float t = 0.0f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w][threadIdx.x];
+        g_action[(size_t)b * gact_stride + threadIdx.x] = t;
+    }
+}
+
+// ---- Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8) + the clip box ------------
+//      planners.py:674, :743-746, :756-764
+__global__ void k_adam(float* __restrict__ act, const float* __restrict__ grad, float* __restrict__ m,
+                       float* __restrict__ v, int n, float step_size, float bc2_sqrt, float4 lo, float4 hi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float g = grad[i];
+    const float mi = m[i] + (g - m[i]) * (1.0f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (1.0f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    float a = act[i] - step_size * (mi / denom);
+    const int c = i & 3;
+    const float l = (c == 0) ? lo.x : (c == 1) ? lo.y : (c == 2) ? lo.z : lo.w;
+    const float h = (c == 0) ? hi.x : (c == 1) ? hi.y : (c == 2) ? hi.z : hi.w;
+    act[i] = fminf(fmaxf(a, l), h);
+}

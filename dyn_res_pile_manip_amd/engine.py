@@ -206,6 +206,36 @@ class Engine(object):
         self._ck(self.lib.drp_debug_fetch(self.h, b'stats', out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
         return {'mean': out[0], 'std': out[1], 'max': out[2], 'argmax': int(out[3]), 'Z': out[4], 'm': out[5]}
 
+    # ---- gradient-descent planner (horizon 1) ---------------------------------------
+    def gd_begin(self, s0, attr, dens, actions, lr, act_lo, act_hi):
+        s0, attr, dens, actions = _f32(s0), _f32(attr), _f32(dens), _f32(actions)
+        nb, N, _ = s0.shape
+        B, H, _ = actions.shape
+        lo, hi = _f32(act_lo), _f32(act_hi)
+        self._ck(self.lib.drp_gd_begin(self.h, _fp(s0), _fp(attr), _fp(dens), nb, N, _fp(actions), B, H,
+                                       float(lr), _fp(lo), _fp(hi)))
+        self._gd = (B, H, N)
+
+    def gd_grad(self, want_state_grad=False):
+        B, H, N = self._gd
+        r = np.empty((B,), np.float32)
+        g = np.empty((B, H, 4), np.float32)
+        gs = np.empty((B, H, N, 3), np.float32) if want_state_grad else None
+        self._ck(self.lib.drp_gd_grad(self.h, _fp(r), _fp(g), _fp(gs) if want_state_grad else None))
+        return r, g, gs
+
+    def gd_step(self):
+        B, H, N = self._gd
+        r = np.empty((B,), np.float32)
+        self._ck(self.lib.drp_gd_step(self.h, _fp(r)))
+        return r
+
+    def gd_actions(self):
+        B, H, N = self._gd
+        a = np.empty((B, H, 4), np.float32)
+        self._ck(self.lib.drp_gd_get(self.h, _fp(a)))
+        return a
+
     # ---- multi-GPU ------------------------------------------------------------------
     def comm_unique_id(self):
         buf = ctypes.create_string_buffer(128)

@@ -258,44 +258,72 @@ class PlannerGD(Planner):
                     best_actions_of_samples[j] = actions[idx[j] * n_batch + j]
             return r
 
-        # iteration 0: score the traj_num candidates
-        cand = np.repeat(act_seq.transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)  # [traj*nb,H,4]
-        eng.mpc_begin(state_cur_np, attr_cur_np, state_param, act_seq[:, 0, :], n_sample=traj_num,
-                      sigma=sigma, beta_filter=cfg['mppi']['beta_filter'],
-                      reward_weight=cfg['mppi']['reward_weight'], act_lo=lo, act_hi=hi, seed=seed)
-        eng.mpc_set_actions(cand)
-        t0 = time.perf_counter()
-        eng.mpc_rollout(False)
-        got = eng.mpc_get(rewards=True)
-        rollout_time += (time.perf_counter() - t0) * 1e3
-        r0 = aggregate(got['rewards'], cand, traj_num)
-        reward_seqs = got['rewards'].copy()
-        act_seqs_last = cand
-        nominal = act_seq[:, int(np.argmax(r0.mean(1))), :].astype(np.float64)
+        mpc_type = cfg.get('mpc_type', 'MPPI')
+        if mpc_type == 'GD' and H != 1:
+            raise NotImplementedError('the reverse-mode kernels cover n_look_ahead = 1 (the reference\'s demo '
+                                      'setting); use mpc_type MPPI for longer horizons')
         i = 0
-        if n_iter > 0:
-            rew_mean[0, 0] = r0[:, 0].mean()
-            rew_std[0, 0] = r0[:, 0].std(ddof=1) if traj_num > 1 else 0.0
-        if n_iter > 1:
-            eng.mpc_begin(state_cur_np, attr_cur_np, state_param, nominal, n_sample=n_sample,
+        if mpc_type == 'GD':
+            # the reference's live loop (planners.py:661-764): every trajectory x batch column is an
+            # independent Adam problem on its own push; rollout, reward, backward, Adam and the clip all
+            # run on the device
+            assert n_sample == traj_num, 'GD optimises the traj_num given trajectories (n_sample == traj_num)'
+            cand = np.repeat(act_seq.transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)   # [traj*nb,1,4]
+            eng.gd_begin(state_cur_np, attr_cur_np, state_param, cand, cfg['gd']['lr'], lo, hi)
+            reward_seqs = np.zeros((traj_num * n_batch,), np.float32)
+            act_seqs_last = cand
+            for i in range(n_iter):
+                before = eng.gd_actions() if i == 0 else act_seqs_last
+                t0 = time.perf_counter()
+                reward_seqs = eng.gd_step()
+                act_seqs_last = eng.gd_actions()
+                optim_time += (time.perf_counter() - t0) * 1e3
+                r = aggregate(reward_seqs, before, traj_num)       # rewards belong to the pre-update pushes
+                rew_mean[0, i] = r[:, 0].mean()
+                rew_std[0, i] = r[:, 0].std(ddof=1) if traj_num > 1 else 0.0
+                if (time.time() - start) > time_lim_s:
+                    break
+            nominal = None
+        else:
+            # iteration 0: score the traj_num candidates
+            cand = np.repeat(act_seq.transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)  # [traj*nb,H,4]
+            eng.mpc_begin(state_cur_np, attr_cur_np, state_param, act_seq[:, 0, :], n_sample=traj_num,
                           sigma=sigma, beta_filter=cfg['mppi']['beta_filter'],
                           reward_weight=cfg['mppi']['reward_weight'], act_lo=lo, act_hi=hi, seed=seed)
-        for i in range(1, n_iter):
+            eng.mpc_set_actions(cand)
             t0 = time.perf_counter()
-            eng.mpc_sample(i)
             eng.mpc_rollout(False)
-            t1 = time.perf_counter()
-            eng.mpc_update_device()
-            got = eng.mpc_get(rewards=True, actions=True)
-            t2 = time.perf_counter()
-            rollout_time += (t1 - t0) * 1e3
-            optim_time += (t2 - t1) * 1e3
-            r = aggregate(got['rewards'], got['actions'], n_sample)
-            reward_seqs, act_seqs_last = got['rewards'], got['actions']
-            rew_mean[0, i] = r[:, 0].mean()
-            rew_std[0, i] = r[:, 0].std(ddof=1) if n_sample > 1 else 0.0
-            if (time.time() - start) > time_lim_s:
-                break
+            got = eng.mpc_get(rewards=True)
+            rollout_time += (time.perf_counter() - t0) * 1e3
+            r0 = aggregate(got['rewards'], cand, traj_num)
+            reward_seqs = got['rewards'].copy()
+            act_seqs_last = cand
+            nominal = act_seq[:, int(np.argmax(r0.mean(1))), :].astype(np.float64)
+            if n_iter > 0:
+                rew_mean[0, 0] = r0[:, 0].mean()
+                rew_std[0, 0] = r0[:, 0].std(ddof=1) if traj_num > 1 else 0.0
+            if n_iter > 1:
+                eng.mpc_begin(state_cur_np, attr_cur_np, state_param, nominal, n_sample=n_sample,
+                              sigma=sigma, beta_filter=cfg['mppi']['beta_filter'],
+                              reward_weight=cfg['mppi']['reward_weight'], act_lo=lo, act_hi=hi, seed=seed)
+            for i in range(1, n_iter):
+                t0 = time.perf_counter()
+                eng.mpc_sample(i)
+                eng.mpc_rollout(False)
+                t1 = time.perf_counter()
+                eng.mpc_update_device()
+                got = eng.mpc_get(rewards=True, actions=True)
+                t2 = time.perf_counter()
+                rollout_time += (t1 - t0) * 1e3
+                optim_time += (t2 - t1) * 1e3
+                r = aggregate(got['rewards'], got['actions'], n_sample)
+                reward_seqs, act_seqs_last = got['rewards'], got['actions']
+                rew_mean[0, i] = r[:, 0].mean()
+                rew_std[0, i] = r[:, 0].std(ddof=1) if n_sample > 1 else 0.0
+                if (time.time() - start) > time_lim_s:
+                    break
+            if n_iter > 1:
+                nominal = eng.mpc_get(nominal=True)['nominal']
 
         # planners.py:773-781: vote = most frequent best-trajectory index over the columns,
         # ties -> the column with the highest reward
@@ -325,7 +353,7 @@ class PlannerGD(Planner):
                 'next_r': next_r,
                 'rew_mean': rew_mean,
                 'rew_std': rew_std,
-                'nominal_sequence': eng.mpc_get(nominal=True)['nominal'] if n_iter > 1 else nominal,
+                'nominal_sequence': nominal,
                 'times': {'total_time': time.time() - start, 'rollout_time': rollout_time,
                           'optim_time': optim_time},
                 'iter_num': i}

@@ -146,6 +146,20 @@ int drp_mpc_update_device(drp_ctx* ctx);
 int drp_mpc_get(drp_ctx* ctx, float* actions /*[B,H,4]*/, float* rewards /*[B] final*/,
                 float* rewards_all /*[B,H]*/, float* states /*[B,H,N,3]*/, double* nominal);
 
+/* ---- gradient-descent planner (the reference's live mpc_type 'GD') ----------------------------
+ * One iteration of planners.py:682-764: rollout -> final-step reward -> loss = -sum(reward)
+ * -> d loss / d pushes by reverse mode -> Adam(lr) step -> clip box.  This round the horizon
+ * is 1 (config/mpc/config.yaml:38 n_look_ahead); longer horizons return DRP_EINVAL.
+ * actions [B,1,4] with B = traj_num * n_batch rows (row = traj * n_batch + batch). */
+int drp_gd_begin(drp_ctx* ctx, const float* s0, const float* attr, const float* dens, int nb, int N,
+                 const float* actions, int B, int H, double lr, const float act_lo[4], const float act_hi[4]);
+/* forward + backward only: rewards [B], d loss / d actions [B,H,4], d loss / d state_pred
+ * [B,H,N,3] (each nullable) */
+int drp_gd_grad(drp_ctx* ctx, float* rewards_out, float* grad_act_out, float* grad_state_out);
+/* one full iteration (forward, backward, Adam, clip); rewards of the iterate BEFORE the update */
+int drp_gd_step(drp_ctx* ctx, float* rewards_out);
+int drp_gd_get(drp_ctx* ctx, float* actions_out);
+
 /* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------ */
 int drp_comm_unique_id(char* id128);                       /* ncclGetUniqueId */
 int drp_comm_init(drp_ctx* ctx, const char* id128, int rank, int n_ranks);

@@ -289,3 +289,15 @@ def optimize_action(act_seqs, reward_seqs, reward_weight):
     w = np.exp(z - z.max())
     w = w / w.sum()
     return (w[:, None, None] * np.asarray(act_seqs, dtype=np.float64)).sum(0)
+
+
+def gd_loss_and_grads(W, s0, dens, attr, act_seqs, G, cam_params, goal_coor, cam_extrinsic, global_scale):
+    """planners.py:685-745 for one iteration: rollout, final-step reward, loss = -sum(reward),
+    autograd.  Returns (reward [B], d loss / d act_seqs [B,H,4], d loss / d state_pred [B,H,N,3])."""
+    acts = torch.tensor(np.asarray(act_seqs, dtype=np.float32), requires_grad=True)
+    st = rollout(W, s0, dens, attr, acts, cam_extrinsic, global_scale)
+    st.retain_grad()
+    r = config_reward_ptcl(st[:, -1], G, cam_params, goal_coor)
+    loss = torch.sum(-r)
+    loss.backward()
+    return r.detach().numpy(), acts.grad.numpy(), st.grad.numpy()

@@ -334,6 +334,34 @@ def main():
     gd['out/iter_num'] = np.array(res['iter_num'])
     np.savez_compressed(os.path.join(HERE, 'gd_planner.npz'), **gd)
 
+    # ---- gradients of the GD planner's loss (f1): -sum(reward) w.r.t. the pushes ------------
+    gr = {}
+    for name, N, nb, traj, H, seed in [('h1', 40, 3, 10, 1, 41), ('h2', 32, 2, 4, 2, 42), ('h1_n100', 100, 2, 6, 1, 43)]:
+        s, dens, attr = syn.make_pile(N, n_batch=nb, seed=seed)
+        planner.particle_num = N
+        goal_coor = syn.goal_coor_strided(obs_goal, 5 * N)
+        acts0 = np.stack([syn.nominal_pushes(H, seed=200 + seed + i) for i in range(traj)])      # [traj,H,4]
+        acts0 = np.repeat(acts0, nb, axis=0).astype(np.float32)                                    # row = traj*nb + b
+        a_t = torch.tensor(acts0, requires_grad=True)
+        out = planner.ptcl_model_rollout(torch.from_numpy(s), torch.from_numpy(dens), torch.from_numpy(attr),
+                                         model, a_t)
+        sp = out['model_rollout']['state_pred']                  # [B,H,N,3]
+        sp.retain_grad()
+        obs_seqs = sp.reshape(traj * nb, 1, H, N, 3).permute(0, 2, 1, 3, 4)
+        rs, _ = planner.ptcl_evaluate_traj(obs_seqs, torch.from_numpy(obs_goal), torch.from_numpy(goal_coor))
+        loss = torch.sum(-rs)
+        loss.backward()
+        gr[name + '/s_cur'] = s
+        gr[name + '/dens'] = dens
+        gr[name + '/attr'] = attr
+        gr[name + '/act_seqs'] = acts0
+        gr[name + '/goal_coor'] = goal_coor
+        gr[name + '/state_pred'] = sp.detach().numpy()
+        gr[name + '/reward'] = rs.detach().numpy()
+        gr[name + '/grad_state_pred'] = sp.grad.numpy()
+        gr[name + '/grad_act'] = a_t.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'grad.npz'), **gr)
+
     cap.close()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):

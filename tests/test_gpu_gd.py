@@ -1,0 +1,78 @@
+"""GPU, scope row f1: the reverse-mode kernels and the gradient-descent planner (the
+reference's live mpc_type 'GD', horizon 1) against gradients and a full planner run
+captured from the reference (tests/golden/grad.npz, gd_planner.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from dyn_res_pile_manip_amd import synthetic as syn, weights
+from dyn_res_pile_manip_amd.gnn_dyn import PropNetDiffDenModel
+from dyn_res_pile_manip_amd.planners import PlannerGD, world2cam_affine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx(golden):
+    from dyn_res_pile_manip_amd.engine import Engine
+    eng = Engine(0)
+    eng.load_weights(weights.blob_from_state_dict(golden.weights_seed0), 0.08)
+    eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+    yield eng
+    eng.close()
+
+
+@pytest.mark.parametrize('case', ['h1', 'h1_n100'])
+def test_gradients_match_the_reference(ctx, golden, case):
+    g = golden.grad
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    ctx.set_goal(syn.goal_field(obs_goal), g[case + '/goal_coor'])
+    lo, hi = syn.action_limits()
+    ctx.gd_begin(g[case + '/s_cur'], g[case + '/attr'], g[case + '/dens'], g[case + '/act_seqs'], 0.05, lo, hi)
+    r, ga, gs = ctx.gd_grad(want_state_grad=True)
+    np.testing.assert_allclose(r, g[case + '/reward'][:, 0], rtol=2e-5)
+    ref_gs, ref_ga = g[case + '/grad_state_pred'], g[case + '/grad_act']
+    # d loss / d predicted state: bilinear-sample and chamfer arg-min gradients through the projection
+    assert np.abs(gs - ref_gs).max() < 1e-3 * np.abs(ref_gs).max()
+    # d loss / d push through predictor, 3 propagation steps, particle encoder and gen_s_delta
+    assert np.abs(ga - ref_ga).max() < 2e-3 * np.abs(ref_ga).max()
+    assert np.abs(ga - ref_ga).max() < 1e-4
+    # rows whose push misses the pile have exactly zero gradient in both
+    np.testing.assert_array_equal(np.abs(ga).sum((1, 2)) == 0, np.abs(ref_ga).sum((1, 2)) == 0)
+
+
+def test_horizon_two_is_refused_loudly(ctx, golden):
+    from dyn_res_pile_manip_amd import _lib
+    g = golden.grad
+    lo, hi = syn.action_limits()
+    with pytest.raises(_lib.DrpError, match='horizon 1'):
+        ctx.gd_begin(g['h2/s_cur'], g['h2/attr'], g['h2/dens'], g['h2/act_seqs'], 0.05, lo, hi)
+
+
+def test_adam_iterations_and_planner_dict_match_the_reference(golden):
+    """The reference's own GD planner run (3 Adam iterations, 10 trajectories x 3 columns, N = 40),
+    called exactly as env/flex_env.py:1048-1065 calls it."""
+    config = syn.default_config()
+    config['mpc']['mpc_type'] = 'GD'
+    env = syn.SyntheticEnv(config)
+    model = PropNetDiffDenModel(config, True)
+    model.load_state_dict({k[2:]: torch.from_numpy(golden.weights_seed0[k]) for k in golden.weights_seed0.files
+                           if k.startswith('w/')}, strict=False)
+    planner = PlannerGD(config, env)
+    g = golden.gd_planner
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    res = planner.trajectory_optimization_ptcl_multi_traj(
+        g['s_cur'], g['dens'], g['attr'], obs_goal, model, g['act_seq'], np.zeros(1), n_sample=10, n_look_ahead=1,
+        n_update_iter=3, action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=1e9)
+    model.engine.close()
+    # goal pixels are subsampled by farthest-point sampling from index 0 (planners.py:621): deterministic
+    np.testing.assert_allclose(res['rew_mean'], g['out/rew_mean'], rtol=1e-4)
+    np.testing.assert_allclose(res['rew_std'], g['out/rew_std'], rtol=2e-3)
+    np.testing.assert_allclose(res['action_full'], g['out/action_full'], atol=2e-3)
+    np.testing.assert_allclose(res['reward_full'], g['out/reward_full'], rtol=1e-4)
+    np.testing.assert_allclose(res['action_sequence'], g['out/action_sequence'], atol=2e-3)
+    np.testing.assert_allclose(res['observation_sequence'], g['out/observation_sequence'], atol=5e-6)
+    np.testing.assert_allclose(res['reward'], g['out/reward'], rtol=1e-4)
+    np.testing.assert_allclose(res['next_r'], g['out/next_r'], rtol=1e-4)
+    assert res['iter_num'] == int(g['out/iter_num'])

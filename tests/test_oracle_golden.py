@@ -134,3 +134,16 @@ def test_mppi(golden):
     np.testing.assert_allclose(samp.mean(0), g['sample_mean'][:, 0], atol=0.05)
     np.testing.assert_allclose(samp.std(0), g['sample_std'][:, 0], rtol=0.08)
     assert (samp.min(0) >= lo - 1e-12).all() and (samp.max(0) <= hi + 1e-12).all()
+
+
+@pytest.mark.parametrize('case', ['h1', 'h2', 'h1_n100'])
+def test_gd_gradients(golden, W, case):
+    """Row f1: the oracle differentiated by autograd == the reference differentiated by autograd."""
+    g = golden.grad
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    r, ga, gs = od.gd_loss_and_grads(W[0], g[case + '/s_cur'], g[case + '/dens'], g[case + '/attr'],
+                                     g[case + '/act_seqs'], syn.goal_field(obs_goal), syn.demo_cam_params(),
+                                     g[case + '/goal_coor'], syn.demo_cam_extrinsics(), 24)
+    np.testing.assert_allclose(r, g[case + '/reward'][:, 0], rtol=2e-6)
+    np.testing.assert_allclose(gs, g[case + '/grad_state_pred'], rtol=0, atol=1e-3 * np.abs(g[case + '/grad_state_pred']).max())
+    np.testing.assert_allclose(ga, g[case + '/grad_act'], rtol=0, atol=1e-3 * np.abs(g[case + '/grad_act']).max())
