@@ -75,6 +75,7 @@ struct drp_ctx {
     double gd_lr = 0.05;
     float gd_lo[4] = {0, 0, 0, 0}, gd_hi[4] = {0, 0, 0, 0};
     DevBuf eff_hist, proj_hist, g_eff, g_cnode, g_agg, g_proj, g_state, g_sdelta, g_act, adam_m, adam_v;
+    DevBuf tape_sdelta, tape_idx, tape_cnt, tape_cedge, g_cedge;
 
     // last shapes (for debug fetch)
     int lastB = 0, lastN = 0, lastH = 0;
@@ -495,7 +496,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    DevBuf* bufs[] = {&c->eff_hist, &c->proj_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
+    DevBuf* bufs[] = {&c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->tape_cedge, &c->g_cedge, &c->eff_hist, &c->proj_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
@@ -840,55 +841,92 @@ int drp_mpc_get(drp_ctx* c, float* actions, float* rewards, float* rewards_all, 
     return drp_sync(c);
 }
 
-// ---- gradient-descent planner (row f1), horizon 1 -------------------------------------------
+// ---- gradient-descent planner (row f1) ----------------------------------------------------------
 namespace {
 int gd_forward_backward(drp_ctx* c) {
-    const int nb = c->gd_nb, N = c->gd_N, B = c->gd_B;
+    const int nb = c->gd_nb, N = c->gd_N, B = c->gd_B, H = c->gd_H;
     const size_t bn = (size_t)B * N;
+    const size_t hstride = (size_t)H * N * 3;
     hipStream_t st = c->stream;
-    // forward on the fp32 MFMA pipeline, keeping what the backward pass needs
-    const int saved_engine = c->engine;
-    c->engine = DRP_ENGINE_MFMA;
-    StepArgs a{};
-    a.s_prev = ptr<float>(c->s_in); a.prev_mod = nb; a.prev_stride = (size_t)N * 3;
-    a.attr = ptr<float>(c->attr); a.attr_mod = nb;
-    a.dens = ptr<float>(c->dens); a.dens_mod = nb;
-    a.actions = ptr<float>(c->actions); a.act_stride = 4;
-    a.build_graph = true;
-    a.s_out = ptr<float>(c->states); a.out_stride = (size_t)N * 3;
-    a.B = B; a.N = N;
-    a.eff_hist = ptr<float>(c->eff_hist);
-    a.proj_hist = ptr<float>(c->proj_hist);
-    int rc = run_step(c, a);
-    c->engine = saved_engine;
-    CHK(rc);
-    CHK(run_reward(c, ptr<float>(c->states), (size_t)N * 3, B, N, 1, ptr<float>(c->rewards)));
-    // backward
-    const float* vw = ptr<float>(c->w_valu);
-    const float* wraw = ptr<float>(c->w_raw);
+    float* states = ptr<float>(c->states);
     float* eh = ptr<float>(c->eff_hist);
     float* ph = ptr<float>(c->proj_hist);
-    hipLaunchKernelGGL(kb_reward, dim3(B), dim3(256), 4 * N * sizeof(float), st, ptr<float>(c->states), (size_t)N * 3,
-                       N, ptr<float>(c->goal_field), c->goal_h, c->goal_w, ptr<float>(c->goal_coor), c->goal_m, c->cam,
-                       1, ptr<float>(c->g_state), (size_t)N * 3);
-    hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eh + 3 * bn * 64, ptr<float>(c->g_state),
-                       (size_t)N * 3, N, ptr<float>(c->g_eff));
-    for (int p = DRP_PSTEP - 1; p >= 0; --p) {
-        hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eh + (size_t)(p + 1) * bn * 64,
-                           ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N,
-                           ptr<float>(c->g_agg));
-        HIPCHK(c, hipMemsetAsync(c->g_proj.p, 0, bn * 128 * sizeof(float), st));
-        hipLaunchKernelGGL(kb_edges, dim3(B), dim3(256), 0, st, ptr<float>(c->c_edge), ph + (size_t)p * bn * 128,
-                           ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), ptr<float>(c->g_agg), N,
-                           ptr<float>(c->g_proj));
-        hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff));
+    auto d2d = [&](void* dst, const void* src, size_t bytes) -> int {
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+        return DRP_OK;
+    };
+    // ---- forward on the fp32 MFMA pipeline, keeping per step what the backward pass needs
+    const int saved_engine = c->engine;
+    c->engine = DRP_ENGINE_MFMA;
+    int rc = DRP_OK;
+    for (int t = 0; t < H && rc == DRP_OK; ++t) {
+        StepArgs a{};
+        if (t == 0) { a.s_prev = ptr<float>(c->s_in); a.prev_mod = nb; a.prev_stride = (size_t)N * 3; }
+        else { a.s_prev = states + (size_t)(t - 1) * N * 3; a.prev_mod = B; a.prev_stride = hstride; }
+        a.attr = ptr<float>(c->attr); a.attr_mod = nb;
+        a.dens = ptr<float>(c->dens); a.dens_mod = nb;
+        a.actions = ptr<float>(c->actions) + (size_t)t * 4; a.act_stride = (size_t)H * 4;
+        a.build_graph = true;
+        a.s_out = states + (size_t)t * N * 3; a.out_stride = hstride;
+        a.B = B; a.N = N;
+        a.eff_hist = eh + (size_t)t * 4 * bn * 64;
+        a.proj_hist = ph + (size_t)t * 3 * bn * 128;
+        rc = run_step(c, a);
+        if (rc != DRP_OK) break;
+        rc = d2d(ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, c->s_delta.p, bn * 3 * sizeof(float));
+        if (rc == DRP_OK) rc = d2d(ptr<int16_t>(c->tape_idx) + (size_t)t * bn * DRP_K, c->nbr_idx.p, bn * DRP_K * sizeof(int16_t));
+        if (rc == DRP_OK) rc = d2d(ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn, c->nbr_cnt.p, bn);
+        if (rc == DRP_OK) rc = d2d(ptr<float>(c->tape_cedge) + (size_t)t * bn * DRP_K * 64, c->c_edge.p, bn * DRP_K * 64 * sizeof(float));
     }
-    hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw, ptr<float>(c->s_delta), ptr<float>(c->attr),
-                       nb, ptr<float>(c->dens), nb, eh, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N,
-                       ptr<float>(c->g_sdelta));
-    hipLaunchKernelGGL(kb_sdelta, dim3(B), dim3(256), 0, st, ptr<float>(c->s_in), nb, (size_t)N * 3,
-                       ptr<float>(c->actions), (size_t)4, ptr<float>(c->g_sdelta), N, c->cam, ptr<float>(c->g_act),
-                       (size_t)4);
+    c->engine = saved_engine;
+    CHK(rc);
+    // reward of the final step only (planners.py:436-438)
+    CHK(run_reward(c, states + (size_t)(H - 1) * N * 3, hstride, B, N, 1, ptr<float>(c->rewards)));
+    // ---- backward through time
+    const float* vw = ptr<float>(c->w_valu);
+    const float* wraw = ptr<float>(c->w_raw);
+    float* g_state = ptr<float>(c->g_state);                 // [H][B,N,3]
+    hipLaunchKernelGGL(kb_reward, dim3(B), dim3(256), 4 * N * sizeof(float), st, states + (size_t)(H - 1) * N * 3, hstride,
+                       N, ptr<float>(c->goal_field), c->goal_h, c->goal_w, ptr<float>(c->goal_coor), c->goal_m, c->cam,
+                       1, g_state + (size_t)(H - 1) * bn * 3, (size_t)N * 3);
+    for (int t = H - 1; t >= 0; --t) {
+        const float* s_prev = (t == 0) ? ptr<float>(c->s_in) : states + (size_t)(t - 1) * N * 3;
+        const int prev_mod = (t == 0) ? nb : B;
+        const size_t prev_stride = (t == 0) ? (size_t)N * 3 : hstride;
+        float* eht = eh + (size_t)t * 4 * bn * 64;
+        float* pht = ph + (size_t)t * 3 * bn * 128;
+        const float* cedge = ptr<float>(c->tape_cedge) + (size_t)t * bn * DRP_K * 64;
+        const int16_t* idx = ptr<int16_t>(c->tape_idx) + (size_t)t * bn * DRP_K;
+        const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
+        float* g_out = g_state + (size_t)t * bn * 3;
+        float* g_cedge = (t > 0) ? ptr<float>(c->g_cedge) : nullptr;
+        hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn * 64, g_out, (size_t)N * 3, N,
+                           ptr<float>(c->g_eff));
+        for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+            hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn * 64,
+                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N,
+                               ptr<float>(c->g_agg));
+            HIPCHK(c, hipMemsetAsync(c->g_proj.p, 0, bn * 128 * sizeof(float), st));
+            hipLaunchKernelGGL(kb_edges, dim3(B), dim3(256), 0, st, cedge, pht + (size_t)p * bn * 128, idx, cnt,
+                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), g_cedge, p == DRP_PSTEP - 1 ? 1 : 0);
+            hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff));
+        }
+        hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw,
+                           ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb, ptr<float>(c->dens),
+                           nb, eht, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta));
+        float* g_prev = nullptr;
+        if (t > 0) {
+            // d loss / d state[t-1] = residual share + relation encoder + gen_s_delta's position dependence
+            g_prev = g_state + (size_t)(t - 1) * bn * 3;
+            CHK(d2d(g_prev, g_out, bn * 3 * sizeof(float)));
+            hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), (6 * 64 + 2 * 4096) * sizeof(float), st, vw, wraw,
+                               s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx, cnt,
+                               g_cedge, N, g_prev, (size_t)N * 3);
+        }
+        hipLaunchKernelGGL(kb_sdelta, dim3(B), dim3(256), 0, st, s_prev, prev_mod, prev_stride,
+                           ptr<float>(c->actions) + (size_t)t * 4, (size_t)H * 4, ptr<float>(c->g_sdelta), N, c->cam,
+                           ptr<float>(c->g_act) + (size_t)t * 4, (size_t)H * 4, g_prev, (size_t)N * 3);
+    }
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
@@ -899,8 +937,7 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     CHK(need(c, true, true, true));
     CHK(check_bn(c, B, N));
     if (!s0 || !attr || !dens || !actions || !act_lo || !act_hi) return fail(c, DRP_EINVAL, "null argument");
-    if (H != 1)
-        return fail(c, DRP_EINVAL, "the reverse-mode kernels cover horizon 1 (the reference's demo setting); H=%d", H);
+    if (H < 1 || H > 64) return fail(c, DRP_EINVAL, "bad horizon H=%d", H);
     if (nb <= 0 || B % nb != 0) return fail(c, DRP_EINVAL, "B must be a multiple of n_batch");
 #ifndef DRP_HAVE_MFMA
     return fail(c, DRP_ESTATE, "built without the MFMA engine");
@@ -910,28 +947,33 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
     CHK(h2d(c, c->attr, attr, (size_t)nb * N * sizeof(float)));
     CHK(h2d(c, c->dens, dens, (size_t)nb * sizeof(float)));
-    CHK(h2d(c, c->actions, actions, (size_t)B * 4 * sizeof(float)));
+    CHK(h2d(c, c->actions, actions, (size_t)B * H * 4 * sizeof(float)));
     CHK(ensure_step_ws(c, B, N));
-    CHK(ensure(c, c->states, bn * 3 * sizeof(float)));
+    CHK(ensure(c, c->states, (size_t)H * bn * 3 * sizeof(float)));
     CHK(ensure(c, c->rewards, (size_t)B * sizeof(float)));
-    CHK(ensure(c, c->eff_hist, 4 * bn * 64 * sizeof(float)));
-    CHK(ensure(c, c->proj_hist, 3 * bn * 128 * sizeof(float)));
+    CHK(ensure(c, c->eff_hist, (size_t)H * 4 * bn * 64 * sizeof(float)));
+    CHK(ensure(c, c->proj_hist, (size_t)H * 3 * bn * 128 * sizeof(float)));
+    CHK(ensure(c, c->tape_sdelta, (size_t)H * bn * 3 * sizeof(float)));
+    CHK(ensure(c, c->tape_idx, (size_t)H * bn * DRP_K * sizeof(int16_t)));
+    CHK(ensure(c, c->tape_cnt, (size_t)H * bn));
+    CHK(ensure(c, c->tape_cedge, (size_t)H * bn * DRP_K * 64 * sizeof(float)));
+    CHK(ensure(c, c->g_cedge, bn * DRP_K * 64 * sizeof(float)));
     CHK(ensure(c, c->g_eff, bn * 64 * sizeof(float)));
     CHK(ensure(c, c->g_cnode, bn * 64 * sizeof(float)));
     CHK(ensure(c, c->g_agg, bn * 64 * sizeof(float)));
     CHK(ensure(c, c->g_proj, bn * 128 * sizeof(float)));
-    CHK(ensure(c, c->g_state, bn * 3 * sizeof(float)));
+    CHK(ensure(c, c->g_state, (size_t)H * bn * 3 * sizeof(float)));
     CHK(ensure(c, c->g_sdelta, bn * 3 * sizeof(float)));
-    CHK(ensure(c, c->g_act, (size_t)B * 4 * sizeof(float)));
-    CHK(ensure(c, c->adam_m, (size_t)B * 4 * sizeof(float)));
-    CHK(ensure(c, c->adam_v, (size_t)B * 4 * sizeof(float)));
-    HIPCHK(c, hipMemsetAsync(c->adam_m.p, 0, (size_t)B * 4 * sizeof(float), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->adam_v.p, 0, (size_t)B * 4 * sizeof(float), c->stream));
+    CHK(ensure(c, c->g_act, (size_t)B * H * 4 * sizeof(float)));
+    CHK(ensure(c, c->adam_m, (size_t)B * H * 4 * sizeof(float)));
+    CHK(ensure(c, c->adam_v, (size_t)B * H * 4 * sizeof(float)));
+    HIPCHK(c, hipMemsetAsync(c->adam_m.p, 0, (size_t)B * H * 4 * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->adam_v.p, 0, (size_t)B * H * 4 * sizeof(float), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->gd_nb = nb; c->gd_N = N; c->gd_B = B; c->gd_H = H; c->gd_iter = 0; c->gd_lr = lr;
     memcpy(c->gd_lo, act_lo, 4 * sizeof(float));
     memcpy(c->gd_hi, act_hi, 4 * sizeof(float));
-    c->lastH = 1;
+    c->lastH = H;
     c->gd_on = true;
     c->mpc_on = false;
     return DRP_OK;
@@ -943,8 +985,15 @@ int drp_gd_grad(drp_ctx* c, float* rewards_out, float* grad_act_out, float* grad
     CHK(gd_forward_backward(c));
     const size_t bn = (size_t)c->gd_B * c->gd_N;
     if (rewards_out) CHK(d2h(c, rewards_out, c->rewards.p, (size_t)c->gd_B * sizeof(float)));
-    if (grad_act_out) CHK(d2h(c, grad_act_out, c->g_act.p, (size_t)c->gd_B * 4 * sizeof(float)));
-    if (grad_state_out) CHK(d2h(c, grad_state_out, c->g_state.p, bn * 3 * sizeof(float)));
+    if (grad_act_out) CHK(d2h(c, grad_act_out, c->g_act.p, (size_t)c->gd_B * c->gd_H * 4 * sizeof(float)));
+    if (grad_state_out) {
+        // device layout [H][B,N,3] -> caller layout [B,H,N,3]
+        const size_t row = (size_t)c->gd_N * 3 * sizeof(float);
+        for (int t = 0; t < c->gd_H; ++t)
+            HIPCHK(c, hipMemcpy2DAsync(grad_state_out + (size_t)t * c->gd_N * 3, (size_t)c->gd_H * row,
+                                       ptr<float>(c->g_state) + (size_t)t * bn * 3, row, row, c->gd_B,
+                                       hipMemcpyDeviceToHost, c->stream));
+    }
     return drp_sync(c);
 }
 
@@ -955,7 +1004,7 @@ int drp_gd_step(drp_ctx* c, float* rewards_out) {
     c->gd_iter += 1;
     // torch.optim.Adam: step_size = lr / (1 - beta1^t), denom = sqrt(v) / sqrt(1 - beta2^t) + eps
     const double bc1 = 1.0 - pow(0.9, (double)c->gd_iter), bc2 = 1.0 - pow(0.999, (double)c->gd_iter);
-    const int n = c->gd_B * 4;
+    const int n = c->gd_B * c->gd_H * 4;
     hipLaunchKernelGGL(k_adam, dim3((n + 255) / 256), dim3(256), 0, c->stream, ptr<float>(c->actions),
                        ptr<float>(c->g_act), ptr<float>(c->adam_m), ptr<float>(c->adam_v), n, (float)(c->gd_lr / bc1),
                        (float)sqrt(bc2), make_float4(c->gd_lo[0], c->gd_lo[1], c->gd_lo[2], c->gd_lo[3]),
@@ -971,7 +1020,7 @@ int drp_gd_step(drp_ctx* c, float* rewards_out) {
 int drp_gd_get(drp_ctx* c, float* actions_out) {
     if (!c || !c->gd_on) return fail(c, DRP_ESTATE, "drp_gd_begin not called");
     if (!actions_out) return fail(c, DRP_EINVAL, "null buffer");
-    CHK(d2h(c, actions_out, c->actions.p, (size_t)c->gd_B * 4 * sizeof(float)));
+    CHK(d2h(c, actions_out, c->actions.p, (size_t)c->gd_B * c->gd_H * 4 * sizeof(float)));
     return drp_sync(c);
 }
 

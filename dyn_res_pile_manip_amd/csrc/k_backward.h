@@ -5,9 +5,10 @@
 // topk / the radius test) and gen_s_delta (planners.py:211-257; the hard mask is constant,
 // the soft mask and the projections are differentiated, the direction depends on the push).
 //
-// This round: horizon 1 (the reference's demo setting, config/mpc/config.yaml:38), so the
-// particle positions are constants and only the impulse path s_delta -> particle encoder ->
-// propagation -> predictor carries gradient.  Correctness-first fp32 VALU kernels over the
+// Any horizon: the reward is taken at the final step only (planners.py:436-438); going back
+// through a step, the gradient w.r.t. its input positions is the residual's share, plus the
+// relation encoder's (its inputs are position differences), plus gen_s_delta's dependence
+// on the particle position.  Correctness-first fp32 VALU kernels over the
 // activations the fp32 MFMA engine saved in HBM (eff after every step, proj per step, c_edge,
 // c_node); ReLU masks are recomputed from them.  The one scatter of the backward pass
 // (gradient of the gathered sender rows) uses fp32 global atomics, 256 B per wave
@@ -169,7 +170,8 @@ kb_update(const float* __restrict__ wraw, const float* __restrict__ eff_next, fl
 // same 16-lanes-per-receiver layout as k_aggregate; g_proj must be zeroed before the launch.
 __global__ void __launch_bounds__(256)
 kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const int16_t* __restrict__ nbr_idx,
-         const uint8_t* __restrict__ nbr_cnt, const float* __restrict__ g_agg, int N, float* __restrict__ g_proj) {
+         const uint8_t* __restrict__ nbr_cnt, const float* __restrict__ g_agg, int N, float* __restrict__ g_proj,
+         float* __restrict__ g_cedge /* nullable: [B,N,10,64], summed over the propagation steps */, int first) {
     const int b = blockIdx.x;
     const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
     const float4* ce = reinterpret_cast<const float4*>(c_edge) + (size_t)b * N * DRP_K * 16;
@@ -193,6 +195,11 @@ kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const
             gu.z = ((c.z + pr.z) + ps.z > 0.0f) ? gi.z : 0.0f;
             gu.w = ((c.w + pr.w) + ps.w > 0.0f) ? gi.w : 0.0f;
             acc.x += gu.x; acc.y += gu.y; acc.z += gu.z; acc.w += gu.w;
+            if (g_cedge != nullptr) {
+                float4* gc = reinterpret_cast<float4*>(g_cedge) + ((size_t)b * N * DRP_K + (size_t)i * DRP_K + k) * 16 + q;
+                if (first) *gc = gu;
+                else { float4 o = *gc; o.x += gu.x; o.y += gu.y; o.z += gu.z; o.w += gu.w; *gc = o; }
+            }
             float* dst = gp + (size_t)j * 128 + 64 + q * 4;
             atomicAdd(dst + 0, gu.x);
             atomicAdd(dst + 1, gu.y);
@@ -279,75 +286,106 @@ kb_node_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
 
 // ---- gen_s_delta backward: g_action[b, 0:4] = sum_n J_n^T g_s_delta[n], forward-mode over the four
 //      push parameters (sx, sy, ex, ey); the hard mask is a constant (planners.py:248)
-struct Dual4 {
-    float v, d[4];
+template <int ND>
+struct Dual {
+    float v, d[ND];
 };
-__device__ __forceinline__ Dual4 dconst(float v) { return Dual4{v, {0.f, 0.f, 0.f, 0.f}}; }
-__device__ __forceinline__ Dual4 operator+(const Dual4& a, const Dual4& b) {
-    return Dual4{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2], a.d[3] + b.d[3]}};
+template <int ND> __device__ __forceinline__ Dual<ND> dconst(float v) {
+    Dual<ND> r; r.v = v;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) r.d[c] = 0.0f;
+    return r;
 }
-__device__ __forceinline__ Dual4 operator-(const Dual4& a, const Dual4& b) {
-    return Dual4{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2], a.d[3] - b.d[3]}};
+template <int ND> __device__ __forceinline__ Dual<ND> operator+(const Dual<ND>& a, const Dual<ND>& b) {
+    Dual<ND> r; r.v = a.v + b.v;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) r.d[c] = a.d[c] + b.d[c];
+    return r;
 }
-__device__ __forceinline__ Dual4 operator*(const Dual4& a, const Dual4& b) {
-    return Dual4{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2],
-                             a.d[3] * b.v + a.v * b.d[3]}};
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND>& a, const Dual<ND>& b) {
+    Dual<ND> r; r.v = a.v - b.v;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) r.d[c] = a.d[c] - b.d[c];
+    return r;
 }
-__device__ __forceinline__ Dual4 operator/(const Dual4& a, const Dual4& b) {
-    const float q = a.v / b.v, ib = 1.0f / b.v;
-    return Dual4{q, {(a.d[0] - q * b.d[0]) * ib, (a.d[1] - q * b.d[1]) * ib, (a.d[2] - q * b.d[2]) * ib,
-                     (a.d[3] - q * b.d[3]) * ib}};
+template <int ND> __device__ __forceinline__ Dual<ND> operator*(const Dual<ND>& a, const Dual<ND>& b) {
+    Dual<ND> r; r.v = a.v * b.v;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) r.d[c] = a.d[c] * b.v + a.v * b.d[c];
+    return r;
 }
-__device__ __forceinline__ Dual4 dsqrt(const Dual4& a) {
-    const float r = sqrtf(a.v), k = 0.5f / r;
-    return Dual4{r, {a.d[0] * k, a.d[1] * k, a.d[2] * k, a.d[3] * k}};
+template <int ND> __device__ __forceinline__ Dual<ND> operator/(const Dual<ND>& a, const Dual<ND>& b) {
+    Dual<ND> r; r.v = a.v / b.v;
+    const float ib = 1.0f / b.v;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) r.d[c] = (a.d[c] - r.v * b.d[c]) * ib;
+    return r;
 }
-__device__ __forceinline__ Dual4 dscale(const Dual4& a, float s) {
-    return Dual4{a.v * s, {a.d[0] * s, a.d[1] * s, a.d[2] * s, a.d[3] * s}};
+template <int ND> __device__ __forceinline__ Dual<ND> dsqrt(const Dual<ND>& a) {
+    Dual<ND> r; r.v = sqrtf(a.v);
+    const float k = 0.5f / r.v;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) r.d[c] = a.d[c] * k;
+    return r;
 }
 
+// directions 0..3: the push (sx, sy, ex, ey); 4..6: the particle's own position (x, y, z).
+// g_action[b, 0:4] = sum_n J_n^T g_s_delta[n];  g_pos[b, n, 0:3] += J_pos^T g_s_delta[n] (nullable)
 __global__ void __launch_bounds__(256)
 kb_sdelta(const float* __restrict__ s_cur, int s_mod, size_t s_stride, const float* __restrict__ actions,
           size_t act_stride, const float* __restrict__ g_sdelta, int N, DrpCam cam, float* __restrict__ g_action,
-          size_t gact_stride) {
+          size_t gact_stride, float* __restrict__ g_pos, size_t gpos_stride) {
+    typedef Dual<7> D;
     __shared__ float red[4][4];
     const int b = blockIdx.x;
     const float* act = actions + (size_t)b * act_stride;
     const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
     const float* gs = g_sdelta + (size_t)b * N * 3;
     // camera-frame start / end as duals of (sx, sy, ex, ey): s3 = (sx, 0, -sy), e3 = (ex, 0, -ey)
-    Dual4 sc[3], ec[3];
+    D sc[3], ec[3];
     const float igs = 1.0f / cam.gs;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const float m0 = cam.m[r * 4 + 0], m2 = cam.m[r * 4 + 2], m3 = cam.m[r * 4 + 3];
-        sc[r] = Dual4{(m0 * act[0] - m2 * act[1] + m3) * igs, {m0 * igs, -m2 * igs, 0.f, 0.f}};
-        ec[r] = Dual4{(m0 * act[2] - m2 * act[3] + m3) * igs, {0.f, 0.f, m0 * igs, -m2 * igs}};
+        sc[r] = dconst<7>((m0 * act[0] - m2 * act[1] + m3) * igs);
+        sc[r].d[0] = m0 * igs; sc[r].d[1] = -m2 * igs;
+        ec[r] = dconst<7>((m0 * act[2] - m2 * act[3] + m3) * igs);
+        ec[r].d[2] = m0 * igs; ec[r].d[3] = -m2 * igs;
     }
-    const Dual4 vx = ec[0] - sc[0], vy = ec[1] - sc[1], vz = ec[2] - sc[2];
-    const Dual4 len = dsqrt(vx * vx + vy * vy + vz * vz);
-    const Dual4 dx = vx / len, dy = vy / len, dz = vz / len;
+    const D vx = ec[0] - sc[0], vy = ec[1] - sc[1], vz = ec[2] - sc[2];
+    const D len = dsqrt(vx * vx + vy * vy + vz * vz);
+    const D dx = vx / len, dy = vy / len, dz = vz / len;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        const float px = s[n * 3 + 0], py = s[n * 3 + 1], pz = s[n * 3 + 2];
-        const Dual4 rx = dconst(px) - sc[0], ry = dconst(py) - sc[1], rz = dconst(pz) - sc[2];
-        const Dual4 v = ry * dx - rx * dy;                                  // (p - s) . ortho, ortho = (-dy, dx, 0)
-        const Dual4 u = rx * dx + ry * dy + rz * dz;
-        if (!(u.v < len.v && u.v > 0.0f)) continue;                          // hard mask (constant)
-        // soft = exp(-max(relu(-w - v), relu(v - w)) / 0.01)
-        Dual4 pen = dconst(0.0f);
-        const float lo = -DRP_PUSHER_W - v.v, hi = v.v - DRP_PUSHER_W;
-        if (lo > 0.0f && lo >= hi) pen = dconst(-DRP_PUSHER_W) - v;
-        else if (hi > 0.0f) pen = v - dconst(DRP_PUSHER_W);
-        const float e = expf(-pen.v / DRP_SOFT_SCALE);
-        const Dual4 soft = Dual4{e, {-e * pen.d[0] / DRP_SOFT_SCALE, -e * pen.d[1] / DRP_SOFT_SCALE,
-                                     -e * pen.d[2] / DRP_SOFT_SCALE, -e * pen.d[3] / DRP_SOFT_SCALE}};
-        const Dual4 te = (ec[0] - dconst(px)) * dx + (ec[1] - dconst(py)) * dy + (ec[2] - dconst(pz)) * dz;
-        const Dual4 base = te * soft;
-        const Dual4 ox = base * dx, oy = base * dy, oz = base * dz;
-        const float g0 = gs[n * 3 + 0], g1 = gs[n * 3 + 1], g2 = gs[n * 3 + 2];
+        D px = dconst<7>(s[n * 3 + 0]), py = dconst<7>(s[n * 3 + 1]), pz = dconst<7>(s[n * 3 + 2]);
+        px.d[4] = 1.0f; py.d[5] = 1.0f; pz.d[6] = 1.0f;
+        const D rx = px - sc[0], ry = py - sc[1], rz = pz - sc[2];
+        const D v = ry * dx - rx * dy;                                  // (p - s) . ortho, ortho = (-dy, dx, 0)
+        const D u = rx * dx + ry * dy + rz * dz;
+        float g7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (u.v < len.v && u.v > 0.0f) {                                 // hard mask (constant)
+            // soft = exp(-max(relu(-w - v), relu(v - w)) / 0.01)
+            D pen = dconst<7>(0.0f);
+            const float lo = -DRP_PUSHER_W - v.v, hi = v.v - DRP_PUSHER_W;
+            if (lo > 0.0f && lo >= hi) pen = dconst<7>(-DRP_PUSHER_W) - v;
+            else if (hi > 0.0f) pen = v - dconst<7>(DRP_PUSHER_W);
+            const float e = expf(-pen.v / DRP_SOFT_SCALE);
+            D soft = dconst<7>(e);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] += g0 * ox.d[c] + g1 * oy.d[c] + g2 * oz.d[c];
+            for (int c = 0; c < 7; ++c) soft.d[c] = -e * pen.d[c] / DRP_SOFT_SCALE;
+            const D te = (ec[0] - px) * dx + (ec[1] - py) * dy + (ec[2] - pz) * dz;
+            const D base = te * soft;
+            const D ox = base * dx, oy = base * dy, oz = base * dz;
+            const float g0 = gs[n * 3 + 0], g1 = gs[n * 3 + 1], g2 = gs[n * 3 + 2];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) g7[c] = g0 * ox.d[c] + g1 * oy.d[c] + g2 * oz.d[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += g7[c];
+        if (g_pos != nullptr) {
+            float* gp = g_pos + (size_t)b * gpos_stride + (size_t)n * 3;
+            gp[0] += g7[4]; gp[1] += g7[5]; gp[2] += g7[6];
+        }
     }
     const int wave = threadIdx.x >> 6;
 #pragma unroll
@@ -360,6 +398,85 @@ kb_sdelta(const float* __restrict__ s_cur, int s_mod, size_t s_stride, const flo
         float t = 0.0f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w][threadIdx.x];
         g_action[(size_t)b * gact_stride + threadIdx.x] = t;
+    }
+}
+
+// ---- relation encoder backward (horizons > 1): g_cedge [B,N,10,64] -> through W_e and the three
+//      Linear+ReLU layers (forward recomputed per slot) to the position-difference inputs
+//      x[2:5] = s_r - s_s (gnn_dyn.py:179-180):  g_pos[recv] += g,  g_pos[send] -= g  (atomics)
+// One wave = the slots of one receiver, as k_edge_encode.
+__global__ void __launch_bounds__(256)
+kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, const float* __restrict__ s_cur, int s_mod,
+               size_t s_stride, const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens,
+               int dens_mod, const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
+               const float* __restrict__ g_cedge, int N, float* __restrict__ g_pos, size_t gpos_stride) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w0 = lds;               // [6][64] forward packs
+    float* w2 = w0 + 6 * 64;
+    float* w4 = w2 + 4096;
+    lds_copy(w0, vw + V_RE0_T, 6 * 64);
+    lds_copy(w2, vw + V_RE2_T, 4096);
+    lds_copy(w4, vw + V_RE4_T, 4096);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+    const float b0 = vw[V_RE0_B + lane], b2 = vw[V_RE2_B + lane], b4 = vw[V_RE4_B + lane];
+    const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
+    const float* at = attr + (size_t)(b % attr_mod) * N;
+    float* gp = g_pos + (size_t)b * gpos_stride;
+    const float wx = wraw[W_RE0_W + lane * 6 + 2], wy = wraw[W_RE0_W + lane * 6 + 3], wz = wraw[W_RE0_W + lane * 6 + 4];
+    constexpr int R = 5;           // two passes of five slots keep the register count moderate
+    for (int i = wave; i < N; i += nwave) {
+        const int cnt = nbr_cnt[(size_t)b * N + i];
+        const int16_t* nb = nbr_idx + ((size_t)b * N + i) * DRP_K;
+        const float ar = at[i];
+        const float sr = (lane >= 2 && lane < 5) ? s[i * 3 + lane - 2] : 0.0f;
+        for (int k0 = 0; k0 < cnt; k0 += R) {
+            float x[R], h1[R], h2[R], h3[R], g[R], t[R];
+            int js[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                js[r] = (k0 + r < cnt) ? (int)nb[k0 + r] : i;
+                float v = 0.0f;
+                if (lane == 0) v = ar;
+                else if (lane == 1) v = at[js[r]];
+                else if (lane < 5) v = sr - s[js[r] * 3 + lane - 2];
+                else if (lane == 5) v = d;
+                x[r] = v;
+                h1[r] = b0;
+            }
+            dense_bcast<6, R>(w0, x, h1, lane);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { x[r] = fmaxf(h1[r], 0.0f); h2[r] = b2; }
+            dense_bcast<64, R>(w2, x, h2, lane);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { x[r] = fmaxf(h2[r], 0.0f); h3[r] = b4; }
+            dense_bcast<64, R>(w4, x, h3, lane);
+            // backward
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                g[r] = (k0 + r < cnt) ? g_cedge[(((size_t)b * N + i) * DRP_K + k0 + r) * 64 + lane] : 0.0f;
+                t[r] = 0.0f;
+            }
+            dense_bcast_ld<64, R>(wraw + W_RP_W, 193, 0, g, t, lane);             // W_e^T
+#pragma unroll
+            for (int r = 0; r < R; ++r) { g[r] = (h3[r] > 0.0f) ? t[r] : 0.0f; t[r] = 0.0f; }
+            dense_bcast_ld<64, R>(wraw + W_RE4_W, 64, 0, g, t, lane);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { g[r] = (h2[r] > 0.0f) ? t[r] : 0.0f; t[r] = 0.0f; }
+            dense_bcast_ld<64, R>(wraw + W_RE2_W, 64, 0, g, t, lane);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float gh = (h1[r] > 0.0f) ? t[r] : 0.0f;
+                const float ox = wave_sum(gh * wx), oy = wave_sum(gh * wy), oz = wave_sum(gh * wz);
+                if (k0 + r < cnt && lane < 3) {
+                    const float v = (lane == 0) ? ox : (lane == 1) ? oy : oz;
+                    atomicAdd(gp + (size_t)i * 3 + lane, v);
+                    atomicAdd(gp + (size_t)js[r] * 3 + lane, -v);
+                }
+            }
+        }
     }
 }
 

@@ -259,16 +259,13 @@ class PlannerGD(Planner):
             return r
 
         mpc_type = cfg.get('mpc_type', 'MPPI')
-        if mpc_type == 'GD' and H != 1:
-            raise NotImplementedError('the reverse-mode kernels cover n_look_ahead = 1 (the reference\'s demo '
-                                      'setting); use mpc_type MPPI for longer horizons')
         i = 0
         if mpc_type == 'GD':
             # the reference's live loop (planners.py:661-764): every trajectory x batch column is an
             # independent Adam problem on its own push; rollout, reward, backward, Adam and the clip all
             # run on the device
             assert n_sample == traj_num, 'GD optimises the traj_num given trajectories (n_sample == traj_num)'
-            cand = np.repeat(act_seq.transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)   # [traj*nb,1,4]
+            cand = np.repeat(act_seq.transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)   # [traj*nb,H,4]
             eng.gd_begin(state_cur_np, attr_cur_np, state_param, cand, cfg['gd']['lr'], lo, hi)
             reward_seqs = np.zeros((traj_num * n_batch,), np.float32)
             act_seqs_last = cand

@@ -148,9 +148,8 @@ int drp_mpc_get(drp_ctx* ctx, float* actions /*[B,H,4]*/, float* rewards /*[B] f
 
 /* ---- gradient-descent planner (the reference's live mpc_type 'GD') ----------------------------
  * One iteration of planners.py:682-764: rollout -> final-step reward -> loss = -sum(reward)
- * -> d loss / d pushes by reverse mode -> Adam(lr) step -> clip box.  This round the horizon
- * is 1 (config/mpc/config.yaml:38 n_look_ahead); longer horizons return DRP_EINVAL.
- * actions [B,1,4] with B = traj_num * n_batch rows (row = traj * n_batch + batch). */
+ * -> d loss / d pushes by reverse mode (through every step of the horizon) -> Adam(lr) step
+ * -> clip box.  actions [B,H,4] with B = traj_num * n_batch rows (row = traj * n_batch + batch). */
 int drp_gd_begin(drp_ctx* ctx, const float* s0, const float* attr, const float* dens, int nb, int N,
                  const float* actions, int B, int H, double lr, const float act_lo[4], const float act_hi[4]);
 /* forward + backward only: rewards [B], d loss / d actions [B,H,4], d loss / d state_pred

@@ -1,5 +1,5 @@
 """GPU, scope row f1: the reverse-mode kernels and the gradient-descent planner (the
-reference's live mpc_type 'GD', horizon 1) against gradients and a full planner run
+reference's live mpc_type 'GD') against gradients and a full planner run
 captured from the reference (tests/golden/grad.npz, gd_planner.npz)."""
 import numpy as np
 import pytest
@@ -22,7 +22,7 @@ def ctx(golden):
     eng.close()
 
 
-@pytest.mark.parametrize('case', ['h1', 'h1_n100'])
+@pytest.mark.parametrize('case', ['h1', 'h1_n100', 'h2'])
 def test_gradients_match_the_reference(ctx, golden, case):
     g = golden.grad
     obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
@@ -33,20 +33,15 @@ def test_gradients_match_the_reference(ctx, golden, case):
     np.testing.assert_allclose(r, g[case + '/reward'][:, 0], rtol=2e-5)
     ref_gs, ref_ga = g[case + '/grad_state_pred'], g[case + '/grad_act']
     # d loss / d predicted state: bilinear-sample and chamfer arg-min gradients through the projection
-    assert np.abs(gs - ref_gs).max() < 1e-3 * np.abs(ref_gs).max()
+    # (the reference's retained gradient of its in-place-filled state_pred tensor only shows the final
+    # step's slice: earlier slices were read through an older version of the tensor)
+    assert gs.shape == ref_gs.shape
+    assert np.abs(gs[:, -1] - ref_gs[:, -1]).max() < 1e-3 * np.abs(ref_gs).max()
     # d loss / d push through predictor, 3 propagation steps, particle encoder and gen_s_delta
     assert np.abs(ga - ref_ga).max() < 2e-3 * np.abs(ref_ga).max()
     assert np.abs(ga - ref_ga).max() < 1e-4
     # rows whose push misses the pile have exactly zero gradient in both
     np.testing.assert_array_equal(np.abs(ga).sum((1, 2)) == 0, np.abs(ref_ga).sum((1, 2)) == 0)
-
-
-def test_horizon_two_is_refused_loudly(ctx, golden):
-    from dyn_res_pile_manip_amd import _lib
-    g = golden.grad
-    lo, hi = syn.action_limits()
-    with pytest.raises(_lib.DrpError, match='horizon 1'):
-        ctx.gd_begin(g['h2/s_cur'], g['h2/attr'], g['h2/dens'], g['h2/act_seqs'], 0.05, lo, hi)
 
 
 def test_adam_iterations_and_planner_dict_match_the_reference(golden):
