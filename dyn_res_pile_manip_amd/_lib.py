@@ -72,6 +72,8 @@ SIGNATURES = {
     'drp_mpc_update_device': (ctypes.c_int, [ctypes.c_void_p]),
     'drp_mpc_get': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                    c_double_p]),
+    'drp_fps': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                               ctypes.POINTER(ctypes.c_int32), c_float_p]),
     'drp_gd_begin': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                     c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_float_p, c_float_p]),
     'drp_gd_grad': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p]),

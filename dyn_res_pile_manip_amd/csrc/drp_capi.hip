@@ -20,6 +20,7 @@
 #include "k_mppi.h"
 #include "k_reward.h"
 #include "k_backward.h"
+#include "k_fps.h"
 #ifdef DRP_HAVE_MFMA
 #include "k_mlp_mfma.h"
 #include "k_mlp_split.h"
@@ -838,6 +839,29 @@ int drp_mpc_get(drp_ctx* c, float* actions, float* rewards, float* rewards_all, 
     if (rewards_all) CHK(d2h(c, rewards_all, c->rewards.p, (size_t)B * H * sizeof(float)));
     if (states) CHK(d2h(c, states, c->states.p, (size_t)B * H * N * 3 * sizeof(float)));
     if (nominal) CHK(d2h(c, nominal, c->nominal.p, (size_t)H * 4 * sizeof(double)));
+    return drp_sync(c);
+}
+
+int drp_fps(drp_ctx* c, const float* pts, int n, int dim, int k, int init_idx, int32_t* idx_out, float* max_dist_out) {
+    if (!c || !pts || !idx_out) return fail(c, DRP_EINVAL, "null argument");
+    if (n <= 0 || k <= 0 || k > n || init_idx < 0 || init_idx >= n || (dim != 2 && dim != 3))
+        return fail(c, DRP_EINVAL, "bad fps arguments n=%d dim=%d k=%d init=%d", n, dim, k, init_idx);
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(h2d(c, c->scratch, pts, (size_t)n * dim * sizeof(float)));
+    CHK(ensure(c, c->g_agg, (size_t)n * sizeof(float) + (size_t)(k + 1) * sizeof(int)));   // dist | chosen | max
+    float* dist = ptr<float>(c->g_agg);
+    int* chosen = reinterpret_cast<int*>(dist + n);
+    CHK(ensure(c, c->stats, 8 * sizeof(double)));
+    float* md = reinterpret_cast<float*>(ptr<double>(c->stats) + 7);
+    if (dim == 2)
+        hipLaunchKernelGGL(k_fps<2>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, dist,
+                           chosen, md);
+    else
+        hipLaunchKernelGGL(k_fps<3>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, dist,
+                           chosen, md);
+    HIPCHK(c, hipGetLastError());
+    CHK(d2h(c, idx_out, chosen, (size_t)k * sizeof(int)));
+    if (max_dist_out) CHK(d2h(c, max_dist_out, md, sizeof(float)));
     return drp_sync(c);
 }
 

@@ -206,7 +206,17 @@ class Engine(object):
         self._ck(self.lib.drp_debug_fetch(self.h, b'stats', out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
         return {'mean': out[0], 'std': out[1], 'max': out[2], 'argmax': int(out[3]), 'Z': out[4], 'm': out[5]}
 
-    # ---- gradient-descent planner (horizon 1) ---------------------------------------
+    def fps(self, pts, k, init_idx=0):
+        """utils.fps_np on the device: returns (pts[chosen], max distance, chosen indices)."""
+        pts = _f32(pts)
+        n, dim = pts.shape
+        idx = np.empty((k,), np.int32)
+        md = ctypes.c_float()
+        self._ck(self.lib.drp_fps(self.h, _fp(pts), n, dim, int(k), int(init_idx),
+                                  idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.byref(md)))
+        return pts[idx], md.value, idx
+
+    # ---- gradient-descent planner ---------------------------------------
     def gd_begin(self, s0, attr, dens, actions, lr, act_lo, act_hi):
         s0, attr, dens, actions = _f32(s0), _f32(attr), _f32(dens), _f32(actions)
         nb, N, _ = s0.shape

@@ -226,7 +226,7 @@ class PlannerGD(Planner):
             # planners.py:620-624: goal pixels (col,row), farthest-point subsample to 5N
             rc = np.argwhere(obs_goal < 0.5)
             cr = rc[:, ::-1].astype(np.float32)
-            goal_coor = fps_np(cr, min(N * 5, cr.shape[0]), 0)[0]
+            goal_coor = eng.fps(cr, min(N * 5, cr.shape[0]), 0)[0]      # fps_np on the device, same selection
         self._set_goal(eng, obs_goal, goal_coor)
 
         lo, hi = self._clip_box()

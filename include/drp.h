@@ -146,6 +146,12 @@ int drp_mpc_update_device(drp_ctx* ctx);
 int drp_mpc_get(drp_ctx* ctx, float* actions /*[B,H,4]*/, float* rewards /*[B] final*/,
                 float* rewards_all /*[B,H]*/, float* states /*[B,H,N,3]*/, double* nominal);
 
+/* fps_np (utils.py:451-466): farthest-point subsample of pts [n,dim] (dim 2 or 3) to k points
+ * starting from init_idx; idx_out [k] are indices into pts, max_dist_out the largest distance
+ * of any point to the chosen set.  Used for the goal pixels (planners.py:620-624). */
+int drp_fps(drp_ctx* ctx, const float* pts, int n, int dim, int k, int init_idx, int32_t* idx_out,
+            float* max_dist_out);
+
 /* ---- gradient-descent planner (the reference's live mpc_type 'GD') ----------------------------
  * One iteration of planners.py:682-764: rollout -> final-step reward -> loss = -sum(reward)
  * -> d loss / d pushes by reverse mode (through every step of the horizon) -> Adam(lr) step

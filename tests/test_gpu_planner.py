@@ -129,3 +129,22 @@ def test_trajectory_optimization_contract(stack, golden):
     # the planner must not do worse than the best initial candidate
     cand_best = res['rew_mean'][0, 0]
     assert res['reward'][0] >= cand_best - 1e-3
+
+
+def test_device_fps_equals_fps_np(stack):
+    """utils.py:451-466 as used at planners.py:620-624: same points in the same order."""
+    from dyn_res_pile_manip_amd.planners import fps_np
+    _, _, model, _ = stack
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    rc = np.argwhere(obs_goal < 0.5)
+    cr = rc[:, ::-1].astype(np.float32)
+    for k in (7, 320, 1500):
+        want, want_md = fps_np(cr, k, 0)
+        got, got_md, idx = model.engine.fps(cr, k, 0)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_allclose(got_md, want_md, rtol=1e-6)
+        assert len(set(idx.tolist())) == k
+    pts3 = np.random.default_rng(0).uniform(-0.2, 0.2, (5000, 3)).astype(np.float32)
+    want, _ = fps_np(pts3, 100, 17)
+    got, _, _ = model.engine.fps(pts3, 100, 17)
+    np.testing.assert_array_equal(got, want)
