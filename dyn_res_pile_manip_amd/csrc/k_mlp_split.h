@@ -502,6 +502,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         float p0x = s[j0 * 3 + 0], p0y = s[j0 * 3 + 1], p0z = s[j0 * 3 + 2], p0a = at[j0];
 #pragma unroll 1
         for (int k = 0; k < DRP_K; ++k) {
+            if (__all(k >= cnt)) break;              // sparse piles: no receiver of this tile has a slot k
             asm volatile("" ::: "memory");          // keep the packed-weight reads inside the loop
             const int jcur = j0;
             const float p1x = s[j1 * 3 + 0], p1y = s[j1 * 3 + 1], p1z = s[j1 * 3 + 2], p1a = at[j1];
