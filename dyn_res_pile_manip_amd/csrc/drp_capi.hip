@@ -48,7 +48,6 @@ struct drp_ctx {
     std::string err;
     int engine = DRP_ENGINE_VALU;
     int n_cu = 256;
-    bool fused_agg_only = false;    // DRP_FUSED_AGG_ONLY=1: fused engine keeps km_update separate
     bool agg_global_only = false;   // DRP_AGG_GLOBAL=1: always gather sender rows from L2/HBM
 
     // model constants
@@ -254,7 +253,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                                a.s_prev, a.prev_mod, a.prev_stride, a.attr, a.attr_mod, a.dens, a.dens_mod,
                                ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N, B, ptr<float>(c->c_edge));
     }
-    if (fused && !c->fused_agg_only) {
+    if (fused) {
         // graph -> node_encode -> 3 x km_prop: the whole propagation step in one launch each
         float* pa = ptr<float>(c->proj);
         float* pb = ptr<float>(c->proj2);
@@ -274,15 +273,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
         return DRP_OK;
     }
     for (int p = 0; p < DRP_PSTEP; ++p) {
-        if (fused) {
-            ProbeScope ps(c, KC_AGGREGATE);
-            hipLaunchKernelGGL(km_edge_agg_split_flat, dim3(mfma_grid(c, node_tiles)), blk, KM_FLAT_LDS, st,
-                               ptr<uint16_t>(c->w_split), mw, a.s_prev, a.prev_mod, a.prev_stride, a.attr,
-                               a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx),
-                               ptr<uint8_t>(c->nbr_cnt), ptr<float>(c->proj), N, B, ptr<float>(c->agg));
-        } else {
-            launch_aggregate(c, B, N);
-        }
+        launch_aggregate(c, B, N);
         ProbeScope ps(c, p + 1 < DRP_PSTEP ? KC_UPDATE : KC_PREDICT);
         if (p + 1 < DRP_PSTEP)
             hipLaunchKernelGGL(km_update<false>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
@@ -464,7 +455,6 @@ int drp_create(int device, drp_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
     c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
-    c->fused_agg_only = getenv("DRP_FUSED_AGG_ONLY") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_aggregate_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                             K_AGG_LDS_MAX_N * 256) != hipSuccess) {

@@ -96,17 +96,6 @@ struct FragB {
 
 template <bool RELU>
 __device__ __forceinline__ void split_frag(const Frag& in, FragB& o) {
-#ifdef DRP_ABLATE_NOSPLIT      // timing experiment: dependent, but no vector work (wrong results)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        f32x4 t = {in.v[s >> 1][8 * (s & 1)], in.v[s >> 1][8 * (s & 1) + 1], in.v[s >> 1][8 * (s & 1) + 2], in.v[s >> 1][8 * (s & 1) + 3]};
-        f32x4 u = {in.v[s >> 1][8 * (s & 1) + 4], in.v[s >> 1][8 * (s & 1) + 5], in.v[s >> 1][8 * (s & 1) + 6], in.v[s >> 1][8 * (s & 1) + 7]};
-        o.hi[s] = __builtin_bit_cast(bf16x8, t);
-        o.lo[s] = __builtin_bit_cast(bf16x8, u);
-    }
-    return;
-#endif
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -256,90 +245,6 @@ km_edge_encode_split(const uint16_t* __restrict__ sw, const float* __restrict__ 
 
 #define KM_EDGE_SPLIT_LDS ((S_TOTAL * 4 + 256 + MFMA_WAVES * TILE_FLOATS) * sizeof(float))
 
-// ---- fused: relation encoder recomputed per propagation step + segmented aggregate -----------
-// With the split chain the encoder is cheap enough to recompute in each of the three
-// propagation steps, so the [B,N,10,64] edge-constant buffer (786 MB at 1024 x 300, written
-// once and read three times per rollout step: 55 % of all HBM traffic of the unfused
-// pipeline) never exists.  A wave owns a tile of 32 receivers, loops over the 10 slots,
-// runs the chain for the 32 edges (slot k of each receiver) and accumulates
-//     agg[i] += relu(c_edge + (W_r eff)[i] + (W_s eff)[send])      gnn_dyn.py:183-189
-// in the accumulator layout (receiver on the lane, 32 features in registers); the sender
-// rows are gathered from L2 early in the iteration and consumed after the chain.
-// No per-sample state in LDS, so receiver tiles of all samples are dealt to the waves of
-// the whole grid (perfect balance, any N).
-__global__ void __launch_bounds__(64 * MFMA_WAVES)
-km_edge_agg_split_flat(const uint16_t* __restrict__ sw, const float* __restrict__ mw,
-                       const float* __restrict__ s_cur, int s_mod, size_t s_stride,
-                       const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
-                       const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
-                       const float* __restrict__ proj, int N, int B, float* __restrict__ agg) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wsp_f = lds;
-    float* rows = wsp_f + S_TOTAL * 4;
-    lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
-    lds_fill(rows, mw + R_RE2_B, 256);
-    __syncthreads();
-    const bf16x8* wsp = reinterpret_cast<const bf16x8*>(wsp_f);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int tps = (N + 31) >> 5;
-    const long ntiles = (long)B * tps;
-    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
-        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
-        const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
-        const float* at = attr + (size_t)(b % attr_mod) * N;
-        const float* pj = proj + (size_t)b * N * 128;
-        const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
-        const int i = min(t * 32 + j, N - 1);
-        const int cnt = nbr_cnt[(size_t)b * N + i];
-        const int16_t* nb = nbr_idx + ((size_t)b * N + i) * DRP_K;
-        Frag bpr, acc;
-        {
-            Frag pr;
-            frag_bias_dens(rows + 128, rows + 192, d, h, bpr);
-            frag_from_row(pj + (size_t)i * 128, h, pr);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
-        }
-        frag_zero(acc);
-        const float pix = s[i * 3 + 0], piy = s[i * 3 + 1], piz = s[i * 3 + 2], pia = at[i];
-        int jn = (0 < cnt) ? (int)nb[0] : i;
-#pragma unroll 1
-        for (int k = 0; k < DRP_K; ++k) {
-            asm volatile("" ::: "memory");
-            const int jcur = jn;
-            if (k + 1 < DRP_K) jn = (k + 1 < cnt) ? (int)nb[k + 1] : i;
-            float x[8];
-            x[0] = pia; x[1] = at[jcur];
-            x[2] = pix - s[jcur * 3 + 0]; x[3] = piy - s[jcur * 3 + 1]; x[4] = piz - s[jcur * 3 + 2];
-            x[5] = d; x[6] = 1.0f; x[7] = 0.0f;
-            Frag sv;                                        // issued now, consumed after the chain
-            frag_from_row(pj + (size_t)jcur * 128 + 64, h, sv);
-            Frag a, c;
-            FragB fb;
-            frag_zero(a);
-            mfma_layer8_split(wsp + S_RE0, x, h, a, lane);
-            split_frag<true>(a, fb);
-            frag_from_row(rows + 0, h, c);
-            mfma_layer64_split(wsp + S_RE2, fb, c, lane);
-            split_frag<true>(c, fb);
-            frag_from_row(rows + 64, h, a);
-            mfma_layer64_split(wsp + S_RE4, fb, a, lane);
-            split_frag<true>(a, fb);
-            c = bpr;
-            mfma_layer64_split(wsp + S_RPE, fb, c, lane);
-            const float keep = (k < cnt) ? 1.0f : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc.v[0][r] += keep * fmaxf(c.v[0][r] + sv.v[0][r], 0.0f);
-                acc.v[1][r] += keep * fmaxf(c.v[1][r] + sv.v[1][r], 0.0f);
-            }
-        }
-        if (t * 32 + j < N) frag_to_row(agg + ((size_t)b * N + i) * 64, h, acc);
-    }
-}
-#define KM_FLAT_LDS ((size_t)(S_TOTAL * 4 + 256) * sizeof(float))
-
 // ---- whole propagation step in one kernel -----------------------------------------------------
 // km_prop<LAST>: per tile of 32 receivers
 //     agg  = sum_k relu(c_edge_k + (W_r eff)[i] + (W_s eff)[send_k])   (chain recomputed, above)
@@ -441,8 +346,6 @@ __device__ __forceinline__ void mfma_layer64_split6(const bf16x8* __restrict__ w
 #ifndef PROP_WAVES
 #define PROP_WAVES 8
 #endif
-// PROP_LOWREG: rebuild the receiver term each slot and gather the sender row after the chain
-// (64 fewer live registers, for three waves per SIMD)
 template <bool LAST>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
@@ -482,9 +385,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         const size_t row = (size_t)b * N + i;
         const int cnt = nbr_cnt[row];
         const int16_t* nb = nbr_idx + row * DRP_K;
-        Frag acc;
-#ifndef PROP_LOWREG
-        Frag bpr;
+        Frag acc, bpr;
         {
             Frag pr;
             frag_bias_dens(rows + 128, rows + 192, d, h, bpr);
@@ -492,7 +393,6 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
         }
-#endif
         frag_zero(acc);
         const float pix = s[i * 3 + 0], piy = s[i * 3 + 1], piz = s[i * 3 + 2], pia = at[i];
         // two-deep software pipeline on the dependent loads (index -> sender position): the
@@ -512,13 +412,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
             x[2] = pix - p0x; x[3] = piy - p0y; x[4] = piz - p0z;
             x[5] = d; x[6] = 1.0f; x[7] = 0.0f;
             Frag sv;                                 // issued now, consumed after the chain
-#ifndef PROP_LOWREG
-#ifdef DRP_ABLATE_NOGATHER
-            frag_from_row(rows + 0, h, sv);
-#else
             frag_from_row(pj + (size_t)jcur * 128 + 64, h, sv);
-#endif
-#endif
             Frag a, c;
             FragB fb;
             frag_zero(a);
@@ -531,43 +425,16 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
             frag_from_row(rows + 64, h, a);
             mfma_layer64_split(wsp + S_RE4, fb, a, lane, wn, wsp + S_RPE, w0);
             split_frag<true>(a, fb);
-#ifdef PROP_LOWREG
-            {
-                Frag pr;
-                frag_bias_dens(rows + 128, rows + 192, d, h, c);
-                frag_from_row(pj + (size_t)i * 128, h, pr);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { c.v[0][r] += pr.v[0][r]; c.v[1][r] += pr.v[1][r]; }
-            }
-#else
             c = bpr;
-#endif
             mfma_layer64_split(wsp + S_RPE, fb, c, lane, w0, nullptr, wn);
-#ifdef PROP_LOWREG
-            frag_from_row(pj + (size_t)jcur * 128 + 64, h, sv);
-#endif
             const float keep = (k < cnt) ? 1.0f : 0.0f;
-#ifdef DRP_ABLATE_NOEPI
-            acc.v[0][0] += keep * (c.v[0][0] + sv.v[0][0]);
-            acc.v[1][15] += keep * (c.v[1][15] + sv.v[1][15]);
-#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc.v[0][r] += keep * fmaxf(c.v[0][r] + sv.v[0][r], 0.0f);
                 acc.v[1][r] += keep * fmaxf(c.v[1][r] + sv.v[1][r], 0.0f);
             }
-#endif
             j0 = j1; j1 = j2;
             p0x = p1x; p0y = p1y; p0z = p1z; p0a = p1a;
-#ifdef DRP_SCHED_PIPE
-            // scheduling pipeline for this loop body: one MFMA, then the vector work that fits
-            // under it (78 MFMAs, ~600 VALU per iteration)
-#pragma unroll
-            for (int q = 0; q < 78; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, DRP_SCHED_PIPE, 0);
-            }
-#endif
         }
         // ---- node update on the aggregate still in registers
         asm volatile("" ::: "memory");
