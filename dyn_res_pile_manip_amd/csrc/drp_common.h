@@ -81,3 +81,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float bcast_lane(float v, int lane_const) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
 }
+
+// ReLU as ONE instruction: hipcc canonicalises the operand of fmaxf (an extra v_max_f32 x, x in
+// front of every v_max_f32 whose input comes from an MFMA or a load: 96 of 613 vector
+// instructions per slot in km_prop), and folds v_med3(x, 0, inf) back into that pair.  On the
+// bit pattern ReLU is an integer max with 0: non-negative floats are non-negative ints and
+// keep their bits, anything with the sign bit set (incl. -0) becomes +0, a +NaN stays a NaN.
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+// min of two NON-NEGATIVE floats (squared distances): their bit patterns order like ints
+__device__ __forceinline__ float min_nonneg(float a, float b) { return __int_as_float(min(__float_as_int(a), __float_as_int(b))); }

@@ -141,7 +141,7 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int q = DRP_K - 1; q > 0; --q) best[q] = __builtin_amdgcn_fmed3f(d4[u], best[q - 1], best[q]);
-            best[0] = fminf(best[0], d4[u]);
+            best[0] = min_nonneg(d4[u], best[0]);
         }
     }
     for (; j < N; ++j) {
@@ -149,7 +149,7 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
         const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
 #pragma unroll
         for (int q = DRP_K - 1; q > 0; --q) best[q] = __builtin_amdgcn_fmed3f(d, best[q - 1], best[q]);
-        best[0] = fminf(best[0], d);
+        best[0] = min_nonneg(d, best[0]);
     }
     const float kth = best[DRP_K - 1];
     int16_t* out = nbr_idx + ((size_t)b * N + i) * DRP_K;

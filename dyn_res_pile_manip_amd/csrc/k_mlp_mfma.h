@@ -52,7 +52,8 @@ enum {
     R_PR0_B = R_PP_WD + 64,
     R_PR1_W = R_PR0_B + 64,     // [3][64]
     R_PR1_B = R_PR1_W + 192,    // [4]
-    M_TOTAL = R_PR1_B + 4
+    R_SINK = R_PR1_B + 4,       // [64] of -1e30: the "sender row" of a padded slot, relu(c + sink) == 0
+    M_TOTAL = R_SINK + 64
 };
 
 inline int mfma_kidx(int s, int h) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; }
@@ -102,6 +103,7 @@ inline void pack_mfma(const float* w, std::vector<float>& m) {
     C(R_PR0_B, W_PR0_B, 64);
     C(R_PR1_W, W_PR1_W, 192);
     C(R_PR1_B, W_PR1_B, 3);
+    for (int o = 0; o < 64; ++o) m[R_SINK + o] = -1e30f;
 }
 
 // ---- fragments ------------------------------------------------------------------------------
@@ -137,7 +139,7 @@ __device__ __forceinline__ void frag_to_row(float* row, int h, const Frag& f) {
 
 __device__ __forceinline__ void frag_relu(Frag& f) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { f.v[0][r] = fmaxf(f.v[0][r], 0.0f); f.v[1][r] = fmaxf(f.v[1][r], 0.0f); }
+    for (int r = 0; r < 16; ++r) { f.v[0][r] = relu1(f.v[0][r]); f.v[1][r] = relu1(f.v[1][r]); }
 }
 
 // LDS accesses of one wave complete in order; this only stops the compiler from moving them.
@@ -198,7 +200,7 @@ __device__ __forceinline__ void mfma_layer64(const float4* __restrict__ wp, cons
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float b = in.v[s4 >> 2][4 * (s4 & 3) + c];
-            if (RELU_IN) b = fmaxf(b, 0.0f);
+            if (RELU_IN) b = relu1(b);
             acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c[c], b, acc.v[0], 0, 0, 0);
             acc.v[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c[c], b, acc.v[1], 0, 0, 0);
         }

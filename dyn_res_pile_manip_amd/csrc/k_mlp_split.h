@@ -101,7 +101,7 @@ __device__ __forceinline__ void split_frag(const Frag& in, FragB& o) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             float x = in.v[s >> 1][8 * (s & 1) + jj];
-            if (RELU) x = fmaxf(x, 0.0f);
+            if (RELU) x = relu1(x);
             const __bf16 hi = (__bf16)x;
             o.hi[s][jj] = hi;
             o.lo[s][jj] = (__bf16)(x - (float)hi);
@@ -411,8 +411,9 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
             x[0] = pia; x[1] = p0a;
             x[2] = pix - p0x; x[3] = piy - p0y; x[4] = piz - p0z;
             x[5] = d; x[6] = 1.0f; x[7] = 0.0f;
-            Frag sv;                                 // issued now, consumed after the chain
-            frag_from_row(pj + (size_t)jcur * 128 + 64, h, sv);
+            Frag sv;                                 // issued now, consumed after the chain; a padded slot
+            // reads the sink row (-1e30), so its relu(c + sv) is exactly 0
+            frag_from_row((k < cnt) ? pj + (size_t)jcur * 128 + 64 : mw + R_SINK, h, sv);
             Frag a, c;
             FragB fb;
             frag_zero(a);
@@ -427,11 +428,10 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
             split_frag<true>(a, fb);
             c = bpr;
             mfma_layer64_split(wsp + S_RPE, fb, c, lane, w0, nullptr, wn);
-            const float keep = (k < cnt) ? 1.0f : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                acc.v[0][r] += keep * fmaxf(c.v[0][r] + sv.v[0][r], 0.0f);
-                acc.v[1][r] += keep * fmaxf(c.v[1][r] + sv.v[1][r], 0.0f);
+                acc.v[0][r] += relu1(c.v[0][r] + sv.v[0][r]);
+                acc.v[1][r] += relu1(c.v[1][r] + sv.v[1][r]);
             }
             j0 = j1; j1 = j2;
             p0x = p1x; p0y = p1y; p0z = p1z; p0a = p1a;
