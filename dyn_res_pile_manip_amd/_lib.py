@@ -74,6 +74,19 @@ SIGNATURES = {
                                    c_double_p]),
     'drp_fps': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                ctypes.POINTER(ctypes.c_int32), c_float_p]),
+    'drp_depth2fgpcd': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int,
+                                       ctypes.c_int, c_double_p, c_double_p, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_int)]),
+    'drp_downsample_pcd': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_double, c_double_p,
+                                          ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    'drp_fps_pcd': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.POINTER(ctypes.c_int32), ctypes.c_uint64, c_float_p, c_double_p]),
+    'drp_recenter': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int,
+                                    c_double_p, c_float_p]),
+    'drp_obs2ptcl': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                    c_double_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
+                                    ctypes.c_uint64, c_double_p, c_double_p, ctypes.POINTER(ctypes.c_int),
+                                    ctypes.POINTER(ctypes.c_int)]),
     'drp_gd_begin': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                     c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_float_p, c_float_p]),
     'drp_gd_grad': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p]),

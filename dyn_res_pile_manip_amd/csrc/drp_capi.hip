@@ -21,6 +21,7 @@
 #include "k_reward.h"
 #include "k_backward.h"
 #include "k_fps.h"
+#include "k_particles.h"
 #ifdef DRP_HAVE_MFMA
 #include "k_mlp_mfma.h"
 #include "k_mlp_split.h"
@@ -76,6 +77,10 @@ struct drp_ctx {
     float gd_lo[4] = {0, 0, 0, 0}, gd_hi[4] = {0, 0, 0, 0};
     DevBuf eff_hist, proj_hist, g_eff, g_cnode, g_agg, g_proj, g_state, g_sdelta, g_act, adam_m, adam_v;
     DevBuf tape_sdelta, tape_idx, tape_cnt, tape_cedge, g_cedge;
+
+    // particle extraction (row f2)
+    DevBuf px_depth, px_mask, px_blk, px_bmin, px_bmax, px_grid, px_pcd, px_keys, px_cellcnt, px_cellfill,
+        px_celloff, px_list, px_down, px_down32, px_init, px_dist, px_chosen, px_pts, px_r, px_rr, px_out;
 
     // last shapes (for debug fetch)
     int lastB = 0, lastN = 0, lastH = 0;
@@ -491,7 +496,10 @@ void drp_destroy(drp_ctx* c) {
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
-                      &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats};
+                      &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats,
+                      &c->px_depth, &c->px_mask, &c->px_blk, &c->px_bmin, &c->px_bmax, &c->px_grid, &c->px_pcd, &c->px_keys,
+                      &c->px_cellcnt, &c->px_cellfill, &c->px_celloff, &c->px_list, &c->px_down, &c->px_down32, &c->px_init,
+                      &c->px_dist, &c->px_chosen, &c->px_pts, &c->px_r, &c->px_rr, &c->px_out};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : c->probe_ev) (void)hipEventDestroy(ev);
@@ -852,6 +860,221 @@ int drp_fps(drp_ctx* c, const float* pts, int n, int dim, int k, int init_idx, i
     HIPCHK(c, hipGetLastError());
     CHK(d2h(c, idx_out, chosen, (size_t)k * sizeof(int)));
     if (max_dist_out) CHK(d2h(c, max_dist_out, md, sizeof(float)));
+    return drp_sync(c);
+}
+
+// ---- particle extraction (row f2) ---------------------------------------------------------------
+namespace {
+const long long PX_MAX_CELLS = 1ll << 24;
+const float PX_FG_DEPTH = (float)(0.599 / 0.8);    // env/flex_env.py:945, compared in float32
+
+int px_nblk(size_t n) { return (int)((n + PX_TILE - 1) / PX_TILE); }
+
+// depth image on the device -> c->px_pcd [n,3] float64 + per-block bounds; *n_out after a sync
+int px_stage_pcd(drp_ctx* c, const float* d_depth, const uint8_t* d_mask, int h, int w, float gs, const double cam[4],
+                 int* n_out) {
+    const size_t npix = (size_t)h * w;
+    const int nblk = px_nblk(npix);
+    hipStream_t st = c->stream;
+    CHK(ensure(c, c->px_blk, (size_t)(2 * nblk + 2) * sizeof(unsigned long long)));
+    unsigned long long* cnt = ptr<unsigned long long>(c->px_blk);
+    unsigned long long* off = cnt + nblk;
+    hipLaunchKernelGGL(k_px_count, dim3(nblk), dim3(PX_BLOCK), 0, st, d_depth, d_mask, gs, PX_FG_DEPTH, npix, cnt);
+    hipLaunchKernelGGL(k_px_scan_u64, dim3(1), dim3(1024), 0, st, cnt, nblk, off);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long total = 0;
+    CHK(d2h(c, &total, off + nblk, sizeof(total)));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (total > 0x7fffffffull) return fail(c, DRP_EINVAL, "too many foreground pixels");
+    const int n = (int)total;
+    *n_out = n;
+    CHK(ensure(c, c->px_pcd, (size_t)(n > 0 ? n : 1) * 3 * sizeof(double)));
+    CHK(ensure(c, c->px_bmin, (size_t)nblk * 3 * sizeof(double)));
+    CHK(ensure(c, c->px_bmax, (size_t)nblk * 3 * sizeof(double)));
+    hipLaunchKernelGGL(k_px_compact, dim3(nblk), dim3(PX_BLOCK), 0, st, d_depth, d_mask, gs, PX_FG_DEPTH, w, npix,
+                       cam[0], cam[1], cam[2], cam[3], off, ptr<double>(c->px_pcd), ptr<double>(c->px_bmin),
+                       ptr<double>(c->px_bmax));
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+// per-block bounds (c->px_bmin/bmax, nblk blocks) -> voxel grid; cloud d_pcd[n] -> c->px_down[m]
+int px_stage_down(drp_ctx* c, const double* d_pcd, int n, int nblk_bounds, double voxel, int* m_out) {
+    hipStream_t st = c->stream;
+    if (n <= 0) { *m_out = 0; return DRP_OK; }
+    CHK(ensure(c, c->px_grid, sizeof(PxGrid)));
+    PxGrid* g = ptr<PxGrid>(c->px_grid);
+    hipLaunchKernelGGL(k_px_bounds, dim3(1), dim3(64), 0, st, ptr<double>(c->px_bmin), ptr<double>(c->px_bmax),
+                       nblk_bounds, n, voxel, g);
+    HIPCHK(c, hipGetLastError());
+    PxGrid hg;
+    CHK(d2h(c, &hg, g, sizeof(hg)));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (hg.cells <= 0 || hg.cells > PX_MAX_CELLS)
+        return fail(c, DRP_EINVAL, "voxel grid %d x %d x %d exceeds %lld cells", hg.dims[0], hg.dims[1], hg.dims[2],
+                    PX_MAX_CELLS);
+    const long long cells = hg.cells;
+    const int cblk = px_nblk((size_t)cells);
+    CHK(ensure(c, c->px_keys, (size_t)n * sizeof(int)));
+    CHK(ensure(c, c->px_list, (size_t)n * sizeof(int)));
+    CHK(ensure(c, c->px_cellcnt, (size_t)cells * sizeof(int)));
+    CHK(ensure(c, c->px_cellfill, (size_t)cells * sizeof(int)));
+    CHK(ensure(c, c->px_celloff, (size_t)cells * sizeof(unsigned long long)));
+    CHK(ensure(c, c->px_blk, (size_t)(2 * cblk + 2) * sizeof(unsigned long long)));
+    unsigned long long* bsum = ptr<unsigned long long>(c->px_blk);
+    unsigned long long* boff = bsum + cblk;
+    HIPCHK(c, hipMemsetAsync(c->px_cellcnt.p, 0, (size_t)cells * sizeof(int), st));
+    HIPCHK(c, hipMemsetAsync(c->px_cellfill.p, 0, (size_t)cells * sizeof(int), st));
+    const int pblk = (n + 255) / 256;
+    hipLaunchKernelGGL(k_px_cell_count, dim3(pblk), dim3(256), 0, st, d_pcd, n, voxel, g, ptr<int>(c->px_keys),
+                       ptr<int>(c->px_cellcnt));
+    hipLaunchKernelGGL(k_px_cell_blocksum, dim3(cblk), dim3(PX_BLOCK), 0, st, ptr<int>(c->px_cellcnt), cells, bsum);
+    hipLaunchKernelGGL(k_px_scan_u64, dim3(1), dim3(1024), 0, st, bsum, cblk, boff);
+    hipLaunchKernelGGL(k_px_cell_offsets, dim3(cblk), dim3(PX_BLOCK), 0, st, ptr<int>(c->px_cellcnt), cells, boff,
+                       ptr<unsigned long long>(c->px_celloff));
+    HIPCHK(c, hipGetLastError());
+    unsigned long long total = 0;
+    CHK(d2h(c, &total, boff + cblk, sizeof(total)));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const int m = (int)(total >> 32);
+    if ((int)(total & 0xffffffffull) != n) return fail(c, DRP_ESTATE, "voxel scan lost points");
+    *m_out = m;
+    CHK(ensure(c, c->px_down, (size_t)m * 3 * sizeof(double)));
+    CHK(ensure(c, c->px_down32, (size_t)m * 3 * sizeof(float)));
+    hipLaunchKernelGGL(k_px_cell_fill, dim3(pblk), dim3(256), 0, st, ptr<int>(c->px_keys), n,
+                       ptr<unsigned long long>(c->px_celloff), ptr<int>(c->px_cellfill), ptr<int>(c->px_list));
+    hipLaunchKernelGGL(k_px_voxel_mean, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, ptr<int>(c->px_cellcnt),
+                       ptr<unsigned long long>(c->px_celloff), ptr<int>(c->px_list), d_pcd, cells,
+                       ptr<double>(c->px_down), ptr<float>(c->px_down32));
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+// sampler + particle_r (+ recentering radius) on a device cloud (float64 + its float32 copy)
+int px_stage_fps(drp_ctx* c, const double* d_pcd, const float* d_pcd32, int m, int npoints, int batch,
+                 const int32_t* init_idx, uint64_t seed) {
+    hipStream_t st = c->stream;
+    const int* d_init = nullptr;
+    if (init_idx) {
+        for (int b = 0; b < batch; ++b)
+            if (init_idx[b] < 0 || init_idx[b] >= m)
+                return fail(c, DRP_EINVAL, "init_idx[%d]=%d outside the cloud of %d points", b, init_idx[b], m);
+        CHK(h2d(c, c->px_init, init_idx, (size_t)batch * sizeof(int)));
+        d_init = ptr<int>(c->px_init);
+    }
+    CHK(ensure(c, c->px_dist, (size_t)batch * m * sizeof(float)));
+    CHK(ensure(c, c->px_chosen, (size_t)batch * npoints * sizeof(int)));
+    CHK(ensure(c, c->px_pts, (size_t)batch * npoints * 3 * sizeof(float)));
+    CHK(ensure(c, c->px_r, (size_t)batch * sizeof(double)));
+    CHK(ensure(c, c->px_rr, (size_t)batch * sizeof(double)));
+    hipLaunchKernelGGL(k_px_fps, dim3(batch), dim3(1024), 0, st, d_pcd32, m, npoints, d_init,
+                       (unsigned long long)seed, ptr<float>(c->px_dist), ptr<int>(c->px_chosen), ptr<float>(c->px_pts));
+    hipLaunchKernelGGL(k_px_radius, dim3(batch), dim3(1024), 0, st, d_pcd, m, ptr<float>(c->px_pts), npoints,
+                       ptr<double>(c->px_r), ptr<double>(c->px_rr));
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+int px_check_cloud(drp_ctx* c, int n, int npoints, int batch) {
+    if (npoints <= 0 || batch <= 0) return fail(c, DRP_EINVAL, "bad npoints=%d batch=%d", npoints, batch);
+    if (n < npoints) return fail(c, DRP_EINVAL, "cloud of %d points, %d particles asked", n, npoints);
+    return DRP_OK;
+}
+}  // namespace
+
+int drp_depth2fgpcd(drp_ctx* c, const float* depth, const uint8_t* mask, int h, int w, const double cam[4],
+                    double* pcd_out, int cap, int* n_out) {
+    if (!c || !depth || !cam || !n_out) return fail(c, DRP_EINVAL, "null argument");
+    if (h <= 0 || w <= 0) return fail(c, DRP_EINVAL, "bad image size %d x %d", h, w);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)h * w;
+    CHK(h2d(c, c->px_depth, depth, npix * sizeof(float)));
+    if (mask) CHK(h2d(c, c->px_mask, mask, npix));
+    int n = 0;
+    CHK(px_stage_pcd(c, ptr<float>(c->px_depth), mask ? ptr<uint8_t>(c->px_mask) : nullptr, h, w, 1.0f, cam, &n));
+    *n_out = n;
+    if (pcd_out) {
+        if (cap < n) return fail(c, DRP_EINVAL, "capacity %d < %d foreground points", cap, n);
+        if (n > 0) CHK(d2h(c, pcd_out, c->px_pcd.p, (size_t)n * 3 * sizeof(double)));
+    }
+    return drp_sync(c);
+}
+
+int drp_downsample_pcd(drp_ctx* c, const double* pcd, int n, double voxel, double* out, int cap, int* m_out) {
+    if (!c || !pcd || !m_out) return fail(c, DRP_EINVAL, "null argument");
+    if (n <= 0 || !(voxel > 0.0)) return fail(c, DRP_EINVAL, "bad downsample arguments n=%d voxel=%g", n, voxel);
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(h2d(c, c->px_pcd, pcd, (size_t)n * 3 * sizeof(double)));
+    const int nblk = px_nblk((size_t)n);
+    CHK(ensure(c, c->px_bmin, (size_t)nblk * 3 * sizeof(double)));
+    CHK(ensure(c, c->px_bmax, (size_t)nblk * 3 * sizeof(double)));
+    hipLaunchKernelGGL(k_px_point_bounds, dim3(nblk), dim3(PX_BLOCK), 0, c->stream, ptr<double>(c->px_pcd), n,
+                       ptr<double>(c->px_bmin), ptr<double>(c->px_bmax));
+    int m = 0;
+    CHK(px_stage_down(c, ptr<double>(c->px_pcd), n, nblk, voxel, &m));
+    *m_out = m;
+    if (out) {
+        if (cap < m) return fail(c, DRP_EINVAL, "capacity %d < %d voxels", cap, m);
+        CHK(d2h(c, out, c->px_down.p, (size_t)m * 3 * sizeof(double)));
+    }
+    return drp_sync(c);
+}
+
+int drp_fps_pcd(drp_ctx* c, const double* pcd, int n, int npoints, int batch, const int32_t* init_idx,
+                uint64_t seed, float* pts_out, double* r_out) {
+    if (!c || !pcd || !pts_out) return fail(c, DRP_EINVAL, "null argument");
+    CHK(px_check_cloud(c, n, npoints, batch));
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(h2d(c, c->px_down, pcd, (size_t)n * 3 * sizeof(double)));
+    CHK(ensure(c, c->px_down32, (size_t)n * 3 * sizeof(float)));
+    hipLaunchKernelGGL(k_px_to_f32, dim3((unsigned)(((size_t)n * 3 + 255) / 256)), dim3(256), 0, c->stream,
+                       ptr<double>(c->px_down), (size_t)n * 3, ptr<float>(c->px_down32));
+    CHK(px_stage_fps(c, ptr<double>(c->px_down), ptr<float>(c->px_down32), n, npoints, batch, init_idx, seed));
+    CHK(d2h(c, pts_out, c->px_pts.p, (size_t)batch * npoints * 3 * sizeof(float)));
+    if (r_out) CHK(d2h(c, r_out, c->px_r.p, (size_t)batch * sizeof(double)));
+    return drp_sync(c);
+}
+
+int drp_recenter(drp_ctx* c, const double* pcd, int n, const float* sampled, int npoints, int batch, const double* r,
+                 float* out) {
+    if (!c || !pcd || !sampled || !r || !out) return fail(c, DRP_EINVAL, "null argument");
+    if (n <= 0 || npoints <= 0 || batch <= 0) return fail(c, DRP_EINVAL, "bad recenter arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(h2d(c, c->px_down, pcd, (size_t)n * 3 * sizeof(double)));
+    CHK(h2d(c, c->px_pts, sampled, (size_t)batch * npoints * 3 * sizeof(float)));
+    CHK(h2d(c, c->px_rr, r, (size_t)batch * sizeof(double)));
+    CHK(ensure(c, c->px_out, (size_t)batch * npoints * 3 * sizeof(double)));
+    float* o32 = ptr<float>(c->px_out);
+    hipLaunchKernelGGL(k_px_recenter, dim3((batch * npoints + 3) / 4), dim3(256), 0, c->stream, ptr<double>(c->px_down), n,
+                       ptr<float>(c->px_pts), npoints, batch, ptr<double>(c->px_rr), o32, (double*)nullptr);
+    HIPCHK(c, hipGetLastError());
+    CHK(d2h(c, out, o32, (size_t)batch * npoints * 3 * sizeof(float)));
+    return drp_sync(c);
+}
+
+int drp_obs2ptcl(drp_ctx* c, const float* depth_raw, int h, int w, float global_scale, const double cam[4],
+                 int npoints, int batch, const int32_t* init_idx, uint64_t seed, double* ptcl_out, double* r_out,
+                 int* n_fg, int* n_down) {
+    if (!c || !depth_raw || !cam || !ptcl_out || !r_out) return fail(c, DRP_EINVAL, "null argument");
+    if (h <= 0 || w <= 0 || !(global_scale > 0.0f)) return fail(c, DRP_EINVAL, "bad image %d x %d scale %g", h, w, global_scale);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)h * w;
+    CHK(h2d(c, c->px_depth, depth_raw, npix * sizeof(float)));
+    int n = 0, m = 0;
+    CHK(px_stage_pcd(c, ptr<float>(c->px_depth), nullptr, h, w, global_scale, cam, &n));
+    if (n_fg) *n_fg = n;
+    if (n <= 0) return fail(c, DRP_EINVAL, "no foreground pixel (depth < 0.599/0.8 of the scaled image)");
+    CHK(px_stage_down(c, ptr<double>(c->px_pcd), n, px_nblk(npix), 0.01, &m));   // env/flex_env.py:947
+    if (n_down) *n_down = m;
+    CHK(px_check_cloud(c, m, npoints, batch));
+    CHK(px_stage_fps(c, ptr<double>(c->px_down), ptr<float>(c->px_down32), m, npoints, batch, init_idx, seed));
+    CHK(ensure(c, c->px_out, (size_t)batch * npoints * 3 * sizeof(double)));
+    hipLaunchKernelGGL(k_px_recenter, dim3((batch * npoints + 3) / 4), dim3(256), 0, c->stream, ptr<double>(c->px_down), m,
+                       ptr<float>(c->px_pts), npoints, batch, ptr<double>(c->px_rr), (float*)nullptr,
+                       ptr<double>(c->px_out));
+    HIPCHK(c, hipGetLastError());
+    CHK(d2h(c, ptcl_out, c->px_out.p, (size_t)batch * npoints * 3 * sizeof(double)));
+    CHK(d2h(c, r_out, c->px_r.p, (size_t)batch * sizeof(double)));
     return drp_sync(c);
 }
 

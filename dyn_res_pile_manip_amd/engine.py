@@ -10,6 +10,10 @@ def _f32(x):
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+def _f64(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
 def _fp(a):
     return a.ctypes.data_as(L.c_float_p)
 
@@ -215,6 +219,75 @@ class Engine(object):
         self._ck(self.lib.drp_fps(self.h, _fp(pts), n, dim, int(k), int(init_idx),
                                   idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.byref(md)))
         return pts[idx], md.value, idx
+
+    # ---- particle extraction (row f2) -------------------------------------
+    def depth2fgpcd(self, depth, mask, cam_params):
+        """utils.depth2fgpcd on the device -> [n,3] float64."""
+        depth = _f32(depth)
+        h, w = depth.shape
+        cam = _f64(cam_params)
+        m8 = None if mask is None else np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        mp = None if m8 is None else m8.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+        n = ctypes.c_int()
+        self._ck(self.lib.drp_depth2fgpcd(self.h, _fp(depth), mp, h, w, _dp(cam), None, 0, ctypes.byref(n)))
+        out = np.empty((n.value, 3), np.float64)
+        if n.value:
+            self._ck(self.lib.drp_depth2fgpcd(self.h, _fp(depth), mp, h, w, _dp(cam), _dp(out), n.value,
+                                              ctypes.byref(n)))
+        return out
+
+    def downsample_pcd(self, pcd, voxel_size):
+        """utils.downsample_pcd (open3d voxel_down_sample) on the device -> [m,3] float64."""
+        pcd = _f64(pcd)
+        n = pcd.shape[0]
+        out = np.empty((n, 3), np.float64)
+        m = ctypes.c_int()
+        self._ck(self.lib.drp_downsample_pcd(self.h, _dp(pcd), n, float(voxel_size), _dp(out), n, ctypes.byref(m)))
+        return out[:m.value].copy()
+
+    def fps_pcd(self, pcd, particle_num, init_idx=None, batch=None, seed=0):
+        """utils.fps for a batch of starts -> (pts [batch,N,3] float32, particle_r [batch] float64)."""
+        pcd = _f64(pcd)
+        if init_idx is not None:
+            init = np.ascontiguousarray(np.atleast_1d(init_idx), dtype=np.int32)
+            batch = init.shape[0]
+            ip = init.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        else:
+            batch = int(batch or 1)
+            ip = None
+        pts = np.empty((batch, int(particle_num), 3), np.float32)
+        r = np.empty((batch,), np.float64)
+        self._ck(self.lib.drp_fps_pcd(self.h, _dp(pcd), pcd.shape[0], int(particle_num), batch, ip, int(seed),
+                                      _fp(pts), _dp(r)))
+        return pts, r
+
+    def recenter(self, pcd, sampled, r):
+        """utils.recenter for a batch: sampled [batch,N,3] float32, r [batch] -> [batch,N,3] float32."""
+        pcd, sampled = _f64(pcd), _f32(sampled)
+        batch, npts, _ = sampled.shape
+        rr = _f64(np.broadcast_to(np.asarray(r, dtype=np.float64), (batch,)))
+        out = np.empty_like(sampled)
+        self._ck(self.lib.drp_recenter(self.h, _dp(pcd), pcd.shape[0], _fp(sampled), npts, batch, _dp(rr), _fp(out)))
+        return out
+
+    def obs2ptcl(self, depth_raw, global_scale, cam_params, particle_num, batch, init_idx=None, seed=0):
+        """FlexEnv.obs2ptcl_fixed_num_batch on the device -> (ptcl [batch,N,3] f64, particle_r [batch],
+        (#foreground points, #voxels))."""
+        depth_raw = _f32(depth_raw)
+        h, w = depth_raw.shape
+        cam = _f64(cam_params)
+        ip = None
+        if init_idx is not None:
+            init = np.ascontiguousarray(init_idx, dtype=np.int32)
+            assert init.shape == (batch,)
+            ip = init.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        out = np.empty((int(batch), int(particle_num), 3), np.float64)
+        r = np.empty((int(batch),), np.float64)
+        nfg, nd = ctypes.c_int(), ctypes.c_int()
+        self._ck(self.lib.drp_obs2ptcl(self.h, _fp(depth_raw), h, w, float(global_scale), _dp(cam), int(particle_num),
+                                       int(batch), ip, int(seed), _dp(out), _dp(r), ctypes.byref(nfg),
+                                       ctypes.byref(nd)))
+        return out, r, (nfg.value, nd.value)
 
     # ---- gradient-descent planner ---------------------------------------
     def gd_begin(self, s0, attr, dens, actions, lr, act_lo, act_hi):

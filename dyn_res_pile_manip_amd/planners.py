@@ -357,13 +357,6 @@ class PlannerGD(Planner):
 
 
 def fps_np(pcd, particle_num, init_idx=-1):
-    """utils.py:451-466: farthest-point subsample (host, once per planner call)."""
-    pcd = np.asarray(pcd)
-    idx = np.random.randint(pcd.shape[0]) if init_idx == -1 else init_idx
-    chosen = [idx]
-    dist = np.linalg.norm(pcd - pcd[idx], axis=1)
-    while len(chosen) < particle_num:
-        idx = int(dist.argmax())
-        chosen.append(idx)
-        dist = np.minimum(dist, np.linalg.norm(pcd - pcd[idx], axis=1))
-    return pcd[chosen], dist.max()
+    """utils.py:451-466: farthest-point subsample, on the device (see `utils.fps_np`)."""
+    from . import utils
+    return utils.fps_np(pcd, particle_num, init_idx)

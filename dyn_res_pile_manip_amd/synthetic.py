@@ -174,3 +174,40 @@ def goal_coor_strided(obs_goal, m):
     m = min(m, cr.shape[0])
     idx = np.linspace(0, cr.shape[0] - 1, m).astype(np.int64)
     return np.ascontiguousarray(cr[idx])
+
+
+def render_depth(n_granules=1500, seed=0, kind='blob', size=SCREEN, grain=0.006, global_scale=GLOBAL_SCALE,
+                 cam_params=None):
+    """A stand-in for `pyflex.render(render_depth=True)` (env/flex_env.py:874-885): obs
+    [size,size,5] float32, channels 0-2 colour in [0,255], 3 alpha, 4 depth in world units
+    (camera z x global_scale).  Granules are spheres of radius `grain` (camera units) lying
+    on the table plane z = 0.75, about a fifth of them stacked on a second layer."""
+    rng = np.random.default_rng(seed)
+    s, _, _ = make_pile(n_granules, 1, seed=seed, kind=kind)
+    cx_w, cy_w = s[0, :, 0].astype(np.float64), s[0, :, 1].astype(np.float64)
+    layer = (rng.uniform(0, 1, n_granules) < 0.2).astype(np.float64)
+    zc = 0.75 - grain - layer * 1.6 * grain
+    fx, fy, cx, cy = cam_params if cam_params is not None else demo_cam_params()
+    depth = np.full((size, size), 0.75, dtype=np.float64)
+    pr = int(np.ceil(fx * grain / 0.7)) + 1
+    for g in range(n_granules):
+        u0 = int(round(cx_w[g] * fx / 0.75 + cx))
+        v0 = int(round(cy_w[g] * fy / 0.75 + cy))
+        ua, ub = max(u0 - pr, 0), min(u0 + pr + 1, size)
+        va, vb = max(v0 - pr, 0), min(v0 + pr + 1, size)
+        if ua >= ub or va >= vb:
+            continue
+        uu, vv = np.meshgrid(np.arange(ua, ub), np.arange(va, vb))
+        x = (uu - cx) * 0.75 / fx - cx_w[g]
+        y = (vv - cy) * 0.75 / fy - cy_w[g]
+        rr = grain * grain - x * x - y * y
+        z = np.where(rr > 0, zc[g] - np.sqrt(np.maximum(rr, 0)), 0.75)
+        depth[va:vb, ua:ub] = np.minimum(depth[va:vb, ua:ub], z)
+    obs = np.zeros((size, size, 5), dtype=np.float32)
+    fg = depth < 0.7499
+    obs[..., 0] = np.where(fg, 200.0, 255.0)
+    obs[..., 1] = np.where(fg, 120.0, 255.0)
+    obs[..., 2] = np.where(fg, 40.0, 255.0)
+    obs[..., 3] = 255.0
+    obs[..., 4] = (depth * global_scale).astype(np.float32)
+    return obs

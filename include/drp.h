@@ -152,6 +152,47 @@ int drp_mpc_get(drp_ctx* ctx, float* actions /*[B,H,4]*/, float* rewards /*[B] f
 int drp_fps(drp_ctx* ctx, const float* pts, int n, int dim, int k, int init_idx, int32_t* idx_out,
             float* max_dist_out);
 
+/* ---- particle extraction from the depth image (row f2; env/flex_env.py:933-951) --------------
+ * The reference runs this chain on the host between every pair of planner calls, 30 times per
+ * observation (batch_size=30, env/flex_env.py:1020,1093).  All clouds are float64 [n,3] in the
+ * camera frame, exactly as the reference's numpy arrays. */
+
+/* utils.py:491-506 depth2fgpcd(depth, mask, cam_params): row-major foreground pixels
+ * (mask != 0 and depth > 0) -> points ((x-cx)*d/fx, (y-cy)*d/fy, d).  mask NULL selects the
+ * rule of env/flex_env.py:945, depth < 0.599/0.8 in float32.  cam = {fx, fy, cx, cy}.
+ * pcd_out may be NULL (count only); DRP_EINVAL if cap < n (n_out is still set). */
+int drp_depth2fgpcd(drp_ctx* ctx, const float* depth, const uint8_t* mask, int h, int w, const double cam[4],
+                    double* pcd_out, int cap, int* n_out);
+
+/* utils.py:533-544 downsample_pcd(pcd, voxel_size) = open3d voxel_down_sample: one point per
+ * occupied voxel (index floor((p - (min_bound - voxel/2)) / voxel)), the mean of its points
+ * summed in index order; voxels are emitted in ascending (ix, iy, iz) (open3d's order is that
+ * of an unordered_map, i.e. unspecified). */
+int drp_downsample_pcd(drp_ctx* ctx, const double* pcd, int n, double voxel, double* out, int cap, int* m_out);
+
+/* utils.py:423-436 fps(pcd, particle_num, init_idx) for `batch` independent starts:
+ * dgl.geometry.farthest_point_sampler on the float32 copy of the cloud (squared float32
+ * distances, first maximum), pts_out[batch, npoints, 3] float32 = the chosen points,
+ * r_out[batch] = max_i min_j |pcd_i - pts_j| in float64.  init_idx NULL: start b is drawn
+ * from `seed` (dgl draws it from torch's global generator). */
+int drp_fps_pcd(drp_ctx* ctx, const double* pcd, int n, int npoints, int batch, const int32_t* init_idx,
+                uint64_t seed, float* pts_out, double* r_out);
+
+/* utils.py:468-477 recenter(pcd, sampled_pcd, r): out[b, j] = float32 mean of the cloud points
+ * with |p - sampled[b, j]| < r[b] (NaN when there is none, as numpy's mean of an empty set). */
+int drp_recenter(drp_ctx* ctx, const double* pcd, int n, const float* sampled, int npoints, int batch,
+                 const double* r, float* out);
+
+/* env/flex_env.py:933-951 FlexEnv.obs2ptcl_fixed_num_batch(obs, particle_num, batch_size), the
+ * whole chain on the device with one upload and one download: depth_raw = obs[..., -1] [h, w]
+ * (world units), depth = depth_raw / global_scale, foreground depth < 0.599/0.8, voxel 0.01,
+ * recentering radius min(0.02, 0.5 * particle_r).  ptcl_out[batch, npoints, 3] float64 (float32
+ * values, as the reference's array), r_out[batch] = particle_r (dens = 1 / r^2,
+ * env/flex_env.py:1022).  n_fg / n_down (nullable) return the cloud sizes. */
+int drp_obs2ptcl(drp_ctx* ctx, const float* depth_raw, int h, int w, float global_scale, const double cam[4],
+                 int npoints, int batch, const int32_t* init_idx, uint64_t seed, double* ptcl_out, double* r_out,
+                 int* n_fg, int* n_down);
+
 /* ---- gradient-descent planner (the reference's live mpc_type 'GD') ----------------------------
  * One iteration of planners.py:682-764: rollout -> final-step reward -> loss = -sum(reward)
  * -> d loss / d pushes by reverse mode (through every step of the horizon) -> Adam(lr) step

@@ -133,7 +133,7 @@ def test_trajectory_optimization_contract(stack, golden):
 
 def test_device_fps_equals_fps_np(stack):
     """utils.py:451-466 as used at planners.py:620-624: same points in the same order."""
-    from dyn_res_pile_manip_amd.planners import fps_np
+    from oracle.particles import fps_np
     _, _, model, _ = stack
     obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
     rc = np.argwhere(obs_goal < 0.5)
