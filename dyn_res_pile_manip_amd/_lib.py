@@ -18,6 +18,7 @@ ENGINE_VALU = 0
 ENGINE_MFMA = 1
 ENGINE_SPLIT = 2
 ENGINE_FUSED = 3
+DIST_TRANSFORMS = {'cv5': 0, 'exact': 1}
 ENGINES = {'valu': ENGINE_VALU, 'mfma': ENGINE_MFMA, 'split': ENGINE_SPLIT, 'fused': ENGINE_FUSED}
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -49,6 +50,11 @@ SIGNATURES = {
     'drp_set_camera': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_float, c_float_p]),
     'drp_set_goal': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                     c_float_p, ctypes.c_int]),
+    'drp_distance_transform': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, c_float_p]),
+    'drp_set_goal_image': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, c_float_p, c_float_p,
+                                          ctypes.POINTER(ctypes.c_int)]),
     'drp_gen_s_delta': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int,
                                        ctypes.c_int, c_float_p]),
     'drp_build_graph': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int,

@@ -22,6 +22,7 @@
 #include "k_backward.h"
 #include "k_fps.h"
 #include "k_particles.h"
+#include "k_goal.h"
 #ifdef DRP_HAVE_MFMA
 #include "k_mlp_mfma.h"
 #include "k_mlp_split.h"
@@ -81,6 +82,9 @@ struct drp_ctx {
     // particle extraction (row f2)
     DevBuf px_depth, px_mask, px_blk, px_bmin, px_bmax, px_grid, px_pcd, px_keys, px_cellcnt, px_cellfill,
         px_celloff, px_list, px_down, px_down32, px_init, px_dist, px_chosen, px_pts, px_r, px_rr, px_out;
+
+    // goal pre-processing (row f3)
+    DevBuf gl_goal, gl_seg, gl_tmp, gl_dist, gl_blk, gl_pix, gl_fps;
 
     // last shapes (for debug fetch)
     int lastB = 0, lastN = 0, lastH = 0;
@@ -499,7 +503,8 @@ void drp_destroy(drp_ctx* c) {
                       &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats,
                       &c->px_depth, &c->px_mask, &c->px_blk, &c->px_bmin, &c->px_bmax, &c->px_grid, &c->px_pcd, &c->px_keys,
                       &c->px_cellcnt, &c->px_cellfill, &c->px_celloff, &c->px_list, &c->px_down, &c->px_down32, &c->px_init,
-                      &c->px_dist, &c->px_chosen, &c->px_pts, &c->px_r, &c->px_rr, &c->px_out};
+                      &c->px_dist, &c->px_chosen, &c->px_pts, &c->px_r, &c->px_rr, &c->px_out,
+                      &c->gl_goal, &c->gl_seg, &c->gl_tmp, &c->gl_dist, &c->gl_blk, &c->gl_pix, &c->gl_fps};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : c->probe_ev) (void)hipEventDestroy(ev);
@@ -1076,6 +1081,99 @@ int drp_obs2ptcl(drp_ctx* c, const float* depth_raw, int h, int w, float global_
     CHK(d2h(c, ptcl_out, c->px_out.p, (size_t)batch * npoints * 3 * sizeof(double)));
     CHK(d2h(c, r_out, c->px_r.p, (size_t)batch * sizeof(double)));
     return drp_sync(c);
+}
+
+// ---- goal pre-processing (row f3) ---------------------------------------------------------------
+namespace {
+// seg (device, [h,w] u8) -> c->gl_dist [h,w] float32
+int goal_stage_dt(drp_ctx* c, const uint8_t* d_seg, int h, int w, int mode) {
+    const size_t npix = (size_t)h * w;
+    hipStream_t st = c->stream;
+    CHK(ensure(c, c->gl_tmp, npix * sizeof(int)));
+    CHK(ensure(c, c->gl_dist, npix * sizeof(float)));
+    if (mode == DRP_DT_CV5) {
+        const size_t lds = (size_t)3 * (w + 4) * sizeof(int);
+        if (lds > 60000) return fail(c, DRP_EINVAL, "image width %d too large for the chamfer kernel", w);
+        hipLaunchKernelGGL(k_dt_cv5, dim3(1), dim3(DT_THREADS), lds, st, d_seg, h, w, ptr<int>(c->gl_tmp),
+                           ptr<float>(c->gl_dist));
+    } else if (mode == DRP_DT_EXACT) {
+        if ((size_t)w * sizeof(int) > 60000) return fail(c, DRP_EINVAL, "image width %d too large", w);
+        hipLaunchKernelGGL(k_edt_cols, dim3((w + 255) / 256), dim3(256), 0, st, d_seg, h, w, ptr<int>(c->gl_tmp));
+        hipLaunchKernelGGL(k_edt_rows, dim3(h), dim3(256), (size_t)w * sizeof(int), st, ptr<int>(c->gl_tmp), h, w,
+                           ptr<float>(c->gl_dist));
+    } else {
+        return fail(c, DRP_EINVAL, "unknown distance transform mode %d", mode);
+    }
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+}  // namespace
+
+int drp_distance_transform(drp_ctx* c, const uint8_t* src, int h, int w, int mode, float* dist_out) {
+    if (!c || !src || !dist_out) return fail(c, DRP_EINVAL, "null argument");
+    if (h <= 0 || w <= 0) return fail(c, DRP_EINVAL, "bad image size %d x %d", h, w);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)h * w;
+    CHK(h2d(c, c->gl_seg, src, npix));
+    CHK(goal_stage_dt(c, ptr<uint8_t>(c->gl_seg), h, w, mode));
+    CHK(d2h(c, dist_out, c->gl_dist.p, npix * sizeof(float)));
+    return drp_sync(c);
+}
+
+int drp_set_goal_image(drp_ctx* c, const float* obs_goal, int h, int w, int mode, int max_goal_pts, int fps_init,
+                       float* field_out, float* goal_coor_out, int* m_out) {
+    if (!c || !obs_goal) return fail(c, DRP_EINVAL, "null argument");
+    if (h <= 0 || w <= 0 || max_goal_pts <= 0) return fail(c, DRP_EINVAL, "bad goal image arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t npix = (size_t)h * w;
+    const unsigned eb = (unsigned)((npix + 255) / 256);
+    CHK(h2d(c, c->gl_goal, obs_goal, npix * sizeof(float)));
+    CHK(ensure(c, c->gl_seg, npix));
+    hipLaunchKernelGGL(k_goal_seg, dim3(eb), dim3(256), 0, st, ptr<float>(c->gl_goal), npix, ptr<uint8_t>(c->gl_seg));
+    // goal pixels first: an image without any is an error before anything is installed
+    const int nblk = px_nblk(npix);
+    CHK(ensure(c, c->gl_blk, (size_t)(2 * nblk + 2) * sizeof(unsigned long long) + (size_t)(eb + 1) * sizeof(float)));
+    unsigned long long* cnt = ptr<unsigned long long>(c->gl_blk);
+    unsigned long long* off = cnt + nblk;
+    float* bmin = reinterpret_cast<float*>(off + nblk + 2);
+    hipLaunchKernelGGL(k_goal_count, dim3(nblk), dim3(PX_BLOCK), 0, st, ptr<uint8_t>(c->gl_seg), npix, cnt);
+    hipLaunchKernelGGL(k_px_scan_u64, dim3(1), dim3(1024), 0, st, cnt, nblk, off);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long total = 0;
+    CHK(d2h(c, &total, off + nblk, sizeof(total)));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const int count = (int)total;
+    if (count <= 0) return fail(c, DRP_EINVAL, "the goal image has no pixel below 0.5");
+    if (count == (int)npix) return fail(c, DRP_EINVAL, "the goal image has no pixel at or above 0.5");
+    if (fps_init < 0 || fps_init >= count) return fail(c, DRP_EINVAL, "fps_init=%d outside the %d goal pixels", fps_init, count);
+    const int m = max_goal_pts < count ? max_goal_pts : count;
+    CHK(ensure(c, c->gl_pix, (size_t)count * 2 * sizeof(float)));
+    hipLaunchKernelGGL(k_goal_compact, dim3(nblk), dim3(PX_BLOCK), 0, st, ptr<uint8_t>(c->gl_seg), w, npix, off,
+                       ptr<float>(c->gl_pix));
+    CHK(ensure(c, c->gl_fps, (size_t)count * sizeof(float) + (size_t)(m + 2) * sizeof(int)));
+    float* fdist = ptr<float>(c->gl_fps);
+    int* chosen = reinterpret_cast<int*>(fdist + count);
+    float* md = reinterpret_cast<float*>(chosen + m);
+    hipLaunchKernelGGL(k_fps<2>, dim3(1), dim3(1024), 0, st, ptr<float>(c->gl_pix), count, m, fps_init, fdist, chosen, md);
+    CHK(ensure(c, c->goal_coor, (size_t)m * 2 * sizeof(float)));
+    hipLaunchKernelGGL(k_goal_gather, dim3((m + 255) / 256), dim3(256), 0, st, ptr<float>(c->gl_pix), chosen, m,
+                       ptr<float>(c->goal_coor));
+    // the field
+    CHK(goal_stage_dt(c, ptr<uint8_t>(c->gl_seg), h, w, mode));
+    CHK(ensure(c, c->goal_field, npix * sizeof(float)));
+    hipLaunchKernelGGL(k_goal_sub, dim3(eb), dim3(256), 0, st, ptr<float>(c->gl_goal), ptr<float>(c->gl_dist), npix,
+                       ptr<float>(c->goal_field), bmin);
+    hipLaunchKernelGGL(k_goal_min, dim3(1), dim3(1024), 0, st, bmin, (int)eb, bmin + eb);
+    hipLaunchKernelGGL(k_goal_shift, dim3(eb), dim3(256), 0, st, ptr<float>(c->goal_field), npix, bmin + eb);
+    HIPCHK(c, hipGetLastError());
+    if (field_out) CHK(d2h(c, field_out, c->goal_field.p, npix * sizeof(float)));
+    if (goal_coor_out) CHK(d2h(c, goal_coor_out, c->goal_coor.p, (size_t)m * 2 * sizeof(float)));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (m_out) *m_out = m;
+    c->goal_h = h; c->goal_w = w; c->goal_m = m;
+    c->have_goal = true;
+    return DRP_OK;
 }
 
 // ---- gradient-descent planner (row f1) ----------------------------------------------------------

@@ -88,6 +88,33 @@ class Engine(object):
         self._ck(self.lib.drp_set_goal(self.h, _fp(field), field.shape[0], field.shape[1],
                                        _fp(goal_coor), goal_coor.shape[0]))
 
+    def distance_transform(self, src, mode='cv5'):
+        """cv2.distanceTransform(src, cv2.DIST_L2, 5) on the device ('cv5': OpenCV's 5x5 chamfer;
+        'exact': Euclidean) -> [h,w] float32."""
+        src = np.ascontiguousarray(np.asarray(src) != 0, dtype=np.uint8)
+        out = np.empty(src.shape, np.float32)
+        self._ck(self.lib.drp_distance_transform(self.h, src.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                                 src.shape[0], src.shape[1], L.DIST_TRANSFORMS[mode], _fp(out)))
+        return out
+
+    def set_goal_image(self, obs_goal, max_goal_pts, fps_init=0, mode='cv5', want=False):
+        """Goal field (env/flex_rewards.py:172-177) and goal pixel subsample (planners.py:620-624) from
+        the goal distance image, computed and kept on the device.  want=True also returns
+        (field [h,w], goal_coor [m,2])."""
+        g = _f32(obs_goal)
+        assert g.ndim == 2
+        m = ctypes.c_int()
+        if not want:
+            self._ck(self.lib.drp_set_goal_image(self.h, _fp(g), g.shape[0], g.shape[1], L.DIST_TRANSFORMS[mode],
+                                                 int(max_goal_pts), int(fps_init), None, None, ctypes.byref(m)))
+            return m.value
+        field = np.empty(g.shape, np.float32)
+        coor = np.empty((int(max_goal_pts), 2), np.float32)
+        self._ck(self.lib.drp_set_goal_image(self.h, _fp(g), g.shape[0], g.shape[1], L.DIST_TRANSFORMS[mode],
+                                             int(max_goal_pts), int(fps_init), _fp(field), _fp(coor),
+                                             ctypes.byref(m)))
+        return field, coor[:m.value].copy()
+
     # ---- single operations --------------------------------------------------------
     def gen_s_delta(self, s_cur, action):
         s_cur, action = _f32(s_cur), _f32(action)

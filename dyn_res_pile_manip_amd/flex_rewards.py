@@ -1,14 +1,18 @@
 """Host-side mirror of `config_reward_ptcl` (env/flex_rewards.py:156-214)."""
 import numpy as np
 
-from . import synthetic as _syn
+# Which transform stands for cv2.distanceTransform(., cv2.DIST_L2, 5) at env/flex_rewards.py:174:
+# 'cv5' = OpenCV's 5x5 chamfer (what the reference runs), 'exact' = Euclidean.
+DIST_TRANSFORM = 'cv5'
 
 
-def goal_field(goal):
+def goal_field(goal, engine=None, mode=None):
     """env/flex_rewards.py:172-177: G = goal - distanceTransform(goal < 0.5), shifted to
-    min 0.  The reference uses OpenCV's 5x5-mask approximate transform; here SciPy's exact
-    Euclidean transform (the one deviation on this path)."""
-    return _syn.goal_field(np.asarray(goal, dtype=np.float32))
+    min 0, computed on the device (it also becomes the engine's current field)."""
+    if engine is None:
+        raise ValueError('goal_field needs the Engine to run on (no CPU fallback)')
+    field, _ = engine.set_goal_image(np.asarray(goal, dtype=np.float32), 1, 0, mode or DIST_TRANSFORM, want=True)
+    return field
 
 
 def config_reward_ptcl(state, goal, cam_params, goal_coor, normalize=True, offset=(0., 0.),
@@ -24,5 +28,5 @@ def config_reward_ptcl(state, goal, cam_params, goal_coor, normalize=True, offse
     g, _ = _to_np(goal)
     gc, _ = _to_np(goal_coor)
     engine.set_camera_intrinsics(cam_params) if hasattr(engine, 'set_camera_intrinsics') else None
-    engine.set_goal(field if field is not None else goal_field(g), gc)
+    engine.set_goal(field if field is not None else goal_field(g, engine), gc)
     return _like(engine.reward(st, normalize=normalize), proto)

@@ -70,13 +70,23 @@ class PlannerGD(Planner):
         eng.set_camera(self._m34, float(self.global_scale), self.cam_params)
         return eng
 
-    def _set_goal(self, eng, obs_goal, goal_coor):
+    def _set_goal(self, eng, obs_goal, goal_coor=None, max_goal_pts=None):
+        """Install the reward's constants on the device, once per (goal image, goal pixels):
+        goal_coor given -> field from the image + the caller's pixels; None -> the image also
+        yields the farthest-point subsample of its goal pixels (planners.py:620-624)."""
         from . import flex_rewards
         g, _ = _to_np(obs_goal)
+        mode = flex_rewards.DIST_TRANSFORM
+        if goal_coor is None:
+            key = (id(eng), mode, g.shape, float(g.sum()), int(max_goal_pts))
+            if key != self._goal_key:
+                eng.set_goal_image(g, max_goal_pts, 0, mode)
+                self._goal_key = key
+            return
         gc, _ = _to_np(goal_coor)
-        key = (id(eng), g.shape, float(g.sum()), gc.shape, float(gc.sum()))
+        key = (id(eng), mode, g.shape, float(g.sum()), gc.shape, float(gc.sum()))
         if key != self._goal_key:
-            eng.set_goal(flex_rewards.goal_field(g), gc)
+            eng.set_goal(flex_rewards.goal_field(g, eng), gc)
             self._goal_key = key
 
     def _clip_box(self):
@@ -222,12 +232,9 @@ class PlannerGD(Planner):
         self._eng = eng
 
         obs_goal = obs_goal.astype(np.float32)
-        if goal_coor is None:
-            # planners.py:620-624: goal pixels (col,row), farthest-point subsample to 5N
-            rc = np.argwhere(obs_goal < 0.5)
-            cr = rc[:, ::-1].astype(np.float32)
-            goal_coor = eng.fps(cr, min(N * 5, cr.shape[0]), 0)[0]      # fps_np on the device, same selection
-        self._set_goal(eng, obs_goal, goal_coor)
+        # planners.py:620-624 + env/flex_rewards.py:172-177: goal pixels (col,row), their
+        # farthest-point subsample to 5N and the distance field, all on the device
+        self._set_goal(eng, obs_goal, goal_coor, max_goal_pts=N * 5)
 
         lo, hi = self._clip_box()
         cfg = self.config['mpc']

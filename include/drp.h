@@ -78,6 +78,26 @@ int drp_set_camera(drp_ctx* ctx, const float m34[12], float global_scale, const 
  * goal_coor [m,2] = (col,row) goal pixels. */
 int drp_set_goal(drp_ctx* ctx, const float* field, int h, int w, const float* goal_coor, int m);
 
+/* ---- goal pre-processing on the device (row f3) ------------------------------------------------
+ * cv2.distanceTransform(src, cv2.DIST_L2, 5) (env/flex_rewards.py:174; utils.py:553,572,603):
+ * distance of every non-zero pixel of src [h,w] to the nearest zero pixel.
+ * DRP_DT_CV5: OpenCV's 5x5 fixed-point chamfer (weights 1, 1.4, 2.1969), same integers as its
+ * two raster passes.  DRP_DT_EXACT: exact Euclidean distance (sqrt of the integer squared
+ * distance, in float64, rounded to float32). */
+#define DRP_DT_CV5 0
+#define DRP_DT_EXACT 1
+int drp_distance_transform(drp_ctx* ctx, const uint8_t* src, int h, int w, int mode, float* dist_out);
+
+/* Everything config_reward_ptcl and the planner derive from the goal image, in one call and
+ * kept on the device (replaces drp_set_goal + host work): obs_goal [h,w] = the goal distance
+ * image the caller passes to trajectory_optimization_ptcl_multi_traj (planners.py:567).
+ *   field     = obs_goal - distanceTransform(obs_goal < 0.5); field -= min   (env/flex_rewards.py:172-177)
+ *   goal_coor = fps_np(flip((obs_goal < 0.5).nonzero()), min(max_goal_pts, count), fps_init)
+ *               (planners.py:620-624; max_goal_pts = 5 * particle_num there)
+ * field_out [h,w] / goal_coor_out [m,2] / m_out are optional copies for the caller. */
+int drp_set_goal_image(drp_ctx* ctx, const float* obs_goal, int h, int w, int mode, int max_goal_pts,
+                       int fps_init, float* field_out, float* goal_coor_out, int* m_out);
+
 /* ---- single operations on host buffers (unit parity with the reference) -------- */
 /* PlannerGD.gen_s_delta (planners.py:211-257). s_cur [B,N,3], action [B,4] -> [B,N,3] */
 int drp_gen_s_delta(drp_ctx* ctx, const float* s_cur, const float* action, int B, int N,

@@ -22,3 +22,15 @@ def golden():
         def __getattr__(self, name):
             return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
     return G()
+
+
+@pytest.fixture
+def exact_goal_transform():
+    """The reward / planner fixtures were captured from the reference with cv2.distanceTransform
+    stubbed by SciPy's exact transform (tests/golden/make_golden.py); comparisons against them
+    select the same transform instead of the default OpenCV chamfer."""
+    from dyn_res_pile_manip_amd import flex_rewards
+    old = flex_rewards.DIST_TRANSFORM
+    flex_rewards.DIST_TRANSFORM = 'exact'
+    yield
+    flex_rewards.DIST_TRANSFORM = old

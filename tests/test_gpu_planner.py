@@ -9,7 +9,7 @@ from dyn_res_pile_manip_amd import synthetic as syn
 from dyn_res_pile_manip_amd.gnn_dyn import PropNetDiffDenModel
 from dyn_res_pile_manip_amd.planners import PlannerGD
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('exact_goal_transform')]
 
 
 @pytest.fixture(scope='module')
