@@ -18,6 +18,7 @@ ENGINE_VALU = 0
 ENGINE_MFMA = 1
 ENGINE_SPLIT = 2
 ENGINE_FUSED = 3
+TRAIN_MODES = {'eval': 0, 'grad': 1, 'update': 2}
 DIST_TRANSFORMS = {'cv5': 0, 'exact': 1}
 ENGINES = {'valu': ENGINE_VALU, 'mfma': ENGINE_MFMA, 'split': ENGINE_SPLIT, 'fused': ENGINE_FUSED}
 
@@ -80,6 +81,11 @@ SIGNATURES = {
                                    c_double_p]),
     'drp_fps': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                ctypes.POINTER(ctypes.c_int32), c_float_p]),
+    'drp_train_begin': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double]),
+    'drp_train_step': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, ctypes.POINTER(ctypes.c_int32),
+                                      c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_float_p]),
+    'drp_train_set_lr': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
+    'drp_get_weights': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t]),
     'drp_depth2fgpcd': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int,
                                        ctypes.c_int, c_double_p, c_double_p, ctypes.c_int,
                                        ctypes.POINTER(ctypes.c_int)]),

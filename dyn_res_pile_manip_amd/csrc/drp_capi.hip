@@ -23,6 +23,7 @@
 #include "k_fps.h"
 #include "k_particles.h"
 #include "k_goal.h"
+#include "k_train.h"
 #ifdef DRP_HAVE_MFMA
 #include "k_mlp_mfma.h"
 #include "k_mlp_split.h"
@@ -82,6 +83,14 @@ struct drp_ctx {
     // particle extraction (row f2)
     DevBuf px_depth, px_mask, px_blk, px_bmin, px_bmax, px_grid, px_pcd, px_keys, px_cellcnt, px_cellfill,
         px_celloff, px_list, px_down, px_down32, px_init, px_dist, px_chosen, px_pts, px_r, px_rr, px_out;
+
+    // training (row f4)
+    bool tr_on = false;
+    int tr_nroll = 0, tr_iter = 0;
+    double tr_lr = 1e-3, tr_beta1 = 0.9;
+    std::vector<float> w_host;
+    DevBuf tr_states, tr_sdelta, tr_nums, tr_grad, tr_m, tr_v, tr_loss, agg_hist, tr_hact, tr_gh, tr_gpe, tr_a1n,
+        tr_gh1, tr_xn, ed_re, ed_a2, ed_a1, ed_x0, ed_g3, ed_g2, ed_g1;
 
     // goal pre-processing (row f3)
     DevBuf gl_goal, gl_seg, gl_tmp, gl_dist, gl_blk, gl_pix, gl_fps;
@@ -192,6 +201,7 @@ struct StepArgs {
     int B, N;
     float* eff_hist = nullptr;      // [4][B*N*64]: effect after the encoder and after every propagation step
     float* proj_hist = nullptr;     // [3][B*N*128]: node projections used by every propagation step
+    float* agg_hist = nullptr;      // [3][B*N*64]: aggregated edge effects of every propagation step (training)
 };
 
 int graph_chunks(int N) { return (N + GRAPH_THREADS - 1) / GRAPH_THREADS; }
@@ -283,6 +293,9 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     }
     for (int p = 0; p < DRP_PSTEP; ++p) {
         launch_aggregate(c, B, N);
+        if (a.agg_hist)
+            HIPCHK(c, hipMemcpyAsync(a.agg_hist + (size_t)p * bn64, c->agg.p, bn64 * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st));
         ProbeScope ps(c, p + 1 < DRP_PSTEP ? KC_UPDATE : KC_PREDICT);
         if (p + 1 < DRP_PSTEP)
             hipLaunchKernelGGL(km_update<false>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
@@ -434,6 +447,16 @@ int need(drp_ctx* c, bool weights, bool cam, bool goal) {
     return DRP_OK;
 }
 
+template <int IN>
+void launch_wgrad(drp_ctx* c, const float* g, int ldg, const float* x, int ldx, long M, float* dW, int lane_stride,
+                  int k_stride, float* db, float* dwd, const float* dens, int dens_mod, long rows_per_sample) {
+    long blocks = (M + 63) / 64;
+    if (blocks > 128) blocks = 128;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kt_wgrad<IN>, dim3((unsigned)blocks), dim3(256), KT_WGRAD_LDS(IN), c->stream, g, ldg, x, ldx, M, dW,
+                       lane_stride, k_stride, db, dwd, dens, dens_mod, rows_per_sample);
+}
+
 int check_bn(drp_ctx* c, int B, int N) {
     if (B <= 0 || N <= 0 || N > 4096) return fail(c, DRP_EINVAL, "bad shape B=%d N=%d (N <= 4096)", B, N);
     return DRP_OK;
@@ -504,7 +527,10 @@ void drp_destroy(drp_ctx* c) {
                       &c->px_depth, &c->px_mask, &c->px_blk, &c->px_bmin, &c->px_bmax, &c->px_grid, &c->px_pcd, &c->px_keys,
                       &c->px_cellcnt, &c->px_cellfill, &c->px_celloff, &c->px_list, &c->px_down, &c->px_down32, &c->px_init,
                       &c->px_dist, &c->px_chosen, &c->px_pts, &c->px_r, &c->px_rr, &c->px_out,
-                      &c->gl_goal, &c->gl_seg, &c->gl_tmp, &c->gl_dist, &c->gl_blk, &c->gl_pix, &c->gl_fps};
+                      &c->gl_goal, &c->gl_seg, &c->gl_tmp, &c->gl_dist, &c->gl_blk, &c->gl_pix, &c->gl_fps,
+                      &c->tr_states, &c->tr_sdelta, &c->tr_nums, &c->tr_grad, &c->tr_m, &c->tr_v, &c->tr_loss, &c->agg_hist,
+                      &c->tr_hact, &c->tr_gh, &c->tr_gpe, &c->tr_a1n, &c->tr_gh1, &c->tr_xn, &c->ed_re, &c->ed_a2, &c->ed_a1,
+                      &c->ed_x0, &c->ed_g3, &c->ed_g2, &c->ed_g1};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : c->probe_ev) (void)hipEventDestroy(ev);
@@ -567,6 +593,7 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
     }
 #endif
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->w_host.assign(blob, blob + n_floats);
     c->adj_thresh = adj_thresh;
     // threshold = adj_thresh * adj_thresh in Python doubles, then an fp32 scalar
     // (model/gnn_dyn.py:229,236)
@@ -1236,7 +1263,7 @@ int gd_forward_backward(drp_ctx* c) {
         float* g_out = g_state + (size_t)t * bn * 3;
         float* g_cedge = (t > 0) ? ptr<float>(c->g_cedge) : nullptr;
         hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn * 64, g_out, (size_t)N * 3, N,
-                           ptr<float>(c->g_eff));
+                           ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr);
         for (int p = DRP_PSTEP - 1; p >= 0; --p) {
             hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn * 64,
                                ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N,
@@ -1248,7 +1275,8 @@ int gd_forward_backward(drp_ctx* c) {
         }
         hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw,
                            ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb, ptr<float>(c->dens),
-                           nb, eht, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta));
+                           nb, eht, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta),
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
         float* g_prev = nullptr;
         if (t > 0) {
             // d loss / d state[t-1] = residual share + relation encoder + gen_s_delta's position dependence
@@ -1256,7 +1284,7 @@ int gd_forward_backward(drp_ctx* c) {
             CHK(d2d(g_prev, g_out, bn * 3 * sizeof(float)));
             hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), (6 * 64 + 2 * 4096) * sizeof(float), st, vw, wraw,
                                s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx, cnt,
-                               g_cedge, N, g_prev, (size_t)N * 3);
+                               g_cedge, N, g_prev, (size_t)N * 3, KbEdgeDump{});
         }
         hipLaunchKernelGGL(kb_sdelta, dim3(B), dim3(256), 0, st, s_prev, prev_mod, prev_stride,
                            ptr<float>(c->actions) + (size_t)t * 4, (size_t)H * 4, ptr<float>(c->g_sdelta), N, c->cam,
@@ -1357,6 +1385,252 @@ int drp_gd_get(drp_ctx* c, float* actions_out) {
     if (!actions_out) return fail(c, DRP_EINVAL, "null buffer");
     CHK(d2h(c, actions_out, c->actions.p, (size_t)c->gd_B * c->gd_H * 4 * sizeof(float)));
     return drp_sync(c);
+}
+
+// ---- training on the same kernels (row f4) ------------------------------------------------------
+namespace {
+// forward over n_rollout steps (+ loss), optionally the backward pass with weight gradients
+int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
+    const int H = c->tr_nroll;
+    const size_t bn = (size_t)B * N, bn64 = bn * 64, bnk = bn * DRP_K;
+    const size_t hstride = (size_t)H * N * 3;                 // predicted states [B][H][N][3]
+    const size_t in_stride = (size_t)(H + 1) * N * 3;         // given states     [B][H+1][N][3]
+    hipStream_t st = c->stream;
+    float* states = ptr<float>(c->states);
+    const float* given = ptr<float>(c->tr_states);
+    float* eh = ptr<float>(c->eff_hist);
+    float* ph = ptr<float>(c->proj_hist);
+    float* ah = ptr<float>(c->agg_hist);
+    float* g_state = ptr<float>(c->g_state);
+    double* loss = ptr<double>(c->tr_loss);
+    const float scale = 1.0f / (float)(H * B);
+    HIPCHK(c, hipMemsetAsync(loss, 0, sizeof(double), st));
+    const int saved_engine = c->engine;
+    c->engine = DRP_ENGINE_MFMA;
+    int rc = DRP_OK;
+    for (int t = 0; t < H && rc == DRP_OK; ++t) {
+        // this step's impulses are data (train/train_gnn_dyn.py:181)
+        hipError_t e = hipMemcpy2DAsync(c->s_delta.p, (size_t)N * 3 * sizeof(float),
+                                        ptr<float>(c->tr_sdelta) + (size_t)t * N * 3, hstride * sizeof(float),
+                                        (size_t)N * 3 * sizeof(float), B, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { rc = fail(c, DRP_EHIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e)); break; }
+        StepArgs a{};
+        if (t == 0) { a.s_prev = given; a.prev_mod = B; a.prev_stride = in_stride; }
+        else { a.s_prev = states + (size_t)(t - 1) * N * 3; a.prev_mod = B; a.prev_stride = hstride; }
+        a.attr = ptr<float>(c->attr); a.attr_mod = B;
+        a.dens = ptr<float>(c->dens); a.dens_mod = B;
+        a.actions = nullptr; a.act_stride = 0;
+        a.build_graph = true;
+        a.s_out = states + (size_t)t * N * 3; a.out_stride = hstride;
+        a.B = B; a.N = N;
+        if (backward) {
+            a.eff_hist = eh + (size_t)t * 4 * bn64;
+            a.proj_hist = ph + (size_t)t * 3 * bn64 * 2;
+            a.agg_hist = ah + (size_t)t * 3 * bn64;
+        }
+        rc = run_step(c, a);
+        if (rc != DRP_OK) break;
+        if (backward) {
+            auto d2d = [&](void* dst, const void* src, size_t bytes) {
+                return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+            };
+            bool ok = d2d(ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, c->s_delta.p, bn * 3 * sizeof(float));
+            ok = ok && d2d(ptr<int16_t>(c->tape_idx) + (size_t)t * bnk, c->nbr_idx.p, bnk * sizeof(int16_t));
+            ok = ok && d2d(ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn, c->nbr_cnt.p, bn);
+            ok = ok && d2d(ptr<float>(c->tape_cedge) + (size_t)t * bnk * 64, c->c_edge.p, bnk * 64 * sizeof(float));
+            if (!ok) { rc = fail(c, DRP_EHIP, "tape copy failed"); break; }
+        }
+        // loss of this step and d loss / d s_pred_t (train/train_gnn_dyn.py:184-186, :203)
+        hipLaunchKernelGGL(kt_mse_grad, dim3(B), dim3(256), 0, st, states + (size_t)t * N * 3, hstride,
+                           given + (size_t)(t + 1) * N * 3, in_stride, ptr<int>(c->tr_nums), N, scale,
+                           g_state + (size_t)t * bn * 3, loss);
+    }
+    c->engine = saved_engine;
+    CHK(rc);
+    HIPCHK(c, hipGetLastError());
+    if (!backward) return DRP_OK;
+
+    const float* vw = ptr<float>(c->w_valu);
+    const float* wraw = ptr<float>(c->w_raw);
+    float* G = ptr<float>(c->tr_grad);
+    const float* dens = ptr<float>(c->dens);
+    HIPCHK(c, hipMemsetAsync(G, 0, (size_t)W_TOTAL * sizeof(float), st));
+    KbEdgeDump ed{ptr<float>(c->ed_re), ptr<float>(c->ed_a2), ptr<float>(c->ed_a1), ptr<float>(c->ed_x0),
+                  ptr<float>(c->ed_g3), ptr<float>(c->ed_g2), ptr<float>(c->ed_g1)};
+    for (int t = H - 1; t >= 0; --t) {
+        const float* s_prev = (t == 0) ? given : states + (size_t)(t - 1) * N * 3;
+        const size_t prev_stride = (t == 0) ? in_stride : hstride;
+        float* eht = eh + (size_t)t * 4 * bn64;
+        float* pht = ph + (size_t)t * 3 * bn64 * 2;
+        float* aht = ah + (size_t)t * 3 * bn64;
+        const float* cedge = ptr<float>(c->tape_cedge) + (size_t)t * bnk * 64;
+        const int16_t* idx = ptr<int16_t>(c->tape_idx) + (size_t)t * bnk;
+        const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
+        float* g_out = g_state + (size_t)t * bn * 3;
+        float* g_cedge = ptr<float>(c->g_cedge);
+        // predictor
+        hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn64, g_out, (size_t)N * 3, N,
+                           ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh));
+        launch_wgrad<64>(c, ptr<float>(c->tr_gh), 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
+                         nullptr, 1, 1);
+        launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
+        hipLaunchKernelGGL(kt_colsum3, dim3(16), dim3(256), 0, st, g_out, (long)bn, G + W_PR1_B);
+        HIPCHK(c, hipMemsetAsync(g_cedge, 0, bnk * 64 * sizeof(float), st));
+        for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+            hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn64,
+                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N,
+                               ptr<float>(c->g_agg));
+            // particle propagator, aggregate columns: g_eff now holds the pre-activation gradient
+            launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
+                             nullptr, nullptr, nullptr, 1, 1);
+            HIPCHK(c, hipMemsetAsync(c->g_proj.p, 0, bn * 128 * sizeof(float), st));
+            hipLaunchKernelGGL(kb_edges, dim3(B), dim3(256), 0, st, cedge, pht + (size_t)p * bn64 * 2, idx, cnt,
+                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), g_cedge, 0);
+            // relation propagator, receiver and sender columns
+            launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
+                             nullptr, nullptr, nullptr, 1, 1);
+            launch_wgrad<64>(c, ptr<float>(c->g_proj) + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
+                             1, nullptr, nullptr, nullptr, 1, 1);
+            hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff));
+        }
+        // particle propagator, encoder columns + density column + bias; particle encoder
+        launch_wgrad<64>(c, ptr<float>(c->g_cnode), 64, eht, 64, (long)bn, G + W_PP_W, 129, 1, G + W_PP_B, G + W_PP_W + 128,
+                         dens, B, (long)N);
+        hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw,
+                           ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), B, dens, B, eht,
+                           ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta), ptr<float>(c->tr_gpe),
+                           ptr<float>(c->tr_a1n), ptr<float>(c->tr_gh1), ptr<float>(c->tr_xn));
+        launch_wgrad<64>(c, ptr<float>(c->tr_gpe), 64, ptr<float>(c->tr_a1n), 64, (long)bn, G + W_PE2_W, 64, 1, G + W_PE2_B,
+                         nullptr, nullptr, 1, 1);
+        launch_wgrad<5>(c, ptr<float>(c->tr_gh1), 64, ptr<float>(c->tr_xn), 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
+                        nullptr, nullptr, 1, 1);
+        // the previous step's output feeds this step as s_cur: residual + relation encoder
+        float* g_prev = nullptr;
+        if (t > 0) {
+            g_prev = g_state + (size_t)(t - 1) * bn * 3;
+            hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
+        }
+        hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), (6 * 64 + 2 * 4096) * sizeof(float), st, vw, wraw, s_prev, B,
+                           prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, g_cedge, N, g_prev, (size_t)N * 3, ed);
+        launch_wgrad<64>(c, g_cedge, 64, ed.re, 64, (long)bnk, G + W_RP_W, 193, 1, G + W_RP_B, G + W_RP_W + 192, dens, B,
+                         (long)N * DRP_K);
+        launch_wgrad<64>(c, ed.g3, 64, ed.a2, 64, (long)bnk, G + W_RE4_W, 64, 1, G + W_RE4_B, nullptr, nullptr, 1, 1);
+        launch_wgrad<64>(c, ed.g2, 64, ed.a1, 64, (long)bnk, G + W_RE2_W, 64, 1, G + W_RE2_B, nullptr, nullptr, 1, 1);
+        launch_wgrad<6>(c, ed.g1, 64, ed.x0, 8, (long)bnk, G + W_RE0_W, 6, 1, G + W_RE0_B, nullptr, nullptr, 1, 1);
+    }
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+int install_weights(drp_ctx* c, const std::vector<float>& blob) {
+    std::vector<float> tmp(blob);
+    return drp_load_weights(c, tmp.data(), tmp.size(), c->adj_thresh);
+}
+}  // namespace
+
+int drp_train_begin(drp_ctx* c, int n_rollout, double lr, double beta1) {
+    CHK(need(c, true, false, false));
+    if (n_rollout < 1 || n_rollout > 64 || !(lr > 0.0) || !(beta1 >= 0.0 && beta1 < 1.0))
+        return fail(c, DRP_EINVAL, "bad training arguments n_rollout=%d lr=%g beta1=%g", n_rollout, lr, beta1);
+#ifndef DRP_HAVE_MFMA
+    return fail(c, DRP_ESTATE, "built without the MFMA engine");
+#endif
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure(c, c->tr_grad, (size_t)W_TOTAL * sizeof(float)));
+    CHK(ensure(c, c->tr_m, (size_t)W_TOTAL * sizeof(float)));
+    CHK(ensure(c, c->tr_v, (size_t)W_TOTAL * sizeof(float)));
+    CHK(ensure(c, c->tr_loss, sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(c->tr_m.p, 0, (size_t)W_TOTAL * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->tr_v.p, 0, (size_t)W_TOTAL * sizeof(float), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tr_nroll = n_rollout; c->tr_lr = lr; c->tr_beta1 = beta1; c->tr_iter = 0;
+    c->tr_on = true;
+    c->gd_on = false;
+    c->mpc_on = false;
+    return DRP_OK;
+}
+
+int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, const float* attrs,
+                   const int32_t* particle_nums, const float* particle_dens, int B, int N, int mode, double* loss_out,
+                   float* grad_out) {
+    if (!c || !c->tr_on) return fail(c, DRP_ESTATE, "drp_train_begin not called");
+    CHK(check_bn(c, B, N));
+    if (!states || !states_delta || !attrs || !particle_nums || !particle_dens) return fail(c, DRP_EINVAL, "null argument");
+    if (mode < DRP_TRAIN_EVAL || mode > DRP_TRAIN_UPDATE) return fail(c, DRP_EINVAL, "bad mode %d", mode);
+    for (int b = 0; b < B; ++b)
+        if (particle_nums[b] <= 0 || particle_nums[b] > N)
+            return fail(c, DRP_EINVAL, "particle_nums[%d]=%d outside 1..%d", b, particle_nums[b], N);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int H = c->tr_nroll;
+    const size_t bn = (size_t)B * N, bn64 = bn * 64, bnk = bn * DRP_K;
+    const bool backward = mode != DRP_TRAIN_EVAL;
+    CHK(h2d(c, c->tr_states, states, (size_t)B * (H + 1) * N * 3 * sizeof(float)));
+    CHK(h2d(c, c->tr_sdelta, states_delta, (size_t)B * H * N * 3 * sizeof(float)));
+    CHK(h2d(c, c->tr_nums, particle_nums, (size_t)B * sizeof(int)));
+    CHK(h2d(c, c->dens, particle_dens, (size_t)B * sizeof(float)));
+    // a_cur = attrs[:, 0] for every step (train/train_gnn_dyn.py:173)
+    CHK(ensure(c, c->attr, bn * sizeof(float)));
+    CHK(h2d(c, c->scratch, attrs, (size_t)B * (H + 1) * N * sizeof(float)));
+    HIPCHK(c, hipMemcpy2DAsync(c->attr.p, (size_t)N * sizeof(float), c->scratch.p, (size_t)(H + 1) * N * sizeof(float),
+                               (size_t)N * sizeof(float), B, hipMemcpyDeviceToDevice, c->stream));
+    CHK(ensure_step_ws(c, B, N));
+    CHK(ensure(c, c->states, (size_t)H * bn * 3 * sizeof(float)));
+    CHK(ensure(c, c->g_state, (size_t)H * bn * 3 * sizeof(float)));
+    if (backward) {
+        CHK(ensure(c, c->eff_hist, (size_t)H * 4 * bn64 * sizeof(float)));
+        CHK(ensure(c, c->proj_hist, (size_t)H * 3 * bn64 * 2 * sizeof(float)));
+        CHK(ensure(c, c->agg_hist, (size_t)H * 3 * bn64 * sizeof(float)));
+        CHK(ensure(c, c->tape_sdelta, (size_t)H * bn * 3 * sizeof(float)));
+        CHK(ensure(c, c->tape_idx, (size_t)H * bnk * sizeof(int16_t)));
+        CHK(ensure(c, c->tape_cnt, (size_t)H * bn));
+        CHK(ensure(c, c->tape_cedge, (size_t)H * bnk * 64 * sizeof(float)));
+        CHK(ensure(c, c->g_cedge, bnk * 64 * sizeof(float)));
+        CHK(ensure(c, c->g_eff, bn64 * sizeof(float)));
+        CHK(ensure(c, c->g_cnode, bn64 * sizeof(float)));
+        CHK(ensure(c, c->g_agg, bn64 * sizeof(float)));
+        CHK(ensure(c, c->g_proj, bn64 * 2 * sizeof(float)));
+        CHK(ensure(c, c->g_sdelta, bn * 3 * sizeof(float)));
+        DevBuf* node64[] = {&c->tr_hact, &c->tr_gh, &c->tr_gpe, &c->tr_a1n, &c->tr_gh1};
+        for (DevBuf* b : node64) CHK(ensure(c, *b, bn64 * sizeof(float)));
+        CHK(ensure(c, c->tr_xn, bn * 8 * sizeof(float)));
+        DevBuf* edge64[] = {&c->ed_re, &c->ed_a2, &c->ed_a1, &c->ed_g3, &c->ed_g2, &c->ed_g1};
+        for (DevBuf* b : edge64) CHK(ensure(c, *b, bnk * 64 * sizeof(float)));
+        CHK(ensure(c, c->ed_x0, bnk * 8 * sizeof(float)));
+    }
+    c->lastH = H;
+    CHK(train_forward_backward(c, B, N, backward));
+    if (loss_out) CHK(d2h(c, loss_out, c->tr_loss.p, sizeof(double)));
+    if (grad_out && backward) CHK(d2h(c, grad_out, c->tr_grad.p, (size_t)W_TOTAL * sizeof(float)));
+    if (mode == DRP_TRAIN_UPDATE) {
+        c->tr_iter += 1;
+        const double bc1 = 1.0 - pow(c->tr_beta1, (double)c->tr_iter), bc2 = 1.0 - pow(0.999, (double)c->tr_iter);
+        const float inf = __builtin_inff();
+        hipLaunchKernelGGL(k_adam, dim3((W_TOTAL + 255) / 256), dim3(256), 0, c->stream, ptr<float>(c->w_raw),
+                           ptr<float>(c->tr_grad), ptr<float>(c->tr_m), ptr<float>(c->tr_v), (int)W_TOTAL,
+                           (float)(c->tr_lr / bc1), (float)sqrt(bc2), make_float4(-inf, -inf, -inf, -inf),
+                           make_float4(inf, inf, inf, inf), (float)c->tr_beta1);
+        HIPCHK(c, hipGetLastError());
+        // the engines read packed copies of the weights: rebuild them from the updated blob
+        std::vector<float> blob((size_t)W_TOTAL);
+        CHK(d2h(c, blob.data(), c->w_raw.p, (size_t)W_TOTAL * sizeof(float)));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        CHK(install_weights(c, blob));
+    }
+    return drp_sync(c);
+}
+
+int drp_train_set_lr(drp_ctx* c, double lr) {
+    if (!c || !c->tr_on) return fail(c, DRP_ESTATE, "drp_train_begin not called");
+    if (!(lr > 0.0)) return fail(c, DRP_EINVAL, "bad lr %g", lr);
+    c->tr_lr = lr;
+    return DRP_OK;
+}
+
+int drp_get_weights(drp_ctx* c, float* blob_out, size_t n_floats) {
+    CHK(need(c, true, false, false));
+    if (!blob_out || n_floats != (size_t)W_TOTAL) return fail(c, DRP_EINVAL, "blob_out must hold %d floats", (int)W_TOTAL);
+    memcpy(blob_out, c->w_host.data(), n_floats * sizeof(float));
+    return DRP_OK;
 }
 
 // ---- RCCL -------------------------------------------------------------------------------------

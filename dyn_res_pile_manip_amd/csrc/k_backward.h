@@ -104,7 +104,9 @@ kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float
 // ---- predictor backward: g_eff = W0^T ((W1^T g_out) . [W0 eff + b0 > 0]) ------------------------
 __global__ void __launch_bounds__(256)
 kb_predict(const float* __restrict__ vw, const float* __restrict__ wraw, const float* __restrict__ eff,
-           const float* __restrict__ g_out, size_t g_stride, int N, float* __restrict__ g_eff) {
+           const float* __restrict__ g_out, size_t g_stride, int N, float* __restrict__ g_eff,
+           float* __restrict__ dump_hact /* nullable [B*N,64]: relu(W0 eff + b0) */,
+           float* __restrict__ dump_gh /* nullable [B*N,64]: gradient at the hidden pre-activation */) {
     __shared__ float w0t[4096], w0[4096];
     lds_copy(w0t, vw + V_PR0_T, 4096);
     lds_copy(w0, wraw + W_PR0_W, 4096);
@@ -132,7 +134,11 @@ kb_predict(const float* __restrict__ vw, const float* __restrict__ wraw, const f
         dense_bcast_ld<64, KB_R>(w0, 64, 0, gh, ge, lane);
 #pragma unroll
         for (int r = 0; r < KB_R; ++r)
-            if (base + r < N) g_eff[((size_t)b * N + base + r) * 64 + lane] = ge[r];
+            if (base + r < N) {
+                const size_t row = (size_t)b * N + base + r;
+                g_eff[row * 64 + lane] = ge[r];
+                if (dump_hact != nullptr) { dump_hact[row * 64 + lane] = fmaxf(h[r], 0.0f); dump_gh[row * 64 + lane] = gh[r]; }
+            }
     }
 }
 
@@ -239,7 +245,11 @@ __global__ void __launch_bounds__(256)
 kb_node_encode(const float* __restrict__ vw, const float* __restrict__ wraw, const float* __restrict__ s_delta,
                const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
                const float* __restrict__ pe, const float* __restrict__ g_eff0, const float* __restrict__ g_cnode,
-               int N, float* __restrict__ g_sdelta) {
+               int N, float* __restrict__ g_sdelta,
+               float* __restrict__ dump_gpe /* nullable [B*N,64]: gradient at the encoder's output pre-activation */,
+               float* __restrict__ dump_a1 /* [B*N,64]: relu(W1 x + b1) */,
+               float* __restrict__ dump_gh1 /* [B*N,64]: gradient at the first layer's pre-activation */,
+               float* __restrict__ dump_x /* [B*N,8]: the 5 encoder inputs */) {
     __shared__ float w0t[5 * 64];
     lds_copy(w0t, vw + V_PE0_T, 5 * 64);
     __syncthreads();
@@ -280,6 +290,13 @@ kb_node_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
             const float ox = wave_sum(g * w1x), oy = wave_sum(g * w1y), oz = wave_sum(g * w1z);
             const int i = base + r;
             if (i < N && lane < 3) g_sdelta[((size_t)b * N + i) * 3 + lane] = (lane == 0) ? ox : (lane == 1) ? oy : oz;
+            if (dump_gpe != nullptr && i < N) {
+                const size_t row = (size_t)b * N + i;
+                dump_gpe[row * 64 + lane] = gpe[r];
+                dump_a1[row * 64 + lane] = fmaxf(h1[r], 0.0f);
+                dump_gh1[row * 64 + lane] = g;
+                if (lane < 8) dump_x[row * 8 + lane] = x[r];
+            }
         }
     }
 }
@@ -401,6 +418,18 @@ kb_sdelta(const float* __restrict__ s_cur, int s_mod, size_t s_stride, const flo
     }
 }
 
+// what the weight-gradient pass of the training path needs from kb_edge_encode, per edge slot
+// (row = (b*N + i)*10 + k; every slot is written, padded ones with zero gradients)
+struct KbEdgeDump {
+    float* re;    // [rows,64] relation encoding relu(h3)
+    float* a2;    // [rows,64] relu(h2)
+    float* a1;    // [rows,64] relu(h1)
+    float* x0;    // [rows,8]  the 6 encoder inputs
+    float* g3;    // [rows,64] gradients at the three pre-activations
+    float* g2;
+    float* g1;
+};
+
 // ---- relation encoder backward (horizons > 1): g_cedge [B,N,10,64] -> through W_e and the three
 //      Linear+ReLU layers (forward recomputed per slot) to the position-difference inputs
 //      x[2:5] = s_r - s_s (gnn_dyn.py:179-180):  g_pos[recv] += g,  g_pos[send] -= g  (atomics)
@@ -409,7 +438,8 @@ __global__ void __launch_bounds__(256)
 kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, const float* __restrict__ s_cur, int s_mod,
                size_t s_stride, const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens,
                int dens_mod, const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
-               const float* __restrict__ g_cedge, int N, float* __restrict__ g_pos, size_t gpos_stride) {
+               const float* __restrict__ g_cedge, int N, float* __restrict__ g_pos /* nullable */, size_t gpos_stride,
+               KbEdgeDump dump) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w0 = lds;               // [6][64] forward packs
     float* w2 = w0 + 6 * 64;
@@ -424,7 +454,8 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
     const float b0 = vw[V_RE0_B + lane], b2 = vw[V_RE2_B + lane], b4 = vw[V_RE4_B + lane];
     const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
     const float* at = attr + (size_t)(b % attr_mod) * N;
-    float* gp = g_pos + (size_t)b * gpos_stride;
+    float* gp = g_pos ? g_pos + (size_t)b * gpos_stride : nullptr;
+    const bool dumping = dump.re != nullptr;
     const float wx = wraw[W_RE0_W + lane * 6 + 2], wy = wraw[W_RE0_W + lane * 6 + 3], wz = wraw[W_RE0_W + lane * 6 + 4];
     constexpr int R = 5;           // two passes of five slots keep the register count moderate
     for (int i = wave; i < N; i += nwave) {
@@ -432,9 +463,10 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
         const int16_t* nb = nbr_idx + ((size_t)b * N + i) * DRP_K;
         const float ar = at[i];
         const float sr = (lane >= 2 && lane < 5) ? s[i * 3 + lane - 2] : 0.0f;
-        for (int k0 = 0; k0 < cnt; k0 += R) {
+        for (int k0 = 0; k0 < (dumping ? DRP_K : cnt); k0 += R) {
             float x[R], h1[R], h2[R], h3[R], g[R], t[R];
             int js[R];
+            const size_t row0 = ((size_t)b * N + i) * DRP_K + k0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 js[r] = (k0 + r < cnt) ? (int)nb[k0 + r] : i;
@@ -445,14 +477,24 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
                 else if (lane == 5) v = d;
                 x[r] = v;
                 h1[r] = b0;
+                if (dumping && lane < 8) dump.x0[(row0 + r) * 8 + lane] = v;
             }
             dense_bcast<6, R>(w0, x, h1, lane);
 #pragma unroll
             for (int r = 0; r < R; ++r) { x[r] = fmaxf(h1[r], 0.0f); h2[r] = b2; }
+            if (dumping)
+#pragma unroll
+                for (int r = 0; r < R; ++r) dump.a1[(row0 + r) * 64 + lane] = x[r];
             dense_bcast<64, R>(w2, x, h2, lane);
 #pragma unroll
             for (int r = 0; r < R; ++r) { x[r] = fmaxf(h2[r], 0.0f); h3[r] = b4; }
+            if (dumping)
+#pragma unroll
+                for (int r = 0; r < R; ++r) dump.a2[(row0 + r) * 64 + lane] = x[r];
             dense_bcast<64, R>(w4, x, h3, lane);
+            if (dumping)
+#pragma unroll
+                for (int r = 0; r < R; ++r) dump.re[(row0 + r) * 64 + lane] = fmaxf(h3[r], 0.0f);
             // backward
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -462,13 +504,21 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
             dense_bcast_ld<64, R>(wraw + W_RP_W, 193, 0, g, t, lane);             // W_e^T
 #pragma unroll
             for (int r = 0; r < R; ++r) { g[r] = (h3[r] > 0.0f) ? t[r] : 0.0f; t[r] = 0.0f; }
+            if (dumping)
+#pragma unroll
+                for (int r = 0; r < R; ++r) dump.g3[(row0 + r) * 64 + lane] = g[r];
             dense_bcast_ld<64, R>(wraw + W_RE4_W, 64, 0, g, t, lane);
 #pragma unroll
             for (int r = 0; r < R; ++r) { g[r] = (h2[r] > 0.0f) ? t[r] : 0.0f; t[r] = 0.0f; }
+            if (dumping)
+#pragma unroll
+                for (int r = 0; r < R; ++r) dump.g2[(row0 + r) * 64 + lane] = g[r];
             dense_bcast_ld<64, R>(wraw + W_RE2_W, 64, 0, g, t, lane);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float gh = (h1[r] > 0.0f) ? t[r] : 0.0f;
+                if (dumping) dump.g1[(row0 + r) * 64 + lane] = gh;
+                if (gp == nullptr) continue;
                 const float ox = wave_sum(gh * wx), oy = wave_sum(gh * wy), oz = wave_sum(gh * wz);
                 if (k0 + r < cnt && lane < 3) {
                     const float v = (lane == 0) ? ox : (lane == 1) ? oy : oz;
@@ -483,10 +533,11 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
 // ---- Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8) + the clip box ------------
 //      planners.py:674, :743-746, :756-764
 __global__ void k_adam(float* __restrict__ act, const float* __restrict__ grad, float* __restrict__ m,
-                       float* __restrict__ v, int n, float step_size, float bc2_sqrt, float4 lo, float4 hi) {
+                       float* __restrict__ v, int n, float step_size, float bc2_sqrt, float4 lo, float4 hi,
+                       float b1 = 0.9f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float b2 = 0.999f, eps = 1e-8f;
     const float g = grad[i];
     const float mi = m[i] + (g - m[i]) * (1.0f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
     const float vi = v[i] * b2 + (1.0f - b2) * g * g;

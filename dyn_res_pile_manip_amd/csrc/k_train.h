@@ -1,0 +1,106 @@
+// Training on the same kernels: train/train_gnn_dyn.py:159-189
+//   loss = sum_t sum_b mse(s_pred_t[b, :n_b], s_nxt_t[b, :n_b]) / (n_rollout * B),   s_cur <- s_pred
+//   loss.backward(); Adam(lr, betas=(beta1, 0.999)).step()
+// The state gradients run through the reverse-mode kernels of k_backward.h (graph masks constant,
+// s_delta is data); this file adds the loss, the weight gradients and the optimiser.
+// Weight gradients are plain fp32 outer-product sums over the rows the backward kernels leave in
+// HBM: lane = output feature keeps one row of dW in registers, the input row is broadcast lane by
+// lane (v_readlane), waves stride over the rows, partial sums meet in LDS and then in global
+// atomics (the summation order across workgroups is not fixed: results agree to rounding).
+#pragma once
+#include "drp_common.h"
+
+// d loss / d s_pred_t and the loss itself.  particle_nums[b] real particles per sample, the rest of
+// the N rows are padding (zero rows at the origin, never connected to a real particle).
+__global__ void __launch_bounds__(256)
+kt_mse_grad(const float* __restrict__ s_pred, size_t pred_stride, const float* __restrict__ s_nxt, size_t nxt_stride,
+            const int* __restrict__ particle_nums, int N, float scale, float* __restrict__ g_out,
+            double* __restrict__ loss) {
+    __shared__ double s_w[4];
+    const int b = blockIdx.x;
+    const int nb = particle_nums[b];
+    const float* p = s_pred + (size_t)b * pred_stride;
+    const float* q = s_nxt + (size_t)b * nxt_stride;
+    float* g = g_out + (size_t)b * N * 3;
+    const float inv = scale / (float)(3 * nb);
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < N * 3; i += 256) {
+        float gv = 0.0f;
+        if (i < nb * 3) {
+            const float d = p[i] - q[i];
+            gv = 2.0f * d * inv;
+            acc += (double)d * (double)d;
+        }
+        g[i] = gv;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (s_w[0] + s_w[1] + s_w[2] + s_w[3]) * (double)inv);
+}
+
+__global__ void kt_add(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+// dW[lane * lane_stride + k * k_stride] += sum_rows g[row][lane] * x[row][k]      k < IN
+// db[lane]                              += sum_rows g[row][lane]                   (nullable)
+// dwd[lane * lane_stride]               += sum_rows g[row][lane] * dens[row / rows_per_sample] / 5000   (nullable)
+template <int IN>
+__global__ void __launch_bounds__(256)
+kt_wgrad(const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx, long M, float* __restrict__ dW,
+         int lane_stride, int k_stride, float* __restrict__ db, float* __restrict__ dwd,
+         const float* __restrict__ dens, int dens_mod, long rows_per_sample) {
+    extern __shared__ float s_part[];                  // [3][IN + 2][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) acc[k] = 0.0f;
+    float accb = 0.0f, accd = 0.0f;
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+        const float gv = g[row * ldg + lane];
+        const float xv = (IN == 64 || lane < IN) ? x[row * ldx + lane] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < IN; ++k) acc[k] = fmaf(gv, bcast_lane(xv, k), acc[k]);
+        accb += gv;
+        if (dwd != nullptr) accd = fmaf(gv, dens[(row / rows_per_sample) % dens_mod] / DRP_DENS_SCALE, accd);
+    }
+    if (wave > 0) {
+        float* dst = s_part + (size_t)(wave - 1) * (IN + 2) * 64;
+#pragma unroll
+        for (int k = 0; k < IN; ++k) dst[k * 64 + lane] = acc[k];
+        dst[IN * 64 + lane] = accb;
+        dst[(IN + 1) * 64 + lane] = accd;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float* src = s_part + (size_t)w * (IN + 2) * 64;
+#pragma unroll
+            for (int k = 0; k < IN; ++k) acc[k] += src[k * 64 + lane];
+            accb += src[IN * 64 + lane];
+            accd += src[(IN + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < IN; ++k) atomicAdd(dW + (size_t)lane * lane_stride + (size_t)k * k_stride, acc[k]);
+        if (db != nullptr) atomicAdd(db + lane, accb);
+        if (dwd != nullptr) atomicAdd(dwd + (size_t)lane * lane_stride, accd);
+    }
+}
+#define KT_WGRAD_LDS(IN) ((size_t)3 * ((IN) + 2) * 64 * sizeof(float))
+
+// column sums of a [M,3] gradient (bias of the predictor's last layer)
+__global__ void __launch_bounds__(256) kt_colsum3(const float* __restrict__ g, long M, float* __restrict__ out) {
+    float a[3] = {0.f, 0.f, 0.f};
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+        a[0] += g[r * 3]; a[1] += g[r * 3 + 1]; a[2] += g[r * 3 + 2];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float t = wave_sum(a[c]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(out + c, t);
+    }
+}

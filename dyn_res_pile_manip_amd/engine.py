@@ -247,6 +247,34 @@ class Engine(object):
                                   idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.byref(md)))
         return pts[idx], md.value, idx
 
+    # ---- training (row f4) -------------------------------------------------
+    def train_begin(self, n_rollout, lr=1e-3, beta1=0.9):
+        self._ck(self.lib.drp_train_begin(self.h, int(n_rollout), float(lr), float(beta1)))
+        self._n_rollout = int(n_rollout)
+
+    def train_step(self, states, states_delta, attrs, particle_nums, particle_dens, mode='update', want_grad=False):
+        """One body of the loop at train/train_gnn_dyn.py:159-210 -> (loss, gradient blob or None)."""
+        states, states_delta, attrs = _f32(states), _f32(states_delta), _f32(attrs)
+        dens = _f32(particle_dens)
+        nums = np.ascontiguousarray(particle_nums, dtype=np.int32)
+        B, T1, N, _ = states.shape
+        assert T1 == self._n_rollout + 1 and states_delta.shape == (B, T1 - 1, N, 3)
+        assert attrs.shape == (B, T1, N) and nums.shape == (B,) and dens.shape == (B,)
+        loss = ctypes.c_double()
+        grad = np.empty((38403,), np.float32) if (want_grad and mode != 'eval') else None
+        self._ck(self.lib.drp_train_step(self.h, _fp(states), _fp(states_delta), _fp(attrs),
+                                         nums.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _fp(dens), B, N,
+                                         L.TRAIN_MODES[mode], ctypes.byref(loss), None if grad is None else _fp(grad)))
+        return loss.value, grad
+
+    def train_set_lr(self, lr):
+        self._ck(self.lib.drp_train_set_lr(self.h, float(lr)))
+
+    def get_weights(self):
+        blob = np.empty((38403,), np.float32)
+        self._ck(self.lib.drp_get_weights(self.h, _fp(blob), blob.size))
+        return blob
+
     # ---- particle extraction (row f2) -------------------------------------
     def depth2fgpcd(self, depth, mask, cam_params):
         """utils.depth2fgpcd on the device -> [n,3] float64."""

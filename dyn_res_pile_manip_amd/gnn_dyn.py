@@ -82,6 +82,7 @@ class PropNetDiffDenModel(object):
         return self
 
     def eval(self):
+        self.training = False
         return self
 
     def to(self, *a, **k):
@@ -95,7 +96,12 @@ class PropNetDiffDenModel(object):
     def state_dict(self):
         if self._blob is None:
             raise RuntimeError('no weights loaded')
+        self._blob = self.engine.get_weights()       # training updates them on the device
         return _weights.state_dict_from_blob(self._blob)
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
 
     def predict_one_step(self, a_cur, s_cur, s_delta, particle_dens, particle_nums=None):
         a, proto = _to_np(a_cur)

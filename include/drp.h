@@ -172,6 +172,27 @@ int drp_mpc_get(drp_ctx* ctx, float* actions /*[B,H,4]*/, float* rewards /*[B] f
 int drp_fps(drp_ctx* ctx, const float* pts, int n, int dim, int k, int init_idx, int32_t* idx_out,
             float* max_dist_out);
 
+/* ---- training on the same kernels (row f4; train/train_gnn_dyn.py:159-214) ---------------------
+ * One iteration of the reference's training loop body for one collated batch
+ * (train/train_gnn_dyn.py:20-45 collate_fn: samples zero-padded to the batch's largest
+ * particle count N):
+ *   s_cur = states[:, 0]; for t < n_rollout: s_pred = predict_one_step(attrs[:, 0], s_cur,
+ *   states_delta[:, t], particle_dens); loss += sum_b mse(s_pred[b, :n_b], states[b, t+1, :n_b]);
+ *   s_cur = s_pred;  loss /= n_rollout * B;  loss.backward();  Adam(lr, betas=(beta1, .999)).step()
+ * states [B, n_rollout+1, N, 3], states_delta [B, n_rollout, N, 3], attrs [B, n_rollout+1, N],
+ * particle_nums [B], particle_dens [B].  loss_out receives the loss (before the update),
+ * grad_out (nullable, 38 403 floats in state_dict order) the gradient of every parameter. */
+#define DRP_TRAIN_EVAL 0     /* loss only ('valid' phase, torch.set_grad_enabled(False)) */
+#define DRP_TRAIN_GRAD 1     /* loss + gradients, weights untouched */
+#define DRP_TRAIN_UPDATE 2   /* loss + gradients + one Adam step on the context's weights */
+int drp_train_begin(drp_ctx* ctx, int n_rollout, double lr, double beta1);
+int drp_train_step(drp_ctx* ctx, const float* states, const float* states_delta, const float* attrs,
+                   const int32_t* particle_nums, const float* particle_dens, int B, int N, int mode,
+                   double* loss_out, float* grad_out);
+int drp_train_set_lr(drp_ctx* ctx, double lr);
+/* model.state_dict() (train/train_gnn_dyn.py:226,244): the current weights, drp_load_weights layout */
+int drp_get_weights(drp_ctx* ctx, float* blob_out, size_t n_floats);
+
 /* ---- particle extraction from the depth image (row f2; env/flex_env.py:933-951) --------------
  * The reference runs this chain on the host between every pair of planner calls, 30 times per
  * observation (batch_size=30, env/flex_env.py:1020,1093).  All clouds are float64 [n,3] in the

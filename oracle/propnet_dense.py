@@ -301,3 +301,46 @@ def gd_loss_and_grads(W, s0, dens, attr, act_seqs, G, cam_params, goal_coor, cam
     loss = torch.sum(-r)
     loss.backward()
     return r.detach().numpy(), acts.grad.numpy(), st.grad.numpy()
+
+
+def train_loss_and_grads(W, states, states_delta, attrs, particle_nums, particle_dens, adj_thresh=0.08):
+    """train/train_gnn_dyn.py:159-210 for one collated batch: n_rollout autoregressive steps from
+    states[:, 0] with the given impulses, per-sample MSE over the real (unpadded) particles,
+    loss / (n_rollout * B), autograd.  W: dict of weight arrays (state_dict keys).
+    Returns (loss float, {key: gradient array})."""
+    Wt = {k: torch.tensor(np.asarray(v, dtype=np.float32), requires_grad=True) for k, v in W.items()}
+    states = _t(states)
+    states_delta = _t(states_delta)
+    attrs = _t(attrs)
+    dens = _t(particle_dens)
+    B, T1, N, _ = states.shape
+    n_rollout = T1 - 1
+    loss = 0.0
+    s_cur = states[:, 0]
+    a_cur = attrs[:, 0]
+    for t in range(n_rollout):
+        s_pred = predict_one_step(Wt, a_cur, s_cur, states_delta[:, t], dens, adj_thresh)
+        for j in range(B):
+            n = int(particle_nums[j])
+            loss = loss + torch.nn.functional.mse_loss(s_pred[j, :n], states[j, t + 1, :n])
+        s_cur = s_pred
+    loss = loss / (n_rollout * B)
+    loss.backward()
+    return float(loss.item()), {k: v.grad.numpy() for k, v in Wt.items()}
+
+
+def adam_steps(W, grads_fn, n_steps, lr=1e-3, beta1=0.9):
+    """torch.optim.Adam(params, lr, betas=(beta1, 0.999)) for n_steps on a fixed batch
+    (train/train_gnn_dyn.py:128-131, :206-209).  grads_fn(W) -> (loss, grads).  Returns
+    (losses, final weights)."""
+    params = {k: torch.tensor(np.asarray(v, dtype=np.float32), requires_grad=True) for k, v in W.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=lr, betas=(beta1, 0.999))
+    losses = []
+    for _ in range(n_steps):
+        loss, grads = grads_fn({k: v.detach().numpy() for k, v in params.items()})
+        losses.append(loss)
+        opt.zero_grad()
+        for k, v in params.items():
+            v.grad = torch.from_numpy(np.ascontiguousarray(grads[k]))
+        opt.step()
+    return losses, {k: v.detach().numpy().copy() for k, v in params.items()}

@@ -1,0 +1,101 @@
+"""GPU: training on the same kernels (row f4) through the C ABI, against the reference model's
+own loss, autograd gradients and torch.optim.Adam trajectory (tests/golden/train.npz)."""
+import numpy as np
+import pytest
+
+from dyn_res_pile_manip_amd import synthetic as syn
+from dyn_res_pile_manip_amd import train_gnn_dyn as T
+from dyn_res_pile_manip_amd import weights
+from dyn_res_pile_manip_amd.gnn_dyn import PropNetDiffDenModel
+
+pytestmark = pytest.mark.gpu
+CASES = ['b4_r3', 'b2_r5']
+
+
+def _model(golden):
+    import torch
+    config = syn.default_config()
+    model = PropNetDiffDenModel(config, True)
+    model.load_state_dict({k[2:]: torch.from_numpy(golden.weights_seed0[k]) for k in golden.weights_seed0.files
+                           if k.startswith('w/')}, strict=False)
+    return model
+
+
+def _batch(g, case):
+    return [g[case + '/' + k] for k in ('states', 'states_delta', 'attrs', 'particle_nums', 'particle_dens')]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_loss_and_weight_gradients(golden, case):
+    g = golden.train
+    model = _model(golden)
+    batch = _batch(g, case)
+    model.engine.train_begin(batch[0].shape[1] - 1, 1e-3, 0.9)
+    loss, grad = model.engine.train_step(*batch, mode='grad', want_grad=True)
+    loss_eval, _ = model.engine.train_step(*batch, mode='eval')
+    model.engine.close()
+    assert abs(loss - g[case + '/losses'][0]) < 1e-4 * g[case + '/losses'][0]
+    assert abs(loss_eval - loss) < 1e-9
+    got = weights.state_dict_from_blob(grad)
+    for k, _ in weights.STATE_DICT_KEYS:
+        ref = g[case + '/grad/' + k]
+        gk = np.asarray(got[k]).reshape(ref.shape)
+        scale = max(np.abs(ref).max(), 1e-8)
+        assert np.abs(gk - ref).max() < 2e-4 * scale + 1e-9, k
+        # inputs that are identically zero (the attribute columns) have exactly zero gradient in both
+        np.testing.assert_array_equal(ref == 0, np.abs(gk) < 1e-12 * scale + 1e-30)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_adam_trajectory(golden, case):
+    g = golden.train
+    model = _model(golden)
+    batch = _batch(g, case)
+    lr, beta1 = g[case + '/lr_beta1']
+    opt = T.DeviceAdam(model, lr, betas=(beta1, 0.999), n_rollout=batch[0].shape[1] - 1)
+    losses = [T.run_batch(model, opt, batch, 'train') for _ in range(3)]
+    sd = model.state_dict()
+    model.engine.close()
+    np.testing.assert_allclose(losses, g[case + '/losses'], rtol=2e-3)
+    for k, _ in weights.STATE_DICT_KEYS:
+        ref = g[case + '/after3/' + k]
+        got = sd[k].numpy() if hasattr(sd[k], 'numpy') else np.asarray(sd[k])
+        gr = g[case + '/grad/' + k]
+        firm = np.abs(gr) > 1e-3 * np.abs(gr).max()           # Adam's first steps are +-lr: sign of tiny gradients is noise
+        assert np.abs(got - ref)[firm].max() < 2e-5, k
+        assert np.abs(got - ref).max() < 3.5 * lr, k
+
+
+def test_training_reduces_the_loss_and_valid_phase_leaves_weights(golden):
+    g = golden.train
+    model = _model(golden)
+    config = syn.default_config()
+    config['train'].update({'n_rollout': 3, 'n_history': 1, 'lr': 2e-4, 'adam_beta1': 0.9, 'log_per_iter': 50,
+                            'n_epoch': 6})
+    batch = _batch(g, 'b4_r3') + [None]
+    w0 = model.engine.get_weights().copy()
+    best = []
+    res = T.train(config, model, {'train': [batch] * 4, 'valid': [batch]}, on_best=lambda sd: best.append(sd))
+    rmse_valid = [h[2] for h in res['history'] if h[1] == 'valid']
+    assert rmse_valid[-1] < 0.99 * rmse_valid[0] and min(rmse_valid) == rmse_valid[-1]
+    assert len(best) >= 2 and abs(res['best_valid_loss'] - min(rmse_valid) ** 2) < 1e-12
+    assert np.abs(model.engine.get_weights() - w0).max() > 1e-4
+    # the updated weights serve inference: one step with the trained model differs from the initial one
+    w1 = model.engine.get_weights()
+    l_a, _ = model.engine.train_step(*batch[:5], mode='eval')
+    l_b, _ = model.engine.train_step(*batch[:5], mode='eval')
+    assert l_a == l_b
+    np.testing.assert_array_equal(model.engine.get_weights(), w1)
+    model.engine.close()
+
+
+def test_collate_fn_pads_like_the_reference():
+    rng = np.random.default_rng(0)
+    data = []
+    for n in (5, 9, 3):
+        data.append((rng.normal(size=(4, n, 3)), rng.normal(size=(3, n, 3)), np.zeros((4, n)), n, 100.0 + n, None))
+    st, sd, at, pn, pd, _ = T.collate_fn(data)
+    assert st.shape == (3, 4, 9, 3) and sd.shape == (3, 3, 9, 3) and at.shape == (3, 4, 9)
+    assert st.dtype == np.float32 and pn.dtype == np.int32 and pd.dtype == np.float32
+    assert (st[0, :, 5:] == 0).all() and (st[2, :, 3:] == 0).all()
+    np.testing.assert_allclose(st[1], data[1][0].astype(np.float32))

@@ -147,3 +147,23 @@ def test_gd_gradients(golden, W, case):
     np.testing.assert_allclose(r, g[case + '/reward'][:, 0], rtol=2e-6)
     np.testing.assert_allclose(gs, g[case + '/grad_state_pred'], rtol=0, atol=1e-3 * np.abs(g[case + '/grad_state_pred']).max())
     np.testing.assert_allclose(ga, g[case + '/grad_act'], rtol=0, atol=1e-3 * np.abs(g[case + '/grad_act']).max())
+
+
+# ---- training (row f4): loss, autograd weight gradients and Adam steps of the reference model ----
+@pytest.mark.parametrize('case', ['b4_r3', 'b2_r5'])
+def test_training_loss_gradients_and_adam(golden, case):
+    g = golden.train
+    W = {k[2:]: golden.weights_seed0[k] for k in golden.weights_seed0.files if k.startswith('w/')}
+    batch = [g[case + '/' + k] for k in ('states', 'states_delta', 'attrs', 'particle_nums', 'particle_dens')]
+    loss, grads = od.train_loss_and_grads(W, *batch)
+    assert abs(loss - g[case + '/losses'][0]) < 1e-6 * abs(loss)
+    for k, v in grads.items():
+        ref = g[case + '/grad/' + k]
+        assert np.abs(v - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-8), k
+    lr, beta1 = g[case + '/lr_beta1']
+    losses, W3 = od.adam_steps(W, lambda w: od.train_loss_and_grads(w, *batch), 3, lr, beta1)
+    np.testing.assert_allclose(losses, g[case + '/losses'], rtol=1e-4)
+    for k, v in W3.items():
+        gr = g[case + '/grad/' + k]
+        firm = np.abs(gr) > 1e-3 * np.abs(gr).max()
+        assert np.abs(v - g[case + '/after3/' + k])[firm].max() < 1e-5, k
