@@ -89,7 +89,7 @@ struct drp_ctx {
     int tr_nroll = 0, tr_iter = 0;
     double tr_lr = 1e-3, tr_beta1 = 0.9;
     std::vector<float> w_host;
-    DevBuf tr_states, tr_sdelta, tr_nums, tr_grad, tr_m, tr_v, tr_loss, agg_hist, tr_hact, tr_gh, tr_gpe, tr_a1n,
+    DevBuf tr_part, tr_states, tr_sdelta, tr_nums, tr_grad, tr_m, tr_v, tr_loss, agg_hist, tr_hact, tr_gh, tr_gpe, tr_a1n,
         tr_gh1, tr_xn, ed_re, ed_a2, ed_a1, ed_x0, ed_g3, ed_g2, ed_g1;
 
     // goal pre-processing (row f3)
@@ -451,10 +451,13 @@ template <int IN>
 void launch_wgrad(drp_ctx* c, const float* g, int ldg, const float* x, int ldx, long M, float* dW, int lane_stride,
                   int k_stride, float* db, float* dwd, const float* dens, int dens_mod, long rows_per_sample) {
     long blocks = (M + 63) / 64;
-    if (blocks > 128) blocks = 128;
+    if (blocks > KT_WGRAD_MAX_BLOCKS) blocks = KT_WGRAD_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(kt_wgrad<IN>, dim3((unsigned)blocks), dim3(256), KT_WGRAD_LDS(IN), c->stream, g, ldg, x, ldx, M, dW,
-                       lane_stride, k_stride, db, dwd, dens, dens_mod, rows_per_sample);
+    float* part = static_cast<float*>(c->tr_part.p);       // sized for KT_WGRAD_MAX_BLOCKS x 66 x 64 by drp_train_begin
+    hipLaunchKernelGGL(kt_wgrad<IN>, dim3((unsigned)blocks), dim3(256), KT_WGRAD_LDS(IN), c->stream, g, ldg, x, ldx, M, part,
+                       dwd ? dens : nullptr, dens_mod, rows_per_sample);
+    hipLaunchKernelGGL(kt_wgrad_reduce<IN>, dim3(IN + 2), dim3(64), 0, c->stream, part, (int)blocks, dW, lane_stride, k_stride,
+                       db, dwd);
 }
 
 int check_bn(drp_ctx* c, int B, int N) {
@@ -528,7 +531,7 @@ void drp_destroy(drp_ctx* c) {
                       &c->px_cellcnt, &c->px_cellfill, &c->px_celloff, &c->px_list, &c->px_down, &c->px_down32, &c->px_init,
                       &c->px_dist, &c->px_chosen, &c->px_pts, &c->px_r, &c->px_rr, &c->px_out,
                       &c->gl_goal, &c->gl_seg, &c->gl_tmp, &c->gl_dist, &c->gl_blk, &c->gl_pix, &c->gl_fps,
-                      &c->tr_states, &c->tr_sdelta, &c->tr_nums, &c->tr_grad, &c->tr_m, &c->tr_v, &c->tr_loss, &c->agg_hist,
+                      &c->tr_part, &c->tr_states, &c->tr_sdelta, &c->tr_nums, &c->tr_grad, &c->tr_m, &c->tr_v, &c->tr_loss, &c->agg_hist,
                       &c->tr_hact, &c->tr_gh, &c->tr_gpe, &c->tr_a1n, &c->tr_gh1, &c->tr_xn, &c->ed_re, &c->ed_a2, &c->ed_a1,
                       &c->ed_x0, &c->ed_g3, &c->ed_g2, &c->ed_g1};
     for (DevBuf* b : bufs)
@@ -1263,20 +1266,20 @@ int gd_forward_backward(drp_ctx* c) {
         float* g_out = g_state + (size_t)t * bn * 3;
         float* g_cedge = (t > 0) ? ptr<float>(c->g_cedge) : nullptr;
         hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn * 64, g_out, (size_t)N * 3, N,
-                           ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr);
+                           ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr, 1);
         for (int p = DRP_PSTEP - 1; p >= 0; --p) {
             hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn * 64,
                                ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N,
-                               ptr<float>(c->g_agg));
+                               ptr<float>(c->g_agg), 1);
             HIPCHK(c, hipMemsetAsync(c->g_proj.p, 0, bn * 128 * sizeof(float), st));
             hipLaunchKernelGGL(kb_edges, dim3(B), dim3(256), 0, st, cedge, pht + (size_t)p * bn * 128, idx, cnt,
-                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), g_cedge, p == DRP_PSTEP - 1 ? 1 : 0);
-            hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff));
+                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), g_cedge, p == DRP_PSTEP - 1 ? 1 : 0, 1);
+            hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), 1);
         }
         hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw,
                            ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb, ptr<float>(c->dens),
                            nb, eht, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta),
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1);
         float* g_prev = nullptr;
         if (t > 0) {
             // d loss / d state[t-1] = residual share + relation encoder + gen_s_delta's position dependence
@@ -1284,7 +1287,7 @@ int gd_forward_backward(drp_ctx* c) {
             CHK(d2d(g_prev, g_out, bn * 3 * sizeof(float)));
             hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), (6 * 64 + 2 * 4096) * sizeof(float), st, vw, wraw,
                                s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx, cnt,
-                               g_cedge, N, g_prev, (size_t)N * 3, KbEdgeDump{});
+                               g_cedge, N, g_prev, (size_t)N * 3, KbEdgeDump{}, 1);
         }
         hipLaunchKernelGGL(kb_sdelta, dim3(B), dim3(256), 0, st, s_prev, prev_mod, prev_stride,
                            ptr<float>(c->actions) + (size_t)t * 4, (size_t)H * 4, ptr<float>(c->g_sdelta), N, c->cam,
@@ -1404,7 +1407,6 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     float* g_state = ptr<float>(c->g_state);
     double* loss = ptr<double>(c->tr_loss);
     const float scale = 1.0f / (float)(H * B);
-    HIPCHK(c, hipMemsetAsync(loss, 0, sizeof(double), st));
     const int saved_engine = c->engine;
     c->engine = DRP_ENGINE_MFMA;
     int rc = DRP_OK;
@@ -1443,7 +1445,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         // loss of this step and d loss / d s_pred_t (train/train_gnn_dyn.py:184-186, :203)
         hipLaunchKernelGGL(kt_mse_grad, dim3(B), dim3(256), 0, st, states + (size_t)t * N * 3, hstride,
                            given + (size_t)(t + 1) * N * 3, in_stride, ptr<int>(c->tr_nums), N, scale,
-                           g_state + (size_t)t * bn * 3, loss);
+                           g_state + (size_t)t * bn * 3, loss + (size_t)t * B);
     }
     c->engine = saved_engine;
     CHK(rc);
@@ -1453,6 +1455,11 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     const float* vw = ptr<float>(c->w_valu);
     const float* wraw = ptr<float>(c->w_raw);
     float* G = ptr<float>(c->tr_grad);
+    // a training batch is a handful of samples: split each sample's rows over workgroups
+    int chunks = (N + 15) / 16;
+    if (chunks > 1024 / B) chunks = 1024 / B;
+    if (chunks < 1) chunks = 1;
+    const dim3 rgrid((unsigned)(B * chunks));
     const float* dens = ptr<float>(c->dens);
     HIPCHK(c, hipMemsetAsync(G, 0, (size_t)W_TOTAL * sizeof(float), st));
     KbEdgeDump ed{ptr<float>(c->ed_re), ptr<float>(c->ed_a2), ptr<float>(c->ed_a1), ptr<float>(c->ed_x0),
@@ -1469,37 +1476,37 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         float* g_out = g_state + (size_t)t * bn * 3;
         float* g_cedge = ptr<float>(c->g_cedge);
         // predictor
-        hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn64, g_out, (size_t)N * 3, N,
-                           ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh));
+        hipLaunchKernelGGL(kb_predict, rgrid, dim3(256), 0, st, vw, wraw, eht + 3 * bn64, g_out, (size_t)N * 3, N,
+                           ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh), chunks);
         launch_wgrad<64>(c, ptr<float>(c->tr_gh), 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
                          nullptr, 1, 1);
         launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
         hipLaunchKernelGGL(kt_colsum3, dim3(16), dim3(256), 0, st, g_out, (long)bn, G + W_PR1_B);
         HIPCHK(c, hipMemsetAsync(g_cedge, 0, bnk * 64 * sizeof(float), st));
         for (int p = DRP_PSTEP - 1; p >= 0; --p) {
-            hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn64,
+            hipLaunchKernelGGL(kb_update, rgrid, dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn64,
                                ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N,
-                               ptr<float>(c->g_agg));
+                               ptr<float>(c->g_agg), chunks);
             // particle propagator, aggregate columns: g_eff now holds the pre-activation gradient
             launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
                              nullptr, nullptr, nullptr, 1, 1);
             HIPCHK(c, hipMemsetAsync(c->g_proj.p, 0, bn * 128 * sizeof(float), st));
-            hipLaunchKernelGGL(kb_edges, dim3(B), dim3(256), 0, st, cedge, pht + (size_t)p * bn64 * 2, idx, cnt,
-                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), g_cedge, 0);
+            hipLaunchKernelGGL(kb_edges, rgrid, dim3(256), 0, st, cedge, pht + (size_t)p * bn64 * 2, idx, cnt,
+                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), g_cedge, 0, chunks);
             // relation propagator, receiver and sender columns
             launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
                              nullptr, nullptr, nullptr, 1, 1);
             launch_wgrad<64>(c, ptr<float>(c->g_proj) + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
                              1, nullptr, nullptr, nullptr, 1, 1);
-            hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff));
+            hipLaunchKernelGGL(kb_project, rgrid, dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), chunks);
         }
         // particle propagator, encoder columns + density column + bias; particle encoder
         launch_wgrad<64>(c, ptr<float>(c->g_cnode), 64, eht, 64, (long)bn, G + W_PP_W, 129, 1, G + W_PP_B, G + W_PP_W + 128,
                          dens, B, (long)N);
-        hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw,
+        hipLaunchKernelGGL(kb_node_encode, rgrid, dim3(256), 0, st, vw, wraw,
                            ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), B, dens, B, eht,
                            ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta), ptr<float>(c->tr_gpe),
-                           ptr<float>(c->tr_a1n), ptr<float>(c->tr_gh1), ptr<float>(c->tr_xn));
+                           ptr<float>(c->tr_a1n), ptr<float>(c->tr_gh1), ptr<float>(c->tr_xn), chunks);
         launch_wgrad<64>(c, ptr<float>(c->tr_gpe), 64, ptr<float>(c->tr_a1n), 64, (long)bn, G + W_PE2_W, 64, 1, G + W_PE2_B,
                          nullptr, nullptr, 1, 1);
         launch_wgrad<5>(c, ptr<float>(c->tr_gh1), 64, ptr<float>(c->tr_xn), 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
@@ -1510,8 +1517,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             g_prev = g_state + (size_t)(t - 1) * bn * 3;
             hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
         }
-        hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), (6 * 64 + 2 * 4096) * sizeof(float), st, vw, wraw, s_prev, B,
-                           prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, g_cedge, N, g_prev, (size_t)N * 3, ed);
+        hipLaunchKernelGGL(kb_edge_encode, rgrid, dim3(256), (6 * 64 + 2 * 4096) * sizeof(float), st, vw, wraw, s_prev, B,
+                           prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, g_cedge, N, g_prev, (size_t)N * 3, ed, chunks);
         launch_wgrad<64>(c, g_cedge, 64, ed.re, 64, (long)bnk, G + W_RP_W, 193, 1, G + W_RP_B, G + W_RP_W + 192, dens, B,
                          (long)N * DRP_K);
         launch_wgrad<64>(c, ed.g3, 64, ed.a2, 64, (long)bnk, G + W_RE4_W, 64, 1, G + W_RE4_B, nullptr, nullptr, 1, 1);
@@ -1539,7 +1546,7 @@ int drp_train_begin(drp_ctx* c, int n_rollout, double lr, double beta1) {
     CHK(ensure(c, c->tr_grad, (size_t)W_TOTAL * sizeof(float)));
     CHK(ensure(c, c->tr_m, (size_t)W_TOTAL * sizeof(float)));
     CHK(ensure(c, c->tr_v, (size_t)W_TOTAL * sizeof(float)));
-    CHK(ensure(c, c->tr_loss, sizeof(double)));
+    CHK(ensure(c, c->tr_part, (size_t)KT_WGRAD_MAX_BLOCKS * 66 * 64 * sizeof(float)));
     HIPCHK(c, hipMemsetAsync(c->tr_m.p, 0, (size_t)W_TOTAL * sizeof(float), c->stream));
     HIPCHK(c, hipMemsetAsync(c->tr_v.p, 0, (size_t)W_TOTAL * sizeof(float), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1597,9 +1604,11 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         for (DevBuf* b : edge64) CHK(ensure(c, *b, bnk * 64 * sizeof(float)));
         CHK(ensure(c, c->ed_x0, bnk * 8 * sizeof(float)));
     }
+    CHK(ensure(c, c->tr_loss, (size_t)H * B * sizeof(double)));
     c->lastH = H;
     CHK(train_forward_backward(c, B, N, backward));
-    if (loss_out) CHK(d2h(c, loss_out, c->tr_loss.p, sizeof(double)));
+    std::vector<double> parts((size_t)H * B);
+    if (loss_out) CHK(d2h(c, parts.data(), c->tr_loss.p, parts.size() * sizeof(double)));
     if (grad_out && backward) CHK(d2h(c, grad_out, c->tr_grad.p, (size_t)W_TOTAL * sizeof(float)));
     if (mode == DRP_TRAIN_UPDATE) {
         c->tr_iter += 1;
@@ -1616,7 +1625,13 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         HIPCHK(c, hipStreamSynchronize(c->stream));
         CHK(install_weights(c, blob));
     }
-    return drp_sync(c);
+    CHK(drp_sync(c));
+    if (loss_out) {
+        double total = 0.0;                     // fixed order: step-major, then sample
+        for (double v : parts) total += v;
+        *loss_out = total;
+    }
+    return DRP_OK;
 }
 
 int drp_train_set_lr(drp_ctx* c, double lr) {

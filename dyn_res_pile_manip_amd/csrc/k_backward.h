@@ -33,6 +33,19 @@ __device__ __forceinline__ void dense_bcast_ld(const float* __restrict__ W, int 
 
 #define KB_R 4
 
+// The row kernels below run one workgroup per (sample, chunk of rows): `chunks` = 1 when the batch
+// alone fills the chip (the planner's thousands of samples), more for the trainer's handful.
+struct KbRange { int b, lo, hi; };
+__device__ __forceinline__ KbRange kb_range(int N, int chunks) {
+    KbRange r;
+    r.b = blockIdx.x / chunks;
+    const int ch = blockIdx.x - r.b * chunks;
+    const int len = (((N + chunks - 1) / chunks) + KB_R - 1) & ~(KB_R - 1);
+    r.lo = ch * len;
+    r.hi = min(N, r.lo + len);
+    return r;
+}
+
 // ---- reward backward: g_state[b,n,:] = d(-reward_b... ) see below ------------------------------
 // loss = -sum_b reward_b, reward_b = -(r1 + r2)/N  =>  d loss / d r1 = d loss / d r2 = 1/N.
 //   r1 = sum_n bilinear(G, pix_n)      -> grid_sample's gradient w.r.t. the grid (zero where the
@@ -106,17 +119,18 @@ __global__ void __launch_bounds__(256)
 kb_predict(const float* __restrict__ vw, const float* __restrict__ wraw, const float* __restrict__ eff,
            const float* __restrict__ g_out, size_t g_stride, int N, float* __restrict__ g_eff,
            float* __restrict__ dump_hact /* nullable [B*N,64]: relu(W0 eff + b0) */,
-           float* __restrict__ dump_gh /* nullable [B*N,64]: gradient at the hidden pre-activation */) {
+           float* __restrict__ dump_gh /* nullable [B*N,64]: gradient at the hidden pre-activation */, int chunks) {
     __shared__ float w0t[4096], w0[4096];
     lds_copy(w0t, vw + V_PR0_T, 4096);
     lds_copy(w0, wraw + W_PR0_W, 4096);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int b = blockIdx.x;
+    const KbRange rg = kb_range(N, chunks);
+    const int b = rg.b;
     const float b0 = vw[V_PR0_B + lane];
     const float w1x = vw[V_PR1_W + lane], w1y = vw[V_PR1_W + 64 + lane], w1z = vw[V_PR1_W + 128 + lane];
     const float* go = g_out + (size_t)b * g_stride;
-    for (int base = wave * KB_R; base < N; base += nwave * KB_R) {
+    for (int base = rg.lo + wave * KB_R; base < rg.hi; base += nwave * KB_R) {
         float x[KB_R], h[KB_R], gh[KB_R], ge[KB_R];
 #pragma unroll
         for (int r = 0; r < KB_R; ++r) {
@@ -146,11 +160,12 @@ kb_predict(const float* __restrict__ vw, const float* __restrict__ wraw, const f
 //      g_eff <- g_z (the residual's share of the gradient w.r.t. the previous effect)
 __global__ void __launch_bounds__(256)
 kb_update(const float* __restrict__ wraw, const float* __restrict__ eff_next, float* __restrict__ g_eff,
-          float* __restrict__ g_cnode, int first, int N, float* __restrict__ g_agg) {
+          float* __restrict__ g_cnode, int first, int N, float* __restrict__ g_agg, int chunks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int b = blockIdx.x;
+    const KbRange rg = kb_range(N, chunks);
+    const int b = rg.b;
     const float* wpp = wraw + W_PP_W;
-    for (int base = wave * KB_R; base < N; base += nwave * KB_R) {
+    for (int base = rg.lo + wave * KB_R; base < rg.hi; base += nwave * KB_R) {
         float gz[KB_R], ga[KB_R];
 #pragma unroll
         for (int r = 0; r < KB_R; ++r) {
@@ -177,8 +192,10 @@ kb_update(const float* __restrict__ wraw, const float* __restrict__ eff_next, fl
 __global__ void __launch_bounds__(256)
 kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const int16_t* __restrict__ nbr_idx,
          const uint8_t* __restrict__ nbr_cnt, const float* __restrict__ g_agg, int N, float* __restrict__ g_proj,
-         float* __restrict__ g_cedge /* nullable: [B,N,10,64], summed over the propagation steps */, int first) {
-    const int b = blockIdx.x;
+         float* __restrict__ g_cedge /* nullable: [B,N,10,64], summed over the propagation steps */, int first,
+         int chunks) {
+    const KbRange rg = kb_range(N, chunks);
+    const int b = rg.b;
     const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
     const float4* ce = reinterpret_cast<const float4*>(c_edge) + (size_t)b * N * DRP_K * 16;
     const float4* pj = reinterpret_cast<const float4*>(proj) + (size_t)b * N * 32;
@@ -186,7 +203,7 @@ kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const
     float* gp = g_proj + (size_t)b * N * 128;
     const int16_t* nb = nbr_idx + (size_t)b * N * DRP_K;
     const uint8_t* nc = nbr_cnt + (size_t)b * N;
-    for (int i = g; i < N; i += 16) {
+    for (int i = rg.lo + g; i < rg.hi; i += 16) {
         const int cnt = nc[i];
         const float4 pr = pj[(size_t)i * 32 + q];
         const float4 gi = ga[(size_t)i * 16 + q];
@@ -218,11 +235,13 @@ kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const
 
 // ---- projection backward: g_eff += W_r^T g_proj[:, 0:64] + W_s^T g_proj[:, 64:128] -------------
 __global__ void __launch_bounds__(256)
-kb_project(const float* __restrict__ wraw, const float* __restrict__ g_proj, int N, float* __restrict__ g_eff) {
+kb_project(const float* __restrict__ wraw, const float* __restrict__ g_proj, int N, float* __restrict__ g_eff,
+           int chunks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int b = blockIdx.x;
+    const KbRange rg = kb_range(N, chunks);
+    const int b = rg.b;
     const float* wrp = wraw + W_RP_W;
-    for (int base = wave * KB_R; base < N; base += nwave * KB_R) {
+    for (int base = rg.lo + wave * KB_R; base < rg.hi; base += nwave * KB_R) {
         float gr[KB_R], gs[KB_R], ge[KB_R];
 #pragma unroll
         for (int r = 0; r < KB_R; ++r) {
@@ -249,18 +268,19 @@ kb_node_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
                float* __restrict__ dump_gpe /* nullable [B*N,64]: gradient at the encoder's output pre-activation */,
                float* __restrict__ dump_a1 /* [B*N,64]: relu(W1 x + b1) */,
                float* __restrict__ dump_gh1 /* [B*N,64]: gradient at the first layer's pre-activation */,
-               float* __restrict__ dump_x /* [B*N,8]: the 5 encoder inputs */) {
+               float* __restrict__ dump_x /* [B*N,8]: the 5 encoder inputs */, int chunks) {
     __shared__ float w0t[5 * 64];
     lds_copy(w0t, vw + V_PE0_T, 5 * 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int b = blockIdx.x;
+    const KbRange rg = kb_range(N, chunks);
+    const int b = rg.b;
     const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
     const float b0 = vw[V_PE0_B + lane];
     const float* sd = s_delta + (size_t)b * N * 3;
     const float* at = attr + (size_t)(b % attr_mod) * N;
     const float w1x = wraw[W_PE0_W + lane * 5 + 0], w1y = wraw[W_PE0_W + lane * 5 + 1], w1z = wraw[W_PE0_W + lane * 5 + 2];
-    for (int base = wave * KB_R; base < N; base += nwave * KB_R) {
+    for (int base = rg.lo + wave * KB_R; base < rg.hi; base += nwave * KB_R) {
         float x[KB_R], h1[KB_R], gc[KB_R], gpe[KB_R], gh[KB_R];
 #pragma unroll
         for (int r = 0; r < KB_R; ++r) {
@@ -439,7 +459,7 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
                size_t s_stride, const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens,
                int dens_mod, const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
                const float* __restrict__ g_cedge, int N, float* __restrict__ g_pos /* nullable */, size_t gpos_stride,
-               KbEdgeDump dump) {
+               KbEdgeDump dump, int chunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w0 = lds;               // [6][64] forward packs
     float* w2 = w0 + 6 * 64;
@@ -449,7 +469,8 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
     lds_copy(w4, vw + V_RE4_T, 4096);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int b = blockIdx.x;
+    const KbRange rg = kb_range(N, chunks);
+    const int b = rg.b;
     const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
     const float b0 = vw[V_RE0_B + lane], b2 = vw[V_RE2_B + lane], b4 = vw[V_RE4_B + lane];
     const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
@@ -458,7 +479,7 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
     const bool dumping = dump.re != nullptr;
     const float wx = wraw[W_RE0_W + lane * 6 + 2], wy = wraw[W_RE0_W + lane * 6 + 3], wz = wraw[W_RE0_W + lane * 6 + 4];
     constexpr int R = 5;           // two passes of five slots keep the register count moderate
-    for (int i = wave; i < N; i += nwave) {
+    for (int i = rg.lo + wave; i < rg.hi; i += nwave) {
         const int cnt = nbr_cnt[(size_t)b * N + i];
         const int16_t* nb = nbr_idx + ((size_t)b * N + i) * DRP_K;
         const float ar = at[i];

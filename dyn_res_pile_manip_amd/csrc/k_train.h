@@ -5,8 +5,8 @@
 // s_delta is data); this file adds the loss, the weight gradients and the optimiser.
 // Weight gradients are plain fp32 outer-product sums over the rows the backward kernels leave in
 // HBM: lane = output feature keeps one row of dW in registers, the input row is broadcast lane by
-// lane (v_readlane), waves stride over the rows, partial sums meet in LDS and then in global
-// atomics (the summation order across workgroups is not fixed: results agree to rounding).
+// lane (v_readlane), waves stride over the rows, partial sums meet in LDS, then one partial per
+// workgroup in HBM, added up by a second launch in a fixed order (no atomics: deterministic).
 #pragma once
 #include "drp_common.h"
 
@@ -37,7 +37,7 @@ kt_mse_grad(const float* __restrict__ s_pred, size_t pred_stride, const float* _
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (s_w[0] + s_w[1] + s_w[2] + s_w[3]) * (double)inv);
+    if (threadIdx.x == 0) loss[b] = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) * (double)inv;   // one slot per (step, sample)
 }
 
 __global__ void kt_add(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
@@ -48,10 +48,11 @@ __global__ void kt_add(float* __restrict__ dst, const float* __restrict__ src, s
 // dW[lane * lane_stride + k * k_stride] += sum_rows g[row][lane] * x[row][k]      k < IN
 // db[lane]                              += sum_rows g[row][lane]                   (nullable)
 // dwd[lane * lane_stride]               += sum_rows g[row][lane] * dens[row / rows_per_sample] / 5000   (nullable)
+// Two launches, no atomics, fixed summation order: kt_wgrad leaves one partial [IN+2][64] per
+// workgroup in `part`, kt_wgrad_reduce adds them up in workgroup order.
 template <int IN>
 __global__ void __launch_bounds__(256)
-kt_wgrad(const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx, long M, float* __restrict__ dW,
-         int lane_stride, int k_stride, float* __restrict__ db, float* __restrict__ dwd,
+kt_wgrad(const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx, long M, float* __restrict__ part,
          const float* __restrict__ dens, int dens_mod, long rows_per_sample) {
     extern __shared__ float s_part[];                  // [3][IN + 2][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -65,7 +66,7 @@ kt_wgrad(const float* __restrict__ g, int ldg, const float* __restrict__ x, int 
 #pragma unroll
         for (int k = 0; k < IN; ++k) acc[k] = fmaf(gv, bcast_lane(xv, k), acc[k]);
         accb += gv;
-        if (dwd != nullptr) accd = fmaf(gv, dens[(row / rows_per_sample) % dens_mod] / DRP_DENS_SCALE, accd);
+        if (dens != nullptr) accd = fmaf(gv, dens[(row / rows_per_sample) % dens_mod] / DRP_DENS_SCALE, accd);
     }
     if (wave > 0) {
         float* dst = s_part + (size_t)(wave - 1) * (IN + 2) * 64;
@@ -84,13 +85,27 @@ kt_wgrad(const float* __restrict__ g, int ldg, const float* __restrict__ x, int 
             accb += src[IN * 64 + lane];
             accd += src[(IN + 1) * 64 + lane];
         }
+        float* out = part + (size_t)blockIdx.x * (IN + 2) * 64;
 #pragma unroll
-        for (int k = 0; k < IN; ++k) atomicAdd(dW + (size_t)lane * lane_stride + (size_t)k * k_stride, acc[k]);
-        if (db != nullptr) atomicAdd(db + lane, accb);
-        if (dwd != nullptr) atomicAdd(dwd + (size_t)lane * lane_stride, accd);
+        for (int k = 0; k < IN; ++k) out[k * 64 + lane] = acc[k];
+        out[IN * 64 + lane] = accb;
+        out[(IN + 1) * 64 + lane] = accd;
     }
 }
+#define KT_WGRAD_MAX_BLOCKS 256
 #define KT_WGRAD_LDS(IN) ((size_t)3 * ((IN) + 2) * 64 * sizeof(float))
+
+template <int IN>
+__global__ void __launch_bounds__(64)
+kt_wgrad_reduce(const float* __restrict__ part, int nblocks, float* __restrict__ dW, int lane_stride, int k_stride,
+                float* __restrict__ db, float* __restrict__ dwd) {
+    const int lane = threadIdx.x, k = blockIdx.x;      // k in [0, IN + 2)
+    float t = 0.0f;
+    for (int b = 0; b < nblocks; ++b) t += part[((size_t)b * (IN + 2) + k) * 64 + lane];
+    if (k < IN) dW[(size_t)lane * lane_stride + (size_t)k * k_stride] += t;
+    else if (k == IN) { if (db != nullptr) db[lane] += t; }
+    else if (dwd != nullptr) dwd[(size_t)lane * lane_stride] += t;
+}
 
 // column sums of a [M,3] gradient (bias of the predictor's last layer)
 __global__ void __launch_bounds__(256) kt_colsum3(const float* __restrict__ g, long M, float* __restrict__ out) {
