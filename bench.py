@@ -160,7 +160,14 @@ def main():
         ms, n = eng.probe_read()
         per_class[kc] = (ms, n)
     dominant = max(per_class, key=lambda k: per_class[k][0])
-    kbar = float(eng.debug_fetch('nbr_cnt', (ns, N), np.uint8).mean())
+    cnt_last = eng.debug_fetch('nbr_cnt', (ns, N), np.uint8)
+    kbar = float(cnt_last.mean())
+    # slot iterations km_prop runs per 32-receiver tile: the largest in-degree of the tile, minus the
+    # self loop when its encoder chain is replaced by the per-sample constant (attributes are zeros here)
+    pad = (-N) % 32
+    tile_max = np.pad(cnt_last, ((0, 0), (0, pad))).reshape(ns, -1, 32).max(-1).astype(np.float64)
+    self_const = engine == 'fused' and os.environ.get('DRP_NO_SELF_CONST') is None
+    slots_per_tile = float((tile_max - (1.0 if self_const else 0.0)).clip(min=0).mean())
     eng.probe_begin(dominant)
     fence()
     t0 = time.perf_counter()
@@ -200,15 +207,15 @@ def main():
         B = ns
         tiles = B * ((N + 31) // 32)
         if dominant == 'prop':
-            # km_prop: per 32-receiver tile, 10 slots x 78 bf16 MFMAs (the
-            # 3-term split relation-encoder chain) + the 6-term split node layers (144 MFMAs, 96 in
+            # km_prop: per 32-receiver tile, one 78-MFMA chain (the 3-term split
+            # relation encoder) per slot iteration + the 6-term split node layers (144 MFMAs, 96 in
             # the last step); roofline on the bf16 FLOPs actually EXECUTED, 2*32*32*16 per MFMA
-            mfmas = tiles * (10 * 78 + (2 * 144 + 96) / 3.0)
+            mfmas = tiles * (slots_per_tile * 78 + (2 * 144 + 96) / 3.0)
             work = mfmas * 32768.0
             alg = B * N * (kbar * FLOP_PER_EDGE_ENCODE + 2 * 64 * 64 * (1 + 2 * 2 / 3.0 + 1 / 3.0))
             roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                     'mfma_dtype': 'bf16 operands (fp32 values split in 2 or 3 bf16 terms), fp32 accumulate',
-                    'algorithmic_f32_tflops': alg / avg_s / 1e12}
+                    'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile}
         elif dominant == 'aggregate':
             work = B * N * (2 * kbar + 2) * 256.0
             roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}

@@ -52,13 +52,14 @@ struct drp_ctx {
     int engine = DRP_ENGINE_VALU;
     int n_cu = 256;
     bool agg_global_only = false;   // DRP_AGG_GLOBAL=1: always gather sender rows from L2/HBM
+    bool self_const = true;         // DRP_NO_SELF_CONST=1: always run the encoder chain on the self slot too
 
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
     float adj_thresh = 0.08f, thr = 0.0064f;
     DevBuf w_raw, w_valu, w_mfma, w_split, w_split6;
     DrpCam cam{};
-    DevBuf goal_field, goal_coor;
+    DevBuf goal_field, goal_coor, cself;
     int goal_h = 0, goal_w = 0, goal_m = 0;
 
     // workspaces
@@ -202,6 +203,8 @@ struct StepArgs {
     float* eff_hist = nullptr;      // [4][B*N*64]: effect after the encoder and after every propagation step
     float* proj_hist = nullptr;     // [3][B*N*128]: node projections used by every propagation step
     float* agg_hist = nullptr;      // [3][B*N*64]: aggregated edge effects of every propagation step (training)
+    const float* cself = nullptr;   // [B,64] self-edge constant + per-sample validity (fused engine, k_cself)
+    const uint8_t* cself_ok = nullptr;
 };
 
 int graph_chunks(int N) { return (N + GRAPH_THREADS - 1) / GRAPH_THREADS; }
@@ -283,7 +286,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             const dim3 grid((unsigned)(pb_ < c->n_cu ? pb_ : c->n_cu)), pblk(64 * PROP_WAVES);
 #define PROP_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
                   a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, \
-                  ptr<float>(c->c_node), ptr<float>(c->eff), N, B, pb, a.s_out, a.out_stride
+                  ptr<float>(c->c_node), ptr<float>(c->eff), N, B, pb, a.s_out, a.out_stride, a.cself, a.cself_ok
             if (!last) hipLaunchKernelGGL(km_prop<false>, grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS);
             else hipLaunchKernelGGL(km_prop<true>, grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS);
 #undef PROP_ARGS
@@ -323,7 +326,8 @@ int run_step(drp_ctx* c, const StepArgs& a) {
         ProbeScope ps(c, KC_GRAPH);
         hipLaunchKernelGGL(k_graph, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), graph_lds(N), st, a.s_prev,
                            a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, N, nbr_idx,
-                           nbr_cnt, c->cam, c->thr, graph_chunks(N));
+                           nbr_cnt, c->cam, c->thr, graph_chunks(N),
+                           (c->engine == DRP_ENGINE_FUSED && a.cself != nullptr) ? 1 : 0);
     }
 #ifdef DRP_HAVE_MFMA
     if (c->engine != DRP_ENGINE_VALU) {
@@ -384,8 +388,23 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
     c->lastH = H;
     float* states = ptr<float>(c->states);
     const size_t hstride = (size_t)H * N * 3;
+    const float* cself = nullptr;
+    const uint8_t* cself_ok = nullptr;
+#ifdef DRP_HAVE_MFMA
+    if (c->engine == DRP_ENGINE_FUSED && c->self_const) {
+        // constant over the whole rollout: depends on the attributes and the density only
+        CHK(ensure(c, c->cself, (size_t)B * 64 * sizeof(float) + (size_t)B));
+        float* cs = ptr<float>(c->cself);
+        uint8_t* ok = reinterpret_cast<uint8_t*>(cs + (size_t)B * 64);
+        hipLaunchKernelGGL(k_cself, dim3(B), dim3(64), 0, c->stream, ptr<float>(c->w_valu), ptr<float>(c->attr), nb,
+                           ptr<float>(c->dens), nb, N, cs, ok);
+        cself = cs;
+        cself_ok = ok;
+    }
+#endif
     for (int t = 0; t < H; ++t) {
         StepArgs a{};
+        a.cself = cself; a.cself_ok = cself_ok;
         if (t == 0) {
             a.s_prev = ptr<float>(c->s_in); a.prev_mod = nb; a.prev_stride = (size_t)N * 3;
         } else {
@@ -490,6 +509,7 @@ int drp_create(int device, drp_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
     c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
+    c->self_const = getenv("DRP_NO_SELF_CONST") == nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_aggregate_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                             K_AGG_LDS_MAX_N * 256) != hipSuccess) {
@@ -526,7 +546,7 @@ void drp_destroy(drp_ctx* c) {
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
-                      &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats,
+                      &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats, &c->cself,
                       &c->px_depth, &c->px_mask, &c->px_blk, &c->px_bmin, &c->px_bmax, &c->px_grid, &c->px_pcd, &c->px_keys,
                       &c->px_cellcnt, &c->px_cellfill, &c->px_celloff, &c->px_list, &c->px_down, &c->px_down32, &c->px_init,
                       &c->px_dist, &c->px_chosen, &c->px_pts, &c->px_r, &c->px_rr, &c->px_out,
@@ -654,7 +674,7 @@ int drp_build_graph(drp_ctx* c, const float* s_cur, const float* s_delta, int B,
     hipLaunchKernelGGL(k_graph, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), graph_lds(N), c->stream,
                        ptr<float>(c->s_in), B, (size_t)N * 3, (const float*)nullptr, (size_t)0,
                        ptr<float>(c->s_delta), N, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt),
-                       c->cam, c->thr, graph_chunks(N));
+                       c->cam, c->thr, graph_chunks(N), 0);
     }
     HIPCHK(c, hipGetLastError());
     CHK(d2h(c, nbr_idx_out, c->nbr_idx.p, (size_t)B * N * DRP_K * sizeof(int16_t)));

@@ -99,7 +99,8 @@ __device__ __forceinline__ float pair_dis(float xi, float yi, float zi, float xj
 __global__ void __launch_bounds__(GRAPH_THREADS)
 k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
         const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
-        int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks) {
+        int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks,
+        int self_first) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* p4 = reinterpret_cast<float4*>(lds);                       // [N] displaced positions
     const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
@@ -154,18 +155,24 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
     const float kth = best[DRP_K - 1];
     int16_t* out = nbr_idx + ((size_t)b * N + i) * DRP_K;
     int cnt = 0;
+    // self_first (fused engine with a per-sample self-edge constant, km_prop): the self loop --
+    // distance 0, inside any positive radius and never beyond the 10th smallest -- takes slot 0
+    // and the other senders follow in ascending index.  The sum over a receiver's edges does not
+    // depend on their order; the C ABI's drp_build_graph keeps the reference's ascending order.
+    const int skip = (self_first && thr > 0.0f) ? i : -1;
+    if (skip >= 0) out[cnt++] = (int16_t)i;
     for (j = 0; j + 4 <= N; j += 4) {
         const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
         const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
                              pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (d4[u] <= kth && __fsub_rn(d4[u], thr) < 0.0f && cnt < DRP_K) out[cnt++] = (int16_t)(j + u);
+            if (d4[u] <= kth && __fsub_rn(d4[u], thr) < 0.0f && cnt < DRP_K && j + u != skip) out[cnt++] = (int16_t)(j + u);
     }
     for (; j < N; ++j) {
         const float4 pj = p4[j];
         const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
-        if (d <= kth && __fsub_rn(d, thr) < 0.0f && cnt < DRP_K) out[cnt++] = (int16_t)j;
+        if (d <= kth && __fsub_rn(d, thr) < 0.0f && cnt < DRP_K && j != skip) out[cnt++] = (int16_t)j;
     }
     nbr_cnt[(size_t)b * N + i] = (uint8_t)cnt;
     for (int q = cnt; q < DRP_K; ++q) out[q] = -1;

@@ -346,6 +346,40 @@ __device__ __forceinline__ void mfma_layer64_split6(const bf16x8* __restrict__ w
 #ifndef PROP_WAVES
 #define PROP_WAVES 8
 #endif
+// Self-edge constant.  The self loop i <- i feeds the relation encoder [a_i, a_i, 0, 0, 0, d]
+// (gnn_dyn.py:179-180 with s_r - s_s = 0): when a sample's attributes are all equal (they are
+// zeros on the whole MPC path, env/flex_env.py:1044) that input, hence W_e . RelationEncoder(.),
+// is ONE vector per sample, the same at every rollout step and propagation step.  k_cself
+// evaluates it once per rollout in plain fp32 (lane = feature) and flags the samples where it
+// holds; km_prop then starts a receiver's aggregate from relu(c_self + bias + P_r + P_s[i])
+// and skips the self slot: one relation-encoder chain in ten never runs.
+__global__ void __launch_bounds__(64)
+k_cself(const float* __restrict__ vw, const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens,
+        int dens_mod, int N, float* __restrict__ cself, uint8_t* __restrict__ ok) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* at = attr + (size_t)(b % attr_mod) * N;
+    const float a = at[0];
+    bool same = true;
+    for (int i = lane; i < N; i += 64) same = same && (at[i] == a);
+    const bool uniform = __all(same);
+    const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+    float h = vw[V_RE0_B + lane];
+    h = fmaf(a, vw[V_RE0_T + 0 * 64 + lane], h);
+    h = fmaf(a, vw[V_RE0_T + 1 * 64 + lane], h);
+    h = fmaf(d, vw[V_RE0_T + 5 * 64 + lane], h);
+    float x = fmaxf(h, 0.0f);
+    h = vw[V_RE2_B + lane];
+    for (int k = 0; k < 64; ++k) h = fmaf(__shfl(x, k, 64), vw[V_RE2_T + k * 64 + lane], h);
+    x = fmaxf(h, 0.0f);
+    h = vw[V_RE4_B + lane];
+    for (int k = 0; k < 64; ++k) h = fmaf(__shfl(x, k, 64), vw[V_RE4_T + k * 64 + lane], h);
+    x = fmaxf(h, 0.0f);
+    h = 0.0f;
+    for (int k = 0; k < 64; ++k) h = fmaf(__shfl(x, k, 64), vw[V_RPE_T + k * 64 + lane], h);
+    cself[(size_t)b * 64 + lane] = h;
+    if (lane == 0) ok[b] = uniform ? 1 : 0;
+}
+
 template <bool LAST>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
@@ -353,7 +387,8 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
         const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
         const float* __restrict__ proj, const float* __restrict__ c_node, float* __restrict__ eff,
-        int N, int B, float* __restrict__ proj_next, float* __restrict__ s_out, size_t out_stride) {
+        int N, int B, float* __restrict__ proj_next, float* __restrict__ s_out, size_t out_stride,
+        const float* __restrict__ cself /* nullable [B,64] */, const uint8_t* __restrict__ cself_ok) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wsp_f = lds;                              // edge chain, S_TOTAL units
     float* w6_f = wsp_f + S_TOTAL * 4;               // node layers: AGG | (RPR RPS) or (PR0)
@@ -393,15 +428,35 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
         }
-        frag_zero(acc);
+        // self slot first (k_graph self_first) and a per-sample self-edge constant: its effect is
+        // relu(c_self + bias + P_r[i] + P_s[i]) without running the encoder chain
+        int ks = 0;
+        if (cself != nullptr && cself_ok[b] && __all(cnt > 0 && (int)nb[0] == i)) {
+            const float* csr = cself + (size_t)b * 64;
+            const float* psr = pj + (size_t)i * 128 + 64;
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 cs = *reinterpret_cast<const float4*>(csr + 32 * ob + 8 * g + 4 * h);
+                    const float4 ps = *reinterpret_cast<const float4*>(psr + 32 * ob + 8 * g + 4 * h);
+                    acc.v[ob][4 * g + 0] = relu1((bpr.v[ob][4 * g + 0] + cs.x) + ps.x);
+                    acc.v[ob][4 * g + 1] = relu1((bpr.v[ob][4 * g + 1] + cs.y) + ps.y);
+                    acc.v[ob][4 * g + 2] = relu1((bpr.v[ob][4 * g + 2] + cs.z) + ps.z);
+                    acc.v[ob][4 * g + 3] = relu1((bpr.v[ob][4 * g + 3] + cs.w) + ps.w);
+                }
+            ks = 1;
+        } else {
+            frag_zero(acc);
+        }
         const float pix = s[i * 3 + 0], piy = s[i * 3 + 1], piz = s[i * 3 + 2], pia = at[i];
         // two-deep software pipeline on the dependent loads (index -> sender position): the
         // position of slot k+1 and the index of slot k+2 are requested while slot k computes
-        int j0 = (0 < cnt) ? (int)nb[0] : i;
-        int j1 = (1 < cnt) ? (int)nb[1] : i;
+        int j0 = (ks < cnt) ? (int)nb[ks] : i;
+        int j1 = (ks + 1 < cnt) ? (int)nb[ks + 1] : i;
         float p0x = s[j0 * 3 + 0], p0y = s[j0 * 3 + 1], p0z = s[j0 * 3 + 2], p0a = at[j0];
 #pragma unroll 1
-        for (int k = 0; k < DRP_K; ++k) {
+        for (int k = ks; k < DRP_K; ++k) {
             if (__all(k >= cnt)) break;              // sparse piles: no receiver of this tile has a slot k
             asm volatile("" ::: "memory");          // keep the packed-weight reads inside the loop
             const int jcur = j0;

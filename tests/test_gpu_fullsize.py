@@ -82,9 +82,12 @@ def test_dynamic_resolution_sweep(ctx, N):
     assert cnt.min() >= 1 and cnt.max() <= 10          # every particle keeps its self loop
     valid = np.arange(10)[None, None, :] < cnt[..., None]
     assert (idx[valid] >= 0).all() and (idx[valid] < N).all() and (idx[~valid] == -1).all()
-    asc = np.where(valid, idx.astype(np.int32), 1 << 20)
-    assert (np.diff(asc, axis=2) > 0)[valid[..., 1:]].all()   # ascending, no duplicates
-
+    # the fused engine's lists: the self loop in slot 0 (km_prop replaces its encoder chain by the
+    # per-sample self-edge constant), the other senders ascending, no duplicates
+    assert (idx[..., 0] == np.arange(N)[None, :]).all()
+    asc = np.where(valid, idx.astype(np.int32), 1 << 20)[..., 1:]
+    assert (np.diff(asc, axis=2) > 0)[valid[..., 2:]].all()
+    assert (asc != np.arange(N)[None, :, None]).all()
 
 def test_config5_dense_pile(ctx):
     """BASELINE configs[4] per GPU: 1200 particles, 512 samples, 20 steps."""

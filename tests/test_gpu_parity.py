@@ -271,3 +271,30 @@ def test_rccl_communicator_single_rank(ctx, golden):
     finally:
         ctx._ck(ctx.lib.drp_comm_destroy(ctx.h))
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize('attr_kind', ['zero', 'uniform', 'per_sample', 'per_particle'])
+def test_fused_self_edge_constant(ctx, attr_kind):
+    """km_prop replaces the self loop's encoder chain by a per-sample constant when a sample's
+    attributes are all equal (k_cself); otherwise the self slot runs the chain like any other.
+    Both must agree with the fp32 MFMA engine on the same inputs."""
+    nb, N, ns, H = 2, 150, 6, 4
+    s0, dens, attr = syn.make_pile(N, n_batch=nb, seed=17)
+    rng = np.random.default_rng(5)
+    if attr_kind == 'uniform':
+        attr = np.full_like(attr, 0.37)
+    elif attr_kind == 'per_sample':
+        attr = np.repeat(np.array([[0.2], [-0.6]], np.float32), N, axis=1)
+    elif attr_kind == 'per_particle':
+        attr = rng.uniform(-1, 1, attr.shape).astype(np.float32)      # no constant: generic path
+    acts = syn.sample_pushes(ns * nb, H, seed=3)
+    set_engine(ctx, 'mfma')
+    ref, _ = ctx.rollout(s0, attr, dens, acts)
+    set_engine(ctx, 'fused')
+    out, _ = ctx.rollout(s0, attr, dens, acts)
+    prev = np.tile(s0, (ns, 1, 1))
+    for t in range(H):
+        assert disp_rel(out[:, t], ref[:, t], prev) < 1e-4 * (t + 1), t
+        prev = ref[:, t]
+    idx = ctx.debug_fetch('nbr_idx', (ns * nb, N, 10), np.int16)
+    assert (idx[..., 0] == np.arange(N)[None, :]).all()              # self loop in slot 0 on this engine
