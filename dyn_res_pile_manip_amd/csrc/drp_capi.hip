@@ -79,7 +79,7 @@ struct drp_ctx {
     double gd_lr = 0.05;
     float gd_lo[4] = {0, 0, 0, 0}, gd_hi[4] = {0, 0, 0, 0};
     DevBuf eff_hist, proj_hist, g_eff, g_cnode, g_agg, g_proj, g_state, g_sdelta, g_act, adam_m, adam_v;
-    DevBuf tape_sdelta, tape_idx, tape_cnt, tape_cedge, g_cedge;
+    DevBuf tape_sdelta, tape_idx, tape_cnt, tape_cedge, g_cedge, g_u, rev_off, rev;
 
     // particle extraction (row f2)
     DevBuf px_depth, px_mask, px_blk, px_bmin, px_bmax, px_grid, px_pcd, px_keys, px_cellcnt, px_cellfill,
@@ -475,7 +475,7 @@ void launch_wgrad(drp_ctx* c, const float* g, int ldg, const float* x, int ldx, 
     float* part = static_cast<float*>(c->tr_part.p);       // sized for KT_WGRAD_MAX_BLOCKS x 66 x 64 by drp_train_begin
     hipLaunchKernelGGL(kt_wgrad<IN>, dim3((unsigned)blocks), dim3(256), KT_WGRAD_LDS(IN), c->stream, g, ldg, x, ldx, M, part,
                        dwd ? dens : nullptr, dens_mod, rows_per_sample);
-    hipLaunchKernelGGL(kt_wgrad_reduce<IN>, dim3(IN + 2), dim3(64), 0, c->stream, part, (int)blocks, dW, lane_stride, k_stride,
+    hipLaunchKernelGGL(kt_wgrad_reduce<IN>, dim3(IN + 2), dim3(256), 0, c->stream, part, (int)blocks, dW, lane_stride, k_stride,
                        db, dwd);
 }
 
@@ -511,11 +511,12 @@ int drp_create(int device, drp_ctx** out) {
     c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
     c->self_const = getenv("DRP_NO_SELF_CONST") == nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kb_reverse_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_aggregate_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                             K_AGG_LDS_MAX_N * 256) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         delete c;
-        return fail(nullptr, DRP_EHIP, "hipFuncSetAttribute(k_aggregate_lds) failed");
+        return fail(nullptr, DRP_EHIP, "hipFuncSetAttribute (dynamic LDS size of k_graph, kb_reverse_lists or k_aggregate_lds) failed");
     }
 #ifdef DRP_HAVE_MFMA
     // the MFMA kernels keep packed weights + per-wave transposition tiles in LDS (> 64 KiB)
@@ -542,7 +543,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    DevBuf* bufs[] = {&c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->tape_cedge, &c->g_cedge, &c->eff_hist, &c->proj_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
+    DevBuf* bufs[] = {&c->g_u, &c->rev_off, &c->rev, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->tape_cedge, &c->g_cedge, &c->eff_hist, &c->proj_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
@@ -1285,15 +1286,19 @@ int gd_forward_backward(drp_ctx* c) {
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
         float* g_cedge = (t > 0) ? ptr<float>(c->g_cedge) : nullptr;
+        hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, N <= KB_REV_LDS_MAX_N), st, idx,
+                           cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), N <= KB_REV_LDS_MAX_N ? 1 : 0, (const int*)nullptr);
         hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn * 64, g_out, (size_t)N * 3, N,
                            ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr, 1);
         for (int p = DRP_PSTEP - 1; p >= 0; --p) {
             hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn * 64,
                                ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N,
                                ptr<float>(c->g_agg), 1);
-            HIPCHK(c, hipMemsetAsync(c->g_proj.p, 0, bn * 128 * sizeof(float), st));
             hipLaunchKernelGGL(kb_edges, dim3(B), dim3(256), 0, st, cedge, pht + (size_t)p * bn * 128, idx, cnt,
-                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), g_cedge, p == DRP_PSTEP - 1 ? 1 : 0, 1);
+                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), ptr<float>(c->g_u), g_cedge,
+                               p == DRP_PSTEP - 1 ? 1 : 0, 1);
+            hipLaunchKernelGGL(kb_gather_senders, dim3(B), dim3(256), 0, st, ptr<float>(c->g_u), ptr<int>(c->rev_off),
+                               ptr<int>(c->rev), N, ptr<float>(c->g_proj), 1);
             hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), 1);
         }
         hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw,
@@ -1344,6 +1349,9 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     CHK(ensure(c, c->tape_cnt, (size_t)H * bn));
     CHK(ensure(c, c->tape_cedge, (size_t)H * bn * DRP_K * 64 * sizeof(float)));
     CHK(ensure(c, c->g_cedge, bn * DRP_K * 64 * sizeof(float)));
+    CHK(ensure(c, c->g_u, bn * DRP_K * 64 * sizeof(float)));
+    CHK(ensure(c, c->rev_off, (size_t)B * (N + 1) * sizeof(int)));
+    CHK(ensure(c, c->rev, bn * DRP_K * sizeof(int)));
     CHK(ensure(c, c->g_eff, bn * 64 * sizeof(float)));
     CHK(ensure(c, c->g_cnode, bn * 64 * sizeof(float)));
     CHK(ensure(c, c->g_agg, bn * 64 * sizeof(float)));
@@ -1476,10 +1484,14 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     const float* wraw = ptr<float>(c->w_raw);
     float* G = ptr<float>(c->tr_grad);
     // a training batch is a handful of samples: split each sample's rows over workgroups
-    int chunks = (N + 15) / 16;
-    if (chunks > 1024 / B) chunks = 1024 / B;
-    if (chunks < 1) chunks = 1;
-    const dim3 rgrid((unsigned)(B * chunks));
+    // (row kernels: one receiver per wave and pass; edge kernels: one receiver per 16 lanes)
+    auto pick = [&](int rows_per_block) {
+        int ch = (N + rows_per_block - 1) / rows_per_block;
+        if (ch > 4096 / B) ch = 4096 / B;
+        return ch < 1 ? 1 : ch;
+    };
+    const int chunks = pick(4), chunks16 = pick(16);
+    const dim3 rgrid((unsigned)(B * chunks)), egrid((unsigned)(B * chunks16));
     const float* dens = ptr<float>(c->dens);
     HIPCHK(c, hipMemsetAsync(G, 0, (size_t)W_TOTAL * sizeof(float), st));
     KbEdgeDump ed{ptr<float>(c->ed_re), ptr<float>(c->ed_a2), ptr<float>(c->ed_a1), ptr<float>(c->ed_x0),
@@ -1495,6 +1507,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
         float* g_cedge = ptr<float>(c->g_cedge);
+        hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, N <= KB_REV_LDS_MAX_N), st, idx,
+                           cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), N <= KB_REV_LDS_MAX_N ? 1 : 0, ptr<int>(c->tr_nums));
         // predictor
         hipLaunchKernelGGL(kb_predict, rgrid, dim3(256), 0, st, vw, wraw, eht + 3 * bn64, g_out, (size_t)N * 3, N,
                            ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh), chunks);
@@ -1510,9 +1524,10 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             // particle propagator, aggregate columns: g_eff now holds the pre-activation gradient
             launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
                              nullptr, nullptr, nullptr, 1, 1);
-            HIPCHK(c, hipMemsetAsync(c->g_proj.p, 0, bn * 128 * sizeof(float), st));
-            hipLaunchKernelGGL(kb_edges, rgrid, dim3(256), 0, st, cedge, pht + (size_t)p * bn64 * 2, idx, cnt,
-                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), g_cedge, 0, chunks);
+            hipLaunchKernelGGL(kb_edges, egrid, dim3(256), 0, st, cedge, pht + (size_t)p * bn64 * 2, idx, cnt,
+                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), ptr<float>(c->g_u), g_cedge, 0, chunks16);
+            hipLaunchKernelGGL(kb_gather_senders, egrid, dim3(256), 0, st, ptr<float>(c->g_u), ptr<int>(c->rev_off),
+                               ptr<int>(c->rev), N, ptr<float>(c->g_proj), chunks16);
             // relation propagator, receiver and sender columns
             launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
                              nullptr, nullptr, nullptr, 1, 1);
@@ -1612,6 +1627,9 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         CHK(ensure(c, c->tape_cnt, (size_t)H * bn));
         CHK(ensure(c, c->tape_cedge, (size_t)H * bnk * 64 * sizeof(float)));
         CHK(ensure(c, c->g_cedge, bnk * 64 * sizeof(float)));
+        CHK(ensure(c, c->g_u, bnk * 64 * sizeof(float)));
+        CHK(ensure(c, c->rev_off, (size_t)B * (N + 1) * sizeof(int)));
+        CHK(ensure(c, c->rev, bnk * sizeof(int)));
         CHK(ensure(c, c->g_eff, bn64 * sizeof(float)));
         CHK(ensure(c, c->g_cnode, bn64 * sizeof(float)));
         CHK(ensure(c, c->g_agg, bn64 * sizeof(float)));

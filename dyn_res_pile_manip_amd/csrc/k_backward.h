@@ -11,8 +11,8 @@
 // on the particle position.  Correctness-first fp32 VALU kernels over the
 // activations the fp32 MFMA engine saved in HBM (eff after every step, proj per step, c_edge,
 // c_node); ReLU masks are recomputed from them.  The one scatter of the backward pass
-// (gradient of the gathered sender rows) uses fp32 global atomics, 256 B per wave
-// instruction segment.
+// (gradient of the gathered sender rows) is turned into a gather over reversed neighbour lists
+// (kb_reverse_lists, kb_gather_senders): no atomics, reproducible sums.
 #pragma once
 #include "drp_common.h"
 #include "k_graph.h"
@@ -186,12 +186,94 @@ kb_update(const float* __restrict__ wraw, const float* __restrict__ eff_next, fl
     }
 }
 
-// ---- aggregate backward: g_u = g_agg[i] . [c_edge + P_r[i] + P_s[j] > 0];
-//      g_proj[i][0:64] = sum_k g_u (receiver term), g_proj[j][64:128] += g_u (sender term, atomics)
-// same 16-lanes-per-receiver layout as k_aggregate; g_proj must be zeroed before the launch.
+// ---- reversed neighbour lists: for every sender j the edge slots (i*10 + k) it feeds, ascending --
+// The backward pass of the sender gather is a scatter; with the lists reversed it becomes a
+// gather again -- no atomics, a fixed summation order (the first version scattered with fp32 global
+// atomics: 64 per edge, 61 % of a planner iteration, and not reproducible run to run).
+// One workgroup per sample; out-degrees counted and scanned in LDS; the lists are filled and put
+// in order in LDS too when they fit (dynamic LDS = 2*N ints, + 10*N ints with `in_lds`).
+#define KB_REV_THREADS 1024
+#define KB_REV_LDS(N, in_lds) ((size_t)((in_lds) ? 12 : 2) * (N) * sizeof(int))
+#define KB_REV_LDS_MAX_N 3072
+__global__ void __launch_bounds__(KB_REV_THREADS)
+kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt, int N,
+                 int* __restrict__ rev_off /* [B][N+1] */, int* __restrict__ rev /* [B][N*10] */, int in_lds,
+                 const int* __restrict__ n_real /* nullable [B]: receivers >= n_real[b] are padding whose
+                                                   gradient is identically zero (training batches) */) {
+    extern __shared__ int s_rev[];
+    __shared__ int s_w[KB_REV_THREADS / 64];
+    int* deg = s_rev;
+    int* off = s_rev + N;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int16_t* nb = nbr_idx + (size_t)b * N * DRP_K;
+    const uint8_t* nc = nbr_cnt + (size_t)b * N;
+    int* ro = rev_off + (size_t)b * (N + 1);
+    int* rv = rev + (size_t)b * N * DRP_K;
+    int* fill = in_lds ? s_rev + 2 * N : rv;
+    const int n_recv = n_real ? n_real[b] : N;
+    for (int i = tid; i < N; i += KB_REV_THREADS) deg[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < N * DRP_K; e += KB_REV_THREADS) {
+        const int i = e / DRP_K, k = e - i * DRP_K;
+        if (k < nc[i] && i < n_recv) atomicAdd(&deg[nb[e]], 1);
+    }
+    __syncthreads();
+    // exclusive scan of deg: every thread owns a contiguous segment
+    const int seg = (N + KB_REV_THREADS - 1) / KB_REV_THREADS;
+    const int lo = min(tid * seg, N), hi = min(lo + seg, N);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += deg[i];
+    int inc = sum;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int base = inc - sum, total = 0;
+    for (int w = 0; w < KB_REV_THREADS / 64; ++w) {
+        if (w < wave) base += s_w[w];
+        total += s_w[w];
+    }
+    for (int i = lo; i < hi; ++i) { off[i] = base; base += deg[i]; }
+    __syncthreads();
+    for (int i = tid; i < N; i += KB_REV_THREADS) { ro[i] = off[i]; deg[i] = 0; }
+    if (tid == 0) ro[N] = total;
+    __syncthreads();
+    for (int e = tid; e < N * DRP_K; e += KB_REV_THREADS) {
+        const int i = e / DRP_K, k = e - i * DRP_K;
+        if (k < nc[i] && i < n_recv) {
+            const int j = nb[e];
+            fill[off[j] + atomicAdd(&deg[j], 1)] = e;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += KB_REV_THREADS) {  // fixed order inside every sender's list
+        int* seg_j = fill + off[j];
+        const int n = deg[j];
+        for (int a = 1; a < n; ++a) {
+            const int v = seg_j[a];
+            int c = a - 1;
+            while (c >= 0 && seg_j[c] > v) { seg_j[c + 1] = seg_j[c]; --c; }
+            seg_j[c + 1] = v;
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int p = tid; p < total; p += KB_REV_THREADS) rv[p] = fill[p];
+    }
+}
+
+// ---- aggregate backward: g_u = g_agg[i] . [c_edge + P_r[i] + P_s[j] > 0]  per edge slot;
+//      g_proj[i][0:64] = sum_k g_u (receiver term); the rows g_u[b,i,k,:] are kept for the sender
+//      term (kb_gather_senders) and summed over the propagation steps into g_cedge (nullable).
+// same 16-lanes-per-receiver layout as k_aggregate.
 __global__ void __launch_bounds__(256)
 kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const int16_t* __restrict__ nbr_idx,
          const uint8_t* __restrict__ nbr_cnt, const float* __restrict__ g_agg, int N, float* __restrict__ g_proj,
+         float* __restrict__ g_u /* [B,N,10,64] */,
          float* __restrict__ g_cedge /* nullable: [B,N,10,64], summed over the propagation steps */, int first,
          int chunks) {
     const KbRange rg = kb_range(N, chunks);
@@ -200,6 +282,7 @@ kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const
     const float4* ce = reinterpret_cast<const float4*>(c_edge) + (size_t)b * N * DRP_K * 16;
     const float4* pj = reinterpret_cast<const float4*>(proj) + (size_t)b * N * 32;
     const float4* ga = reinterpret_cast<const float4*>(g_agg) + (size_t)b * N * 16;
+    float4* gu4 = reinterpret_cast<float4*>(g_u) + (size_t)b * N * DRP_K * 16;
     float* gp = g_proj + (size_t)b * N * 128;
     const int16_t* nb = nbr_idx + (size_t)b * N * DRP_K;
     const uint8_t* nc = nbr_cnt + (size_t)b * N;
@@ -218,18 +301,37 @@ kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const
             gu.z = ((c.z + pr.z) + ps.z > 0.0f) ? gi.z : 0.0f;
             gu.w = ((c.w + pr.w) + ps.w > 0.0f) ? gi.w : 0.0f;
             acc.x += gu.x; acc.y += gu.y; acc.z += gu.z; acc.w += gu.w;
+            gu4[((size_t)i * DRP_K + k) * 16 + q] = gu;
             if (g_cedge != nullptr) {
                 float4* gc = reinterpret_cast<float4*>(g_cedge) + ((size_t)b * N * DRP_K + (size_t)i * DRP_K + k) * 16 + q;
                 if (first) *gc = gu;
                 else { float4 o = *gc; o.x += gu.x; o.y += gu.y; o.z += gu.z; o.w += gu.w; *gc = o; }
             }
-            float* dst = gp + (size_t)j * 128 + 64 + q * 4;
-            atomicAdd(dst + 0, gu.x);
-            atomicAdd(dst + 1, gu.y);
-            atomicAdd(dst + 2, gu.z);
-            atomicAdd(dst + 3, gu.w);
         }
         *reinterpret_cast<float4*>(gp + (size_t)i * 128 + q * 4) = acc;
+    }
+}
+
+// sender term: g_proj[j][64:128] = sum over the edges j feeds of g_u, in the order of the
+// reversed lists (ascending receiver, then slot)
+__global__ void __launch_bounds__(256)
+kb_gather_senders(const float* __restrict__ g_u, const int* __restrict__ rev_off, const int* __restrict__ rev, int N,
+                  float* __restrict__ g_proj, int chunks) {
+    const KbRange rg = kb_range(N, chunks);
+    const int b = rg.b;
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const float4* gu4 = reinterpret_cast<const float4*>(g_u) + (size_t)b * N * DRP_K * 16;
+    const int* ro = rev_off + (size_t)b * (N + 1);
+    const int* rv = rev + (size_t)b * N * DRP_K;
+    float* gp = g_proj + (size_t)b * N * 128;
+    for (int j = rg.lo + g; j < rg.hi; j += 16) {
+        const int p0 = ro[j], p1 = ro[j + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = p0; p < p1; ++p) {
+            const float4 v = gu4[(size_t)rv[p] * 16 + q];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(gp + (size_t)j * 128 + 64 + q * 4) = acc;
     }
 }
 

@@ -92,16 +92,30 @@ kt_wgrad(const float* __restrict__ g, int ldg, const float* __restrict__ x, int 
         out[(IN + 1) * 64 + lane] = accd;
     }
 }
-#define KT_WGRAD_MAX_BLOCKS 256
+#define KT_WGRAD_MAX_BLOCKS 128
 #define KT_WGRAD_LDS(IN) ((size_t)3 * ((IN) + 2) * 64 * sizeof(float))
 
 template <int IN>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 kt_wgrad_reduce(const float* __restrict__ part, int nblocks, float* __restrict__ dW, int lane_stride, int k_stride,
                 float* __restrict__ db, float* __restrict__ dwd) {
-    const int lane = threadIdx.x, k = blockIdx.x;      // k in [0, IN + 2)
-    float t = 0.0f;
-    for (int b = 0; b < nblocks; ++b) t += part[((size_t)b * (IN + 2) + k) * 64 + lane];
+    __shared__ float s_w[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = blockIdx.x;      // k in [0, IN + 2)
+    // wave w adds the partials w, w+4, ... (four independent loads in flight), then the four wave
+    // sums are added in wave order: a fixed order for a given number of partials
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+    int b = wave;
+    for (; b + 12 < nblocks; b += 16) {
+        t0 += part[((size_t)b * (IN + 2) + k) * 64 + lane];
+        t1 += part[((size_t)(b + 4) * (IN + 2) + k) * 64 + lane];
+        t2 += part[((size_t)(b + 8) * (IN + 2) + k) * 64 + lane];
+        t3 += part[((size_t)(b + 12) * (IN + 2) + k) * 64 + lane];
+    }
+    for (; b < nblocks; b += 4) t0 += part[((size_t)b * (IN + 2) + k) * 64 + lane];
+    s_w[wave][lane] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (wave != 0) return;
+    const float t = (s_w[0][lane] + s_w[1][lane]) + (s_w[2][lane] + s_w[3][lane]);
     if (k < IN) dW[(size_t)lane * lane_stride + (size_t)k * k_stride] += t;
     else if (k == IN) { if (db != nullptr) db[lane] += t; }
     else if (dwd != nullptr) dwd[(size_t)lane * lane_stride] += t;
