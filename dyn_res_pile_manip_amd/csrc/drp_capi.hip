@@ -212,14 +212,21 @@ size_t graph_lds(int N) { return (size_t)4 * N * sizeof(float); }
 
 void launch_aggregate(drp_ctx* c, int B, int N) {
     ProbeScope ps(c, KC_AGGREGATE);
-    if (N <= K_AGG_LDS_MAX_N && !c->agg_global_only)
+    // a handful of samples (training batches): several workgroups per sample on the global variant
+    int chunks = 1;
+    if (B < c->n_cu / 2) {
+        chunks = (N + 15) / 16;
+        if (chunks > 2048 / B) chunks = 2048 / B;
+        if (chunks < 1) chunks = 1;
+    }
+    if (N <= K_AGG_LDS_MAX_N && !c->agg_global_only && chunks == 1)
         hipLaunchKernelGGL(k_aggregate_lds, dim3(B), dim3(512), (size_t)N * 256, c->stream,
                            ptr<float>(c->c_edge), ptr<float>(c->proj), ptr<int16_t>(c->nbr_idx),
                            ptr<uint8_t>(c->nbr_cnt), N, ptr<float>(c->agg));
     else
-        hipLaunchKernelGGL(k_aggregate, dim3(B), dim3(256), 0, c->stream, ptr<float>(c->c_edge),
+        hipLaunchKernelGGL(k_aggregate, dim3(B * chunks), dim3(256), 0, c->stream, ptr<float>(c->c_edge),
                            ptr<float>(c->proj), ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N,
-                           ptr<float>(c->agg));
+                           ptr<float>(c->agg), chunks);
 }
 
 #ifdef DRP_HAVE_MFMA
@@ -511,12 +518,13 @@ int drp_create(int device, drp_ctx** out) {
     c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
     c->self_const = getenv("DRP_NO_SELF_CONST") == nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reverse_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_aggregate_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                             K_AGG_LDS_MAX_N * 256) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         delete c;
-        return fail(nullptr, DRP_EHIP, "hipFuncSetAttribute (dynamic LDS size of k_graph, kb_reverse_lists or k_aggregate_lds) failed");
+        return fail(nullptr, DRP_EHIP, "hipFuncSetAttribute (dynamic LDS size of k_graph, kb_edge_encode, kb_reverse_lists or k_aggregate_lds) failed");
     }
 #ifdef DRP_HAVE_MFMA
     // the MFMA kernels keep packed weights + per-wave transposition tiles in LDS (> 64 KiB)
@@ -1310,7 +1318,7 @@ int gd_forward_backward(drp_ctx* c) {
             // d loss / d state[t-1] = residual share + relation encoder + gen_s_delta's position dependence
             g_prev = g_state + (size_t)(t - 1) * bn * 3;
             CHK(d2d(g_prev, g_out, bn * 3 * sizeof(float)));
-            hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), (6 * 64 + 2 * 4096) * sizeof(float), st, vw, wraw,
+            hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw,
                                s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx, cnt,
                                g_cedge, N, g_prev, (size_t)N * 3, KbEdgeDump{}, 1);
         }
@@ -1552,7 +1560,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             g_prev = g_state + (size_t)(t - 1) * bn * 3;
             hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
         }
-        hipLaunchKernelGGL(kb_edge_encode, rgrid, dim3(256), (6 * 64 + 2 * 4096) * sizeof(float), st, vw, wraw, s_prev, B,
+        hipLaunchKernelGGL(kb_edge_encode, rgrid, dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw, s_prev, B,
                            prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, g_cedge, N, g_prev, (size_t)N * 3, ed, chunks);
         launch_wgrad<64>(c, g_cedge, 64, ed.re, 64, (long)bnk, G + W_RP_W, 193, 1, G + W_RP_B, G + W_RP_W + 192, dens, B,
                          (long)N * DRP_K);

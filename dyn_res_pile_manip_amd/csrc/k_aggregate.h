@@ -19,8 +19,10 @@
 __global__ void __launch_bounds__(256)
 k_aggregate(const float* __restrict__ c_edge, const float* __restrict__ proj,
             const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt, int N,
-            float* __restrict__ agg) {
-    const int b = blockIdx.x;
+            float* __restrict__ agg, int chunks /* workgroups per sample: > 1 when the batch alone cannot fill the chip */) {
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const int len = (((N + chunks - 1) / chunks) + 15) & ~15;
+    const int lo = ch * len, hi = min(N, lo + len);
     const int q = threadIdx.x & 15;          // float4 column within the 64-feature row
     const int g = threadIdx.x >> 4;          // receiver slot within the pass (0..15)
     const float4* ce = reinterpret_cast<const float4*>(c_edge) + (size_t)b * N * DRP_K * 16;
@@ -28,7 +30,7 @@ k_aggregate(const float* __restrict__ c_edge, const float* __restrict__ proj,
     float4* out = reinterpret_cast<float4*>(agg) + (size_t)b * N * 16;
     const int16_t* nb = nbr_idx + (size_t)b * N * DRP_K;
     const uint8_t* nc = nbr_cnt + (size_t)b * N;
-    for (int i = g; i < N; i += 16) {
+    for (int i = lo + g; i < hi; i += 16) {
         const int cnt = nc[i];
         const float4 pr = pj[(size_t)i * 32 + q];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -556,6 +556,7 @@ struct KbEdgeDump {
 //      Linear+ReLU layers (forward recomputed per slot) to the position-difference inputs
 //      x[2:5] = s_r - s_s (gnn_dyn.py:179-180):  g_pos[recv] += g,  g_pos[send] -= g  (atomics)
 // One wave = the slots of one receiver, as k_edge_encode.
+#define KB_EDGE_ENCODE_LDS ((size_t)(6 * 64 + 5 * 4096) * sizeof(float))
 __global__ void __launch_bounds__(256)
 kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, const float* __restrict__ s_cur, int s_mod,
                size_t s_stride, const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens,
@@ -566,9 +567,15 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
     float* w0 = lds;               // [6][64] forward packs
     float* w2 = w0 + 6 * 64;
     float* w4 = w2 + 4096;
+    float* bwe = w4 + 4096;        // backward (torch [out][in]) copies: W_e, RE4, RE2 -- read 64 rows per
+    float* bw4 = bwe + 4096;       // layer and slot pass; from L2 their latency was the kernel's time
+    float* bw2 = bw4 + 4096;
     lds_copy(w0, vw + V_RE0_T, 6 * 64);
     lds_copy(w2, vw + V_RE2_T, 4096);
     lds_copy(w4, vw + V_RE4_T, 4096);
+    for (int t = threadIdx.x; t < 4096; t += blockDim.x) bwe[t] = wraw[W_RP_W + (t >> 6) * 193 + (t & 63)];
+    lds_copy(bw4, wraw + W_RE4_W, 4096);
+    lds_copy(bw2, wraw + W_RE2_W, 4096);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const KbRange rg = kb_range(N, chunks);
@@ -624,19 +631,19 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
                 g[r] = (k0 + r < cnt) ? g_cedge[(((size_t)b * N + i) * DRP_K + k0 + r) * 64 + lane] : 0.0f;
                 t[r] = 0.0f;
             }
-            dense_bcast_ld<64, R>(wraw + W_RP_W, 193, 0, g, t, lane);             // W_e^T
+            dense_bcast_ld<64, R>(bwe, 64, 0, g, t, lane);                        // W_e^T
 #pragma unroll
             for (int r = 0; r < R; ++r) { g[r] = (h3[r] > 0.0f) ? t[r] : 0.0f; t[r] = 0.0f; }
             if (dumping)
 #pragma unroll
                 for (int r = 0; r < R; ++r) dump.g3[(row0 + r) * 64 + lane] = g[r];
-            dense_bcast_ld<64, R>(wraw + W_RE4_W, 64, 0, g, t, lane);
+            dense_bcast_ld<64, R>(bw4, 64, 0, g, t, lane);
 #pragma unroll
             for (int r = 0; r < R; ++r) { g[r] = (h2[r] > 0.0f) ? t[r] : 0.0f; t[r] = 0.0f; }
             if (dumping)
 #pragma unroll
                 for (int r = 0; r < R; ++r) dump.g2[(row0 + r) * 64 + lane] = g[r];
-            dense_bcast_ld<64, R>(wraw + W_RE2_W, 64, 0, g, t, lane);
+            dense_bcast_ld<64, R>(bw2, 64, 0, g, t, lane);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float gh = (h1[r] > 0.0f) ? t[r] : 0.0f;

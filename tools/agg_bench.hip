@@ -112,7 +112,7 @@ int main() {
         CK(hipGetLastError());
         printf("%-28s best %.4f ms  mean %.4f ms  compulsory 1.022 GB -> %.2f TB/s\n", name, best, tot / 10, 1.022e9 / (best * 1e-3) / 1e12);
     };
-    timeit("k_aggregate (global gather)", [&] { hipLaunchKernelGGL(k_aggregate, dim3(B), dim3(256), 0, 0, c_edge, proj, idx, cnt, N, agg); });
+    timeit("k_aggregate (global gather)", [&] { hipLaunchKernelGGL(k_aggregate, dim3(B), dim3(256), 0, 0, c_edge, proj, idx, cnt, N, agg, 1); });
     timeit("k_aggregate_lds", [&] { hipLaunchKernelGGL(k_aggregate_lds, dim3(B), dim3(512), N * 256, 0, c_edge, proj, idx, cnt, N, agg); });
     timeit("v_stream (no gather)", [&] { hipLaunchKernelGGL(v_stream, dim3(B), dim3(512), 0, 0, c_edge, proj, cnt, N, agg); });
     timeit("v_lds2<512,nopipe>", [&] { hipLaunchKernelGGL((v_lds2<512, false>), dim3(B), dim3(512), N * 256, 0, c_edge, proj, idx, cnt, N, agg); });
