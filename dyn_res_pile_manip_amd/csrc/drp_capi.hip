@@ -52,6 +52,7 @@ struct drp_ctx {
     int engine = DRP_ENGINE_VALU;
     int n_cu = 256;
     bool agg_global_only = false;   // DRP_AGG_GLOBAL=1: always gather sender rows from L2/HBM
+    bool rev_global_only = false;   // DRP_REV_GLOBAL=1: reversed neighbour lists built in global memory (the N > 3072 path)
     bool self_const = true;         // DRP_NO_SELF_CONST=1: always run the encoder chain on the self slot too
 
     // model constants
@@ -79,7 +80,7 @@ struct drp_ctx {
     double gd_lr = 0.05;
     float gd_lo[4] = {0, 0, 0, 0}, gd_hi[4] = {0, 0, 0, 0};
     DevBuf eff_hist, proj_hist, g_eff, g_cnode, g_agg, g_proj, g_state, g_sdelta, g_act, adam_m, adam_v;
-    DevBuf tape_sdelta, tape_idx, tape_cnt, tape_cedge, g_cedge, g_u, rev_off, rev;
+    DevBuf tape_sdelta, tape_idx, tape_cnt, tape_cedge, g_cedge, g_u, rev_off, rev, gpos_edge;
 
     // particle extraction (row f2)
     DevBuf px_depth, px_mask, px_blk, px_bmin, px_bmax, px_grid, px_pcd, px_keys, px_cellcnt, px_cellfill,
@@ -517,7 +518,9 @@ int drp_create(int device, drp_ctx** out) {
         c->n_cu = prop.multiProcessorCount;
     c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
     c->self_const = getenv("DRP_NO_SELF_CONST") == nullptr;
+    c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kb_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REWARD_LDS(4096)) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reverse_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_aggregate_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -551,7 +554,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    DevBuf* bufs[] = {&c->g_u, &c->rev_off, &c->rev, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->tape_cedge, &c->g_cedge, &c->eff_hist, &c->proj_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
+    DevBuf* bufs[] = {&c->g_u, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->tape_cedge, &c->g_cedge, &c->eff_hist, &c->proj_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
@@ -1242,6 +1245,7 @@ int gd_forward_backward(drp_ctx* c) {
     const size_t bn = (size_t)B * N;
     const size_t hstride = (size_t)H * N * 3;
     hipStream_t st = c->stream;
+    const bool rev_lds = N <= KB_REV_LDS_MAX_N && !c->rev_global_only;
     float* states = ptr<float>(c->states);
     float* eh = ptr<float>(c->eff_hist);
     float* ph = ptr<float>(c->proj_hist);
@@ -1280,7 +1284,7 @@ int gd_forward_backward(drp_ctx* c) {
     const float* vw = ptr<float>(c->w_valu);
     const float* wraw = ptr<float>(c->w_raw);
     float* g_state = ptr<float>(c->g_state);                 // [H][B,N,3]
-    hipLaunchKernelGGL(kb_reward, dim3(B), dim3(256), 4 * N * sizeof(float), st, states + (size_t)(H - 1) * N * 3, hstride,
+    hipLaunchKernelGGL(kb_reward, dim3(B), dim3(256), KB_REWARD_LDS(N), st, states + (size_t)(H - 1) * N * 3, hstride,
                        N, ptr<float>(c->goal_field), c->goal_h, c->goal_w, ptr<float>(c->goal_coor), c->goal_m, c->cam,
                        1, g_state + (size_t)(H - 1) * bn * 3, (size_t)N * 3);
     for (int t = H - 1; t >= 0; --t) {
@@ -1294,8 +1298,8 @@ int gd_forward_backward(drp_ctx* c) {
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
         float* g_cedge = (t > 0) ? ptr<float>(c->g_cedge) : nullptr;
-        hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, N <= KB_REV_LDS_MAX_N), st, idx,
-                           cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), N <= KB_REV_LDS_MAX_N ? 1 : 0, (const int*)nullptr);
+        hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
+                           cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
         hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn * 64, g_out, (size_t)N * 3, N,
                            ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr, 1);
         for (int p = DRP_PSTEP - 1; p >= 0; --p) {
@@ -1320,7 +1324,9 @@ int gd_forward_backward(drp_ctx* c) {
             CHK(d2d(g_prev, g_out, bn * 3 * sizeof(float)));
             hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw,
                                s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx, cnt,
-                               g_cedge, N, g_prev, (size_t)N * 3, KbEdgeDump{}, 1);
+                               g_cedge, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), KbEdgeDump{}, 1);
+            hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
+                               ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3);
         }
         hipLaunchKernelGGL(kb_sdelta, dim3(B), dim3(256), 0, st, s_prev, prev_mod, prev_stride,
                            ptr<float>(c->actions) + (size_t)t * 4, (size_t)H * 4, ptr<float>(c->g_sdelta), N, c->cam,
@@ -1360,6 +1366,7 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     CHK(ensure(c, c->g_u, bn * DRP_K * 64 * sizeof(float)));
     CHK(ensure(c, c->rev_off, (size_t)B * (N + 1) * sizeof(int)));
     CHK(ensure(c, c->rev, bn * DRP_K * sizeof(int)));
+    CHK(ensure(c, c->gpos_edge, bn * DRP_K * 4 * sizeof(float)));
     CHK(ensure(c, c->g_eff, bn * 64 * sizeof(float)));
     CHK(ensure(c, c->g_cnode, bn * 64 * sizeof(float)));
     CHK(ensure(c, c->g_agg, bn * 64 * sizeof(float)));
@@ -1435,6 +1442,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     const size_t hstride = (size_t)H * N * 3;                 // predicted states [B][H][N][3]
     const size_t in_stride = (size_t)(H + 1) * N * 3;         // given states     [B][H+1][N][3]
     hipStream_t st = c->stream;
+    const bool rev_lds = N <= KB_REV_LDS_MAX_N && !c->rev_global_only;
     float* states = ptr<float>(c->states);
     const float* given = ptr<float>(c->tr_states);
     float* eh = ptr<float>(c->eff_hist);
@@ -1515,8 +1523,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
         float* g_cedge = ptr<float>(c->g_cedge);
-        hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, N <= KB_REV_LDS_MAX_N), st, idx,
-                           cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), N <= KB_REV_LDS_MAX_N ? 1 : 0, ptr<int>(c->tr_nums));
+        hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
+                           cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums));
         // predictor
         hipLaunchKernelGGL(kb_predict, rgrid, dim3(256), 0, st, vw, wraw, eht + 3 * bn64, g_out, (size_t)N * 3, N,
                            ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh), chunks);
@@ -1561,7 +1569,10 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
         }
         hipLaunchKernelGGL(kb_edge_encode, rgrid, dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw, s_prev, B,
-                           prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, g_cedge, N, g_prev, (size_t)N * 3, ed, chunks);
+                           prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, g_cedge, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), ed, chunks);
+        if (g_prev != nullptr)
+            hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
+                               ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3);
         launch_wgrad<64>(c, g_cedge, 64, ed.re, 64, (long)bnk, G + W_RP_W, 193, 1, G + W_RP_B, G + W_RP_W + 192, dens, B,
                          (long)N * DRP_K);
         launch_wgrad<64>(c, ed.g3, 64, ed.a2, 64, (long)bnk, G + W_RE4_W, 64, 1, G + W_RE4_B, nullptr, nullptr, 1, 1);
@@ -1638,6 +1649,7 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         CHK(ensure(c, c->g_u, bnk * 64 * sizeof(float)));
         CHK(ensure(c, c->rev_off, (size_t)B * (N + 1) * sizeof(int)));
         CHK(ensure(c, c->rev, bnk * sizeof(int)));
+        CHK(ensure(c, c->gpos_edge, bnk * 4 * sizeof(float)));
         CHK(ensure(c, c->g_eff, bn64 * sizeof(float)));
         CHK(ensure(c, c->g_cnode, bn64 * sizeof(float)));
         CHK(ensure(c, c->g_agg, bn64 * sizeof(float)));

@@ -52,7 +52,8 @@ __device__ __forceinline__ KbRange kb_range(int N, int chunks) {
 //                                          border clamp is active, as torch does)
 //   r2 = sum_m min_n |g_m - pix_n|     -> -(g_m - pix_n*) / dist to the arg-min particle n*
 //   pix = (x fx / z + cx, y fy / z + cy)
-// one workgroup per state row; gradient accumulated in LDS, then written.
+// one workgroup per state row; gradient accumulated in LDS, then written.  dynamic LDS = KB_REWARD_LDS(N).
+#define KB_REWARD_LDS(N) ((size_t)(2 * (N)) * sizeof(float) + (size_t)(2 * (N)) * sizeof(long long))
 __global__ void __launch_bounds__(256)
 kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float* __restrict__ G, int Hh, int Ww,
           const float* __restrict__ goal_coor, int M, DrpCam cam, int normalize, float* __restrict__ g_state,
@@ -60,8 +61,12 @@ kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* px = lds;
     float* py = lds + N;
-    float* gx = lds + 2 * N;     // d loss / d pixel x
-    float* gy = lds + 3 * N;
+    // d loss / d pixel, accumulated as 2^-40 fixed point: integer adds commute, so the many goal
+    // points whose nearest particle is the same one can add in any order and the sum is the same
+    // bits every run (fp32 LDS atomics were the last source of run-to-run differences)
+    long long* gx = reinterpret_cast<long long*>(lds + 2 * N);
+    long long* gy = gx + N;
+    const float FIX = 1099511627776.0f, UNFIX = 1.0f / 1099511627776.0f;
     const float* s = state + (size_t)blockIdx.x * row_stride;
     const float scale = normalize ? 1.0f / (float)N : 1.0f;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
@@ -86,8 +91,8 @@ kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float
         const float g11 = (x1 < Ww && y1 < Hh) ? G[(size_t)y1 * Ww + x1] : 0.0f;
         const float dgx = (g01 - g00) * (1.0f - ty) + (g11 - g10) * ty;
         const float dgy = (g10 - g00) * (1.0f - tx) + (g11 - g01) * tx;
-        gx[n] = scale * dgx * mx;
-        gy[n] = scale * dgy * my;
+        gx[n] = __float2ll_rn(scale * dgx * mx * FIX);
+        gy[n] = __float2ll_rn(scale * dgy * my * FIX);
     }
     __syncthreads();
     for (int m = threadIdx.x; m < M; m += blockDim.x) {
@@ -101,16 +106,17 @@ kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float
         }
         const float dist = sqrtf(best);
         // d |q - p| / d p = -(q - p) / dist
-        atomicAdd(&gx[arg], -scale * (qx - px[arg]) / dist);
-        atomicAdd(&gy[arg], -scale * (qy - py[arg]) / dist);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&gx[arg]), (unsigned long long)__float2ll_rn(-scale * (qx - px[arg]) / dist * FIX));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&gy[arg]), (unsigned long long)__float2ll_rn(-scale * (qy - py[arg]) / dist * FIX));
     }
     __syncthreads();
     float* g = g_state + (size_t)blockIdx.x * g_stride;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const float x = s[n * 3 + 0], y = s[n * 3 + 1], z = s[n * 3 + 2];
-        g[n * 3 + 0] = gx[n] * cam.fx / z;
-        g[n * 3 + 1] = gy[n] * cam.fy / z;
-        g[n * 3 + 2] = -(gx[n] * x * cam.fx + gy[n] * y * cam.fy) / (z * z);
+        const float gxn = (float)((double)gx[n] * (double)UNFIX), gyn = (float)((double)gy[n] * (double)UNFIX);
+        g[n * 3 + 0] = gxn * cam.fx / z;
+        g[n * 3 + 1] = gyn * cam.fy / z;
+        g[n * 3 + 2] = -(gxn * x * cam.fx + gyn * y * cam.fy) / (z * z);
     }
 }
 
@@ -562,6 +568,7 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
                size_t s_stride, const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens,
                int dens_mod, const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
                const float* __restrict__ g_cedge, int N, float* __restrict__ g_pos /* nullable */, size_t gpos_stride,
+               float* __restrict__ gpos_edge /* [B,N,10,4]: the slot's gradient w.r.t. s_r - s_s, for kb_gather_pos */,
                KbEdgeDump dump, int chunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w0 = lds;               // [6][64] forward packs
@@ -593,6 +600,7 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
         const int16_t* nb = nbr_idx + ((size_t)b * N + i) * DRP_K;
         const float ar = at[i];
         const float sr = (lane >= 2 && lane < 5) ? s[i * 3 + lane - 2] : 0.0f;
+        float recv_sum = 0.0f;       // lanes 0..2: sum over this receiver's slots, in slot order
         for (int k0 = 0; k0 < (dumping ? DRP_K : cnt); k0 += R) {
             float x[R], h1[R], h2[R], h3[R], g[R], t[R];
             int js[R];
@@ -650,14 +658,35 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
                 if (dumping) dump.g1[(row0 + r) * 64 + lane] = gh;
                 if (gp == nullptr) continue;
                 const float ox = wave_sum(gh * wx), oy = wave_sum(gh * wy), oz = wave_sum(gh * wz);
-                if (k0 + r < cnt && lane < 3) {
-                    const float v = (lane == 0) ? ox : (lane == 1) ? oy : oz;
-                    atomicAdd(gp + (size_t)i * 3 + lane, v);
-                    atomicAdd(gp + (size_t)js[r] * 3 + lane, -v);
+                if (lane < 4) {
+                    const float v = (k0 + r < cnt && lane < 3) ? ((lane == 0) ? ox : (lane == 1) ? oy : oz) : 0.0f;
+                    recv_sum += v;
+                    if (k0 + r < DRP_K) gpos_edge[(((size_t)b * N + i) * DRP_K + k0 + r) * 4 + lane] = v;
                 }
             }
         }
+        if (gp != nullptr && lane < 3) gp[(size_t)i * 3 + lane] += recv_sum;     // this wave is the only writer of row i
     }
+}
+
+// sender part of the relation encoder's position gradient: g_pos[j] -= sum over the edges j feeds,
+// in the order of the reversed lists (no atomics)
+__global__ void __launch_bounds__(256)
+kb_gather_pos(const float* __restrict__ gpos_edge, const int* __restrict__ rev_off, const int* __restrict__ rev, int N,
+              float* __restrict__ g_pos, size_t gpos_stride) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const int* ro = rev_off + (size_t)b * (N + 1);
+    const int* rv = rev + (size_t)b * N * DRP_K;
+    const float4* ge = reinterpret_cast<const float4*>(gpos_edge) + (size_t)b * N * DRP_K;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for (int p = ro[j]; p < ro[j + 1]; ++p) {
+        const float4 v = ge[rv[p]];
+        ax += v.x; ay += v.y; az += v.z;
+    }
+    float* gp = g_pos + (size_t)b * gpos_stride + (size_t)j * 3;
+    gp[0] -= ax; gp[1] -= ay; gp[2] -= az;
 }
 
 // ---- Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8) + the clip box ------------

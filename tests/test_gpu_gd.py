@@ -71,3 +71,35 @@ def test_adam_iterations_and_planner_dict_match_the_reference(golden):
     np.testing.assert_allclose(res['reward'], g['out/reward'], rtol=1e-4)
     np.testing.assert_allclose(res['next_r'], g['out/next_r'], rtol=1e-4)
     assert res['iter_num'] == int(g['out/iter_num'])
+
+
+def test_gradients_are_reproducible_and_both_list_paths_agree(ctx, golden, monkeypatch):
+    """No atomics in the backward pass: two evaluations give bit-identical gradients, and the
+    reversed neighbour lists built in LDS or in global memory (samples beyond 3072 particles,
+    forced here with DRP_REV_GLOBAL) give the same bits too."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    monkeypatch.setenv('DRP_REV_GLOBAL', '1')
+    other = Engine(0)
+    monkeypatch.delenv('DRP_REV_GLOBAL')
+    other.load_weights(weights.blob_from_state_dict(golden.weights_seed0), 0.08)
+    other.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+    for N, B, H in ((120, 6, 1), (300, 3, 2), (3200, 2, 1)):
+        s0, dens, attr = syn.make_pile(N, 1, seed=N)
+        gc = syn.goal_coor_strided(obs_goal, min(5 * N, 2000))
+        acts = np.stack([syn.nominal_pushes(H, seed=50 + i) for i in range(B)]).astype(np.float32)
+        acts[:, 0] = [-3.5, 0.3, 2.5, -0.2]           # through the pile: every row has a gradient
+        acts[:, 0, 1] += 0.1 * np.arange(B)
+        res = []
+        for eng in (ctx, other):
+            eng.set_goal(syn.goal_field(obs_goal), gc)
+            eng.gd_begin(s0, attr, dens, acts, 0.05, lo, hi)
+            r0, g0, _ = eng.gd_grad()
+            r1, g1, _ = eng.gd_grad()
+            np.testing.assert_array_equal(g0, g1)
+            np.testing.assert_array_equal(r0, r1)
+            assert np.isfinite(g0).all() and np.abs(g0).max() > 0
+            res.append(g0)
+        np.testing.assert_array_equal(res[0], res[1])
+    other.close()
