@@ -80,7 +80,7 @@ struct drp_ctx {
     double gd_lr = 0.05;
     float gd_lo[4] = {0, 0, 0, 0}, gd_hi[4] = {0, 0, 0, 0};
     DevBuf eff_hist, proj_hist, g_eff, g_cnode, g_agg, g_proj, g_state, g_sdelta, g_act, adam_m, adam_v;
-    DevBuf tape_sdelta, tape_idx, tape_cnt, tape_cedge, g_cedge, g_u, rev_off, rev, gpos_edge;
+    DevBuf tape_sdelta, tape_idx, tape_cnt, tape_cedge, g_mask, g_agg_hist, rev_off, rev, gpos_edge;
 
     // particle extraction (row f2)
     DevBuf px_depth, px_mask, px_blk, px_bmin, px_bmax, px_grid, px_pcd, px_keys, px_cellcnt, px_cellfill,
@@ -92,7 +92,7 @@ struct drp_ctx {
     double tr_lr = 1e-3, tr_beta1 = 0.9;
     std::vector<float> w_host;
     DevBuf tr_part, tr_states, tr_sdelta, tr_nums, tr_grad, tr_m, tr_v, tr_loss, agg_hist, tr_hact, tr_gh, tr_gpe, tr_a1n,
-        tr_gh1, tr_xn, ed_re, ed_a2, ed_a1, ed_x0, ed_g3, ed_g2, ed_g1;
+        tr_gh1, tr_xn, ed_re, ed_a2, ed_a1, ed_x0, ed_gce, ed_g3, ed_g2, ed_g1;
 
     // goal pre-processing (row f3)
     DevBuf gl_goal, gl_seg, gl_tmp, gl_dist, gl_blk, gl_pix, gl_fps;
@@ -554,7 +554,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    DevBuf* bufs[] = {&c->g_u, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->tape_cedge, &c->g_cedge, &c->eff_hist, &c->proj_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
+    DevBuf* bufs[] = {&c->g_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->tape_cedge, &c->eff_hist, &c->proj_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
@@ -565,7 +565,7 @@ void drp_destroy(drp_ctx* c) {
                       &c->gl_goal, &c->gl_seg, &c->gl_tmp, &c->gl_dist, &c->gl_blk, &c->gl_pix, &c->gl_fps,
                       &c->tr_part, &c->tr_states, &c->tr_sdelta, &c->tr_nums, &c->tr_grad, &c->tr_m, &c->tr_v, &c->tr_loss, &c->agg_hist,
                       &c->tr_hact, &c->tr_gh, &c->tr_gpe, &c->tr_a1n, &c->tr_gh1, &c->tr_xn, &c->ed_re, &c->ed_a2, &c->ed_a1,
-                      &c->ed_x0, &c->ed_g3, &c->ed_g2, &c->ed_g1};
+                      &c->ed_x0, &c->ed_gce, &c->ed_g3, &c->ed_g2, &c->ed_g1};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : c->probe_ev) (void)hipEventDestroy(ev);
@@ -1297,19 +1297,20 @@ int gd_forward_backward(drp_ctx* c) {
         const int16_t* idx = ptr<int16_t>(c->tape_idx) + (size_t)t * bn * DRP_K;
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
-        float* g_cedge = (t > 0) ? ptr<float>(c->g_cedge) : nullptr;
+        unsigned long long* gmask = ptr<unsigned long long>(c->g_mask);
+        float* gah = ptr<float>(c->g_agg_hist);
         hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
                            cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
         hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn * 64, g_out, (size_t)N * 3, N,
                            ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr, 1);
         for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+            float* g_agg_p = gah + (size_t)p * bn * 64;
+            unsigned long long* mask_p = gmask + (size_t)p * bn * DRP_K;
             hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn * 64,
-                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N,
-                               ptr<float>(c->g_agg), 1);
-            hipLaunchKernelGGL(kb_edges, dim3(B), dim3(256), 0, st, cedge, pht + (size_t)p * bn * 128, idx, cnt,
-                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), ptr<float>(c->g_u), g_cedge,
-                               p == DRP_PSTEP - 1 ? 1 : 0, 1);
-            hipLaunchKernelGGL(kb_gather_senders, dim3(B), dim3(256), 0, st, ptr<float>(c->g_u), ptr<int>(c->rev_off),
+                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, 1);
+            hipLaunchKernelGGL(kb_edges, dim3(B), dim3(256), 0, st, cedge, pht + (size_t)p * bn * 128, idx, cnt, g_agg_p, N,
+                               ptr<float>(c->g_proj), mask_p, 1);
+            hipLaunchKernelGGL(kb_gather_senders, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
                                ptr<int>(c->rev), N, ptr<float>(c->g_proj), 1);
             hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), 1);
         }
@@ -1324,7 +1325,7 @@ int gd_forward_backward(drp_ctx* c) {
             CHK(d2d(g_prev, g_out, bn * 3 * sizeof(float)));
             hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw,
                                s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx, cnt,
-                               g_cedge, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), KbEdgeDump{}, 1);
+                               gah, gmask, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), KbEdgeDump{}, 1);
             hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
                                ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3);
         }
@@ -1362,8 +1363,8 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     CHK(ensure(c, c->tape_idx, (size_t)H * bn * DRP_K * sizeof(int16_t)));
     CHK(ensure(c, c->tape_cnt, (size_t)H * bn));
     CHK(ensure(c, c->tape_cedge, (size_t)H * bn * DRP_K * 64 * sizeof(float)));
-    CHK(ensure(c, c->g_cedge, bn * DRP_K * 64 * sizeof(float)));
-    CHK(ensure(c, c->g_u, bn * DRP_K * 64 * sizeof(float)));
+    CHK(ensure(c, c->g_mask, (size_t)DRP_PSTEP * bn * DRP_K * sizeof(unsigned long long)));
+    CHK(ensure(c, c->g_agg_hist, (size_t)DRP_PSTEP * bn * 64 * sizeof(float)));
     CHK(ensure(c, c->rev_off, (size_t)B * (N + 1) * sizeof(int)));
     CHK(ensure(c, c->rev, bn * DRP_K * sizeof(int)));
     CHK(ensure(c, c->gpos_edge, bn * DRP_K * 4 * sizeof(float)));
@@ -1511,7 +1512,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     const float* dens = ptr<float>(c->dens);
     HIPCHK(c, hipMemsetAsync(G, 0, (size_t)W_TOTAL * sizeof(float), st));
     KbEdgeDump ed{ptr<float>(c->ed_re), ptr<float>(c->ed_a2), ptr<float>(c->ed_a1), ptr<float>(c->ed_x0),
-                  ptr<float>(c->ed_g3), ptr<float>(c->ed_g2), ptr<float>(c->ed_g1)};
+                  ptr<float>(c->ed_gce), ptr<float>(c->ed_g3), ptr<float>(c->ed_g2), ptr<float>(c->ed_g1)};
     for (int t = H - 1; t >= 0; --t) {
         const float* s_prev = (t == 0) ? given : states + (size_t)(t - 1) * N * 3;
         const size_t prev_stride = (t == 0) ? in_stride : hstride;
@@ -1522,7 +1523,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         const int16_t* idx = ptr<int16_t>(c->tape_idx) + (size_t)t * bnk;
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
-        float* g_cedge = ptr<float>(c->g_cedge);
+        unsigned long long* gmask = ptr<unsigned long long>(c->g_mask);
+        float* gah = ptr<float>(c->g_agg_hist);
         hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
                            cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums));
         // predictor
@@ -1532,17 +1534,17 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                          nullptr, 1, 1);
         launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
         hipLaunchKernelGGL(kt_colsum3, dim3(16), dim3(256), 0, st, g_out, (long)bn, G + W_PR1_B);
-        HIPCHK(c, hipMemsetAsync(g_cedge, 0, bnk * 64 * sizeof(float), st));
         for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+            float* g_agg_p = gah + (size_t)p * bn64;
+            unsigned long long* mask_p = gmask + (size_t)p * bnk;
             hipLaunchKernelGGL(kb_update, rgrid, dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn64,
-                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N,
-                               ptr<float>(c->g_agg), chunks);
+                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, chunks);
             // particle propagator, aggregate columns: g_eff now holds the pre-activation gradient
             launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
                              nullptr, nullptr, nullptr, 1, 1);
-            hipLaunchKernelGGL(kb_edges, egrid, dim3(256), 0, st, cedge, pht + (size_t)p * bn64 * 2, idx, cnt,
-                               ptr<float>(c->g_agg), N, ptr<float>(c->g_proj), ptr<float>(c->g_u), g_cedge, 0, chunks16);
-            hipLaunchKernelGGL(kb_gather_senders, egrid, dim3(256), 0, st, ptr<float>(c->g_u), ptr<int>(c->rev_off),
+            hipLaunchKernelGGL(kb_edges, egrid, dim3(256), 0, st, cedge, pht + (size_t)p * bn64 * 2, idx, cnt, g_agg_p, N,
+                               ptr<float>(c->g_proj), mask_p, chunks16);
+            hipLaunchKernelGGL(kb_gather_senders, egrid, dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
                                ptr<int>(c->rev), N, ptr<float>(c->g_proj), chunks16);
             // relation propagator, receiver and sender columns
             launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
@@ -1569,11 +1571,11 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
         }
         hipLaunchKernelGGL(kb_edge_encode, rgrid, dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw, s_prev, B,
-                           prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, g_cedge, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), ed, chunks);
+                           prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, gah, gmask, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), ed, chunks);
         if (g_prev != nullptr)
             hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
                                ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3);
-        launch_wgrad<64>(c, g_cedge, 64, ed.re, 64, (long)bnk, G + W_RP_W, 193, 1, G + W_RP_B, G + W_RP_W + 192, dens, B,
+        launch_wgrad<64>(c, ed.gce, 64, ed.re, 64, (long)bnk, G + W_RP_W, 193, 1, G + W_RP_B, G + W_RP_W + 192, dens, B,
                          (long)N * DRP_K);
         launch_wgrad<64>(c, ed.g3, 64, ed.a2, 64, (long)bnk, G + W_RE4_W, 64, 1, G + W_RE4_B, nullptr, nullptr, 1, 1);
         launch_wgrad<64>(c, ed.g2, 64, ed.a1, 64, (long)bnk, G + W_RE2_W, 64, 1, G + W_RE2_B, nullptr, nullptr, 1, 1);
@@ -1645,8 +1647,8 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         CHK(ensure(c, c->tape_idx, (size_t)H * bnk * sizeof(int16_t)));
         CHK(ensure(c, c->tape_cnt, (size_t)H * bn));
         CHK(ensure(c, c->tape_cedge, (size_t)H * bnk * 64 * sizeof(float)));
-        CHK(ensure(c, c->g_cedge, bnk * 64 * sizeof(float)));
-        CHK(ensure(c, c->g_u, bnk * 64 * sizeof(float)));
+        CHK(ensure(c, c->g_mask, (size_t)DRP_PSTEP * bnk * sizeof(unsigned long long)));
+        CHK(ensure(c, c->g_agg_hist, (size_t)DRP_PSTEP * bn64 * sizeof(float)));
         CHK(ensure(c, c->rev_off, (size_t)B * (N + 1) * sizeof(int)));
         CHK(ensure(c, c->rev, bnk * sizeof(int)));
         CHK(ensure(c, c->gpos_edge, bnk * 4 * sizeof(float)));
@@ -1658,7 +1660,7 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         DevBuf* node64[] = {&c->tr_hact, &c->tr_gh, &c->tr_gpe, &c->tr_a1n, &c->tr_gh1};
         for (DevBuf* b : node64) CHK(ensure(c, *b, bn64 * sizeof(float)));
         CHK(ensure(c, c->tr_xn, bn * 8 * sizeof(float)));
-        DevBuf* edge64[] = {&c->ed_re, &c->ed_a2, &c->ed_a1, &c->ed_g3, &c->ed_g2, &c->ed_g1};
+        DevBuf* edge64[] = {&c->ed_re, &c->ed_a2, &c->ed_a1, &c->ed_gce, &c->ed_g3, &c->ed_g2, &c->ed_g1};
         for (DevBuf* b : edge64) CHK(ensure(c, *b, bnk * 64 * sizeof(float)));
         CHK(ensure(c, c->ed_x0, bnk * 8 * sizeof(float)));
     }

@@ -272,23 +272,27 @@ kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict_
     }
 }
 
-// ---- aggregate backward: g_u = g_agg[i] . [c_edge + P_r[i] + P_s[j] > 0]  per edge slot;
-//      g_proj[i][0:64] = sum_k g_u (receiver term); the rows g_u[b,i,k,:] are kept for the sender
-//      term (kb_gather_senders) and summed over the propagation steps into g_cedge (nullable).
+// ---- aggregate backward.  The gradient of an edge's pre-activation is the receiver's g_agg row
+//      under the edge's ReLU mask: g_u[i,k,:] = g_agg[i,:] . [c_edge + P_r[i] + P_s[j] > 0].  Only the
+//      64 mask bits per edge are kept (8 B instead of a 256-B row): the receiver term is summed
+//      here, g_proj[i][0:64] = sum_k g_u; the sender term (kb_gather_senders), the relation
+//      encoder (kb_edge_encode) and the weight gradients rebuild g_u from g_agg and the mask.
+//      Mask bit c*16 + q <-> feature 4q + c (the float4 component c of lane q).
 // same 16-lanes-per-receiver layout as k_aggregate.
+__device__ __forceinline__ int kb_mask_bit(int feature) { return (feature & 3) * 16 + (feature >> 2); }
+
 __global__ void __launch_bounds__(256)
 kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const int16_t* __restrict__ nbr_idx,
          const uint8_t* __restrict__ nbr_cnt, const float* __restrict__ g_agg, int N, float* __restrict__ g_proj,
-         float* __restrict__ g_u /* [B,N,10,64] */,
-         float* __restrict__ g_cedge /* nullable: [B,N,10,64], summed over the propagation steps */, int first,
-         int chunks) {
+         unsigned long long* __restrict__ mask /* [B,N,10] */, int chunks) {
     const KbRange rg = kb_range(N, chunks);
     const int b = rg.b;
     const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int sh = (threadIdx.x & 48);                 // this receiver's 16 lanes inside the wave's ballot
     const float4* ce = reinterpret_cast<const float4*>(c_edge) + (size_t)b * N * DRP_K * 16;
     const float4* pj = reinterpret_cast<const float4*>(proj) + (size_t)b * N * 32;
     const float4* ga = reinterpret_cast<const float4*>(g_agg) + (size_t)b * N * 16;
-    float4* gu4 = reinterpret_cast<float4*>(g_u) + (size_t)b * N * DRP_K * 16;
+    unsigned long long* mk = mask + (size_t)b * N * DRP_K;
     float* gp = g_proj + (size_t)b * N * 128;
     const int16_t* nb = nbr_idx + (size_t)b * N * DRP_K;
     const uint8_t* nc = nbr_cnt + (size_t)b * N;
@@ -301,18 +305,14 @@ kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const
             const int j = nb[i * DRP_K + k];
             const float4 c = ce[((size_t)i * DRP_K + k) * 16 + q];
             const float4 ps = pj[(size_t)j * 32 + 16 + q];
-            float4 gu;
-            gu.x = ((c.x + pr.x) + ps.x > 0.0f) ? gi.x : 0.0f;
-            gu.y = ((c.y + pr.y) + ps.y > 0.0f) ? gi.y : 0.0f;
-            gu.z = ((c.z + pr.z) + ps.z > 0.0f) ? gi.z : 0.0f;
-            gu.w = ((c.w + pr.w) + ps.w > 0.0f) ? gi.w : 0.0f;
-            acc.x += gu.x; acc.y += gu.y; acc.z += gu.z; acc.w += gu.w;
-            gu4[((size_t)i * DRP_K + k) * 16 + q] = gu;
-            if (g_cedge != nullptr) {
-                float4* gc = reinterpret_cast<float4*>(g_cedge) + ((size_t)b * N * DRP_K + (size_t)i * DRP_K + k) * 16 + q;
-                if (first) *gc = gu;
-                else { float4 o = *gc; o.x += gu.x; o.y += gu.y; o.z += gu.z; o.w += gu.w; *gc = o; }
-            }
+            const bool mx = (c.x + pr.x) + ps.x > 0.0f, my = (c.y + pr.y) + ps.y > 0.0f;
+            const bool mz = (c.z + pr.z) + ps.z > 0.0f, mw = (c.w + pr.w) + ps.w > 0.0f;
+            acc.x += mx ? gi.x : 0.0f; acc.y += my ? gi.y : 0.0f;
+            acc.z += mz ? gi.z : 0.0f; acc.w += mw ? gi.w : 0.0f;
+            const unsigned long long bx = __ballot(mx), by = __ballot(my), bz = __ballot(mz), bw = __ballot(mw);
+            if (q == 0)
+                mk[i * DRP_K + k] = ((bx >> sh) & 0xffffull) | (((by >> sh) & 0xffffull) << 16) |
+                                    (((bz >> sh) & 0xffffull) << 32) | (((bw >> sh) & 0xffffull) << 48);
         }
         *reinterpret_cast<float4*>(gp + (size_t)i * 128 + q * 4) = acc;
     }
@@ -321,12 +321,14 @@ kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const
 // sender term: g_proj[j][64:128] = sum over the edges j feeds of g_u, in the order of the
 // reversed lists (ascending receiver, then slot)
 __global__ void __launch_bounds__(256)
-kb_gather_senders(const float* __restrict__ g_u, const int* __restrict__ rev_off, const int* __restrict__ rev, int N,
-                  float* __restrict__ g_proj, int chunks) {
+kb_gather_senders(const float* __restrict__ g_agg, const unsigned long long* __restrict__ mask,
+                  const int* __restrict__ rev_off, const int* __restrict__ rev, int N, float* __restrict__ g_proj,
+                  int chunks) {
     const KbRange rg = kb_range(N, chunks);
     const int b = rg.b;
     const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const float4* gu4 = reinterpret_cast<const float4*>(g_u) + (size_t)b * N * DRP_K * 16;
+    const float4* ga = reinterpret_cast<const float4*>(g_agg) + (size_t)b * N * 16;
+    const unsigned long long* mk = mask + (size_t)b * N * DRP_K;
     const int* ro = rev_off + (size_t)b * (N + 1);
     const int* rv = rev + (size_t)b * N * DRP_K;
     float* gp = g_proj + (size_t)b * N * 128;
@@ -334,8 +336,13 @@ kb_gather_senders(const float* __restrict__ g_u, const int* __restrict__ rev_off
         const int p0 = ro[j], p1 = ro[j + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int p = p0; p < p1; ++p) {
-            const float4 v = gu4[(size_t)rv[p] * 16 + q];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            const int e = rv[p];
+            const unsigned long long m = mk[e] >> q;
+            const float4 v = ga[(size_t)(e / DRP_K) * 16 + q];
+            acc.x += (m & 1ull) ? v.x : 0.0f;
+            acc.y += ((m >> 16) & 1ull) ? v.y : 0.0f;
+            acc.z += ((m >> 32) & 1ull) ? v.z : 0.0f;
+            acc.w += ((m >> 48) & 1ull) ? v.w : 0.0f;
         }
         *reinterpret_cast<float4*>(gp + (size_t)j * 128 + 64 + q * 4) = acc;
     }
@@ -553,6 +560,7 @@ struct KbEdgeDump {
     float* a2;    // [rows,64] relu(h2)
     float* a1;    // [rows,64] relu(h1)
     float* x0;    // [rows,8]  the 6 encoder inputs
+    float* gce;   // [rows,64] gradient at c_edge (= W_e . re + ...), rebuilt from the masks
     float* g3;    // [rows,64] gradients at the three pre-activations
     float* g2;
     float* g1;
@@ -567,7 +575,9 @@ __global__ void __launch_bounds__(256)
 kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, const float* __restrict__ s_cur, int s_mod,
                size_t s_stride, const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens,
                int dens_mod, const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
-               const float* __restrict__ g_cedge, int N, float* __restrict__ g_pos /* nullable */, size_t gpos_stride,
+               const float* __restrict__ g_agg_hist /* [3][B*N,64]: g_agg of the three propagation steps */,
+               const unsigned long long* __restrict__ mask_hist /* [3][B*N*10] */, size_t bn,
+               int N, float* __restrict__ g_pos /* nullable */, size_t gpos_stride,
                float* __restrict__ gpos_edge /* [B,N,10,4]: the slot's gradient w.r.t. s_r - s_s, for kb_gather_pos */,
                KbEdgeDump dump, int chunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -593,6 +603,7 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
     const float* at = attr + (size_t)(b % attr_mod) * N;
     float* gp = g_pos ? g_pos + (size_t)b * gpos_stride : nullptr;
     const bool dumping = dump.re != nullptr;
+    const int mbit = kb_mask_bit(lane);
     const float wx = wraw[W_RE0_W + lane * 6 + 2], wy = wraw[W_RE0_W + lane * 6 + 3], wz = wraw[W_RE0_W + lane * 6 + 4];
     constexpr int R = 5;           // two passes of five slots keep the register count moderate
     for (int i = rg.lo + wave; i < rg.hi; i += nwave) {
@@ -601,6 +612,9 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
         const float ar = at[i];
         const float sr = (lane >= 2 && lane < 5) ? s[i * 3 + lane - 2] : 0.0f;
         float recv_sum = 0.0f;       // lanes 0..2: sum over this receiver's slots, in slot order
+        float ga3[DRP_PSTEP];
+#pragma unroll
+        for (int p = 0; p < DRP_PSTEP; ++p) ga3[p] = g_agg_hist[((size_t)p * bn + (size_t)b * N + i) * 64 + lane];
         for (int k0 = 0; k0 < (dumping ? DRP_K : cnt); k0 += R) {
             float x[R], h1[R], h2[R], h3[R], g[R], t[R];
             int js[R];
@@ -636,9 +650,20 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
             // backward
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                g[r] = (k0 + r < cnt) ? g_cedge[(((size_t)b * N + i) * DRP_K + k0 + r) * 64 + lane] : 0.0f;
+                // d loss / d c_edge of the slot: the three propagation steps share c_edge
+                float gv = 0.0f;
+                if (k0 + r < cnt) {
+                    const size_t e = ((size_t)b * N + i) * DRP_K + k0 + r;
+#pragma unroll
+                    for (int p = 0; p < DRP_PSTEP; ++p)
+                        if ((mask_hist[(size_t)p * bn * DRP_K + e] >> mbit) & 1ull) gv += ga3[p];
+                }
+                g[r] = gv;
                 t[r] = 0.0f;
             }
+            if (dumping)
+#pragma unroll
+                for (int r = 0; r < R; ++r) dump.gce[(row0 + r) * 64 + lane] = g[r];
             dense_bcast_ld<64, R>(bwe, 64, 0, g, t, lane);                        // W_e^T
 #pragma unroll
             for (int r = 0; r < R; ++r) { g[r] = (h3[r] > 0.0f) ? t[r] : 0.0f; t[r] = 0.0f; }
