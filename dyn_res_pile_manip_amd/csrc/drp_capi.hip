@@ -79,8 +79,8 @@ struct drp_ctx {
     int gd_nb = 0, gd_N = 0, gd_B = 0, gd_H = 0, gd_iter = 0;
     double gd_lr = 0.05;
     float gd_lo[4] = {0, 0, 0, 0}, gd_hi[4] = {0, 0, 0, 0};
-    DevBuf eff_hist, proj_hist, g_eff, g_cnode, g_agg, g_proj, g_state, g_sdelta, g_act, adam_m, adam_v;
-    DevBuf tape_sdelta, tape_idx, tape_cnt, tape_cedge, g_mask, g_agg_hist, rev_off, rev, gpos_edge;
+    DevBuf eff_hist, g_eff, g_cnode, g_agg, g_proj, g_state, g_sdelta, g_act, adam_m, adam_v;
+    DevBuf tape_sdelta, tape_idx, tape_cnt, tape_mask, g_agg_hist, rev_off, rev, gpos_edge;
 
     // particle extraction (row f2)
     DevBuf px_depth, px_mask, px_blk, px_bmin, px_bmax, px_grid, px_pcd, px_keys, px_cellcnt, px_cellfill,
@@ -201,9 +201,10 @@ struct StepArgs {
     bool build_graph;                                         // false: nbr lists already in workspace
     float* s_out; size_t out_stride;
     int B, N;
+    // tape for the backward pass (fused engine only, km_prop<., TAPE>):
     float* eff_hist = nullptr;      // [4][B*N*64]: effect after the encoder and after every propagation step
-    float* proj_hist = nullptr;     // [3][B*N*128]: node projections used by every propagation step
-    float* agg_hist = nullptr;      // [3][B*N*64]: aggregated edge effects of every propagation step (training)
+    unsigned* mask_hist = nullptr;  // [3][B*N*10][2]: ReLU masks of the relation effects of every propagation step
+    float* agg_hist = nullptr;      // [3][B*N*64]: aggregated edge effects of every propagation step (training), nullable
     const float* cself = nullptr;   // [B,64] self-edge constant + per-sample validity (fused engine, k_cself)
     const uint8_t* cself_ok = nullptr;
 };
@@ -245,28 +246,21 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     const dim3 blk(64 * MFMA_WAVES);
     const long node_tiles = (long)B * ((N + 31) / 32);
     const long edge_tiles = (long)B * ((N * DRP_K + 31) / 32);
+    const size_t bn64 = (size_t)B * N * 64;
+    const bool tape = a.eff_hist != nullptr;
+    if (tape && c->engine != DRP_ENGINE_FUSED) return fail(c, DRP_ESTATE, "the backward tape is written by the fused engine");
+    float* eff0 = tape ? a.eff_hist : ptr<float>(c->eff);
     {
         ProbeScope ps(c, KC_NODE_ENCODE);
         if (c->engine == DRP_ENGINE_FUSED)
             hipLaunchKernelGGL(km_node_encode_split, dim3(mfma_grid(c, node_tiles)), blk, KM_NODE_SPLIT_LDS, st,
                                ptr<uint16_t>(c->w_split6), mw, ptr<float>(c->s_delta), a.attr, a.attr_mod, a.dens,
-                               a.dens_mod, N, B, ptr<float>(c->eff), ptr<float>(c->c_node), ptr<float>(c->proj));
+                               a.dens_mod, N, B, eff0, ptr<float>(c->c_node), ptr<float>(c->proj));
         else
             hipLaunchKernelGGL(km_node_encode, dim3(mfma_grid(c, node_tiles)), blk, KM_NODE_LDS, st, mw,
                                ptr<float>(c->s_delta), a.attr, a.attr_mod, a.dens, a.dens_mod, N, B,
                                ptr<float>(c->eff), ptr<float>(c->c_node), ptr<float>(c->proj));
     }
-    const size_t bn64 = (size_t)B * N * 64;
-    auto save_hist = [&](int slot) -> int {
-        if (a.eff_hist)
-            HIPCHK(c, hipMemcpyAsync(a.eff_hist + (size_t)slot * bn64, c->eff.p, bn64 * sizeof(float),
-                                     hipMemcpyDeviceToDevice, st));
-        if (a.proj_hist && slot < DRP_PSTEP)
-            HIPCHK(c, hipMemcpyAsync(a.proj_hist + (size_t)slot * bn64 * 2, c->proj.p, bn64 * 2 * sizeof(float),
-                                     hipMemcpyDeviceToDevice, st));
-        return DRP_OK;
-    };
-    CHK(save_hist(0));
     // split engine, small enough samples: the relation encoder is recomputed inside the
     // aggregate of every propagation step and c_edge is never materialised
     const bool fused = (c->engine == DRP_ENGINE_FUSED);
@@ -292,11 +286,20 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             ProbeScope ps(c, KC_PROP);
             long pb_ = (node_tiles + PROP_WAVES - 1) / PROP_WAVES;
             const dim3 grid((unsigned)(pb_ < c->n_cu ? pb_ : c->n_cu)), pblk(64 * PROP_WAVES);
+            const float* eff_in = tape ? a.eff_hist + (size_t)p * bn64 : ptr<float>(c->eff);
+            float* eff_out = tape ? a.eff_hist + (size_t)(p + 1) * bn64 : ptr<float>(c->eff);
+            unsigned* mask_out = tape ? a.mask_hist + (size_t)p * B * N * DRP_K * 2 : nullptr;
+            float* agg_out = (tape && a.agg_hist) ? a.agg_hist + (size_t)p * bn64 : nullptr;
 #define PROP_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
                   a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, \
-                  ptr<float>(c->c_node), ptr<float>(c->eff), N, B, pb, a.s_out, a.out_stride, a.cself, a.cself_ok
-            if (!last) hipLaunchKernelGGL(km_prop<false>, grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS);
-            else hipLaunchKernelGGL(km_prop<true>, grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS);
+                  ptr<float>(c->c_node), eff_in, eff_out, N, B, pb, a.s_out, a.out_stride, a.cself, a.cself_ok, mask_out, agg_out
+            if (!tape) {
+                if (!last) hipLaunchKernelGGL((km_prop<false, false>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS);
+                else hipLaunchKernelGGL((km_prop<true, false>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS);
+            } else {
+                if (!last) hipLaunchKernelGGL((km_prop<false, true>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS);
+                else hipLaunchKernelGGL((km_prop<true, true>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS);
+            }
 #undef PROP_ARGS
             float* tmp = pa; pa = pb; pb = tmp;
         }
@@ -304,9 +307,6 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     }
     for (int p = 0; p < DRP_PSTEP; ++p) {
         launch_aggregate(c, B, N);
-        if (a.agg_hist)
-            HIPCHK(c, hipMemcpyAsync(a.agg_hist + (size_t)p * bn64, c->agg.p, bn64 * sizeof(float),
-                                     hipMemcpyDeviceToDevice, st));
         ProbeScope ps(c, p + 1 < DRP_PSTEP ? KC_UPDATE : KC_PREDICT);
         if (p + 1 < DRP_PSTEP)
             hipLaunchKernelGGL(km_update<false>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
@@ -316,7 +316,6 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             hipLaunchKernelGGL(km_update<true>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
                                ptr<float>(c->agg), ptr<float>(c->c_node), ptr<float>(c->eff), N, B,
                                ptr<float>(c->proj), a.s_prev, a.prev_mod, a.prev_stride, a.s_out, a.out_stride);
-        CHK(save_hist(p + 1));
     }
     return DRP_OK;
 }
@@ -389,6 +388,25 @@ int run_reward(drp_ctx* c, const float* state, size_t row_stride, int rows, int 
 }
 
 // H-step rollout over device-resident s0/attr/dens (in s_in/attr/dens, nb rows) and actions.
+// Self-edge constant of the fused engine (k_cself): one vector per sample, constant over a whole
+// rollout (it depends on the attributes and the density only).  Null pointers when it does not apply.
+int prepare_cself(drp_ctx* c, int attr_mod, int N, int B, const float** cself, const uint8_t** cself_ok) {
+    *cself = nullptr;
+    *cself_ok = nullptr;
+#ifdef DRP_HAVE_MFMA
+    if (c->engine == DRP_ENGINE_FUSED && c->self_const) {
+        CHK(ensure(c, c->cself, (size_t)B * 64 * sizeof(float) + (size_t)B));
+        float* cs = ptr<float>(c->cself);
+        uint8_t* ok = reinterpret_cast<uint8_t*>(cs + (size_t)B * 64);
+        hipLaunchKernelGGL(k_cself, dim3(B), dim3(64), 0, c->stream, ptr<float>(c->w_valu), ptr<float>(c->attr), attr_mod,
+                           ptr<float>(c->dens), attr_mod, N, cs, ok);
+        *cself = cs;
+        *cself_ok = ok;
+    }
+#endif
+    return DRP_OK;
+}
+
 int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool reward_last) {
     CHK(ensure_step_ws(c, B, N));
     CHK(ensure(c, c->states, (size_t)B * H * N * 3 * sizeof(float)));
@@ -398,18 +416,7 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
     const size_t hstride = (size_t)H * N * 3;
     const float* cself = nullptr;
     const uint8_t* cself_ok = nullptr;
-#ifdef DRP_HAVE_MFMA
-    if (c->engine == DRP_ENGINE_FUSED && c->self_const) {
-        // constant over the whole rollout: depends on the attributes and the density only
-        CHK(ensure(c, c->cself, (size_t)B * 64 * sizeof(float) + (size_t)B));
-        float* cs = ptr<float>(c->cself);
-        uint8_t* ok = reinterpret_cast<uint8_t*>(cs + (size_t)B * 64);
-        hipLaunchKernelGGL(k_cself, dim3(B), dim3(64), 0, c->stream, ptr<float>(c->w_valu), ptr<float>(c->attr), nb,
-                           ptr<float>(c->dens), nb, N, cs, ok);
-        cself = cs;
-        cself_ok = ok;
-    }
-#endif
+    CHK(prepare_cself(c, nb, N, B, &cself, &cself_ok));
     for (int t = 0; t < H; ++t) {
         StepArgs a{};
         a.cself = cself; a.cself_ok = cself_ok;
@@ -535,8 +542,10 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_node_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_edge_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_SPLIT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_node_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_SPLIT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
@@ -554,7 +563,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    DevBuf* bufs[] = {&c->g_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->tape_cedge, &c->eff_hist, &c->proj_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
+    DevBuf* bufs[] = {&c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
@@ -1248,15 +1257,18 @@ int gd_forward_backward(drp_ctx* c) {
     const bool rev_lds = N <= KB_REV_LDS_MAX_N && !c->rev_global_only;
     float* states = ptr<float>(c->states);
     float* eh = ptr<float>(c->eff_hist);
-    float* ph = ptr<float>(c->proj_hist);
+    unsigned* mh = ptr<unsigned>(c->tape_mask);
     auto d2d = [&](void* dst, const void* src, size_t bytes) -> int {
         HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
         return DRP_OK;
     };
-    // ---- forward on the fp32 MFMA pipeline, keeping per step what the backward pass needs
+    // ---- forward on the fused engine; km_prop<., TAPE> leaves what the backward pass needs: the
+    //      effect after the encoder and after every propagation step, and the ReLU masks of the edges
     const int saved_engine = c->engine;
-    c->engine = DRP_ENGINE_MFMA;
-    int rc = DRP_OK;
+    c->engine = DRP_ENGINE_FUSED;
+    const float* cself = nullptr;
+    const uint8_t* cself_ok = nullptr;
+    int rc = prepare_cself(c, nb, N, B, &cself, &cself_ok);
     for (int t = 0; t < H && rc == DRP_OK; ++t) {
         StepArgs a{};
         if (t == 0) { a.s_prev = ptr<float>(c->s_in); a.prev_mod = nb; a.prev_stride = (size_t)N * 3; }
@@ -1268,13 +1280,13 @@ int gd_forward_backward(drp_ctx* c) {
         a.s_out = states + (size_t)t * N * 3; a.out_stride = hstride;
         a.B = B; a.N = N;
         a.eff_hist = eh + (size_t)t * 4 * bn * 64;
-        a.proj_hist = ph + (size_t)t * 3 * bn * 128;
+        a.mask_hist = mh + (size_t)t * DRP_PSTEP * bn * DRP_K * 2;
+        a.cself = cself; a.cself_ok = cself_ok;
         rc = run_step(c, a);
         if (rc != DRP_OK) break;
         rc = d2d(ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, c->s_delta.p, bn * 3 * sizeof(float));
         if (rc == DRP_OK) rc = d2d(ptr<int16_t>(c->tape_idx) + (size_t)t * bn * DRP_K, c->nbr_idx.p, bn * DRP_K * sizeof(int16_t));
         if (rc == DRP_OK) rc = d2d(ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn, c->nbr_cnt.p, bn);
-        if (rc == DRP_OK) rc = d2d(ptr<float>(c->tape_cedge) + (size_t)t * bn * DRP_K * 64, c->c_edge.p, bn * DRP_K * 64 * sizeof(float));
     }
     c->engine = saved_engine;
     CHK(rc);
@@ -1292,12 +1304,10 @@ int gd_forward_backward(drp_ctx* c) {
         const int prev_mod = (t == 0) ? nb : B;
         const size_t prev_stride = (t == 0) ? (size_t)N * 3 : hstride;
         float* eht = eh + (size_t)t * 4 * bn * 64;
-        float* pht = ph + (size_t)t * 3 * bn * 128;
-        const float* cedge = ptr<float>(c->tape_cedge) + (size_t)t * bn * DRP_K * 64;
+        const unsigned* mht = mh + (size_t)t * DRP_PSTEP * bn * DRP_K * 2;
         const int16_t* idx = ptr<int16_t>(c->tape_idx) + (size_t)t * bn * DRP_K;
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
-        unsigned long long* gmask = ptr<unsigned long long>(c->g_mask);
         float* gah = ptr<float>(c->g_agg_hist);
         hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
                            cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
@@ -1305,11 +1315,10 @@ int gd_forward_backward(drp_ctx* c) {
                            ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr, 1);
         for (int p = DRP_PSTEP - 1; p >= 0; --p) {
             float* g_agg_p = gah + (size_t)p * bn * 64;
-            unsigned long long* mask_p = gmask + (size_t)p * bn * DRP_K;
+            const unsigned* mask_p = mht + (size_t)p * bn * DRP_K * 2;
             hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn * 64,
                                ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, 1);
-            hipLaunchKernelGGL(kb_edges, dim3(B), dim3(256), 0, st, cedge, pht + (size_t)p * bn * 128, idx, cnt, g_agg_p, N,
-                               ptr<float>(c->g_proj), mask_p, 1);
+            hipLaunchKernelGGL(kb_recv_sum, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), 1);
             hipLaunchKernelGGL(kb_gather_senders, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
                                ptr<int>(c->rev), N, ptr<float>(c->g_proj), 1);
             hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), 1);
@@ -1325,7 +1334,7 @@ int gd_forward_backward(drp_ctx* c) {
             CHK(d2d(g_prev, g_out, bn * 3 * sizeof(float)));
             hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw,
                                s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx, cnt,
-                               gah, gmask, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), KbEdgeDump{}, 1);
+                               gah, mht, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), KbEdgeDump{}, 1);
             hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
                                ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3);
         }
@@ -1358,12 +1367,10 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     CHK(ensure(c, c->states, (size_t)H * bn * 3 * sizeof(float)));
     CHK(ensure(c, c->rewards, (size_t)B * sizeof(float)));
     CHK(ensure(c, c->eff_hist, (size_t)H * 4 * bn * 64 * sizeof(float)));
-    CHK(ensure(c, c->proj_hist, (size_t)H * 3 * bn * 128 * sizeof(float)));
     CHK(ensure(c, c->tape_sdelta, (size_t)H * bn * 3 * sizeof(float)));
     CHK(ensure(c, c->tape_idx, (size_t)H * bn * DRP_K * sizeof(int16_t)));
     CHK(ensure(c, c->tape_cnt, (size_t)H * bn));
-    CHK(ensure(c, c->tape_cedge, (size_t)H * bn * DRP_K * 64 * sizeof(float)));
-    CHK(ensure(c, c->g_mask, (size_t)DRP_PSTEP * bn * DRP_K * sizeof(unsigned long long)));
+    CHK(ensure(c, c->tape_mask, (size_t)H * DRP_PSTEP * bn * DRP_K * 2 * sizeof(unsigned)));
     CHK(ensure(c, c->g_agg_hist, (size_t)DRP_PSTEP * bn * 64 * sizeof(float)));
     CHK(ensure(c, c->rev_off, (size_t)B * (N + 1) * sizeof(int)));
     CHK(ensure(c, c->rev, bn * DRP_K * sizeof(int)));
@@ -1447,14 +1454,16 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     float* states = ptr<float>(c->states);
     const float* given = ptr<float>(c->tr_states);
     float* eh = ptr<float>(c->eff_hist);
-    float* ph = ptr<float>(c->proj_hist);
+    unsigned* mh = ptr<unsigned>(c->tape_mask);
     float* ah = ptr<float>(c->agg_hist);
     float* g_state = ptr<float>(c->g_state);
     double* loss = ptr<double>(c->tr_loss);
     const float scale = 1.0f / (float)(H * B);
     const int saved_engine = c->engine;
-    c->engine = DRP_ENGINE_MFMA;
-    int rc = DRP_OK;
+    c->engine = DRP_ENGINE_FUSED;
+    const float* cself = nullptr;
+    const uint8_t* cself_ok = nullptr;
+    int rc = prepare_cself(c, B, N, B, &cself, &cself_ok);
     for (int t = 0; t < H && rc == DRP_OK; ++t) {
         // this step's impulses are data (train/train_gnn_dyn.py:181)
         hipError_t e = hipMemcpy2DAsync(c->s_delta.p, (size_t)N * 3 * sizeof(float),
@@ -1470,9 +1479,10 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         a.build_graph = true;
         a.s_out = states + (size_t)t * N * 3; a.out_stride = hstride;
         a.B = B; a.N = N;
+        a.cself = cself; a.cself_ok = cself_ok;
         if (backward) {
             a.eff_hist = eh + (size_t)t * 4 * bn64;
-            a.proj_hist = ph + (size_t)t * 3 * bn64 * 2;
+            a.mask_hist = mh + (size_t)t * DRP_PSTEP * bnk * 2;
             a.agg_hist = ah + (size_t)t * 3 * bn64;
         }
         rc = run_step(c, a);
@@ -1484,7 +1494,6 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             bool ok = d2d(ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, c->s_delta.p, bn * 3 * sizeof(float));
             ok = ok && d2d(ptr<int16_t>(c->tape_idx) + (size_t)t * bnk, c->nbr_idx.p, bnk * sizeof(int16_t));
             ok = ok && d2d(ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn, c->nbr_cnt.p, bn);
-            ok = ok && d2d(ptr<float>(c->tape_cedge) + (size_t)t * bnk * 64, c->c_edge.p, bnk * 64 * sizeof(float));
             if (!ok) { rc = fail(c, DRP_EHIP, "tape copy failed"); break; }
         }
         // loss of this step and d loss / d s_pred_t (train/train_gnn_dyn.py:184-186, :203)
@@ -1517,13 +1526,11 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         const float* s_prev = (t == 0) ? given : states + (size_t)(t - 1) * N * 3;
         const size_t prev_stride = (t == 0) ? in_stride : hstride;
         float* eht = eh + (size_t)t * 4 * bn64;
-        float* pht = ph + (size_t)t * 3 * bn64 * 2;
+        const unsigned* mht = mh + (size_t)t * DRP_PSTEP * bnk * 2;
         float* aht = ah + (size_t)t * 3 * bn64;
-        const float* cedge = ptr<float>(c->tape_cedge) + (size_t)t * bnk * 64;
         const int16_t* idx = ptr<int16_t>(c->tape_idx) + (size_t)t * bnk;
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
-        unsigned long long* gmask = ptr<unsigned long long>(c->g_mask);
         float* gah = ptr<float>(c->g_agg_hist);
         hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
                            cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums));
@@ -1536,14 +1543,13 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         hipLaunchKernelGGL(kt_colsum3, dim3(16), dim3(256), 0, st, g_out, (long)bn, G + W_PR1_B);
         for (int p = DRP_PSTEP - 1; p >= 0; --p) {
             float* g_agg_p = gah + (size_t)p * bn64;
-            unsigned long long* mask_p = gmask + (size_t)p * bnk;
+            const unsigned* mask_p = mht + (size_t)p * bnk * 2;
             hipLaunchKernelGGL(kb_update, rgrid, dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn64,
                                ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, chunks);
             // particle propagator, aggregate columns: g_eff now holds the pre-activation gradient
             launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
                              nullptr, nullptr, nullptr, 1, 1);
-            hipLaunchKernelGGL(kb_edges, egrid, dim3(256), 0, st, cedge, pht + (size_t)p * bn64 * 2, idx, cnt, g_agg_p, N,
-                               ptr<float>(c->g_proj), mask_p, chunks16);
+            hipLaunchKernelGGL(kb_recv_sum, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), chunks16);
             hipLaunchKernelGGL(kb_gather_senders, egrid, dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
                                ptr<int>(c->rev), N, ptr<float>(c->g_proj), chunks16);
             // relation propagator, receiver and sender columns
@@ -1571,7 +1577,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
         }
         hipLaunchKernelGGL(kb_edge_encode, rgrid, dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw, s_prev, B,
-                           prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, gah, gmask, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), ed, chunks);
+                           prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, gah, mht, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), ed, chunks);
         if (g_prev != nullptr)
             hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
                                ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3);
@@ -1641,13 +1647,11 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     CHK(ensure(c, c->g_state, (size_t)H * bn * 3 * sizeof(float)));
     if (backward) {
         CHK(ensure(c, c->eff_hist, (size_t)H * 4 * bn64 * sizeof(float)));
-        CHK(ensure(c, c->proj_hist, (size_t)H * 3 * bn64 * 2 * sizeof(float)));
         CHK(ensure(c, c->agg_hist, (size_t)H * 3 * bn64 * sizeof(float)));
         CHK(ensure(c, c->tape_sdelta, (size_t)H * bn * 3 * sizeof(float)));
         CHK(ensure(c, c->tape_idx, (size_t)H * bnk * sizeof(int16_t)));
         CHK(ensure(c, c->tape_cnt, (size_t)H * bn));
-        CHK(ensure(c, c->tape_cedge, (size_t)H * bnk * 64 * sizeof(float)));
-        CHK(ensure(c, c->g_mask, (size_t)DRP_PSTEP * bnk * sizeof(unsigned long long)));
+        CHK(ensure(c, c->tape_mask, (size_t)H * DRP_PSTEP * bnk * 2 * sizeof(unsigned)));
         CHK(ensure(c, c->g_agg_hist, (size_t)DRP_PSTEP * bn64 * sizeof(float)));
         CHK(ensure(c, c->rev_off, (size_t)B * (N + 1) * sizeof(int)));
         CHK(ensure(c, c->rev, bnk * sizeof(int)));

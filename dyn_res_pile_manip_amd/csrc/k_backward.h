@@ -273,47 +273,45 @@ kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict_
 }
 
 // ---- aggregate backward.  The gradient of an edge's pre-activation is the receiver's g_agg row
-//      under the edge's ReLU mask: g_u[i,k,:] = g_agg[i,:] . [c_edge + P_r[i] + P_s[j] > 0].  Only the
-//      64 mask bits per edge are kept (8 B instead of a 256-B row): the receiver term is summed
-//      here, g_proj[i][0:64] = sum_k g_u; the sender term (kb_gather_senders), the relation
-//      encoder (kb_edge_encode) and the weight gradients rebuild g_u from g_agg and the mask.
-//      Mask bit c*16 + q <-> feature 4q + c (the float4 component c of lane q).
-// same 16-lanes-per-receiver layout as k_aggregate.
-__device__ __forceinline__ int kb_mask_bit(int feature) { return (feature & 3) * 16 + (feature >> 2); }
+//      under the edge's ReLU mask: g_u[i,k,:] = g_agg[i,:] . [relation effect of (i,k) > 0].  The
+//      forward pass (km_prop<., TAPE>) leaves the 64 mask bits of every edge slot and propagation
+//      step (8 B instead of a 256-B row); nothing else of the edge stage is kept.  Here: the
+//      receiver term g_proj[i][0:64] = sum_k g_u and, over the reversed lists, the sender term
+//      g_proj[j][64:128]; kb_edge_encode and the weight gradients rebuild g_u the same way.
+// Mask layout (k_mlp_split.h frag_positive_bits): two words per slot; feature f lives in word
+// (f>>2)&1 at bit 31 - (16*(f>>5) + (f&3) + 4*((f&31)>>3)).  The four features 4q..4q+3 of a float4
+// lane q are one nibble of word q&1.
+__device__ __forceinline__ int kb_mask_word(int f) { return (f >> 2) & 1; }
+__device__ __forceinline__ int kb_mask_bit(int f) { return 31 - (16 * (f >> 5) + (f & 3) + 4 * ((f & 31) >> 3)); }
+__device__ __forceinline__ unsigned kb_mask_nibble(const unsigned* __restrict__ m2, int q) {
+    return (m2[q & 1] >> (28 - 16 * (q >> 3) - 4 * ((q >> 1) & 3))) & 0xfu;      // bit 3 = component x ... bit 0 = w
+}
 
+// same 16-lanes-per-receiver layout as k_aggregate.
 __global__ void __launch_bounds__(256)
-kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const int16_t* __restrict__ nbr_idx,
-         const uint8_t* __restrict__ nbr_cnt, const float* __restrict__ g_agg, int N, float* __restrict__ g_proj,
-         unsigned long long* __restrict__ mask /* [B,N,10] */, int chunks) {
+kb_recv_sum(const float* __restrict__ g_agg, const unsigned* __restrict__ mask, const uint8_t* __restrict__ nbr_cnt,
+            int N, float* __restrict__ g_proj, int chunks) {
     const KbRange rg = kb_range(N, chunks);
     const int b = rg.b;
     const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int sh = (threadIdx.x & 48);                 // this receiver's 16 lanes inside the wave's ballot
-    const float4* ce = reinterpret_cast<const float4*>(c_edge) + (size_t)b * N * DRP_K * 16;
-    const float4* pj = reinterpret_cast<const float4*>(proj) + (size_t)b * N * 32;
     const float4* ga = reinterpret_cast<const float4*>(g_agg) + (size_t)b * N * 16;
-    unsigned long long* mk = mask + (size_t)b * N * DRP_K;
+    const unsigned* mk = mask + (size_t)b * N * DRP_K * 2;
     float* gp = g_proj + (size_t)b * N * 128;
-    const int16_t* nb = nbr_idx + (size_t)b * N * DRP_K;
     const uint8_t* nc = nbr_cnt + (size_t)b * N;
     for (int i = rg.lo + g; i < rg.hi; i += 16) {
         const int cnt = nc[i];
-        const float4 pr = pj[(size_t)i * 32 + q];
         const float4 gi = ga[(size_t)i * 16 + q];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int nx = 0, ny = 0, nz = 0, nw = 0;            // how many of the receiver's edges pass each feature on
         for (int k = 0; k < cnt; ++k) {
-            const int j = nb[i * DRP_K + k];
-            const float4 c = ce[((size_t)i * DRP_K + k) * 16 + q];
-            const float4 ps = pj[(size_t)j * 32 + 16 + q];
-            const bool mx = (c.x + pr.x) + ps.x > 0.0f, my = (c.y + pr.y) + ps.y > 0.0f;
-            const bool mz = (c.z + pr.z) + ps.z > 0.0f, mw = (c.w + pr.w) + ps.w > 0.0f;
-            acc.x += mx ? gi.x : 0.0f; acc.y += my ? gi.y : 0.0f;
-            acc.z += mz ? gi.z : 0.0f; acc.w += mw ? gi.w : 0.0f;
-            const unsigned long long bx = __ballot(mx), by = __ballot(my), bz = __ballot(mz), bw = __ballot(mw);
-            if (q == 0)
-                mk[i * DRP_K + k] = ((bx >> sh) & 0xffffull) | (((by >> sh) & 0xffffull) << 16) |
-                                    (((bz >> sh) & 0xffffull) << 32) | (((bw >> sh) & 0xffffull) << 48);
+            const unsigned nib = kb_mask_nibble(mk + ((size_t)i * DRP_K + k) * 2, q);
+            nx += (nib >> 3) & 1; ny += (nib >> 2) & 1; nz += (nib >> 1) & 1; nw += nib & 1;
         }
+        // sum_k of the same value gi under 0/1 masks, added one by one as the edge loop would
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < nx; ++t) acc.x += gi.x;
+        for (int t = 0; t < ny; ++t) acc.y += gi.y;
+        for (int t = 0; t < nz; ++t) acc.z += gi.z;
+        for (int t = 0; t < nw; ++t) acc.w += gi.w;
         *reinterpret_cast<float4*>(gp + (size_t)i * 128 + q * 4) = acc;
     }
 }
@@ -321,14 +319,14 @@ kb_edges(const float* __restrict__ c_edge, const float* __restrict__ proj, const
 // sender term: g_proj[j][64:128] = sum over the edges j feeds of g_u, in the order of the
 // reversed lists (ascending receiver, then slot)
 __global__ void __launch_bounds__(256)
-kb_gather_senders(const float* __restrict__ g_agg, const unsigned long long* __restrict__ mask,
+kb_gather_senders(const float* __restrict__ g_agg, const unsigned* __restrict__ mask,
                   const int* __restrict__ rev_off, const int* __restrict__ rev, int N, float* __restrict__ g_proj,
                   int chunks) {
     const KbRange rg = kb_range(N, chunks);
     const int b = rg.b;
     const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
     const float4* ga = reinterpret_cast<const float4*>(g_agg) + (size_t)b * N * 16;
-    const unsigned long long* mk = mask + (size_t)b * N * DRP_K;
+    const unsigned* mk = mask + (size_t)b * N * DRP_K * 2;
     const int* ro = rev_off + (size_t)b * (N + 1);
     const int* rv = rev + (size_t)b * N * DRP_K;
     float* gp = g_proj + (size_t)b * N * 128;
@@ -337,12 +335,12 @@ kb_gather_senders(const float* __restrict__ g_agg, const unsigned long long* __r
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int p = p0; p < p1; ++p) {
             const int e = rv[p];
-            const unsigned long long m = mk[e] >> q;
+            const unsigned nib = kb_mask_nibble(mk + (size_t)e * 2, q);
             const float4 v = ga[(size_t)(e / DRP_K) * 16 + q];
-            acc.x += (m & 1ull) ? v.x : 0.0f;
-            acc.y += ((m >> 16) & 1ull) ? v.y : 0.0f;
-            acc.z += ((m >> 32) & 1ull) ? v.z : 0.0f;
-            acc.w += ((m >> 48) & 1ull) ? v.w : 0.0f;
+            acc.x += (nib & 8u) ? v.x : 0.0f;
+            acc.y += (nib & 4u) ? v.y : 0.0f;
+            acc.z += (nib & 2u) ? v.z : 0.0f;
+            acc.w += (nib & 1u) ? v.w : 0.0f;
         }
         *reinterpret_cast<float4*>(gp + (size_t)j * 128 + 64 + q * 4) = acc;
     }
@@ -576,7 +574,7 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
                size_t s_stride, const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens,
                int dens_mod, const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
                const float* __restrict__ g_agg_hist /* [3][B*N,64]: g_agg of the three propagation steps */,
-               const unsigned long long* __restrict__ mask_hist /* [3][B*N*10] */, size_t bn,
+               const unsigned* __restrict__ mask_hist /* [3][B*N*10][2] */, size_t bn,
                int N, float* __restrict__ g_pos /* nullable */, size_t gpos_stride,
                float* __restrict__ gpos_edge /* [B,N,10,4]: the slot's gradient w.r.t. s_r - s_s, for kb_gather_pos */,
                KbEdgeDump dump, int chunks) {
@@ -603,7 +601,7 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
     const float* at = attr + (size_t)(b % attr_mod) * N;
     float* gp = g_pos ? g_pos + (size_t)b * gpos_stride : nullptr;
     const bool dumping = dump.re != nullptr;
-    const int mbit = kb_mask_bit(lane);
+    const int mbit = kb_mask_bit(lane), mword = kb_mask_word(lane);
     const float wx = wraw[W_RE0_W + lane * 6 + 2], wy = wraw[W_RE0_W + lane * 6 + 3], wz = wraw[W_RE0_W + lane * 6 + 4];
     constexpr int R = 5;           // two passes of five slots keep the register count moderate
     for (int i = rg.lo + wave; i < rg.hi; i += nwave) {
@@ -656,7 +654,7 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
                     const size_t e = ((size_t)b * N + i) * DRP_K + k0 + r;
 #pragma unroll
                     for (int p = 0; p < DRP_PSTEP; ++p)
-                        if ((mask_hist[(size_t)p * bn * DRP_K + e] >> mbit) & 1ull) gv += ga3[p];
+                        if ((mask_hist[((size_t)p * bn * DRP_K + e) * 2 + mword] >> mbit) & 1u) gv += ga3[p];
                 }
                 g[r] = gv;
                 t[r] = 0.0f;

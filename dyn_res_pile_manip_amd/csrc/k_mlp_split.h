@@ -380,15 +380,31 @@ k_cself(const float* __restrict__ vw, const float* __restrict__ attr, int attr_m
     if (lane == 0) ok[b] = uniform ? 1 : 0;
 }
 
-template <bool LAST>
+// ReLU mask of an edge's 64 relation-effect features, as the gradient-descent planner's and the
+// trainer's backward pass want it (k_backward.h): two 32-bit words per edge slot, word h = the
+// half-wave that holds the features, bit 31 - (16*ob + r) <-> accumulator register r of output
+// block ob, i.e. feature 32*ob + (r&3) + 8*(r>>2) + 4*h.
+__device__ __forceinline__ unsigned frag_positive_bits(const Frag& f) {
+    unsigned m = 0;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            m = (m << 1) | ((unsigned)(0 - __float_as_int(f.v[ob][r])) >> 31);   // values are relu'd: > 0 <=> bits != 0
+    return m;
+}
+
+template <bool LAST, bool TAPE>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
         const float* __restrict__ s_cur, int s_mod, size_t s_stride,
         const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
         const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
-        const float* __restrict__ proj, const float* __restrict__ c_node, float* __restrict__ eff,
-        int N, int B, float* __restrict__ proj_next, float* __restrict__ s_out, size_t out_stride,
-        const float* __restrict__ cself /* nullable [B,64] */, const uint8_t* __restrict__ cself_ok) {
+        const float* __restrict__ proj, const float* __restrict__ c_node, const float* __restrict__ eff_in,
+        float* __restrict__ eff, int N, int B, float* __restrict__ proj_next, float* __restrict__ s_out,
+        size_t out_stride, const float* __restrict__ cself /* nullable [B,64] */,
+        const uint8_t* __restrict__ cself_ok,
+        unsigned* __restrict__ mask_out /* TAPE: [B*N*10][2] */, float* __restrict__ agg_out /* TAPE, nullable: [B*N,64] */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wsp_f = lds;                              // edge chain, S_TOTAL units
     float* w6_f = wsp_f + S_TOTAL * 4;               // node layers: AGG | (RPR RPS) or (PR0)
@@ -445,6 +461,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
                     acc.v[ob][4 * g + 2] = relu1((bpr.v[ob][4 * g + 2] + cs.z) + ps.z);
                     acc.v[ob][4 * g + 3] = relu1((bpr.v[ob][4 * g + 3] + cs.w) + ps.w);
                 }
+            if (TAPE && live) mask_out[(row * DRP_K + 0) * 2 + h] = frag_positive_bits(acc);
             ks = 1;
         } else {
             frag_zero(acc);
@@ -483,10 +500,21 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
             split_frag<true>(a, fb);
             c = bpr;
             mfma_layer64_split(wsp + S_RPE, fb, c, lane, w0, nullptr, wn);
+            if (!TAPE) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc.v[0][r] += relu1(c.v[0][r] + sv.v[0][r]);
-                acc.v[1][r] += relu1(c.v[1][r] + sv.v[1][r]);
+                for (int r = 0; r < 16; ++r) {
+                    acc.v[0][r] += relu1(c.v[0][r] + sv.v[0][r]);
+                    acc.v[1][r] += relu1(c.v[1][r] + sv.v[1][r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    c.v[0][r] = relu1(c.v[0][r] + sv.v[0][r]);
+                    c.v[1][r] = relu1(c.v[1][r] + sv.v[1][r]);
+                    acc.v[0][r] += c.v[0][r];
+                    acc.v[1][r] += c.v[1][r];
+                }
+                if (live) mask_out[(row * DRP_K + k) * 2 + h] = frag_positive_bits(c);
             }
             j0 = j1; j1 = j2;
             p0x = p1x; p0y = p1y; p0z = p1z; p0a = p1a;
@@ -496,11 +524,12 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         Frag e;
         {
             Frag cn;
-            frag_from_row(eff + row * 64, h, e);
+            frag_from_row((TAPE ? eff_in : eff) + row * 64, h, e);    // in place unless a tape is written
             frag_from_row(c_node + row * 64, h, cn);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { e.v[0][r] += cn.v[0][r]; e.v[1][r] += cn.v[1][r]; }
         }
+        if (TAPE && agg_out != nullptr && live) frag_to_row(agg_out + row * 64, h, acc);
         FragB6 f6;
         split_frag6(acc, f6);
         mfma_layer64_split6(w6, f6, e, lane);
