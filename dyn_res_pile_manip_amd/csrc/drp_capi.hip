@@ -27,6 +27,7 @@
 #ifdef DRP_HAVE_MFMA
 #include "k_mlp_mfma.h"
 #include "k_mlp_split.h"
+#include "k_backward_mfma.h"
 #endif
 
 namespace {
@@ -58,7 +59,7 @@ struct drp_ctx {
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
     float adj_thresh = 0.08f, thr = 0.0064f;
-    DevBuf w_raw, w_valu, w_mfma, w_split, w_split6;
+    DevBuf w_raw, w_valu, w_mfma, w_mfma_bwd, w_split, w_split6;
     DrpCam cam{};
     DevBuf goal_field, goal_coor, cself;
     int goal_h = 0, goal_w = 0, goal_m = 0;
@@ -564,7 +565,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     DevBuf* bufs[] = {&c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
-                      &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
+                      &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
                       &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats, &c->cself,
@@ -626,6 +627,10 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
         std::vector<float> m;
         pack_mfma(blob, m);
         CHK(h2d(c, c->w_mfma, m.data(), m.size() * sizeof(float)));
+        std::vector<float> mbv;
+        pack_mfma_bwd(blob, mbv);
+        CHK(h2d(c, c->w_mfma_bwd, mbv.data(), mbv.size() * sizeof(float)));
+        HIPCHK(c, hipStreamSynchronize(c->stream));     // mbv is about to go out of scope... kept alive until here
         std::vector<uint16_t> sp;
         pack_split(blob, sp);
         CHK(h2d(c, c->w_split, sp.data(), sp.size() * sizeof(uint16_t)));
@@ -1311,22 +1316,55 @@ int gd_forward_backward(drp_ctx* c) {
         float* gah = ptr<float>(c->g_agg_hist);
         hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
                            cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
-        hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn * 64, g_out, (size_t)N * 3, N,
-                           ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr, 1);
-        for (int p = DRP_PSTEP - 1; p >= 0; --p) {
-            float* g_agg_p = gah + (size_t)p * bn * 64;
-            const unsigned* mask_p = mht + (size_t)p * bn * DRP_K * 2;
-            hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn * 64,
-                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, 1);
-            hipLaunchKernelGGL(kb_recv_sum, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), 1);
-            hipLaunchKernelGGL(kb_gather_senders, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
-                               ptr<int>(c->rev), N, ptr<float>(c->g_proj), 1);
-            hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), 1);
+        if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES) {      // node stages on the matrix cores
+            const float* mw = ptr<float>(c->w_mfma);
+            const float* mb = ptr<float>(c->w_mfma_bwd);
+            const long node_tiles = (long)B * ((N + 31) / 32);
+            const dim3 ngrid(mfma_grid(c, node_tiles)), nblk(64 * MFMA_WAVES);
+            hipLaunchKernelGGL(kmb_predict, ngrid, nblk, KMB_PREDICT_LDS, st, mw, mb, eht + 3 * bn * 64, g_out, (size_t)N * 3, N, B,
+                               ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr);
+            // update of the last propagation step, then per step: edge terms, and in one launch the
+            // projection of this step with the update of the one before
+            hipLaunchKernelGGL((kmb_node_step<false, true>), ngrid, nblk, KMB_STEP_LDS(false, true), st, mb, ptr<float>(c->g_eff),
+                               (const float*)nullptr, eht + (size_t)DRP_PSTEP * bn * 64, ptr<float>(c->g_cnode), 1,
+                               gah + (size_t)(DRP_PSTEP - 1) * bn * 64, N, B);
+            for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+                float* g_agg_p = gah + (size_t)p * bn * 64;
+                const unsigned* mask_p = mht + (size_t)p * bn * DRP_K * 2;
+                hipLaunchKernelGGL(kb_recv_sum, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), 1);
+                hipLaunchKernelGGL(kb_gather_senders, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
+                                   ptr<int>(c->rev), N, ptr<float>(c->g_proj), 1);
+                if (p > 0)
+                    hipLaunchKernelGGL((kmb_node_step<true, true>), ngrid, nblk, KMB_STEP_LDS(true, true), st, mb,
+                                       ptr<float>(c->g_eff), ptr<float>(c->g_proj), eht + (size_t)p * bn * 64,
+                                       ptr<float>(c->g_cnode), 0, gah + (size_t)(p - 1) * bn * 64, N, B);
+                else
+                    hipLaunchKernelGGL((kmb_node_step<true, false>), ngrid, nblk, KMB_STEP_LDS(true, false), st, mb,
+                                       ptr<float>(c->g_eff), ptr<float>(c->g_proj), (const float*)nullptr, (float*)nullptr, 0,
+                                       (float*)nullptr, N, B);
+            }
+            hipLaunchKernelGGL(kmb_node_encode, ngrid, nblk, KMB_NODE_ENCODE_LDS, st, mw, mb,
+                               ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb,
+                               eht, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, B, ptr<float>(c->g_sdelta), (float*)nullptr,
+                               (float*)nullptr, (float*)nullptr, (float*)nullptr);
+        } else {
+            hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn * 64, g_out, (size_t)N * 3, N,
+                               ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr, 1);
+            for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+                float* g_agg_p = gah + (size_t)p * bn * 64;
+                const unsigned* mask_p = mht + (size_t)p * bn * DRP_K * 2;
+                hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn * 64,
+                                   ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, 1);
+                hipLaunchKernelGGL(kb_recv_sum, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), 1);
+                hipLaunchKernelGGL(kb_gather_senders, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
+                                   ptr<int>(c->rev), N, ptr<float>(c->g_proj), 1);
+                hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), 1);
+            }
+            hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw,
+                               ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb, ptr<float>(c->dens),
+                               nb, eht, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta),
+                               (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1);
         }
-        hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw,
-                           ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb, ptr<float>(c->dens),
-                           nb, eht, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta),
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1);
         float* g_prev = nullptr;
         if (t > 0) {
             // d loss / d state[t-1] = residual share + relation encoder + gen_s_delta's position dependence
@@ -1534,42 +1572,97 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         float* gah = ptr<float>(c->g_agg_hist);
         hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
                            cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums));
-        // predictor
-        hipLaunchKernelGGL(kb_predict, rgrid, dim3(256), 0, st, vw, wraw, eht + 3 * bn64, g_out, (size_t)N * 3, N,
-                           ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh), chunks);
-        launch_wgrad<64>(c, ptr<float>(c->tr_gh), 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
-                         nullptr, 1, 1);
-        launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
-        hipLaunchKernelGGL(kt_colsum3, dim3(16), dim3(256), 0, st, g_out, (long)bn, G + W_PR1_B);
-        for (int p = DRP_PSTEP - 1; p >= 0; --p) {
-            float* g_agg_p = gah + (size_t)p * bn64;
-            const unsigned* mask_p = mht + (size_t)p * bnk * 2;
-            hipLaunchKernelGGL(kb_update, rgrid, dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn64,
-                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, chunks);
-            // particle propagator, aggregate columns: g_eff now holds the pre-activation gradient
-            launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
-                             nullptr, nullptr, nullptr, 1, 1);
-            hipLaunchKernelGGL(kb_recv_sum, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), chunks16);
-            hipLaunchKernelGGL(kb_gather_senders, egrid, dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
-                               ptr<int>(c->rev), N, ptr<float>(c->g_proj), chunks16);
-            // relation propagator, receiver and sender columns
-            launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
-                             nullptr, nullptr, nullptr, 1, 1);
-            launch_wgrad<64>(c, ptr<float>(c->g_proj) + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
-                             1, nullptr, nullptr, nullptr, 1, 1);
-            hipLaunchKernelGGL(kb_project, rgrid, dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), chunks);
+        // node-level stages: on the matrix cores when the batch has enough 32-row tiles to fill the chip,
+        // otherwise the row kernels chunked over (sample, rows)
+        if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES) {
+            const float* mw = ptr<float>(c->w_mfma);
+            const float* mb = ptr<float>(c->w_mfma_bwd);
+            const long node_tiles = (long)B * ((N + 31) / 32);
+            const dim3 ngrid(mfma_grid(c, node_tiles)), nblk(64 * MFMA_WAVES);
+            // predictor
+            hipLaunchKernelGGL(kmb_predict, ngrid, nblk, KMB_PREDICT_LDS, st, mw, mb, eht + 3 * bn64, g_out, (size_t)N * 3, N, B,
+                               ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh));
+            launch_wgrad<64>(c, ptr<float>(c->tr_gh), 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
+                             nullptr, 1, 1);
+            launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
+            hipLaunchKernelGGL(kt_colsum3, dim3(16), dim3(256), 0, st, g_out, (long)bn, G + W_PR1_B);
+            // update of the last propagation step; then per step the edge terms and, in one launch, the
+            // projection of this step with the update of the one before (k_backward_mfma.h)
+            hipLaunchKernelGGL((kmb_node_step<false, true>), ngrid, nblk, KMB_STEP_LDS(false, true), st, mb, ptr<float>(c->g_eff),
+                               (const float*)nullptr, eht + (size_t)DRP_PSTEP * bn64, ptr<float>(c->g_cnode), 1,
+                               gah + (size_t)(DRP_PSTEP - 1) * bn64, N, B);
+            for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+                float* g_agg_p = gah + (size_t)p * bn64;
+                const unsigned* mask_p = mht + (size_t)p * bnk * 2;
+                // particle propagator, aggregate columns: g_eff holds the pre-activation gradient of step p
+                launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
+                                 nullptr, nullptr, nullptr, 1, 1);
+                hipLaunchKernelGGL(kb_recv_sum, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), chunks16);
+                hipLaunchKernelGGL(kb_gather_senders, egrid, dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
+                                   ptr<int>(c->rev), N, ptr<float>(c->g_proj), chunks16);
+                // relation propagator, receiver and sender columns
+                launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
+                                 nullptr, nullptr, nullptr, 1, 1);
+                launch_wgrad<64>(c, ptr<float>(c->g_proj) + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
+                                 1, nullptr, nullptr, nullptr, 1, 1);
+                if (p > 0)
+                    hipLaunchKernelGGL((kmb_node_step<true, true>), ngrid, nblk, KMB_STEP_LDS(true, true), st, mb,
+                                       ptr<float>(c->g_eff), ptr<float>(c->g_proj), eht + (size_t)p * bn64,
+                                       ptr<float>(c->g_cnode), 0, gah + (size_t)(p - 1) * bn64, N, B);
+                else
+                    hipLaunchKernelGGL((kmb_node_step<true, false>), ngrid, nblk, KMB_STEP_LDS(true, false), st, mb,
+                                       ptr<float>(c->g_eff), ptr<float>(c->g_proj), (const float*)nullptr, (float*)nullptr, 0,
+                                       (float*)nullptr, N, B);
+            }
+            // particle propagator, encoder columns + density column + bias; particle encoder
+            launch_wgrad<64>(c, ptr<float>(c->g_cnode), 64, eht, 64, (long)bn, G + W_PP_W, 129, 1, G + W_PP_B, G + W_PP_W + 128,
+                             dens, B, (long)N);
+            hipLaunchKernelGGL(kmb_node_encode, ngrid, nblk, KMB_NODE_ENCODE_LDS, st, mw, mb,
+                               ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), B, dens, B, eht,
+                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, B, ptr<float>(c->g_sdelta), ptr<float>(c->tr_gpe),
+                               ptr<float>(c->tr_a1n), ptr<float>(c->tr_gh1), ptr<float>(c->tr_xn));
+            launch_wgrad<64>(c, ptr<float>(c->tr_gpe), 64, ptr<float>(c->tr_a1n), 64, (long)bn, G + W_PE2_W, 64, 1, G + W_PE2_B,
+                             nullptr, nullptr, 1, 1);
+            launch_wgrad<5>(c, ptr<float>(c->tr_gh1), 64, ptr<float>(c->tr_xn), 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
+                            nullptr, nullptr, 1, 1);
+        } else {
+            // predictor
+            hipLaunchKernelGGL(kb_predict, rgrid, dim3(256), 0, st, vw, wraw, eht + 3 * bn64, g_out, (size_t)N * 3, N,
+                               ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh), chunks);
+            launch_wgrad<64>(c, ptr<float>(c->tr_gh), 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
+                             nullptr, 1, 1);
+            launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
+            hipLaunchKernelGGL(kt_colsum3, dim3(16), dim3(256), 0, st, g_out, (long)bn, G + W_PR1_B);
+            for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+                float* g_agg_p = gah + (size_t)p * bn64;
+                const unsigned* mask_p = mht + (size_t)p * bnk * 2;
+                hipLaunchKernelGGL(kb_update, rgrid, dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn64,
+                                   ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, chunks);
+                // particle propagator, aggregate columns: g_eff now holds the pre-activation gradient
+                launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
+                                 nullptr, nullptr, nullptr, 1, 1);
+                hipLaunchKernelGGL(kb_recv_sum, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), chunks16);
+                hipLaunchKernelGGL(kb_gather_senders, egrid, dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
+                                   ptr<int>(c->rev), N, ptr<float>(c->g_proj), chunks16);
+                // relation propagator, receiver and sender columns
+                launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
+                                 nullptr, nullptr, nullptr, 1, 1);
+                launch_wgrad<64>(c, ptr<float>(c->g_proj) + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
+                                 1, nullptr, nullptr, nullptr, 1, 1);
+                hipLaunchKernelGGL(kb_project, rgrid, dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), chunks);
+            }
+            // particle propagator, encoder columns + density column + bias; particle encoder
+            launch_wgrad<64>(c, ptr<float>(c->g_cnode), 64, eht, 64, (long)bn, G + W_PP_W, 129, 1, G + W_PP_B, G + W_PP_W + 128,
+                             dens, B, (long)N);
+            hipLaunchKernelGGL(kb_node_encode, rgrid, dim3(256), 0, st, vw, wraw,
+                               ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), B, dens, B, eht,
+                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta), ptr<float>(c->tr_gpe),
+                               ptr<float>(c->tr_a1n), ptr<float>(c->tr_gh1), ptr<float>(c->tr_xn), chunks);
+            launch_wgrad<64>(c, ptr<float>(c->tr_gpe), 64, ptr<float>(c->tr_a1n), 64, (long)bn, G + W_PE2_W, 64, 1, G + W_PE2_B,
+                             nullptr, nullptr, 1, 1);
+            launch_wgrad<5>(c, ptr<float>(c->tr_gh1), 64, ptr<float>(c->tr_xn), 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
+                            nullptr, nullptr, 1, 1);
         }
-        // particle propagator, encoder columns + density column + bias; particle encoder
-        launch_wgrad<64>(c, ptr<float>(c->g_cnode), 64, eht, 64, (long)bn, G + W_PP_W, 129, 1, G + W_PP_B, G + W_PP_W + 128,
-                         dens, B, (long)N);
-        hipLaunchKernelGGL(kb_node_encode, rgrid, dim3(256), 0, st, vw, wraw,
-                           ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), B, dens, B, eht,
-                           ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta), ptr<float>(c->tr_gpe),
-                           ptr<float>(c->tr_a1n), ptr<float>(c->tr_gh1), ptr<float>(c->tr_xn), chunks);
-        launch_wgrad<64>(c, ptr<float>(c->tr_gpe), 64, ptr<float>(c->tr_a1n), 64, (long)bn, G + W_PE2_W, 64, 1, G + W_PE2_B,
-                         nullptr, nullptr, 1, 1);
-        launch_wgrad<5>(c, ptr<float>(c->tr_gh1), 64, ptr<float>(c->tr_xn), 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
-                        nullptr, nullptr, 1, 1);
         // the previous step's output feeds this step as s_cur: residual + relation encoder
         float* g_prev = nullptr;
         if (t > 0) {

@@ -1,0 +1,246 @@
+// Node-level stages of the reverse-mode pass on the fp32 matrix cores (rows f1 / f4).
+// Each stage is a transposed dense product g_in = W^T g_out over B*N rows; computed like the
+// forward chain of k_mlp_mfma.h, D[in][item] = sum_out W^T[in][out] G[out][item], with W^T as the
+// packed A operand and the 32 rows of a tile on the lane columns (v_mfma_f32_32x32x2_f32: exact
+// fp32 products, fp32 accumulation).  The VALU versions (k_backward.h: kb_update, kb_project,
+// kb_predict, kb_node_encode) read their weights row by row from L2 and were latency bound:
+// 930 us of a 2.2 ms planner iteration.
+#pragma once
+#include "k_backward.h"
+#include "k_mlp_mfma.h"
+
+// transposed 64x64 blocks, packed like M_* ([ob 2][s4 8][lane 64][c 4])
+enum {
+    MB_AGG = 0,                 // W_agg^T
+    MB_RPR = MB_AGG + 4096,     // W_r^T
+    MB_RPS = MB_RPR + 4096,     // W_s^T
+    MB_PPE = MB_RPS + 4096,     // W_pe^T
+    MB_PE2 = MB_PPE + 4096,     // particle encoder layer 2, transposed
+    MB_PR0 = MB_PE2 + 4096,     // predictor layer 0, transposed
+    RB_PE0 = MB_PR0 + 4096,     // particle encoder layer 0, columns 0..2 as three 64-rows (d / d s_delta)
+    MB_TOTAL = RB_PE0 + 192
+};
+
+inline void pack_mfma_bwd(const float* w, std::vector<float>& m) {
+    m.assign(MB_TOTAL, 0.0f);
+    auto PT64 = [&](int dst, int src, int ld, int col0) {      // A[i][k] = W[k][col0 + i]
+        for (int ob = 0; ob < 2; ++ob)
+            for (int s = 0; s < 32; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, h = lane >> 5;
+                    m[dst + ((ob * 8 + (s >> 2)) * 64 + lane) * 4 + (s & 3)] =
+                        w[src + mfma_kidx(s, h) * ld + col0 + 32 * ob + i];
+                }
+    };
+    PT64(MB_AGG, W_PP_W, 129, 64);
+    PT64(MB_RPR, W_RP_W, 193, 64);
+    PT64(MB_RPS, W_RP_W, 193, 128);
+    PT64(MB_PPE, W_PP_W, 129, 0);
+    PT64(MB_PE2, W_PE2_W, 64, 0);
+    PT64(MB_PR0, W_PR0_W, 64, 0);
+    for (int c = 0; c < 3; ++c)
+        for (int o = 0; o < 64; ++o) m[RB_PE0 + c * 64 + o] = w[W_PE0_W + o * 5 + c];
+}
+
+// One propagation step of the backward pass on the node rows:
+//   PROJECT: g_eff += W_r^T g_proj[:, 0:64] + W_s^T g_proj[:, 64:128]          (kb_project)
+//   UPDATE : g_z = g_eff . [eff_next > 0]; g_eff <- g_z; g_cnode (+)= g_z; g_agg = W_agg^T g_z   (kb_update)
+// PROJECT of step p and UPDATE of step p-1 touch the same rows only: one launch does both.
+template <bool PROJECT, bool UPDATE>
+__global__ void __launch_bounds__(64 * MFMA_WAVES)
+kmb_node_step(const float* __restrict__ mb, float* __restrict__ g_eff, const float* __restrict__ g_proj,
+              const float* __restrict__ eff_next, float* __restrict__ g_cnode, int first, float* __restrict__ g_agg,
+              int N, int B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wr = lds;
+    float* ws = wr + (PROJECT ? 4096 : 0);
+    float* wa = ws + (PROJECT ? 4096 : 0);
+    if (PROJECT) { lds_fill(wr, mb + MB_RPR, 4096); lds_fill(ws, mb + MB_RPS, 4096); }
+    if (UPDATE) lds_fill(wa, mb + MB_AGG, 4096);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tps = (N + 31) >> 5;
+    const long ntiles = (long)B * tps;
+    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
+        const int i = min(t * 32 + j, N - 1);
+        const bool live = (t * 32 + j) < N;
+        const size_t row = (size_t)b * N + i;
+        Frag ge;
+        frag_from_row(g_eff + row * 64, h, ge);
+        if (PROJECT) {
+            Frag g;
+            frag_from_row(g_proj + row * 128, h, g);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(wr), g, ge, lane);
+            frag_from_row(g_proj + row * 128 + 64, h, g);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(ws), g, ge, lane);
+        }
+        if (UPDATE) {
+            Frag en, ga;
+            frag_from_row(eff_next + row * 64, h, en);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ge.v[0][r] = en.v[0][r] > 0.0f ? ge.v[0][r] : 0.0f;
+                ge.v[1][r] = en.v[1][r] > 0.0f ? ge.v[1][r] : 0.0f;
+            }
+            if (live) frag_to_row(g_eff + row * 64, h, ge);
+            if (!first) {
+                frag_from_row(g_cnode + row * 64, h, en);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { en.v[0][r] += ge.v[0][r]; en.v[1][r] += ge.v[1][r]; }
+                if (live) frag_to_row(g_cnode + row * 64, h, en);
+            } else if (live) {
+                frag_to_row(g_cnode + row * 64, h, ge);
+            }
+            frag_zero(ga);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(wa), ge, ga, lane);
+            if (live) frag_to_row(g_agg + row * 64, h, ga);
+        } else if (live) {
+            frag_to_row(g_eff + row * 64, h, ge);
+        }
+    }
+}
+#define KMB_STEP_LDS(PROJECT, UPDATE) ((size_t)(((PROJECT) ? 2 : 0) + ((UPDATE) ? 1 : 0)) * 4096 * sizeof(float))
+
+// predictor backward (kb_predict): g_eff = W0^T ((W1^T g_out) . [W0 eff + b0 > 0]); optional dumps of
+// relu(hidden) and of the hidden pre-activation gradient for the weight gradients
+__global__ void __launch_bounds__(64 * MFMA_WAVES)
+kmb_predict(const float* __restrict__ mw, const float* __restrict__ mb, const float* __restrict__ eff,
+            const float* __restrict__ g_out, size_t g_stride, int N, int B, float* __restrict__ g_eff,
+            float* __restrict__ dump_hact, float* __restrict__ dump_gh) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w0 = lds;                 // forward pack of predictor layer 0
+    float* w0t = w0 + 4096;          // transposed
+    float* rows = w0t + 4096;        // b_pr0 [64], w_pr1 [3][64]
+    lds_fill(w0, mw + M_PR0, 4096);
+    lds_fill(w0t, mb + MB_PR0, 4096);
+    lds_fill(rows, mw + R_PR0_B, 256);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tps = (N + 31) >> 5;
+    const long ntiles = (long)B * tps;
+    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
+        const int i = min(t * 32 + j, N - 1);
+        const bool live = (t * 32 + j) < N;
+        const size_t row = (size_t)b * N + i;
+        Frag x, hh, gh, ge;
+        frag_from_row(eff + row * 64, h, x);
+        frag_from_row(rows, h, hh);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(w0), x, hh, lane);
+        const float* go = g_out + (size_t)b * g_stride + (size_t)i * 3;
+        const float g0 = go[0], g1 = go[1], g2 = go[2];
+        {
+            Frag wx, wy, wz;
+            frag_from_row(rows + 64, h, wx);
+            frag_from_row(rows + 128, h, wy);
+            frag_from_row(rows + 192, h, wz);
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float g = wx.v[ob][r] * g0 + wy.v[ob][r] * g1 + wz.v[ob][r] * g2;
+                    gh.v[ob][r] = hh.v[ob][r] > 0.0f ? g : 0.0f;
+                }
+        }
+        frag_zero(ge);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(w0t), gh, ge, lane);
+        if (live) {
+            frag_to_row(g_eff + row * 64, h, ge);
+            if (dump_hact != nullptr) {
+                frag_relu(hh);
+                frag_to_row(dump_hact + row * 64, h, hh);
+                frag_to_row(dump_gh + row * 64, h, gh);
+            }
+        }
+    }
+}
+#define KMB_PREDICT_LDS ((size_t)(2 * 4096 + 256) * sizeof(float))
+
+// particle encoder backward (kb_node_encode): g_pe = g_eff0 + W_pe^T g_cnode, through
+// relu(W2 relu(W1 x + b1) + b2) to the three impulse inputs; optional dumps for the weight gradients
+__global__ void __launch_bounds__(64 * MFMA_WAVES)
+kmb_node_encode(const float* __restrict__ mw, const float* __restrict__ mb, const float* __restrict__ s_delta,
+                const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+                const float* __restrict__ pe, const float* __restrict__ g_eff0, const float* __restrict__ g_cnode,
+                int N, int B, float* __restrict__ g_sdelta, float* __restrict__ dump_gpe, float* __restrict__ dump_a1,
+                float* __restrict__ dump_gh1, float* __restrict__ dump_x) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w1 = lds;                 // forward pack of encoder layer 0 (K = 8, bias column)
+    float* wpet = w1 + 512;          // W_pe^T
+    float* w2t = wpet + 4096;        // layer 2, transposed
+    float* rows = w2t + 4096;        // layer-0 columns 0..2: [3][64]
+    lds_fill(w1, mw + M_PE0, 512);
+    lds_fill(wpet, mb + MB_PPE, 4096);
+    lds_fill(w2t, mb + MB_PE2, 4096);
+    lds_fill(rows, mb + RB_PE0, 192);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tps = (N + 31) >> 5;
+    const long ntiles = (long)B * tps;
+    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
+        const int i = min(t * 32 + j, N - 1);
+        const bool live = (t * 32 + j) < N;
+        const size_t row = (size_t)b * N + i;
+        const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+        const float* sd = s_delta + row * 3;
+        const float at = attr[(size_t)(b % attr_mod) * N + i];
+        float x[4];                  // inputs [sdx, sdy, sdz, a, d, 1, 0, 0]; this lane supplies index 2s + h
+        if (h == 0) { x[0] = sd[0]; x[1] = sd[2]; x[2] = d; x[3] = 0.0f; }
+        else { x[0] = sd[1]; x[1] = at; x[2] = 1.0f; x[3] = 0.0f; }
+        Frag h1, gpe, g, gh;
+        frag_zero(h1);
+        mfma_layer8(reinterpret_cast<const float4*>(w1), x, h1, lane);
+        frag_from_row(g_eff0 + row * 64, h, gpe);
+        frag_from_row(g_cnode + row * 64, h, g);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(wpet), g, gpe, lane);
+        frag_from_row(pe + row * 64, h, g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gpe.v[0][r] = g.v[0][r] > 0.0f ? gpe.v[0][r] : 0.0f;
+            gpe.v[1][r] = g.v[1][r] > 0.0f ? gpe.v[1][r] : 0.0f;
+        }
+        frag_zero(gh);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(w2t), gpe, gh, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gh.v[0][r] = h1.v[0][r] > 0.0f ? gh.v[0][r] : 0.0f;
+            gh.v[1][r] = h1.v[1][r] > 0.0f ? gh.v[1][r] : 0.0f;
+        }
+        float out[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            Frag w;
+            frag_from_row(rows + 64 * o, h, w);
+            float p = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p = fmaf(gh.v[0][r], w.v[0][r], p);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p = fmaf(gh.v[1][r], w.v[1][r], p);
+            out[o] = p + __shfl_xor(p, 32, 64);
+        }
+        if (live && h == 0) {
+            g_sdelta[row * 3 + 0] = out[0];
+            g_sdelta[row * 3 + 1] = out[1];
+            g_sdelta[row * 3 + 2] = out[2];
+        }
+        if (live && dump_gpe != nullptr) {
+            frag_to_row(dump_gpe + row * 64, h, gpe);
+            frag_to_row(dump_gh1 + row * 64, h, gh);
+            frag_relu(h1);
+            frag_to_row(dump_a1 + row * 64, h, h1);
+            if (h == 0) {
+                float* dx = dump_x + row * 8;
+                dx[0] = sd[0]; dx[1] = sd[1]; dx[2] = sd[2]; dx[3] = at; dx[4] = d; dx[5] = 0.0f; dx[6] = 0.0f; dx[7] = 0.0f;
+            }
+        }
+    }
+}
+// below this many 32-row tiles the chunked VALU row kernels of k_backward.h are faster (a workgroup's
+// LDS fill of the packed weights is not amortised)
+#define KMB_MIN_TILES 1024
+#define KMB_NODE_ENCODE_LDS ((size_t)(512 + 2 * 4096 + 192) * sizeof(float))

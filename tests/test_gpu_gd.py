@@ -103,3 +103,27 @@ def test_gradients_are_reproducible_and_both_list_paths_agree(ctx, golden, monke
             res.append(g0)
         np.testing.assert_array_equal(res[0], res[1])
     other.close()
+
+
+@pytest.mark.parametrize('case', ['h1', 'h2'])
+def test_large_batches_take_the_matrix_core_node_kernels(ctx, golden, case):
+    """With >= 1024 tiles of 32 rows the node-level backward stages run on the fp32 matrix cores
+    (k_backward_mfma.h) instead of the chunked row kernels: the reference's case replicated to
+    that size must give the reference's gradients in every replica."""
+    g = golden.grad
+    B0 = g[case + '/act_seqs'].shape[0]
+    N = g[case + '/s_cur'].shape[1]
+    reps = -(-1100 // (B0 * ((N + 31) // 32)))
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    ctx.set_goal(syn.goal_field(obs_goal), g[case + '/goal_coor'])
+    lo, hi = syn.action_limits()
+    acts = np.tile(g[case + '/act_seqs'], (reps, 1, 1))           # row = sample * n_batch + batch
+    assert acts.shape[0] * ((N + 31) // 32) >= 1024
+    ctx.gd_begin(g[case + '/s_cur'], g[case + '/attr'], g[case + '/dens'], acts, 0.05, lo, hi)
+    r, ga, _ = ctx.gd_grad()
+    ref_ga = np.tile(g[case + '/grad_act'], (reps, 1, 1))
+    np.testing.assert_allclose(r, np.tile(g[case + '/reward'][:, 0], reps), rtol=2e-5)
+    assert np.abs(ga - ref_ga).max() < 2e-3 * np.abs(ref_ga).max()
+    assert np.abs(ga - ref_ga).max() < 1e-4
+    # replicas are independent samples: identical bits
+    np.testing.assert_array_equal(ga[:B0], ga[-B0:])
