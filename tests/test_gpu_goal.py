@@ -78,3 +78,13 @@ def test_set_goal_image_errors(eng):
         eng.set_goal_image(obs_goal, 10, fps_init=10 ** 7)
     with pytest.raises(KeyError):
         eng.set_goal_image(obs_goal, 10, mode='l1')
+
+
+def test_transform_edge_shapes(eng):
+    one_row = np.array([[1, 1, 0, 1, 1, 1, 1, 0, 1]], np.uint8)
+    for src in (one_row, one_row.T.copy(), np.zeros((5, 7), np.uint8), np.array([[0]], np.uint8),
+                np.pad(np.zeros((1, 1), np.uint8), 3, constant_values=1)):
+        np.testing.assert_array_equal(eng.distance_transform(src, 'cv5'), og.distance_transform_cv5(src))
+        np.testing.assert_array_equal(eng.distance_transform(src, 'exact'), og.distance_transform_edt(src))
+    with pytest.raises(KeyError):
+        eng.distance_transform(one_row, 'l1')

@@ -153,3 +153,36 @@ def test_host_mirror_seeded_starts(eng):
     blank[..., -1] = 18.0
     with pytest.raises(DrpError):
         dev.obs2ptcl_fixed_num_batch(blank, 100, 2, cam, 24.0)
+
+
+def test_edge_cases_small_clouds(eng):
+    """Degenerate shapes the environment can hand over: one-voxel clouds, as many particles as
+    voxels, one particle, a radius that swallows the whole cloud."""
+    rng = np.random.default_rng(0)
+    # every point in one voxel -> one output point = their mean (summed in index order)
+    blob = 0.5 + 1e-3 * rng.uniform(size=(37, 3))
+    down = dev.downsample_pcd(blob, 0.01)
+    np.testing.assert_array_equal(down, orc.downsample_pcd(blob, 0.01))
+    assert down.shape == (1, 3)
+    one = dev.downsample_pcd(blob[:1], 0.01)
+    np.testing.assert_array_equal(one, blob[:1])
+    # as many samples as points: a permutation of the cloud, radius 0 up to float32 rounding of the samples
+    cloud = rng.uniform(-0.2, 0.2, (50, 3)) + [0, 0, 0.7]
+    pts, r = eng.fps_pcd(cloud, 50, [3])
+    want, want_r = orc.fps(cloud, 50, 3)
+    np.testing.assert_array_equal(pts[0], want)
+    assert r[0] == want_r and r[0] < 1e-7
+    assert len({tuple(p) for p in pts[0]}) == 50
+    p1, r1 = eng.fps_pcd(cloud, 1, [7])
+    w1, wr1 = orc.fps(cloud, 1, 7)
+    np.testing.assert_array_equal(p1[0], w1)
+    assert r1[0] == wr1
+    # recentering radius larger than the cloud: every sample becomes the cloud's mean
+    rec = dev.recenter(cloud, pts[0][:5], r=10.0)
+    np.testing.assert_array_equal(rec, orc.recenter(cloud, pts[0][:5], r=10.0))
+    assert np.abs(rec - cloud.mean(0).astype(np.float32)).max() < 1e-6
+    # a 1 x W and an H x 1 depth image
+    cam = [100.0, 100.0, 3.0, 0.0]
+    row = np.array([[0.5, 0.9, 0.0, 0.6, 0.7, -1.0, 0.3]], np.float32)
+    for img in (row, row.T.copy()):
+        np.testing.assert_array_equal(dev.depth2fgpcd(img, img < 0.74875, cam), orc.depth2fgpcd(img, img < np.float32(0.74875), cam))

@@ -99,3 +99,33 @@ def test_collate_fn_pads_like_the_reference():
     assert st.dtype == np.float32 and pn.dtype == np.int32 and pd.dtype == np.float32
     assert (st[0, :, 5:] == 0).all() and (st[2, :, 3:] == 0).all()
     np.testing.assert_allclose(st[1], data[1][0].astype(np.float32))
+
+
+def test_tiny_and_unpadded_batches(golden):
+    """B = 1, a sample of 3 particles (fewer than the in-degree cap), and a batch without padding,
+    against the dense torch-autograd oracle."""
+    from oracle import propnet_dense as od
+    model = _model(golden)
+    W = {k[2:]: golden.weights_seed0[k] for k in golden.weights_seed0.files if k.startswith('w/')}
+    rng = np.random.default_rng(0)
+    for nums, T in (([3], 2), ([20, 20], 3), ([7, 1], 1)):
+        B, N = len(nums), max(nums)
+        states = np.zeros((B, T + 1, N, 3), np.float32)
+        sdelta = np.zeros((B, T, N, 3), np.float32)
+        attrs = np.zeros((B, T + 1, N), np.float32)
+        dens = np.array([300.0 + 50 * b for b in range(B)], np.float32)
+        for b, n in enumerate(nums):
+            s, _, _ = syn.make_pile(n, 1, seed=5 + b, kind='blob')
+            for t in range(T + 1):
+                states[b, t, :n] = s[0] * 0.3 + 0.002 * t * rng.standard_normal((n, 3)).astype(np.float32) + [0, 0, 0.52]
+            sdelta[b, :, :n] = 0.004 * rng.standard_normal((T, n, 3)).astype(np.float32)
+        pn = np.asarray(nums, np.int32)
+        model.engine.train_begin(T, 1e-3, 0.9)
+        loss, grad = model.engine.train_step(states, sdelta, attrs, pn, dens, mode='grad', want_grad=True)
+        ref_loss, ref_grads = od.train_loss_and_grads(W, states, sdelta, attrs, pn, dens)
+        assert abs(loss - ref_loss) < 1e-4 * abs(ref_loss)
+        got = weights.state_dict_from_blob(grad)
+        for k, _ in weights.STATE_DICT_KEYS:
+            scale = max(np.abs(ref_grads[k]).max(), 1e-8)
+            assert np.abs(np.asarray(got[k]).reshape(ref_grads[k].shape) - ref_grads[k]).max() < 5e-4 * scale + 1e-9, (nums, k)
+    model.engine.close()
