@@ -93,6 +93,8 @@ SIGNATURES = {
                                           ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     'drp_fps_pcd': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.POINTER(ctypes.c_int32), ctypes.c_uint64, c_float_p, c_double_p]),
+    'drp_fps_rad': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                   ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int)]),
     'drp_recenter': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int,
                                     c_double_p, c_float_p]),
     'drp_obs2ptcl': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,

@@ -1116,6 +1116,25 @@ int drp_fps_pcd(drp_ctx* c, const double* pcd, int n, int npoints, int batch, co
     return drp_sync(c);
 }
 
+int drp_fps_rad(drp_ctx* c, const double* pcd, int n, double radius, int init_idx, int cap, int32_t* idx_out,
+                int* count_out) {
+    if (!c || !pcd || !idx_out || !count_out) return fail(c, DRP_EINVAL, "null argument");
+    if (n <= 0 || cap <= 0 || init_idx < 0 || init_idx >= n || !(radius >= 0.0))
+        return fail(c, DRP_EINVAL, "bad fps_rad arguments n=%d cap=%d init=%d radius=%g", n, cap, init_idx, radius);
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(h2d(c, c->px_down, pcd, (size_t)n * 3 * sizeof(double)));
+    CHK(ensure(c, c->px_dist, (size_t)n * sizeof(double)));
+    CHK(ensure(c, c->px_chosen, (size_t)(cap + 1) * sizeof(int)));
+    int* chosen = ptr<int>(c->px_chosen);
+    hipLaunchKernelGGL(k_px_fps_rad, dim3(1), dim3(1024), 0, c->stream, ptr<double>(c->px_down), n, radius, init_idx, cap,
+                       ptr<double>(c->px_dist), chosen, chosen + cap);
+    HIPCHK(c, hipGetLastError());
+    CHK(d2h(c, count_out, chosen + cap, sizeof(int)));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(d2h(c, idx_out, chosen, (size_t)*count_out * sizeof(int)));
+    return drp_sync(c);
+}
+
 int drp_recenter(drp_ctx* c, const double* pcd, int n, const float* sampled, int npoints, int batch, const double* r,
                  float* out) {
     if (!c || !pcd || !sampled || !r || !out) return fail(c, DRP_EINVAL, "null argument");

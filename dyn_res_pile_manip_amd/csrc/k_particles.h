@@ -450,3 +450,51 @@ k_px_recenter(const double* __restrict__ pcd, int m, const float* __restrict__ s
         if (out64) out64[(size_t)wid * 3 + lane] = (double)f;
     }
 }
+
+// utils.py:438-449 fps_rad: farthest-point sampling of a float64 cloud until every point is within
+// `radius` of a sample (the dataset's particle sampler, dataset/dataset_gnn_dyn.py:99).  One
+// workgroup; distances as np.linalg.norm evaluates them in float64, first maximum as np.argmax.
+__global__ void __launch_bounds__(1024)
+k_px_fps_rad(const double* __restrict__ pcd, int n, double radius, int init_idx, int cap, double* __restrict__ dist,
+             int* __restrict__ chosen, int* __restrict__ count_out) {
+    __shared__ double sval[16];
+    __shared__ int sidx[16];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int last = init_idx, count = 1;
+    if (tid == 0) chosen[0] = init_idx;
+    for (int it = 0;; ++it) {
+        const double lx = pcd[(size_t)last * 3], ly = pcd[(size_t)last * 3 + 1], lz = pcd[(size_t)last * 3 + 2];
+        double best = -1.0;
+        int arg = 0x7fffffff;
+        for (int i = tid; i < n; i += 1024) {
+            const double dx = pcd[(size_t)i * 3] - lx, dy = pcd[(size_t)i * 3 + 1] - ly, dz = pcd[(size_t)i * 3 + 2] - lz;
+            double nd = sqrt((dx * dx + dy * dy) + dz * dz);
+            if (it > 0) nd = fmin(dist[i], nd);
+            dist[i] = nd;
+            if (nd > best) { best = nd; arg = i; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(arg, off, 64);
+            if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { sval[wave] = best; sidx[wave] = arg; }
+        __syncthreads();
+        if (tid == 0) {
+            double bv = sval[0];
+            int bi = sidx[0];
+            for (int w = 1; w < 16; ++w)
+                if (sval[w] > bv || (sval[w] == bv && sidx[w] < bi)) { bv = sval[w]; bi = sidx[w]; }
+            s_last = (bv > radius && count < cap) ? bi : -1;      // while dist.max() > radius: append
+            if (s_last >= 0) chosen[count] = bi;
+        }
+        __syncthreads();
+        last = s_last;
+        if (last < 0) break;
+        ++count;
+    }
+    if (tid == 0) *count_out = count;
+}

@@ -316,6 +316,18 @@ class Engine(object):
                                       _fp(pts), _dp(r)))
         return pts, r
 
+    def fps_rad(self, pcd, radius, init_idx, cap=None):
+        """utils.fps_rad on the device -> (pcd[chosen] float64, chosen indices)."""
+        pcd = _f64(pcd)
+        n = pcd.shape[0]
+        cap = int(cap or n)
+        idx = np.empty((cap,), np.int32)
+        cnt = ctypes.c_int()
+        self._ck(self.lib.drp_fps_rad(self.h, _dp(pcd), n, float(radius), int(init_idx), cap,
+                                      idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.byref(cnt)))
+        idx = idx[:cnt.value].copy()
+        return pcd[idx], idx
+
     def recenter(self, pcd, sampled, r):
         """utils.recenter for a batch: sampled [batch,N,3] float32, r [batch] -> [batch,N,3] float32."""
         pcd, sampled = _f64(pcd), _f32(sampled)

@@ -50,6 +50,14 @@ def fps(pcd, particle_num, init_idx=-1):
     return pts[0], float(r[0])
 
 
+def fps_rad(pcd, radius, init_idx=-1):
+    """utils.py:438-449 -> pcd_fps [m,3] float64 (m decided by the radius)."""
+    pcd = np.asarray(pcd, dtype=np.float64)
+    if init_idx == -1:
+        init_idx = np.random.randint(pcd.shape[0])
+    return get_engine().fps_rad(pcd, radius, init_idx)[0]
+
+
 def fps_np(pcd, particle_num, init_idx=-1):
     """utils.py:451-466 for 2-D / 3-D float32 point lists -> (pcd[chosen], dist.max())."""
     pcd = np.asarray(pcd)

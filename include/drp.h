@@ -219,6 +219,13 @@ int drp_downsample_pcd(drp_ctx* ctx, const double* pcd, int n, double voxel, dou
 int drp_fps_pcd(drp_ctx* ctx, const double* pcd, int n, int npoints, int batch, const int32_t* init_idx,
                 uint64_t seed, float* pts_out, double* r_out);
 
+/* utils.py:438-449 fps_rad(pcd, radius): farthest-point sampling of the float64 cloud from
+ * `init_idx` (the reference draws it from numpy's global generator) until every point is within
+ * `radius` of a sample -- the dataset's sampler (dataset/dataset_gnn_dyn.py:99).  idx_out holds
+ * up to `cap` indices into pcd, count_out how many were chosen (cap reached: sampling stops). */
+int drp_fps_rad(drp_ctx* ctx, const double* pcd, int n, double radius, int init_idx, int cap, int32_t* idx_out,
+                int* count_out);
+
 /* utils.py:468-477 recenter(pcd, sampled_pcd, r): out[b, j] = float32 mean of the cloud points
  * with |p - sampled[b, j]| < r[b] (NaN when there is none, as numpy's mean of an empty set). */
 int drp_recenter(drp_ctx* ctx, const double* pcd, int n, const float* sampled, int npoints, int batch,

@@ -107,6 +107,18 @@ def main():
         out[name + '/batch_ptcl'] = b_ptcl
         out[name + '/batch_r'] = b_r
         print(name, 'fg', fg.shape, 'down', down.shape, 'r', r, b_ptcl.dtype, rec.dtype)
+    # utils.fps_rad (utils.py:438-449), the dataset's radius-terminated sampler, on the raw foreground cloud
+    for name, radius in (('small', 0.03), ('mid', 0.045)):
+        fg = out[name + '/fgpcd']
+        np.random.seed(21)
+        start = int(np.random.randint(fg.shape[0]))          # what fps_rad draws first
+        np.random.seed(21)
+        sel = ref_utils.fps_rad(fg, radius)
+        assert np.array_equal(sel[0], fg[start])
+        out[name + '/fps_rad_radius'] = np.array(radius)
+        out[name + '/fps_rad_start'] = np.array(start)
+        out[name + '/fps_rad_pts'] = sel
+        print(name, 'fps_rad', radius, '->', sel.shape[0], 'points')
     # utils.fps_np (utils.py:451-466), the numpy sampler used for the goal pixels
     rng = np.random.default_rng(3)
     pts2 = rng.integers(0, 720, (2000, 2)).astype(np.float32)

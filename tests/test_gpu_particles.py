@@ -186,3 +186,19 @@ def test_edge_cases_small_clouds(eng):
     row = np.array([[0.5, 0.9, 0.0, 0.6, 0.7, -1.0, 0.3]], np.float32)
     for img in (row, row.T.copy()):
         np.testing.assert_array_equal(dev.depth2fgpcd(img, img < 0.74875, cam), orc.depth2fgpcd(img, img < np.float32(0.74875), cam))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_fps_rad(gold, name, eng):
+    fg = gold[name + '/fgpcd']
+    radius, start = float(gold[name + '/fps_rad_radius']), int(gold[name + '/fps_rad_start'])
+    pts, idx = eng.fps_rad(fg, radius, start)
+    np.testing.assert_array_equal(pts, gold[name + '/fps_rad_pts'])
+    assert idx[0] == start and len(set(idx.tolist())) == idx.shape[0]
+    # every cloud point ends within the radius of a sample; a capped call stops early
+    d = np.linalg.norm(fg[:, None, :] - pts[None, ::1, :], axis=2).min(1)
+    assert d.max() <= radius
+    few, _ = eng.fps_rad(fg, radius, start, cap=5)
+    np.testing.assert_array_equal(few, pts[:5])
+    np.random.seed(21)
+    np.testing.assert_array_equal(dev.fps_rad(fg, radius), pts)

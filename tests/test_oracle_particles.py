@@ -72,3 +72,9 @@ def test_fps_np(gold):
     sel, md = orc.fps_np(gold['fpsnp/pts'], 50, 3)
     np.testing.assert_array_equal(sel, gold['fpsnp/sel'])
     assert md == gold['fpsnp/max_dist']
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_fps_rad(gold, name):
+    pts, _ = orc.fps_rad(gold[name + '/fgpcd'], float(gold[name + '/fps_rad_radius']), int(gold[name + '/fps_rad_start']))
+    np.testing.assert_array_equal(pts, gold[name + '/fps_rad_pts'])
