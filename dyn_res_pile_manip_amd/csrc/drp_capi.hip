@@ -932,12 +932,14 @@ int drp_fps(drp_ctx* c, const float* pts, int n, int dim, int k, int init_idx, i
     int* chosen = reinterpret_cast<int*>(dist + n);
     CHK(ensure(c, c->stats, 8 * sizeof(double)));
     float* md = reinterpret_cast<float*>(ptr<double>(c->stats) + 7);
-    if (dim == 2)
-        hipLaunchKernelGGL(k_fps<2>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, dist,
-                           chosen, md);
-    else
-        hipLaunchKernelGGL(k_fps<3>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, dist,
-                           chosen, md);
+    const bool in_regs = n <= 1024 * FPS_REG_PT(dim);
+    if (dim == 2) {
+        if (in_regs) hipLaunchKernelGGL(k_fps_reg<2>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, chosen, md);
+        else hipLaunchKernelGGL(k_fps<2>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, dist, chosen, md);
+    } else {
+        if (in_regs) hipLaunchKernelGGL(k_fps_reg<3>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, chosen, md);
+        else hipLaunchKernelGGL(k_fps<3>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, dist, chosen, md);
+    }
     HIPCHK(c, hipGetLastError());
     CHK(d2h(c, idx_out, chosen, (size_t)k * sizeof(int)));
     if (max_dist_out) CHK(d2h(c, max_dist_out, md, sizeof(float)));
@@ -1250,7 +1252,10 @@ int drp_set_goal_image(drp_ctx* c, const float* obs_goal, int h, int w, int mode
     float* fdist = ptr<float>(c->gl_fps);
     int* chosen = reinterpret_cast<int*>(fdist + count);
     float* md = reinterpret_cast<float*>(chosen + m);
-    hipLaunchKernelGGL(k_fps<2>, dim3(1), dim3(1024), 0, st, ptr<float>(c->gl_pix), count, m, fps_init, fdist, chosen, md);
+    if (count <= 1024 * FPS_REG_PT(2))
+        hipLaunchKernelGGL(k_fps_reg<2>, dim3(1), dim3(1024), 0, st, ptr<float>(c->gl_pix), count, m, fps_init, chosen, md);
+    else
+        hipLaunchKernelGGL(k_fps<2>, dim3(1), dim3(1024), 0, st, ptr<float>(c->gl_pix), count, m, fps_init, fdist, chosen, md);
     CHK(ensure(c, c->goal_coor, (size_t)m * 2 * sizeof(float)));
     hipLaunchKernelGGL(k_goal_gather, dim3((m + 255) / 256), dim3(256), 0, st, ptr<float>(c->gl_pix), chosen, m,
                        ptr<float>(c->goal_coor));
