@@ -42,6 +42,17 @@ __global__ void __launch_bounds__(512) k(float* out, int iters, float seed) {
 #pragma unroll
             for (int u = 0; u < 56; ++u) v[u % 24] = fmaf(v[u % 24], 1.0001f, 0.5f);
             for (int i = 0; i < 8; ++i) b[i] = (__bf16)v[i];
+        } else if (MODE == 6) {    // 72 v_dot2c_f32_bf16 on independent accumulators
+#pragma unroll
+            for (int q = 0; q < 72; ++q)
+                asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(v[q % 24]) : "v"(__float_as_uint(v[(q + 7) % 24])), "v"(0xBF800000u));
+        } else if (MODE == 7) {    // 36 v_cvt_pk_bf16_f32 (two values each)
+#pragma unroll
+            for (int q = 0; q < 36; ++q) {
+                unsigned r;
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v[q % 24]), "v"(v[(q + 1) % 24]));
+                v[q % 24] = __uint_as_float(r & 0xffff0000u);
+            }
         } else if (MODE == 5) {    // 72 v_cvt_pk_bf16_f32-style conversions
 #pragma unroll
             for (int q = 0; q < 72; ++q) { __bf16 t = (__bf16)v[q % 24]; v[q % 24] += (float)t; }
@@ -81,6 +92,8 @@ int main() {
         run<3>("12 dependent MFMA interleaved with 72 independent v_fma", w, d);
         run<4>("12 MFMA -> 72 dependent v_fma -> next MFMA operand", w, d);
         run<5>("72 f32->bf16->f32 round trips", w, d);
+        run<6>("72 v_dot2c_f32_bf16", w, d);
+        run<7>("36 v_cvt_pk_bf16_f32 + 36 v_and", w, d);
     }
     return 0;
 }
