@@ -424,9 +424,17 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tps = (N + 31) >> 5;
-    const long ntiles = (long)B * tps;
-    for (long gt = (long)blockIdx.x * PROP_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * PROP_WAVES) {
-        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
+    // one and its L2), so the tiles of a sample -- which gather the same ~150 KB of sender rows -- all go
+    // to workgroups of one residue class of blockIdx.  A placement guess only: wrong means slower, not wrong.
+    const int ngroups = min(8, (int)gridDim.x);
+    const int grp = blockIdx.x % ngroups;
+    const int blocks_in_grp = ((int)gridDim.x - grp + ngroups - 1) / ngroups;
+    const int samples_in_grp = (B - grp + ngroups - 1) / ngroups;
+    const long grp_tiles = (long)(samples_in_grp > 0 ? samples_in_grp : 0) * tps;
+    for (long lt = (long)(blockIdx.x / ngroups) * PROP_WAVES + wave; lt < grp_tiles; lt += (long)blocks_in_grp * PROP_WAVES) {
+        const int m = (int)(lt / tps), t = (int)(lt - (long)m * tps);
+        const int b = grp + ngroups * m;
         const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
         const float* at = attr + (size_t)(b % attr_mod) * N;
         const float* pj = proj + (size_t)b * N * 128;

@@ -23,12 +23,21 @@ CLASS = {'k_graph': 'graph', 'k_node_encode': 'node_encode', 'k_edge_encode': 'e
          'km_prop<false>': 'prop', 'km_prop<true>': 'prop_last'}
 
 
+def norm(name):
+    # km_prop gained a second template argument (tape); both spellings mean the same kernel here
+    if name.startswith('km_prop<false'):
+        return 'km_prop<false>'
+    if name.startswith('km_prop<true'):
+        return 'km_prop<true>'
+    return name
+
+
 def per_kernel(path, counter):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
-        name = r['Kernel_Name'].split('(')[0].replace('void ', '').strip()
+        name = norm(r['Kernel_Name'].split('(')[0].replace('void ', '').strip())
         d[name].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in d.items()}, {k: len(v) for k, v in d.items()}
 
