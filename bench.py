@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3      # dense fp32 (vector == f32-input MFMA rate)
-PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA
+PEAK_BF16_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA (same rate)
 KERNEL_CLASSES = ['graph', 'node_encode', 'edge_encode', 'project', 'aggregate', 'update',
                   'predict', 'reward', 'mppi', 'prop']
 # algorithmic work of one LAUNCH of each class, per particle (node) or per edge
@@ -209,12 +209,12 @@ def main():
         if dominant == 'prop':
             # km_prop: per 32-receiver tile, one 78-MFMA chain (the 3-term split
             # relation encoder) per slot iteration + the 6-term split node layers (144 MFMAs, 96 in
-            # the last step); roofline on the bf16 FLOPs actually EXECUTED, 2*32*32*16 per MFMA
+            # the last step); roofline on the 16-bit FLOPs actually EXECUTED, 2*32*32*16 per MFMA
             mfmas = tiles * (slots_per_tile * 78 + (2 * 144 + 96) / 3.0)
             work = mfmas * 32768.0
             alg = B * N * (kbar * FLOP_PER_EDGE_ENCODE + 2 * 64 * 64 * (1 + 2 * 2 / 3.0 + 1 / 3.0))
             roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                    'mfma_dtype': 'bf16 operands (fp32 values split in 2 or 3 bf16 terms), fp32 accumulate',
+                    'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
                     'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile}
         elif dominant == 'aggregate':
             work = B * N * (2 * kbar + 2) * 256.0
@@ -246,7 +246,7 @@ def main():
             'value': total / dt, 'unit': 'particle-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if engine in ('valu', 'mfma') else 'f32 (MLP products as split-bf16 MFMA terms, fp32 accumulate)',
+            'dtype': 'f32' if engine in ('valu', 'mfma') else 'f32 (MLP products as split fp16 / bf16 MFMA terms, fp32 accumulate)',
             'data': 'synthetic',
             'config': {'workload': '%d-particle pile, %d MPPI samples per GPU, %d-step horizon '
                                    '(BASELINE configs[%d])' % (N, ns, H, 1 if world == 1 else 2),

@@ -1,17 +1,23 @@
-// Split-bf16 ("bf16x3") MFMA version of the relation encoder chain.
+// Split-precision MFMA version of the relation encoder chain.
 //
-// fp32 MFMA runs at 1/16 of the bf16 MFMA rate on gfx950 and there is no TF32 path, so the
+// fp32 MFMA runs at 1/16 of the 16-bit MFMA rate on gfx950 and there is no TF32 path, so the
 // fp32 chain of k_mlp_mfma.h is bound by the matrix pipe (69 % of the fp32 peak measured).
-// Here every fp32 operand is split into two bf16 pieces, x = x_hi + x_lo (round-to-nearest
-// twice, |x - x_hi - x_lo| <= 2^-18 |x|), weights are split the same way on the host, and
-// each product is formed as  W_lo x_hi + W_hi x_lo + W_hi x_hi  with fp32 accumulation inside
-// v_mfma_f32_32x32x16_bf16 (products of bf16 pairs are exact in fp32).  The dropped
-// W_lo x_lo term is <= 2^-18 relative: measured against the reference, the predicted
-// displacement differs by 2.2e-6 relative (fp32 chain: 5.9e-7; parity bound 1e-4), i.e.
-// 9e-9 absolute on positions whose fp32 ulp is 6e-8.  3 bf16 MFMAs of 32 cycles replace
-// 8 fp32 MFMAs of 64 cycles: 5.3x less matrix-pipe time.
+// Here every fp32 operand is written as a sum of two fp16 pieces, x = x_hi + x_lo, weights are
+// split the same way on the host, and each product is formed as
+//     W_lo x_hi + W_hi x_lo + W_hi x_hi
+// with fp32 accumulation inside v_mfma_f32_32x32x16_f16 (a product of two fp16 values has 22
+// significant bits: exact in fp32).  x_hi is x rounded toward zero to fp16 (v_cvt_pkrtz_f16_f32,
+// two values per instruction), the residual x - x_hi is exact in fp32 and is itself rounded to
+// fp16, so |x - x_hi - x_lo| < 2^-20 |x|; the dropped W_lo x_lo term is < 2^-21 relative.  The
+// residuals are fp16 SUBNORMALS for |x| < 0.06: the matrix cores honour them (checked operand by
+// operand, tools/f16_denorm_test.hip).  fp16 tops out at 65 504: activations of this network are
+// O(1); beyond that x_hi saturates (round toward zero never produces inf) and the result is wrong
+// but finite.  3 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles: 5.3x less matrix-pipe time.
+// (The first version split into bf16 pairs: same MFMA count, but v_cvt_pk_bf16_f32 issues at about a
+// third of the rate of v_cvt_pkrtz_f16_f32 -- tools/mfma_bench.hip -- and carries 3 bits less.)
+// The node layers (6-term split further down) stay on three bf16 pieces.
 //
-// Same transposed register chain as k_mlp_mfma.h.  For v_mfma_f32_32x32x16_bf16 the B
+// Same transposed register chain as k_mlp_mfma.h.  For v_mfma_f32_32x32x16_{f16,bf16} the B
 // operand of lane (col j, half h) is 8 consecutive k: k = 8h + jj; the C/D registers
 // 8(s&1)..8(s&1)+7 of output block ob = s>>1 are fed as k-step s, so the weights are packed
 // with   feature(s,h,jj) = 32(s>>1) + (r&3) + 8(r>>2) + 4h,  r = 8(s&1) + jj.
@@ -23,8 +29,10 @@
 #include "k_mlp_mfma.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
 
-// ---- packed split weights, in units of bf16x8 (16 bytes).  64x64: [part 2][ob 2][s 4][lane 64]
+// ---- packed split weights of the edge chain, in units of f16x8 (16 bytes).  64x64: [part 2][ob 2][s 4][lane 64]
 enum {
     S_RE0 = 0,                 // first layer, one k-step: [part 2][ob 2][lane 64]
     S_RE2 = S_RE0 + 256,
@@ -48,18 +56,31 @@ inline float host_bf16_to_f32(uint16_t h) {
     return f;
 }
 
+inline uint16_t host_f16_rne(float f) {      // host pass of hipcc is clang: _Float16 converts with round-to-nearest-even
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+inline float host_f16_to_f32(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
+
 inline int split_feature(int s, int h, int jj) {
     const int r = 8 * (s & 1) + jj;
     return 32 * (s >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
 }
 
-// host: state_dict blob -> split-bf16 fragments (uint16 storage, 8 per bf16x8)
+// host: state_dict blob -> split-fp16 fragments (uint16 storage, 8 per f16x8)
 inline void pack_split(const float* w, std::vector<uint16_t>& out) {
     out.assign((size_t)S_TOTAL * 8, 0);
     auto put = [&](int unit, int jj, int part, float v) {
-        // unit = index of the hi bf16x8; the lo copy sits `part_stride` units later (given by caller)
+        // unit = index of the hi f16x8; the lo copy sits `part_stride` units later (given by caller)
         (void)part;
-        out[(size_t)unit * 8 + jj] = host_bf16_rne(v);
+        out[(size_t)unit * 8 + jj] = host_f16_rne(v);
     };
     auto P64 = [&](int dst, int src, int ld, int col0) {
         for (int ob = 0; ob < 2; ++ob)
@@ -68,7 +89,7 @@ inline void pack_split(const float* w, std::vector<uint16_t>& out) {
                     for (int jj = 0; jj < 8; ++jj) {
                         const int i = lane & 31, h = lane >> 5;
                         const float v = w[src + (32 * ob + i) * ld + col0 + split_feature(s, h, jj)];
-                        const float hi = host_bf16_to_f32(host_bf16_rne(v));
+                        const float hi = host_f16_to_f32(host_f16_rne(v));
                         put(dst + ((0 * 2 + ob) * 4 + s) * 64 + lane, jj, 0, hi);
                         put(dst + ((1 * 2 + ob) * 4 + s) * 64 + lane, jj, 1, v - hi);
                     }
@@ -81,7 +102,7 @@ inline void pack_split(const float* w, std::vector<uint16_t>& out) {
                 float v = 0.0f;
                 if (h == 0 && jj < 6) v = w[W_RE0_W + o * 6 + jj];
                 else if (h == 0 && jj == 6) v = w[W_RE0_B + o];
-                const float hi = host_bf16_to_f32(host_bf16_rne(v));
+                const float hi = host_f16_to_f32(host_f16_rne(v));
                 put(S_RE0 + (0 * 2 + ob) * 64 + lane, jj, 0, hi);
                 put(S_RE0 + (1 * 2 + ob) * 64 + lane, jj, 1, v - hi);
             }
@@ -91,30 +112,41 @@ inline void pack_split(const float* w, std::vector<uint16_t>& out) {
 }
 
 struct FragB {
-    bf16x8 hi[4], lo[4];      // per 16-deep k-step
+    f16x8 hi[4], lo[4];      // per 16-deep k-step
 };
+
+// two values -> their fp16 hi pair (round toward zero) and the fp16 pair of the exact residuals
+__device__ __forceinline__ void split_pair(float x0, float x1, f16x8& hi, f16x8& lo, int q) {
+    const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    // residuals x - hi in one v_fma_mix_f32 each (the fp16 half is read in place; written as asm because
+    // the compiler folds the multiplication by -1 into a convert + subtract)
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(r0), "=&v"(r1) : "v"(h), "v"(x0), "v"(x1));
+    const fp16x2_t l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi[2 * q] = (_Float16)h[0]; hi[2 * q + 1] = (_Float16)h[1];
+    lo[2 * q] = (_Float16)l[0]; lo[2 * q + 1] = (_Float16)l[1];
+}
 
 template <bool RELU>
 __device__ __forceinline__ void split_frag(const Frag& in, FragB& o) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            float x = in.v[s >> 1][8 * (s & 1) + jj];
-            if (RELU) x = relu1(x);
-            const __bf16 hi = (__bf16)x;
-            o.hi[s][jj] = hi;
-            o.lo[s][jj] = (__bf16)(x - (float)hi);
+        for (int q = 0; q < 4; ++q) {
+            float x0 = in.v[s >> 1][8 * (s & 1) + 2 * q], x1 = in.v[s >> 1][8 * (s & 1) + 2 * q + 1];
+            if (RELU) { x0 = relu1(x0); x1 = relu1(x1); }
+            split_pair(x0, x1, o.hi[s], o.lo[s], q);
         }
 }
 
-// acc += W x, W packed as bf16x8[(part*2 + ob)*4 + s][lane]
+// acc += W x, W packed as f16x8[(part*2 + ob)*4 + s][lane]
 // Packed-weight operands of one MFMA group (3 MFMAs: one k-step of one output block).
 struct WOp {
-    bf16x8 hi, lo;
+    f16x8 hi, lo;
 };
 
-__device__ __forceinline__ WOp wop_load(const bf16x8* __restrict__ wp, int s, int ob, int lane) {
+__device__ __forceinline__ WOp wop_load(const f16x8* __restrict__ wp, int s, int ob, int lane) {
     WOp w;
     w.hi = wp[((0 * 2 + ob) * 4 + s) * 64 + lane];
     w.lo = wp[((1 * 2 + ob) * 4 + s) * 64 + lane];
@@ -122,9 +154,9 @@ __device__ __forceinline__ WOp wop_load(const bf16x8* __restrict__ wp, int s, in
 }
 
 __device__ __forceinline__ void mfma_group(const WOp& w, const FragB& b, Frag& acc, int s, int ob) {
-    acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, b.hi[s], acc.v[ob], 0, 0, 0);
-    acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, b.lo[s], acc.v[ob], 0, 0, 0);
-    acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, b.hi[s], acc.v[ob], 0, 0, 0);
+    acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo, b.hi[s], acc.v[ob], 0, 0, 0);
+    acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, b.lo[s], acc.v[ob], 0, 0, 0);
+    acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, b.hi[s], acc.v[ob], 0, 0, 0);
 }
 
 // acc += W x.  24 MFMAs in 8 groups; the LDS reads of group g+1 are issued before the MFMAs
@@ -133,8 +165,8 @@ __device__ __forceinline__ void mfma_group(const WOp& w, const FragB& b, Frag& a
 // output was being split) and `next` receives group 0 of the following layer.
 // Group order: k-steps 0,1 for both output blocks (they need only the first half of the
 // previous layer's split), then k-steps 2,3 of block 0, then of block 1.
-__device__ __forceinline__ void mfma_layer64_split(const bf16x8* __restrict__ wp, const FragB& b, Frag& acc, int lane,
-                                                   const WOp& first, const bf16x8* __restrict__ wp_next, WOp& next) {
+__device__ __forceinline__ void mfma_layer64_split(const f16x8* __restrict__ wp, const FragB& b, Frag& acc, int lane,
+                                                   const WOp& first, const f16x8* __restrict__ wp_next, WOp& next) {
     WOp w1 = wop_load(wp, 0, 1, lane);
     mfma_group(first, b, acc, 0, 0);
     WOp w2 = wop_load(wp, 1, 0, lane);
@@ -153,33 +185,31 @@ __device__ __forceinline__ void mfma_layer64_split(const bf16x8* __restrict__ wp
     mfma_group(w1, b, acc, 3, 1);
 }
 
-__device__ __forceinline__ void mfma_layer64_split(const bf16x8* __restrict__ wp, const FragB& b, Frag& acc, int lane) {
+__device__ __forceinline__ void mfma_layer64_split(const f16x8* __restrict__ wp, const FragB& b, Frag& acc, int lane) {
     WOp first = wop_load(wp, 0, 0, lane), next;
     mfma_layer64_split(wp, b, acc, lane, first, nullptr, next);
 }
 
 // first layer: one k-step over [a_r, a_s, dx, dy, dz, d, 1, 0] (lanes of half 1 supply zeros)
-__device__ __forceinline__ void mfma_layer8_split(const bf16x8* __restrict__ wp, const float (&x)[8], int h, Frag& acc, int lane) {
-    bf16x8 bhi, blo;
+__device__ __forceinline__ void mfma_layer8_split(const f16x8* __restrict__ wp, const float (&x)[8], int h, Frag& acc, int lane) {
+    f16x8 bhi, blo;
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-        const float v = (h == 0) ? x[jj] : 0.0f;
-        const __bf16 hi = (__bf16)v;
-        bhi[jj] = hi;
-        blo[jj] = (__bf16)(v - (float)hi);
+    for (int q = 0; q < 4; ++q) {
+        const float v0 = (h == 0) ? x[2 * q] : 0.0f, v1 = (h == 0) ? x[2 * q + 1] : 0.0f;
+        split_pair(v0, v1, bhi, blo, q);
     }
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob) {
-        const bf16x8 a_hi = wp[(0 * 2 + ob) * 64 + lane];
-        const bf16x8 a_lo = wp[(1 * 2 + ob) * 64 + lane];
-        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, acc.v[ob], 0, 0, 0);
-        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, acc.v[ob], 0, 0, 0);
-        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, acc.v[ob], 0, 0, 0);
+        const f16x8 a_hi = wp[(0 * 2 + ob) * 64 + lane];
+        const f16x8 a_lo = wp[(1 * 2 + ob) * 64 + lane];
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bhi, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, blo, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bhi, acc.v[ob], 0, 0, 0);
     }
 }
 
 // the relation-encoder chain of one tile: inputs -> c_edge fragment
-__device__ __forceinline__ void edge_chain_split(const bf16x8* __restrict__ wsp /*LDS, S_* offsets*/,
+__device__ __forceinline__ void edge_chain_split(const f16x8* __restrict__ wsp /*LDS, S_* offsets*/,
                                                  const float* __restrict__ rows /*b2,b4,b_rp,wd_rp*/,
                                                  const float (&x)[8], float d, int h, int lane, Frag& out) {
     Frag a, c;
@@ -211,7 +241,7 @@ km_edge_encode_split(const uint16_t* __restrict__ sw, const float* __restrict__ 
     lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
     lds_fill(rows, mw + R_RE2_B, 256);
     __syncthreads();
-    const bf16x8* wsp = reinterpret_cast<const bf16x8*>(wsp_f);
+    const f16x8* wsp = reinterpret_cast<const f16x8*>(wsp_f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     float* tile = tiles + wave * TILE_FLOATS;
@@ -419,7 +449,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     }
     lds_fill(rows, mw + R_RE2_B, 256);
     __syncthreads();
-    const bf16x8* wsp = reinterpret_cast<const bf16x8*>(wsp_f);
+    const f16x8* wsp = reinterpret_cast<const f16x8*>(wsp_f);
     const bf16x8* w6 = reinterpret_cast<const bf16x8*>(w6_f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;

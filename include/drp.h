@@ -46,7 +46,7 @@ enum {
 enum {
     DRP_ENGINE_VALU = 0,  /* fp32 VALU reference kernels */
     DRP_ENGINE_MFMA = 1,  /* fp32 MFMA (v_mfma_f32_32x32x2_f32) kernels */
-    DRP_ENGINE_SPLIT = 2, /* as MFMA, relation encoder on split-bf16 (3-pass) MFMA, fp32 accumulate */
+    DRP_ENGINE_SPLIT = 2, /* as MFMA, relation encoder on split-fp16 (two terms, 3 MFMAs per product) MFMA, fp32 accumulate */
     DRP_ENGINE_FUSED = 3  /* as SPLIT, encoder recomputed inside each aggregate: the edge-constant
                              buffer is never materialised */
 };
