@@ -62,6 +62,7 @@ struct drp_ctx {
     DevBuf w_raw, w_valu, w_mfma, w_mfma_bwd, w_split, w_split6;
     DrpCam cam{};
     DevBuf goal_field, goal_coor, cself;
+    unsigned cself_tag = 0;         // bumped by every prepare_cself: who filled c->cself last
     int goal_h = 0, goal_w = 0, goal_m = 0;
 
     // workspaces
@@ -78,6 +79,9 @@ struct drp_ctx {
     // gradient-descent planner state
     bool gd_on = false;
     int gd_nb = 0, gd_N = 0, gd_B = 0, gd_H = 0, gd_iter = 0;
+    unsigned gd_cself_tag = 0;      // the self-edge constants of this GD problem are in c->cself while the tags match
+    const float* gd_cself = nullptr;
+    const uint8_t* gd_cself_ok = nullptr;
     double gd_lr = 0.05;
     float gd_lo[4] = {0, 0, 0, 0}, gd_hi[4] = {0, 0, 0, 0};
     DevBuf eff_hist, g_eff, g_cnode, g_agg, g_proj, g_state, g_sdelta, g_act, adam_m, adam_v;
@@ -403,6 +407,7 @@ int prepare_cself(drp_ctx* c, int attr_mod, int N, int B, const float** cself, c
                            ptr<float>(c->dens), attr_mod, N, cs, ok);
         *cself = cs;
         *cself_ok = ok;
+        ++c->cself_tag;
     }
 #endif
     return DRP_OK;
@@ -1295,9 +1300,15 @@ int gd_forward_backward(drp_ctx* c) {
     //      effect after the encoder and after every propagation step, and the ReLU masks of the edges
     const int saved_engine = c->engine;
     c->engine = DRP_ENGINE_FUSED;
-    const float* cself = nullptr;
-    const uint8_t* cself_ok = nullptr;
-    int rc = prepare_cself(c, nb, N, B, &cself, &cself_ok);
+    // the self-edge constants depend on attributes and densities only: computed once per GD problem,
+    // again only if a rollout in between has reused the buffer
+    int rc = DRP_OK;
+    if (c->gd_cself_tag != c->cself_tag || c->gd_cself_tag == 0) {
+        rc = prepare_cself(c, nb, N, B, &c->gd_cself, &c->gd_cself_ok);
+        c->gd_cself_tag = c->cself_tag;
+    }
+    const float* cself = c->gd_cself;
+    const uint8_t* cself_ok = c->gd_cself_ok;
     for (int t = 0; t < H && rc == DRP_OK; ++t) {
         StepArgs a{};
         if (t == 0) { a.s_prev = ptr<float>(c->s_in); a.prev_mod = nb; a.prev_stride = (size_t)N * 3; }
@@ -1355,8 +1366,7 @@ int gd_forward_backward(drp_ctx* c) {
             for (int p = DRP_PSTEP - 1; p >= 0; --p) {
                 float* g_agg_p = gah + (size_t)p * bn * 64;
                 const unsigned* mask_p = mht + (size_t)p * bn * DRP_K * 2;
-                hipLaunchKernelGGL(kb_recv_sum, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), 1);
-                hipLaunchKernelGGL(kb_gather_senders, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
+                hipLaunchKernelGGL(kb_edge_terms, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, cnt, ptr<int>(c->rev_off),
                                    ptr<int>(c->rev), N, ptr<float>(c->g_proj), 1);
                 if (p > 0)
                     hipLaunchKernelGGL((kmb_node_step<true, true>), ngrid, nblk, KMB_STEP_LDS(true, true), st, mb,
@@ -1379,8 +1389,7 @@ int gd_forward_backward(drp_ctx* c) {
                 const unsigned* mask_p = mht + (size_t)p * bn * DRP_K * 2;
                 hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn * 64,
                                    ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, 1);
-                hipLaunchKernelGGL(kb_recv_sum, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), 1);
-                hipLaunchKernelGGL(kb_gather_senders, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
+                hipLaunchKernelGGL(kb_edge_terms, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, cnt, ptr<int>(c->rev_off),
                                    ptr<int>(c->rev), N, ptr<float>(c->g_proj), 1);
                 hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), 1);
             }
@@ -1450,6 +1459,7 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     HIPCHK(c, hipMemsetAsync(c->adam_v.p, 0, (size_t)B * H * 4 * sizeof(float), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->gd_nb = nb; c->gd_N = N; c->gd_B = B; c->gd_H = H; c->gd_iter = 0; c->gd_lr = lr;
+    c->gd_cself_tag = 0;
     memcpy(c->gd_lo, act_lo, 4 * sizeof(float));
     memcpy(c->gd_hi, act_hi, 4 * sizeof(float));
     c->lastH = H;
@@ -1621,8 +1631,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                 // particle propagator, aggregate columns: g_eff holds the pre-activation gradient of step p
                 launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
                                  nullptr, nullptr, nullptr, 1, 1);
-                hipLaunchKernelGGL(kb_recv_sum, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), chunks16);
-                hipLaunchKernelGGL(kb_gather_senders, egrid, dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
+                hipLaunchKernelGGL(kb_edge_terms, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, ptr<int>(c->rev_off),
                                    ptr<int>(c->rev), N, ptr<float>(c->g_proj), chunks16);
                 // relation propagator, receiver and sender columns
                 launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
@@ -1665,8 +1674,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                 // particle propagator, aggregate columns: g_eff now holds the pre-activation gradient
                 launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
                                  nullptr, nullptr, nullptr, 1, 1);
-                hipLaunchKernelGGL(kb_recv_sum, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, N, ptr<float>(c->g_proj), chunks16);
-                hipLaunchKernelGGL(kb_gather_senders, egrid, dim3(256), 0, st, g_agg_p, mask_p, ptr<int>(c->rev_off),
+                hipLaunchKernelGGL(kb_edge_terms, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, ptr<int>(c->rev_off),
                                    ptr<int>(c->rev), N, ptr<float>(c->g_proj), chunks16);
                 // relation propagator, receiver and sender columns
                 launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,

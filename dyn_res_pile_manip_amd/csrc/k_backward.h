@@ -277,7 +277,7 @@ kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict_
 //      forward pass (km_prop<., TAPE>) leaves the 64 mask bits of every edge slot and propagation
 //      step (8 B instead of a 256-B row); nothing else of the edge stage is kept.  Here: the
 //      receiver term g_proj[i][0:64] = sum_k g_u and, over the reversed lists, the sender term
-//      g_proj[j][64:128]; kb_edge_encode and the weight gradients rebuild g_u the same way.
+//      g_proj[j][64:128] (kb_edge_terms); kb_edge_encode and the weight gradients rebuild g_u the same way.
 // Mask layout (k_mlp_split.h frag_positive_bits): two words per slot; feature f lives in word
 // (f>>2)&1 at bit 31 - (16*(f>>5) + (f&3) + 4*((f&31)>>3)).  The four features 4q..4q+3 of a float4
 // lane q are one nibble of word q&1.
@@ -287,41 +287,13 @@ __device__ __forceinline__ unsigned kb_mask_nibble(const unsigned* __restrict__ 
     return (m2[q & 1] >> (28 - 16 * (q >> 3) - 4 * ((q >> 1) & 3))) & 0xfu;      // bit 3 = component x ... bit 0 = w
 }
 
-// same 16-lanes-per-receiver layout as k_aggregate.
+// both edge terms of a node in one launch: g_proj[n][0:64] from the node's own slots (the same value
+// g_agg[n] under 0/1 masks, added one by one as an edge loop would), g_proj[n][64:128] from the edges it
+// feeds, in the order of the reversed lists (ascending receiver, then slot).
+// Same 16-lanes-per-node layout as k_aggregate.
 __global__ void __launch_bounds__(256)
-kb_recv_sum(const float* __restrict__ g_agg, const unsigned* __restrict__ mask, const uint8_t* __restrict__ nbr_cnt,
-            int N, float* __restrict__ g_proj, int chunks) {
-    const KbRange rg = kb_range(N, chunks);
-    const int b = rg.b;
-    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const float4* ga = reinterpret_cast<const float4*>(g_agg) + (size_t)b * N * 16;
-    const unsigned* mk = mask + (size_t)b * N * DRP_K * 2;
-    float* gp = g_proj + (size_t)b * N * 128;
-    const uint8_t* nc = nbr_cnt + (size_t)b * N;
-    for (int i = rg.lo + g; i < rg.hi; i += 16) {
-        const int cnt = nc[i];
-        const float4 gi = ga[(size_t)i * 16 + q];
-        int nx = 0, ny = 0, nz = 0, nw = 0;            // how many of the receiver's edges pass each feature on
-        for (int k = 0; k < cnt; ++k) {
-            const unsigned nib = kb_mask_nibble(mk + ((size_t)i * DRP_K + k) * 2, q);
-            nx += (nib >> 3) & 1; ny += (nib >> 2) & 1; nz += (nib >> 1) & 1; nw += nib & 1;
-        }
-        // sum_k of the same value gi under 0/1 masks, added one by one as the edge loop would
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = 0; t < nx; ++t) acc.x += gi.x;
-        for (int t = 0; t < ny; ++t) acc.y += gi.y;
-        for (int t = 0; t < nz; ++t) acc.z += gi.z;
-        for (int t = 0; t < nw; ++t) acc.w += gi.w;
-        *reinterpret_cast<float4*>(gp + (size_t)i * 128 + q * 4) = acc;
-    }
-}
-
-// sender term: g_proj[j][64:128] = sum over the edges j feeds of g_u, in the order of the
-// reversed lists (ascending receiver, then slot)
-__global__ void __launch_bounds__(256)
-kb_gather_senders(const float* __restrict__ g_agg, const unsigned* __restrict__ mask,
-                  const int* __restrict__ rev_off, const int* __restrict__ rev, int N, float* __restrict__ g_proj,
-                  int chunks) {
+kb_edge_terms(const float* __restrict__ g_agg, const unsigned* __restrict__ mask, const uint8_t* __restrict__ nbr_cnt,
+              const int* __restrict__ rev_off, const int* __restrict__ rev, int N, float* __restrict__ g_proj, int chunks) {
     const KbRange rg = kb_range(N, chunks);
     const int b = rg.b;
     const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -330,9 +302,23 @@ kb_gather_senders(const float* __restrict__ g_agg, const unsigned* __restrict__ 
     const int* ro = rev_off + (size_t)b * (N + 1);
     const int* rv = rev + (size_t)b * N * DRP_K;
     float* gp = g_proj + (size_t)b * N * 128;
-    for (int j = rg.lo + g; j < rg.hi; j += 16) {
-        const int p0 = ro[j], p1 = ro[j + 1];
+    const uint8_t* nc = nbr_cnt + (size_t)b * N;
+    for (int i = rg.lo + g; i < rg.hi; i += 16) {
+        const int cnt = nc[i];
+        const float4 gi = ga[(size_t)i * 16 + q];
+        int nx = 0, ny = 0, nz = 0, nw = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const unsigned nib = kb_mask_nibble(mk + ((size_t)i * DRP_K + k) * 2, q);
+            nx += (nib >> 3) & 1; ny += (nib >> 2) & 1; nz += (nib >> 1) & 1; nw += nib & 1;
+        }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < nx; ++t) acc.x += gi.x;
+        for (int t = 0; t < ny; ++t) acc.y += gi.y;
+        for (int t = 0; t < nz; ++t) acc.z += gi.z;
+        for (int t = 0; t < nw; ++t) acc.w += gi.w;
+        *reinterpret_cast<float4*>(gp + (size_t)i * 128 + q * 4) = acc;
+        const int p0 = ro[i], p1 = ro[i + 1];
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int p = p0; p < p1; ++p) {
             const int e = rv[p];
             const unsigned nib = kb_mask_nibble(mk + (size_t)e * 2, q);
@@ -342,7 +328,7 @@ kb_gather_senders(const float* __restrict__ g_agg, const unsigned* __restrict__ 
             acc.z += (nib & 2u) ? v.z : 0.0f;
             acc.w += (nib & 1u) ? v.w : 0.0f;
         }
-        *reinterpret_cast<float4*>(gp + (size_t)j * 128 + 64 + q * 4) = acc;
+        *reinterpret_cast<float4*>(gp + (size_t)i * 128 + 64 + q * 4) = acc;
     }
 }
 
