@@ -8,11 +8,11 @@
 // Any horizon: the reward is taken at the final step only (planners.py:436-438); going back
 // through a step, the gradient w.r.t. its input positions is the residual's share, plus the
 // relation encoder's (its inputs are position differences), plus gen_s_delta's dependence
-// on the particle position.  Correctness-first fp32 VALU kernels over the
-// activations the fp32 MFMA engine saved in HBM (eff after every step, proj per step, c_edge,
-// c_node); ReLU masks are recomputed from them.  The one scatter of the backward pass
+// on the particle position.  fp32 VALU kernels (the node-level stages also exist on the matrix cores,
+// k_backward_mfma.h) over what the fused forward pass (km_prop<., TAPE>) left in HBM: the effect after
+// the encoder and after every propagation step, and the edges' ReLU masks.  The one scatter of the backward pass
 // (gradient of the gathered sender rows) is turned into a gather over reversed neighbour lists
-// (kb_reverse_lists, kb_gather_senders): no atomics, reproducible sums.
+// (kb_reverse_lists, kb_edge_terms, kb_gather_pos): no atomics, reproducible sums.
 #pragma once
 #include "drp_common.h"
 #include "k_graph.h"
@@ -550,7 +550,8 @@ struct KbEdgeDump {
     float* g1;
 };
 
-// ---- relation encoder backward (horizons > 1): g_cedge [B,N,10,64] -> through W_e and the three
+// ---- relation encoder backward (horizons > 1, training): the gradient at c_edge (rebuilt from the
+//      propagation steps' masks and g_agg rows) -> through W_e and the three
 //      Linear+ReLU layers (forward recomputed per slot) to the position-difference inputs
 //      x[2:5] = s_r - s_s (gnn_dyn.py:179-180):  g_pos[recv] += g,  g_pos[send] -= g  (atomics)
 // One wave = the slots of one receiver, as k_edge_encode.
