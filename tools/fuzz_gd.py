@@ -28,6 +28,11 @@ for case in range(n_cases):
     traj = int(rng.choice([2, 3, 5]))
     H = int(rng.choice([1, 1, 2, 3]))
     s0, dens, attr = syn.make_pile(N, nb, seed=100 + case, kind=str(rng.choice(['uniform', 'blob'])))
+    mode = int(rng.integers(0, 3))                      # attributes: zeros / one value per sample / per particle
+    if mode == 1:
+        attr = np.repeat(rng.uniform(-0.5, 0.5, (nb, 1)).astype(np.float32), N, axis=1)
+    elif mode == 2:
+        attr = rng.uniform(-0.5, 0.5, attr.shape).astype(np.float32)
     goal_coor = syn.goal_coor_strided(obs_goal, 5 * N)
     eng.set_goal(G, goal_coor)
     acts = np.stack([syn.nominal_pushes(H, seed=7 * case + i) for i in range(traj)])
