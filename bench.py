@@ -121,9 +121,9 @@ def main():
     cam = syn.demo_cam_params()
     eng.set_camera(M34, 24.0, cam)
     obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
-    G = syn.goal_field(obs_goal)
-    goal_coor = syn.goal_coor_strided(obs_goal, 5 * N)
-    eng.set_goal(G, goal_coor)
+    # goal field (OpenCV's 5x5 chamfer, as the reference) and the farthest-point subsample of the goal
+    # pixels, built and kept on the device (rows f3); the copies feed the CPU baseline
+    G, goal_coor = eng.set_goal_image(obs_goal, 5 * N, fps_init=0, mode='cv5', want=True)
     s0, dens, attr = syn.make_pile(N, 1, seed=0)
     lo, hi = syn.action_limits()
     nominal = syn.nominal_pushes(H, seed=0)
