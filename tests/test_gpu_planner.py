@@ -148,3 +148,28 @@ def test_device_fps_equals_fps_np(stack):
     want, _ = fps_np(pts3, 100, 17)
     got, _, _ = model.engine.fps(pts3, 100, 17)
     np.testing.assert_array_equal(got, want)
+
+
+def test_one_mpc_step_end_to_end(stack):
+    """Observation -> particles -> planner -> push, chained as env/flex_env.py:1016-1065 chains them
+    (tools/mpc_step_demo.py), every piece on the device."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import mpc_step_demo as demo
+    from dyn_res_pile_manip_amd import utils as dev
+    config, env, model, _ = stack
+    config = dict(config)
+    config['mpc'] = dict(config['mpc'], mpc_type='GD')
+    planner = PlannerGD(config, env)
+    dev.set_engine(model.engine)
+    obs = syn.render_depth(1500, seed=3, kind='uniform')
+    subgoal = syn.goal_distance_image(syn.goal_mask('I'))
+    act_seq = np.stack([syn.nominal_pushes(1, seed=20 + i) for i in range(6)], axis=1)
+    out, t = demo.mpc_step(obs, subgoal, model, planner, 30, act_seq, syn.demo_cam_params(), 24.0, n_update_iter=4)
+    assert out['action_sequence'].shape == (1, 4) and np.isfinite(out['action_sequence']).all()
+    assert out['observation_sequence'].shape == (1, 30, 3)
+    lo, hi = syn.action_limits()
+    assert (out['action_sequence'][0] >= lo - 1e-6).all() and (out['action_sequence'][0] <= hi + 1e-6).all()
+    assert out['iter_num'] == 3 and np.isfinite(out['reward']).all()
+    dev.set_engine(None)
