@@ -1870,6 +1870,33 @@ int drp_comm_destroy(drp_ctx* c) {
 }
 
 // ---- measurement / debugging -----------------------------------------------------------------
+#ifdef PROP_STAMPS
+int drp_debug_prop_stamps(drp_ctx* c, unsigned long long* out8, int reset) {
+    (void)c;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    std::vector<unsigned long long> h(4096 * 8);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_prop_stamps), h.size() * 8) != hipSuccess) return -1;
+    if (out8) {
+        for (int q = 0; q < 8; ++q) out8[q] = 0;
+        for (size_t i = 0; i < h.size(); ++i) out8[i & 7] += h[i];
+    }
+    if (reset) {
+        std::fill(h.begin(), h.end(), 0ull);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_prop_stamps), h.data(), h.size() * 8) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+#ifdef PROP_STAMPS
+int drp_debug_prop_span(drp_ctx* c, unsigned long long* out, int n) {
+    (void)c;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (n > 4096 * 2) n = 4096 * 2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prop_span), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int drp_probe_begin(drp_ctx* c, const char* kernel_class) {
     if (!c) return DRP_EINVAL;
     c->probe_cls = -1;

@@ -424,6 +424,13 @@ __device__ __forceinline__ unsigned frag_positive_bits(const Frag& f) {
     return m;
 }
 
+#ifdef PROP_STAMPS
+// Diagnostic build only (tools/prop_stamps.py): shader-clock and 100 MHz wall stamps around the slot loop and the
+// node part of every tile, summed here; nothing the kernel computes reads them.
+__device__ unsigned long long g_prop_span[4096 * 2];     // last launch: wall stamps (100 MHz) at wave entry / exit
+__device__ unsigned long long g_prop_stamps[4096 * 8];   // [workgroup * waves + wave][8], summed over launches by the wave itself
+#endif
+
 template <bool LAST, bool TAPE>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
@@ -436,6 +443,9 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         const uint8_t* __restrict__ cself_ok,
         unsigned* __restrict__ mask_out /* TAPE: [B*N*10][2] */, float* __restrict__ agg_out /* TAPE, nullable: [B*N,64] */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef PROP_STAMPS
+    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
     float* wsp_f = lds;                              // edge chain, S_TOTAL units
     float* w6_f = wsp_f + S_TOTAL * 4;               // node layers: AGG | (RPR RPS) or (PR0)
     float* rows = w6_f + (LAST ? 2 : 3) * 1536 * 4;  // b2,b4,b_rp,wd_rp | b_pr0, w_pr1[3], b_pr1
@@ -448,6 +458,8 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         lds_fill(w6_f + 1536 * 4, reinterpret_cast<const float*>(sw6) + S6_RPR * 4, 2 * 1536 * 4);
     }
     lds_fill(rows, mw + R_RE2_B, 256);
+    int* tile_ctr = reinterpret_cast<int*>(rows + 516);      // next tile of this workgroup's share (below)
+    if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
     __syncthreads();
     const f16x8* wsp = reinterpret_cast<const f16x8*>(wsp_f);
     const bf16x8* w6 = reinterpret_cast<const bf16x8*>(w6_f);
@@ -462,7 +474,71 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     const int blocks_in_grp = ((int)gridDim.x - grp + ngroups - 1) / ngroups;
     const int samples_in_grp = (B - grp + ngroups - 1) / ngroups;
     const long grp_tiles = (long)(samples_in_grp > 0 ? samples_in_grp : 0) * tps;
-    for (long lt = (long)(blockIdx.x / ngroups) * PROP_WAVES + wave; lt < grp_tiles; lt += (long)blocks_in_grp * PROP_WAVES) {
+#ifdef PROP_STAMPS
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
+#endif
+    // What a tile needs before its first slot can start hangs on a chain of dependent global loads
+    // (in-degree and first neighbours -> self-loop test -> sender positions: three round trips of 2-3 us
+    // each under load, measured 8 us per tile with tools/prop_stamps.py).  The chain is software-pipelined
+    // across the tiles of a wave: the next tile's head (in-degree, first three neighbours, own position) is
+    // requested when this tile's node part starts, the positions of its first two senders when that part
+    // ends, so a tile begins with everything but its P_r / P_s rows on hand.
+    const long lt_step = (long)blocks_in_grp * PROP_WAVES;
+    struct TileHead {
+        int cnt, ok;
+        unsigned nbw0, nbw1;          // neighbours 0..3 (int16 pairs)
+        float pix, piy, piz, pia;
+    };
+    auto tile_head = [&](long lt) {
+        const int m = (int)(lt / tps), t = (int)(lt - (long)m * tps);
+        const int b = grp + ngroups * m;
+        const int i = min(t * 32 + j, N - 1);
+        const size_t row = (size_t)b * N + i;
+        const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
+        TileHead hd;
+        hd.cnt = nbr_cnt[row];
+        hd.ok = (cself != nullptr) ? (int)cself_ok[b] : 0;
+        const unsigned* nbw = reinterpret_cast<const unsigned*>(nbr_idx + row * DRP_K);   // rows are 20 B: dword aligned
+        hd.nbw0 = nbw[0];
+        hd.nbw1 = nbw[1];
+        hd.pix = s[i * 3 + 0]; hd.piy = s[i * 3 + 1]; hd.piz = s[i * 3 + 2];
+        hd.pia = attr[(size_t)(b % attr_mod) * N + i];
+        return hd;
+    };
+    struct TileFirst {
+        int ks, j0, j1;
+        float p0x, p0y, p0z, p0a;
+    };
+    auto tile_first = [&](long lt, const TileHead& hd) {
+        const int m = (int)(lt / tps), t = (int)(lt - (long)m * tps);
+        const int b = grp + ngroups * m;
+        const int i = min(t * 32 + j, N - 1);
+        const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
+        const float* at = attr + (size_t)(b % attr_mod) * N;
+        const int nb0 = (int)(hd.nbw0 & 0xffffu), nb1 = (int)(hd.nbw0 >> 16), nb2 = (int)(hd.nbw1 & 0xffffu);
+        TileFirst f;
+        // self slot first (k_graph self_first) and a per-sample self-edge constant: the self loop is skipped
+        f.ks = (hd.ok && __all(hd.cnt > 0 && nb0 == i)) ? 1 : 0;
+        f.j0 = (f.ks < hd.cnt) ? (f.ks ? nb1 : nb0) : i;
+        f.j1 = (f.ks + 1 < hd.cnt) ? (f.ks ? nb2 : nb1) : i;
+        f.p0x = s[f.j0 * 3 + 0]; f.p0y = s[f.j0 * 3 + 1]; f.p0z = s[f.j0 * 3 + 2]; f.p0a = at[f.j0];
+        return f;
+    };
+    // A workgroup's share of the tiles (the same as a static deal would give it) is handed out to its waves on
+    // demand through a counter in LDS: the two waves of a SIMD do not advance evenly (tools/prop_stamps.py: with
+    // five tiles each the first wave of the chip was done at 0.7 of the last one's time, and a SIMD with one
+    // wave left runs at about 0.6 of its two-wave rate); on demand the waves end within 10 us of each other.
+    const long wg_base = (long)(blockIdx.x / ngroups) * PROP_WAVES;
+    auto tile_of = [&](int li) { return wg_base + (li & (PROP_WAVES - 1)) + (long)(li / PROP_WAVES) * lt_step; };
+    long lt = tile_of(wave), lt_next = 0;
+    TileHead hd_next = {};
+    TileFirst tf_next = {};
+    if (lt < grp_tiles) {
+        hd_next = tile_head(lt);
+        tf_next = tile_first(lt, hd_next);
+    }
+    for (; lt < grp_tiles; lt = lt_next) {
         const int m = (int)(lt / tps), t = (int)(lt - (long)m * tps);
         const int b = grp + ngroups * m;
         const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
@@ -472,7 +548,9 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         const int i = min(t * 32 + j, N - 1);
         const bool live = (t * 32 + j) < N;
         const size_t row = (size_t)b * N + i;
-        const int cnt = nbr_cnt[row];
+        const TileHead hd = hd_next;
+        const TileFirst tf = tf_next;
+        const int cnt = hd.cnt;
         const int16_t* nb = nbr_idx + row * DRP_K;
         Frag acc, bpr;
         {
@@ -482,10 +560,9 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
         }
-        // self slot first (k_graph self_first) and a per-sample self-edge constant: its effect is
-        // relu(c_self + bias + P_r[i] + P_s[i]) without running the encoder chain
-        int ks = 0;
-        if (cself != nullptr && cself_ok[b] && __all(cnt > 0 && (int)nb[0] == i)) {
+        // the self loop's effect is relu(c_self + bias + P_r[i] + P_s[i]) without running the encoder chain
+        const int ks = tf.ks;
+        if (ks) {
             const float* csr = cself + (size_t)b * 64;
             const float* psr = pj + (size_t)i * 128 + 64;
 #pragma unroll
@@ -500,19 +577,24 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
                     acc.v[ob][4 * g + 3] = relu1((bpr.v[ob][4 * g + 3] + cs.w) + ps.w);
                 }
             if (TAPE && live) mask_out[(row * DRP_K + 0) * 2 + h] = frag_positive_bits(acc);
-            ks = 1;
         } else {
             frag_zero(acc);
         }
-        const float pix = s[i * 3 + 0], piy = s[i * 3 + 1], piz = s[i * 3 + 2], pia = at[i];
+        const float pix = hd.pix, piy = hd.piy, piz = hd.piz, pia = hd.pia;
         // two-deep software pipeline on the dependent loads (index -> sender position): the
         // position of slot k+1 and the index of slot k+2 are requested while slot k computes
-        int j0 = (ks < cnt) ? (int)nb[ks] : i;
-        int j1 = (ks + 1 < cnt) ? (int)nb[ks + 1] : i;
-        float p0x = s[j0 * 3 + 0], p0y = s[j0 * 3 + 1], p0z = s[j0 * 3 + 2], p0a = at[j0];
+        int j0 = tf.j0, j1 = tf.j1;
+        float p0x = tf.p0x, p0y = tf.p0y, p0z = tf.p0z, p0a = tf.p0a;
+#ifdef PROP_STAMPS
+        const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+        int st_slots = 0;
+#endif
 #pragma unroll 1
         for (int k = ks; k < DRP_K; ++k) {
             if (__all(k >= cnt)) break;              // sparse piles: no receiver of this tile has a slot k
+#ifdef PROP_STAMPS
+            ++st_slots;
+#endif
             asm volatile("" ::: "memory");          // keep the packed-weight reads inside the loop
             const int jcur = j0;
             const float p1x = s[j1 * 3 + 0], p1y = s[j1 * 3 + 1], p1z = s[j1 * 3 + 2], p1a = at[j1];
@@ -523,7 +605,11 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
             x[5] = d; x[6] = 1.0f; x[7] = 0.0f;
             Frag sv;                                 // issued now, consumed after the chain; a padded slot
             // reads the sink row (-1e30), so its relu(c + sv) is exactly 0
+#ifdef PROP_NOGATHER   // timing experiment: the receiver's own row instead of the sender's
+            frag_from_row((k < cnt) ? pj + (size_t)i * 128 + 64 + 0 * jcur : mw + R_SINK, h, sv);
+#else
             frag_from_row((k < cnt) ? pj + (size_t)jcur * 128 + 64 : mw + R_SINK, h, sv);
+#endif
             Frag a, c;
             FragB fb;
             frag_zero(a);
@@ -559,6 +645,17 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         }
         // ---- node update on the aggregate still in registers
         asm volatile("" ::: "memory");
+#ifdef PROP_STAMPS
+        const unsigned long long st_c1 = __builtin_amdgcn_s_memtime();
+#endif
+        {
+            int li = 0;
+            if (lane == 0) li = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lt_next = tile_of(__builtin_amdgcn_readfirstlane(li));   // past the share: >= grp_tiles, and so is every later draw
+        }
+        const bool more = lt_next < grp_tiles;
+        if (more) hd_next = tile_head(lt_next);
+        __builtin_amdgcn_sched_barrier(0);
         Frag e;
         {
             Frag cn;
@@ -574,6 +671,9 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         frag_relu(e);
         if (live) frag_to_row(eff + row * 64, h, e);
         split_frag6(e, f6);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) tf_next = tile_first(lt_next, hd_next);     // the head has landed by now
+        __builtin_amdgcn_sched_barrier(0);
         if (!LAST) {
             Frag p;
             frag_zero(p);
@@ -605,7 +705,28 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
                 for (int o = 0; o < 3; ++o) so[o] = (out[o] + rows[256 + 64 + 192 + o]) + s[i * 3 + o];
             }
         }
+#ifdef PROP_STAMPS
+        {
+            const unsigned long long st_c2 = __builtin_amdgcn_s_memtime(), st_r2 = __builtin_amdgcn_s_memrealtime();
+            st_sum[0] += st_c1 - st_c0;        // shader cycles in slot loops
+            st_sum[1] += (unsigned long long)st_slots;
+            st_sum[2] += st_c2 - st_c1;        // shader cycles in node parts
+            st_sum[3] += st_c2 - st_c0;        // shader cycles, whole tile
+            st_sum[4] += st_r2 - st_r0;        // 100 MHz ticks, whole tile
+            st_sum[5] += 1ull;
+        }
+#endif
     }
+#ifdef PROP_STAMPS
+    st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
+    st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // all tiles of this wave
+    if (lane == 0 && blockIdx.x * PROP_WAVES + wave < 4096) {
+        g_prop_span[(blockIdx.x * PROP_WAVES + wave) * 2 + 0] = st_w0;
+        g_prop_span[(blockIdx.x * PROP_WAVES + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (lane == 0 && blockIdx.x * PROP_WAVES + wave < 4096)
+        for (int q = 0; q < 8; ++q) g_prop_stamps[(blockIdx.x * PROP_WAVES + wave) * 8 + q] += st_sum[q];
+#endif
 }
 #define KM_PROP_LDS(LAST) ((size_t)(S_TOTAL * 4 + ((LAST) ? 2 : 3) * 1536 * 4 + 256 + 260 + 4) * sizeof(float))
 
