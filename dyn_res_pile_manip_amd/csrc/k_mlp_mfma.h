@@ -220,9 +220,36 @@ __device__ __forceinline__ void mfma_layer8(const float4* __restrict__ wp, const
     }
 }
 
+// global -> LDS copy by the whole workgroup (n a multiple of 4).  Every workgroup of a launch copies the same
+// packed weights at the same moment; each starts at a different chunk (blockIdx.x / 8 = its rank within the
+// XCD under round-robin placement) so that the 32 CUs of an XCD do not queue on the same L2 channel, and keeps
+// eight 16-B loads in flight per thread.
 __device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ src, int n) {
-    for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
-        *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+    const int step = blockDim.x * 4;
+    const int nchunks = (n + step - 1) / step;
+    const int c0 = (int)(((blockIdx.x >> 3) & 31u) * (unsigned)nchunks / 32u);
+    const int off = threadIdx.x * 4;
+    int u = 0;
+    for (; u + 8 <= nchunks; u += 8) {
+        float4 t[8];
+        int idx[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            int c = u + v + c0;
+            if (c >= nchunks) c -= nchunks;
+            idx[v] = c * step + off;
+            t[v] = (idx[v] < n) ? *reinterpret_cast<const float4*>(src + idx[v]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            if (idx[v] < n) *reinterpret_cast<float4*>(dst + idx[v]) = t[v];
+    }
+    for (; u < nchunks; ++u) {
+        int c = u + c0;
+        if (c >= nchunks) c -= nchunks;
+        const int i = c * step + off;
+        if (i < n) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+    }
 }
 
 // bias row + d * w_d row, as this lane's fragment
