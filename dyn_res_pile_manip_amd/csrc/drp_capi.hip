@@ -55,6 +55,7 @@ struct drp_ctx {
     bool agg_global_only = false;   // DRP_AGG_GLOBAL=1: always gather sender rows from L2/HBM
     bool rev_global_only = false;   // DRP_REV_GLOBAL=1: reversed neighbour lists built in global memory (the N > 3072 path)
     bool self_const = true;         // DRP_NO_SELF_CONST=1: always run the encoder chain on the self slot too
+    bool prop3 = true;              // DRP_NO_PROP3=1: one launch per propagation step even for chip-filling batches
 
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
@@ -283,10 +284,28 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                                ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N, B, ptr<float>(c->c_edge));
     }
     if (fused) {
-        // graph -> node_encode -> 3 x km_prop: the whole propagation step in one launch each
+        // graph -> node_encode -> the three propagation steps: one launch (km_prop3: a workgroup owns whole
+        // samples and barriers locally between steps) when every CU gets a sample and a workgroup at least
+        // PROP_WAVES tiles per step; otherwise one launch per step with the tiles of all samples dealt over the chip
         float* pa = ptr<float>(c->proj);
         float* pb = ptr<float>(c->proj2);
-        for (int p = 0; p < DRP_PSTEP; ++p) {
+        const int tps = (N + 31) / 32;
+        const int spw = (int)((B + c->n_cu - 1) / c->n_cu);
+        const bool prop3 = c->prop3 && B >= c->n_cu && (long)spw * tps >= PROP_WAVES;
+        if (prop3) {
+            ProbeScope ps(c, KC_PROP);
+            const dim3 grid((unsigned)((B + spw - 1) / spw)), pblk(64 * PROP_WAVES);
+            float* eff_base = tape ? a.eff_hist : ptr<float>(c->eff);
+            unsigned* mask_hist = tape ? a.mask_hist : nullptr;
+            float* agg_hist = tape ? a.agg_hist : nullptr;
+#define PROP3_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
+                   a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, pb, \
+                   ptr<float>(c->c_node), eff_base, N, B, spw, a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist
+            if (!tape) hipLaunchKernelGGL((km_prop3<false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
+            else hipLaunchKernelGGL((km_prop3<true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
+#undef PROP3_ARGS
+        }
+        for (int p = 0; p < DRP_PSTEP && !prop3; ++p) {
             const bool last = (p + 1 == DRP_PSTEP);
             ProbeScope ps(c, KC_PROP);
             long pb_ = (node_tiles + PROP_WAVES - 1) / PROP_WAVES;
@@ -531,6 +550,7 @@ int drp_create(int device, drp_ctx** out) {
         c->n_cu = prop.multiProcessorCount;
     c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
     c->self_const = getenv("DRP_NO_SELF_CONST") == nullptr;
+    c->prop3 = getenv("DRP_NO_PROP3") == nullptr;
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REWARD_LDS(4096)) != hipSuccess ||
@@ -552,6 +572,8 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_prop<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);

@@ -431,69 +431,66 @@ __device__ unsigned long long g_prop_span[4096 * 2];     // last launch: wall st
 __device__ unsigned long long g_prop_stamps[4096 * 8];   // [workgroup * waves + wave][8], summed over launches by the wave itself
 #endif
 
-template <bool LAST, bool TAPE>
-__global__ void __launch_bounds__(64 * PROP_WAVES)
-km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
-        const float* __restrict__ s_cur, int s_mod, size_t s_stride,
-        const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
-        const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
-        const float* __restrict__ proj, const float* __restrict__ c_node, const float* __restrict__ eff_in,
-        float* __restrict__ eff, int N, int B, float* __restrict__ proj_next, float* __restrict__ s_out,
-        size_t out_stride, const float* __restrict__ cself /* nullable [B,64] */,
-        const uint8_t* __restrict__ cself_ok,
-        unsigned* __restrict__ mask_out /* TAPE: [B*N*10][2] */, float* __restrict__ agg_out /* TAPE, nullable: [B*N,64] */) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// ---- the tile loop of a propagation step, shared by km_prop (one step per launch, tiles of all samples dealt
+// over the chip) and km_prop3 (the three steps of a rollout step in one launch, a workgroup owning whole samples)
+struct PropArgs {
+    const float* mw;
+    const float* s_cur; int s_mod; size_t s_stride;
+    const float* attr; int attr_mod;
+    const float* dens; int dens_mod;
+    const int16_t* nbr_idx; const uint8_t* nbr_cnt;
+    const float* proj; const float* c_node; const float* eff_in; float* eff;
+    int N, B;
+    float* proj_next; float* s_out; size_t out_stride;
+    const float* cself; const uint8_t* cself_ok;
+    unsigned* mask_out; float* agg_out;
+};
+struct PropLds {
+    const f16x8* wsp;         // edge chain, S_* offsets
+    const bf16x8* w_agg;      // W_agg
+    const bf16x8* w_x;        // !LAST: W_r | W_s;  LAST: predictor layer 0
+    const float* rows;        // b2, b4, b_rp, wd_rp
+    const float* rows_pr;     // LAST: b_pr0, w_pr1[3], b_pr1
+    int* tile_ctr;            // next tile of this workgroup's share
+};
+struct TileId {
+    bool valid;
+    int b, t;
+};
+
+template <bool LAST, bool TAPE, class Decode>
+__device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, Decode decode, int lane, int wave
 #ifdef PROP_STAMPS
-    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
+                                           , unsigned long long (&st_sum)[8]
 #endif
-    float* wsp_f = lds;                              // edge chain, S_TOTAL units
-    float* w6_f = wsp_f + S_TOTAL * 4;               // node layers: AGG | (RPR RPS) or (PR0)
-    float* rows = w6_f + (LAST ? 2 : 3) * 1536 * 4;  // b2,b4,b_rp,wd_rp | b_pr0, w_pr1[3], b_pr1
-    lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
-    lds_fill(w6_f, reinterpret_cast<const float*>(sw6) + S6_AGG * 4, 1536 * 4);
-    if (LAST) {
-        lds_fill(w6_f + 1536 * 4, reinterpret_cast<const float*>(sw6) + S6_PR0 * 4, 1536 * 4);
-        lds_fill(rows + 256, mw + R_PR0_B, 260);
-    } else {
-        lds_fill(w6_f + 1536 * 4, reinterpret_cast<const float*>(sw6) + S6_RPR * 4, 2 * 1536 * 4);
-    }
-    lds_fill(rows, mw + R_RE2_B, 256);
-    int* tile_ctr = reinterpret_cast<int*>(rows + 516);      // next tile of this workgroup's share (below)
-    if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
-    __syncthreads();
-    const f16x8* wsp = reinterpret_cast<const f16x8*>(wsp_f);
-    const bf16x8* w6 = reinterpret_cast<const bf16x8*>(w6_f);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+) {
+    const float* mw = A.mw;
+    const float* s_cur = A.s_cur; const int s_mod = A.s_mod; const size_t s_stride = A.s_stride;
+    const float* attr = A.attr; const int attr_mod = A.attr_mod;
+    const float* dens = A.dens; const int dens_mod = A.dens_mod;
+    const int16_t* nbr_idx = A.nbr_idx; const uint8_t* nbr_cnt = A.nbr_cnt;
+    const float* proj = A.proj; const float* c_node = A.c_node; const float* eff_in = A.eff_in; float* eff = A.eff;
+    const int N = A.N;
+    float* proj_next = A.proj_next; float* s_out = A.s_out; const size_t out_stride = A.out_stride;
+    const float* cself = A.cself; const uint8_t* cself_ok = A.cself_ok;
+    unsigned* mask_out = A.mask_out; float* agg_out = A.agg_out;
+    const f16x8* wsp = L.wsp;
+    const float* rows = L.rows;
     const int j = lane & 31, h = lane >> 5;
-    const int tps = (N + 31) >> 5;
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
-    // one and its L2), so the tiles of a sample -- which gather the same ~150 KB of sender rows -- all go
-    // to workgroups of one residue class of blockIdx.  A placement guess only: wrong means slower, not wrong.
-    const int ngroups = min(8, (int)gridDim.x);
-    const int grp = blockIdx.x % ngroups;
-    const int blocks_in_grp = ((int)gridDim.x - grp + ngroups - 1) / ngroups;
-    const int samples_in_grp = (B - grp + ngroups - 1) / ngroups;
-    const long grp_tiles = (long)(samples_in_grp > 0 ? samples_in_grp : 0) * tps;
-#ifdef PROP_STAMPS
-    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
-#endif
     // What a tile needs before its first slot can start hangs on a chain of dependent global loads
     // (in-degree and first neighbours -> self-loop test -> sender positions: three round trips of 2-3 us
     // each under load, measured 8 us per tile with tools/prop_stamps.py).  The chain is software-pipelined
     // across the tiles of a wave: the next tile's head (in-degree, first three neighbours, own position) is
     // requested when this tile's node part starts, the positions of its first two senders when that part
     // ends, so a tile begins with everything but its P_r / P_s rows on hand.
-    const long lt_step = (long)blocks_in_grp * PROP_WAVES;
     struct TileHead {
         int cnt, ok;
         unsigned nbw0, nbw1;          // neighbours 0..3 (int16 pairs)
         float pix, piy, piz, pia;
     };
-    auto tile_head = [&](long lt) {
-        const int m = (int)(lt / tps), t = (int)(lt - (long)m * tps);
-        const int b = grp + ngroups * m;
-        const int i = min(t * 32 + j, N - 1);
+    auto tile_head = [&](const TileId& id) {
+        const int b = id.b;
+        const int i = min(id.t * 32 + j, N - 1);
         const size_t row = (size_t)b * N + i;
         const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
         TileHead hd;
@@ -510,10 +507,9 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         int ks, j0, j1;
         float p0x, p0y, p0z, p0a;
     };
-    auto tile_first = [&](long lt, const TileHead& hd) {
-        const int m = (int)(lt / tps), t = (int)(lt - (long)m * tps);
-        const int b = grp + ngroups * m;
-        const int i = min(t * 32 + j, N - 1);
+    auto tile_first = [&](const TileId& id, const TileHead& hd) {
+        const int b = id.b;
+        const int i = min(id.t * 32 + j, N - 1);
         const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
         const float* at = attr + (size_t)(b % attr_mod) * N;
         const int nb0 = (int)(hd.nbw0 & 0xffffu), nb1 = (int)(hd.nbw0 >> 16), nb2 = (int)(hd.nbw1 & 0xffffu);
@@ -525,22 +521,19 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         f.p0x = s[f.j0 * 3 + 0]; f.p0y = s[f.j0 * 3 + 1]; f.p0z = s[f.j0 * 3 + 2]; f.p0a = at[f.j0];
         return f;
     };
-    // A workgroup's share of the tiles (the same as a static deal would give it) is handed out to its waves on
-    // demand through a counter in LDS: the two waves of a SIMD do not advance evenly (tools/prop_stamps.py: with
-    // five tiles each the first wave of the chip was done at 0.7 of the last one's time, and a SIMD with one
-    // wave left runs at about 0.6 of its two-wave rate); on demand the waves end within 10 us of each other.
-    const long wg_base = (long)(blockIdx.x / ngroups) * PROP_WAVES;
-    auto tile_of = [&](int li) { return wg_base + (li & (PROP_WAVES - 1)) + (long)(li / PROP_WAVES) * lt_step; };
-    long lt = tile_of(wave), lt_next = 0;
+    // A workgroup's share of the tiles is handed out to its waves on demand through a counter in LDS: the two
+    // waves of a SIMD do not advance evenly (tools/prop_stamps.py: with five tiles each the first wave of the
+    // chip was done at 0.7 of the last one's time, and a SIMD with one wave left runs at about 0.6 of its
+    // two-wave rate); on demand the waves end within 10 us of each other.
+    TileId cur = decode(wave), nxt = {false, 0, 0};
     TileHead hd_next = {};
     TileFirst tf_next = {};
-    if (lt < grp_tiles) {
-        hd_next = tile_head(lt);
-        tf_next = tile_first(lt, hd_next);
+    if (cur.valid) {
+        hd_next = tile_head(cur);
+        tf_next = tile_first(cur, hd_next);
     }
-    for (; lt < grp_tiles; lt = lt_next) {
-        const int m = (int)(lt / tps), t = (int)(lt - (long)m * tps);
-        const int b = grp + ngroups * m;
+    for (; cur.valid; cur = nxt) {
+        const int b = cur.b, t = cur.t;
         const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
         const float* at = attr + (size_t)(b % attr_mod) * N;
         const float* pj = proj + (size_t)b * N * 128;
@@ -650,11 +643,11 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
 #endif
         {
             int li = 0;
-            if (lane == 0) li = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            lt_next = tile_of(__builtin_amdgcn_readfirstlane(li));   // past the share: >= grp_tiles, and so is every later draw
+            if (lane == 0) li = __hip_atomic_fetch_add(L.tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nxt = decode(__builtin_amdgcn_readfirstlane(li));        // past the share: invalid, and so is every later draw
         }
-        const bool more = lt_next < grp_tiles;
-        if (more) hd_next = tile_head(lt_next);
+        const bool more = nxt.valid;
+        if (more) hd_next = tile_head(nxt);
         __builtin_amdgcn_sched_barrier(0);
         Frag e;
         {
@@ -667,31 +660,31 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         if (TAPE && agg_out != nullptr && live) frag_to_row(agg_out + row * 64, h, acc);
         FragB6 f6;
         split_frag6(acc, f6);
-        mfma_layer64_split6(w6, f6, e, lane);
+        mfma_layer64_split6(L.w_agg, f6, e, lane);
         frag_relu(e);
         if (live) frag_to_row(eff + row * 64, h, e);
         split_frag6(e, f6);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) tf_next = tile_first(lt_next, hd_next);     // the head has landed by now
+        if (more) tf_next = tile_first(nxt, hd_next);     // the head has landed by now
         __builtin_amdgcn_sched_barrier(0);
         if (!LAST) {
             Frag p;
             frag_zero(p);
-            mfma_layer64_split6(w6 + 1536, f6, p, lane);
+            mfma_layer64_split6(L.w_x, f6, p, lane);
             if (live) frag_to_row(proj_next + row * 128, h, p);
             frag_zero(p);
-            mfma_layer64_split6(w6 + 2 * 1536, f6, p, lane);
+            mfma_layer64_split6(L.w_x + 1536, f6, p, lane);
             if (live) frag_to_row(proj_next + row * 128 + 64, h, p);
         } else {
             Frag hd;
-            frag_from_row(rows + 256, h, hd);
-            mfma_layer64_split6(w6 + 1536, f6, hd, lane);
+            frag_from_row(L.rows_pr, h, hd);
+            mfma_layer64_split6(L.w_x, f6, hd, lane);
             frag_relu(hd);
             float out[3];
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
                 Frag w;
-                frag_from_row(rows + 256 + 64 + 64 * o, h, w);
+                frag_from_row(L.rows_pr + 64 + 64 * o, h, w);
                 float p = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) p = fmaf(hd.v[0][r], w.v[0][r], p);
@@ -702,7 +695,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
             if (h == 0 && live) {
                 float* so = s_out + (size_t)b * out_stride + (size_t)i * 3;
 #pragma unroll
-                for (int o = 0; o < 3; ++o) so[o] = (out[o] + rows[256 + 64 + 192 + o]) + s[i * 3 + o];
+                for (int o = 0; o < 3; ++o) so[o] = (out[o] + L.rows_pr[64 + 192 + o]) + s[i * 3 + o];
             }
         }
 #ifdef PROP_STAMPS
@@ -717,18 +710,160 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         }
 #endif
     }
+}
+
+#ifdef PROP_STAMPS
+#define PROP_STAMPS_ARG , st_sum
+#else
+#define PROP_STAMPS_ARG
+#endif
+
+template <bool LAST, bool TAPE>
+__global__ void __launch_bounds__(64 * PROP_WAVES)
+km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
+        const float* __restrict__ s_cur, int s_mod, size_t s_stride,
+        const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+        const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
+        const float* __restrict__ proj, const float* __restrict__ c_node, const float* __restrict__ eff_in,
+        float* __restrict__ eff, int N, int B, float* __restrict__ proj_next, float* __restrict__ s_out,
+        size_t out_stride, const float* __restrict__ cself /* nullable [B,64] */,
+        const uint8_t* __restrict__ cself_ok,
+        unsigned* __restrict__ mask_out /* TAPE: [B*N*10][2] */, float* __restrict__ agg_out /* TAPE, nullable: [B*N,64] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef PROP_STAMPS
+    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    float* wsp_f = lds;                              // edge chain, S_TOTAL units
+    float* w6_f = wsp_f + S_TOTAL * 4;               // node layers: AGG | (RPR RPS) or (PR0)
+    float* rows = w6_f + (LAST ? 2 : 3) * 1536 * 4;  // b2,b4,b_rp,wd_rp | b_pr0, w_pr1[3], b_pr1
+    lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
+    lds_fill(w6_f, reinterpret_cast<const float*>(sw6) + S6_AGG * 4, 1536 * 4);
+    if (LAST) {
+        lds_fill(w6_f + 1536 * 4, reinterpret_cast<const float*>(sw6) + S6_PR0 * 4, 1536 * 4);
+        lds_fill(rows + 256, mw + R_PR0_B, 260);
+    } else {
+        lds_fill(w6_f + 1536 * 4, reinterpret_cast<const float*>(sw6) + S6_RPR * 4, 2 * 1536 * 4);
+    }
+    lds_fill(rows, mw + R_RE2_B, 256);
+    int* tile_ctr = reinterpret_cast<int*>(rows + 516);
+    if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tps = (N + 31) >> 5;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
+    // one and its L2), so the tiles of a sample -- which gather the same ~150 KB of sender rows -- all go
+    // to workgroups of one residue class of blockIdx.  A placement guess only: wrong means slower, not wrong.
+    const int ngroups = min(8, (int)gridDim.x);
+    const int grp = blockIdx.x % ngroups;
+    const int blocks_in_grp = ((int)gridDim.x - grp + ngroups - 1) / ngroups;
+    const int samples_in_grp = (B - grp + ngroups - 1) / ngroups;
+    const long grp_tiles = (long)(samples_in_grp > 0 ? samples_in_grp : 0) * tps;
+    const long lt_step = (long)blocks_in_grp * PROP_WAVES;
+    const long wg_base = (long)(blockIdx.x / ngroups) * PROP_WAVES;
+    // the workgroup's share: what a static deal of the group's tiles over its waves would give it
+    auto decode = [&](int li) {
+        const long lt = wg_base + (li & (PROP_WAVES - 1)) + (long)(li / PROP_WAVES) * lt_step;
+        TileId id;
+        id.valid = lt < grp_tiles;
+        const int m = (int)(lt / tps);
+        id.t = (int)(lt - (long)m * tps);
+        id.b = grp + ngroups * m;
+        return id;
+    };
+#ifdef PROP_STAMPS
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
+#endif
+    const PropArgs A = {mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj, c_node, eff_in, eff,
+                        N, B, proj_next, s_out, out_stride, cself, cself_ok, mask_out, agg_out};
+    const PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
+                       reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
+    prop_tiles<LAST, TAPE>(A, L, decode, lane, wave PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS
     st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
     st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // all tiles of this wave
     if (lane == 0 && blockIdx.x * PROP_WAVES + wave < 4096) {
         g_prop_span[(blockIdx.x * PROP_WAVES + wave) * 2 + 0] = st_w0;
         g_prop_span[(blockIdx.x * PROP_WAVES + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
-    }
-    if (lane == 0 && blockIdx.x * PROP_WAVES + wave < 4096)
         for (int q = 0; q < 8; ++q) g_prop_stamps[(blockIdx.x * PROP_WAVES + wave) * 8 + q] += st_sum[q];
+    }
 #endif
 }
 #define KM_PROP_LDS(LAST) ((size_t)(S_TOTAL * 4 + ((LAST) ? 2 : 3) * 1536 * 4 + 256 + 260 + 4) * sizeof(float))
+
+// km_prop3: the three propagation steps of a rollout step in ONE launch.  A step needs the previous step's
+// W_s eff rows of the SAME sample only, so a workgroup that owns whole samples needs no chip-wide barrier
+// between steps: __syncthreads() (workgroup-scope release / acquire: the waves of a workgroup share their CU's
+// L1) orders its own stores and gathers.  Saves two launches per rollout step, each with its refill of the
+// packed weights (5 us), its launch and its end-of-launch imbalance (tools/prop_stamps.py).
+// All four node matrices stay in LDS (153.6 KB).  grid = ceil(B / spw) workgroups, spw = samples per
+// workgroup; the host uses it when every CU gets at least one sample and a workgroup at least PROP_WAVES
+// tiles per step, and the one-step kernels otherwise (small batches spread by tiles, not by samples).
+template <bool TAPE>
+__global__ void __launch_bounds__(64 * PROP_WAVES)
+km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
+         const float* __restrict__ s_cur, int s_mod, size_t s_stride,
+         const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+         const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
+         float* __restrict__ proj_a, float* __restrict__ proj_b, const float* __restrict__ c_node,
+         float* __restrict__ eff /* !TAPE: in place; TAPE: effect history [4][B*N,64] */, int N, int B, int spw,
+         float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself, const uint8_t* __restrict__ cself_ok,
+         unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wsp_f = lds;
+    float* w6_f = wsp_f + S_TOTAL * 4;               // AGG | RPR | RPS | PR0
+    float* rows = w6_f + 4 * 1536 * 4;               // b2,b4,b_rp,wd_rp | b_pr0, w_pr1[3], b_pr1
+    lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
+    lds_fill(w6_f, reinterpret_cast<const float*>(sw6) + S6_AGG * 4, 4 * 1536 * 4);   // S6_AGG, RPR, RPS, PR0 are consecutive
+    lds_fill(rows, mw + R_RE2_B, 256);
+    lds_fill(rows + 256, mw + R_PR0_B, 260);
+    int* tile_ctr = reinterpret_cast<int*>(rows + 516);
+    if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tps = (N + 31) >> 5;
+    const int b0 = blockIdx.x * spw, nb = min(spw, B - b0);
+    const int wg_tiles = (nb > 0 ? nb : 0) * tps;
+    auto decode = [&](int li) {
+        TileId id;
+        id.valid = li < wg_tiles;
+        const int m = li / tps;
+        id.t = li - m * tps;
+        id.b = b0 + m;
+        return id;
+    };
+#ifdef PROP_STAMPS
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const size_t bn64 = (size_t)B * N * 64;
+    PropArgs A = {mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, c_node, eff, eff,
+                  N, B, proj_b, s_out, out_stride, cself, cself_ok, nullptr, nullptr};
+    PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
+                 reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
+#pragma unroll 1
+    for (int p = 0; p < DRP_PSTEP; ++p) {
+        if (p > 0) {
+            __syncthreads();                         // step p-1's rows of this workgroup's samples are written
+            if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
+            __syncthreads();
+        }
+        A.proj = (p & 1) ? proj_b : proj_a;
+        A.proj_next = (p & 1) ? proj_a : proj_b;
+        if (TAPE) {
+            A.eff_in = eff + (size_t)p * bn64;
+            A.eff = eff + (size_t)(p + 1) * bn64;
+            A.mask_out = mask_hist + (size_t)p * B * N * DRP_K * 2;
+            A.agg_out = agg_hist ? agg_hist + (size_t)p * bn64 : nullptr;
+        }
+        if (p + 1 < DRP_PSTEP) {
+            prop_tiles<false, TAPE>(A, L, decode, lane, wave PROP_STAMPS_ARG);
+        } else {
+            L.w_x = reinterpret_cast<const bf16x8*>(w6_f) + 3 * 1536;
+            prop_tiles<true, TAPE>(A, L, decode, lane, wave PROP_STAMPS_ARG);
+        }
+    }
+}
+#define KM_PROP3_LDS ((size_t)(S_TOTAL * 4 + 4 * 1536 * 4 + 256 + 260 + 4) * sizeof(float))
 
 
 // ---- particle encoder, node constant and first projections on the 6-term split --------------

@@ -130,3 +130,33 @@ def test_mpc_iteration_is_reproducible_and_improves(ctx):
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
     lo_, hi_ = np.asarray(lo), np.asarray(hi)
     assert (runs[0][1] >= lo_ - 1e-9).all() and (runs[0][1] <= hi_ + 1e-9).all()
+
+
+def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch):
+    """km_prop3 (a workgroup owns whole samples, the three propagation steps in one launch; chosen for
+    chip-filling batches) against one km_prop launch per step (DRP_NO_PROP3=1): same tiles, same
+    arithmetic in the same order -> the same bits.  700 samples are not a multiple of the samples per
+    workgroup, 70 particles leave a ragged last tile, the second case has per-particle attributes (the
+    self loop then runs the encoder chain like any other edge)."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    N, ns, H = 70, 700, 3
+    s0, dens, attr = syn.make_pile(N, 1, seed=3)
+    acts = syn.sample_pushes(ns, H, seed=3)
+    blob = weights.blob_from_state_dict(weights.random_state_dict(seed=0))
+    M34 = world2cam_affine(syn.demo_cam_extrinsics())
+    res = {}
+    for per_step in (False, True):
+        if per_step:
+            monkeypatch.setenv('DRP_NO_PROP3', '1')
+        else:
+            monkeypatch.delenv('DRP_NO_PROP3', raising=False)
+        eng = Engine(0)
+        eng.load_weights(blob, 0.08)
+        eng.set_camera(M34, 24.0, syn.demo_cam_params())
+        for tag, at in (('uniform', attr), ('mixed', (np.arange(N, dtype=np.float32)[None] % 3) * 0.5)):
+            res[per_step, tag], _ = eng.rollout(s0, at.astype(np.float32), dens, acts)
+        eng.close()
+    for tag in ('uniform', 'mixed'):
+        assert np.isfinite(res[False, tag]).all()
+        assert np.array_equal(res[False, tag], res[True, tag]), tag
+    assert not np.array_equal(res[False, 'uniform'], res[False, 'mixed'])
