@@ -210,12 +210,16 @@ def main():
             # km_prop: per 32-receiver tile, one 78-MFMA chain (the 3-term split
             # relation encoder) per slot iteration + the 6-term split node layers (144 MFMAs, 96 in
             # the last step); roofline on the 16-bit FLOPs actually EXECUTED, 2*32*32*16 per MFMA
-            mfmas = tiles * (slots_per_tile * 78 + (2 * 144 + 96) / 3.0)
+            # a launch covers one propagation step (km_prop) or all three of a rollout step (km_prop3,
+            # chip-filling batches): told apart by the launches the probe counted
+            psteps = max(1, int(round(3.0 * H * args.steps / max(dom_n, 1))))
+            mfmas = psteps * tiles * (slots_per_tile * 78 + (2 * 144 + 96) / 3.0)
             work = mfmas * 32768.0
-            alg = B * N * (kbar * FLOP_PER_EDGE_ENCODE + 2 * 64 * 64 * (1 + 2 * 2 / 3.0 + 1 / 3.0))
+            alg = psteps * B * N * (kbar * FLOP_PER_EDGE_ENCODE + 2 * 64 * 64 * (1 + 2 * 2 / 3.0 + 1 / 3.0))
             roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                     'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
-                    'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile}
+                    'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile,
+                    'propagation_steps_per_launch': psteps}
         elif dominant == 'aggregate':
             work = B * N * (2 * kbar + 2) * 256.0
             roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
@@ -238,7 +242,8 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath) and (N, ns) == (300, 1024):
             try:
-                roof['traffic'] = json.load(open(tpath))[engine][dominant]['hbm_bytes_per_launch']
+                tkey = 'prop3' if (dominant == 'prop' and roof.get('propagation_steps_per_launch') == 3) else dominant
+                roof['traffic'] = json.load(open(tpath))[engine][tkey]['hbm_bytes_per_launch']
             except Exception:
                 pass
         out = {

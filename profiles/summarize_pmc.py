@@ -20,7 +20,7 @@ CLASS = {'k_graph': 'graph', 'k_node_encode': 'node_encode', 'k_edge_encode': 'e
          'k_project': 'project', 'k_aggregate': 'aggregate', 'k_update': 'update',
          'k_predict': 'predict', 'km_node_encode': 'node_encode', 'km_node_encode_split': 'node_encode', 'km_edge_encode': 'edge_encode',
          'km_update<false>': 'update', 'km_update<true>': 'predict', 'k_reward': 'reward',
-         'km_prop<false>': 'prop', 'km_prop<true>': 'prop_last'}
+         'km_prop<false>': 'prop', 'km_prop<true>': 'prop_last', 'km_prop3': 'prop3'}
 
 
 def norm(name):
@@ -29,6 +29,8 @@ def norm(name):
         return 'km_prop<false>'
     if name.startswith('km_prop<true'):
         return 'km_prop<true>'
+    if name.startswith('km_prop3'):      # the three propagation steps of a rollout step in one launch
+        return 'km_prop3'
     return name
 
 
