@@ -226,30 +226,31 @@ __device__ __forceinline__ void mfma_layer8(const float4* __restrict__ wp, const
 // eight 16-B loads in flight per thread.
 __device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ src, int n) {
     const int step = blockDim.x * 4;
-    const int nchunks = (n + step - 1) / step;
-    const int c0 = (int)(((blockIdx.x >> 3) & 31u) * (unsigned)nchunks / 32u);
+    const int nfull = n / step;                      // whole chunks: no bounds test on their loads
+    const int c0 = (int)(((blockIdx.x >> 3) & 31u) * (unsigned)nfull / 32u);
     const int off = threadIdx.x * 4;
     int u = 0;
-    for (; u + 8 <= nchunks; u += 8) {
+    for (; u + 8 <= nfull; u += 8) {
         float4 t[8];
         int idx[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             int c = u + v + c0;
-            if (c >= nchunks) c -= nchunks;
+            if (c >= nfull) c -= nfull;
             idx[v] = c * step + off;
-            t[v] = (idx[v] < n) ? *reinterpret_cast<const float4*>(src + idx[v]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            t[v] = *reinterpret_cast<const float4*>(src + idx[v]);
         }
 #pragma unroll
-        for (int v = 0; v < 8; ++v)
-            if (idx[v] < n) *reinterpret_cast<float4*>(dst + idx[v]) = t[v];
+        for (int v = 0; v < 8; ++v) *reinterpret_cast<float4*>(dst + idx[v]) = t[v];
     }
-    for (; u < nchunks; ++u) {
+    for (; u < nfull; ++u) {
         int c = u + c0;
-        if (c >= nchunks) c -= nchunks;
+        if (c >= nfull) c -= nfull;
         const int i = c * step + off;
-        if (i < n) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+        *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
     }
+    const int i = nfull * step + off;                // the partial last chunk
+    if (i < n) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
 }
 
 // bias row + d * w_d row, as this lane's fragment

@@ -31,13 +31,19 @@ for B, nums in ((4, [300, 240, 150, 280]), (4, [1000, 800, 900, 600]), (32, [300
     eng.train_begin(H, 1e-3, 0.9)
     for _ in range(2):
         eng.train_step(states, sdelta, attrs, pn, dens, mode='update')
+    eng.sync()
     t0 = time.perf_counter()
     for _ in range(10):
         loss, _ = eng.train_step(states, sdelta, attrs, pn, dens, mode='update')
+    eng.sync()
     ms = (time.perf_counter() - t0) / 10 * 1e3
+    for _ in range(2):
+        eng.train_step(states, sdelta, attrs, pn, dens, mode='eval')
+    eng.sync()
     t0 = time.perf_counter()
     for _ in range(10):
         eng.train_step(states, sdelta, attrs, pn, dens, mode='eval')
+    eng.sync()
     ms_eval = (time.perf_counter() - t0) / 10 * 1e3
     line = 'B=%d N<=%d n_rollout=%d: %.2f ms per training iteration (upload, 5 steps forward, backward, weight gradients, Adam, re-pack); %.2f ms forward-only' % (B, N, H, ms, ms_eval)
     if B * N <= 1200:
