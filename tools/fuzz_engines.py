@@ -21,7 +21,9 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 for case in range(n_cases):
     N = int(rng.choice([1, 2, 3, 9, 10, 11, 31, 32, 33, 63, 64, 65, 100, 257, 300, 511, 700]))
     nb = int(rng.choice([1, 1, 2, 3]))
-    ns = int(rng.choice([1, 2, 5, 16]))
+    ns = int(rng.choice([1, 2, 5, 16, 16, 300, 517]))   # >= 256 rows: the fused engine runs km_prop3 (three steps per launch)
+    if ns >= 256 and N > 300:
+        N = 300
     H = int(rng.choice([1, 2, 4]))
     kind = str(rng.choice(['uniform', 'blob']))
     s0, dens, attr = syn.make_pile(N, nb, seed=case, kind=kind)
