@@ -810,6 +810,9 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
          float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself, const uint8_t* __restrict__ cself_ok,
          unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef PROP_STAMPS
+    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
     float* wsp_f = lds;
     float* w6_f = wsp_f + S_TOTAL * 4;               // AGG | RPR | RPS | PR0
     float* rows = w6_f + 4 * 1536 * 4;               // b2,b4,b_rp,wd_rp | b_pr0, w_pr1[3], b_pr1
@@ -834,6 +837,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     };
 #ifdef PROP_STAMPS
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
 #endif
     const size_t bn64 = (size_t)B * N * 64;
     PropArgs A = {mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, c_node, eff, eff,
@@ -862,6 +866,15 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
             prop_tiles<true, TAPE>(A, L, decode, lane, wave PROP_STAMPS_ARG);
         }
     }
+#ifdef PROP_STAMPS
+    st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
+    st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // the three steps of this wave, barrier waits included
+    if (lane == 0 && blockIdx.x * PROP_WAVES + wave < 4096) {
+        g_prop_span[(blockIdx.x * PROP_WAVES + wave) * 2 + 0] = st_w0;
+        g_prop_span[(blockIdx.x * PROP_WAVES + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+        for (int q = 0; q < 8; ++q) g_prop_stamps[(blockIdx.x * PROP_WAVES + wave) * 8 + q] += st_sum[q];
+    }
+#endif
 }
 #define KM_PROP3_LDS ((size_t)(S_TOTAL * 4 + 4 * 1536 * 4 + 256 + 260 + 4) * sizeof(float))
 

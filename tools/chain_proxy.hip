@@ -475,6 +475,64 @@ void run4(const char* name, float* d, f16x8* w, float* rows, int* idx, float* pr
     printf("%-58s threads %d: %8.0f cycles per slot per SIMD (at 2.4 GHz)\n", name, threads, ms * 1e-3 * 2.4e9 / iters / (threads / 256));
 }
 
+
+// 16-item tile: the 3-layer chain on v_mfma_f32_16x16x32_f16 with four 4-register accumulators per layer
+// (half the registers of the 32-item tile), launched with 2, 3 or 4 waves per SIMD.  Same FLOPs per item, twice the
+// LDS weight reads per item.  B operand of k-step ks, lane group g = lane >> 4: k = 8g + jj <-> registers r = jj & 3 of
+// output blocks 2ks + (jj >> 2).
+template <int WPS>
+__global__ void __launch_bounds__(256 * WPS) k5(float* out, const f16x8* __restrict__ wsrc, int iters) {
+    __shared__ f16x8 w[2 * 4 * 2 * 64];            // one layer: [part][ob 4][ks 2][lane]
+    for (int i = threadIdx.x; i < 2 * 4 * 2 * 64; i += blockDim.x) w[i] = wsrc[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    f16x8 bh[2], bl[2];
+    for (int s = 0; s < 2; ++s)
+        for (int j = 0; j < 8; ++j) { bh[s][j] = (_Float16)(0.01f * (lane + j + s)); bl[s][j] = (_Float16)1e-5f; }
+    float keep = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+        for (int layer = 0; layer < 3; ++layer) {
+            f32x4 acc[4];
+            for (int ob = 0; ob < 4; ++ob) for (int r = 0; r < 4; ++r) acc[ob][r] = 0.1f;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f16x8 whi = w[((0 * 4 + ob) * 2 + ks) * 64 + lane], wlo = w[((1 * 4 + ob) * 2 + ks) * 64 + lane];
+                    acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bh[ks], acc[ob], 0, 0, 0);
+                    acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bl[ks], acc[ob], 0, 0, 0);
+                    acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bh[ks], acc[ob], 0, 0, 0);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ob = 2 * ks + (q >> 1), r = 2 * (q & 1);
+                    split_pair(relu1(acc[ob][r]), relu1(acc[ob][r + 1]), bh[ks], bl[ks], q);
+                }
+        }
+        keep += (float)bh[0][0];
+    }
+    if (keep == 123.456f) out[0] = keep;
+}
+
+template <int WPS>
+void run5(float* d, f16x8* w) {
+    const int iters = 4000;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k5<WPS>, dim3(256), dim3(256 * WPS), 0, 0, d, w, 50);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k5<WPS>, dim3(256), dim3(256 * WPS), 0, 0, d, w, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("16-item tile, 16x16x32 f16, %d waves/SIMD: %8.1f cycles per item per SIMD (at 2.4 GHz) [32-item tile, 2 waves: see first block / 64]\n", WPS,
+           ms * 1e-3 * 2.4e9 / iters / (16.0 * WPS));
+}
+
 template <int MODE>
 void run3(const char* name, float* d, f16x8* w, float* rows, int* idx, float* proj) {
     const int iters = 3000;
@@ -548,6 +606,7 @@ int main() {
     run3<0>("restructured: zero-start accumulators, bias in the split", d, w, rows, idx, proj);
     run3<2>("  + next slot's first layer before the epilogue", d, w, rows, idx, proj);
     run3<3>("  + gathered sv", d, w, rows, idx, proj);
+    run5<2>(d, w); run5<3>(d, w); run5<4>(d, w);
     run4<0>("hand-ordered slot, mixlo/mixhi split, bias MFMAs, gathered sv", d, w, rows, idx, proj);
     run4<0>("  one wave per SIMD", d, w, rows, idx, proj, 256);
     run4<1>("  sv from registers", d, w, rows, idx, proj);

@@ -2,7 +2,9 @@
   hipcc ... -DPROP_STAMPS -o ab/libdrp_stamps.so ;  DRP_LIB=ab/libdrp_stamps.so python tools/prop_stamps.py
 (the stamps cost a few per cent themselves; the product build has none)."""
 import ctypes
+import os
 import sys
+os.environ.setdefault('DRP_NO_PROP3', '1')     # the budget of ONE propagation step per launch (km_prop); unset it by DRP_NO_PROP3= for km_prop3
 sys.path.insert(0, '.')
 import numpy as np
 from dyn_res_pile_manip_amd import synthetic as syn, weights, _lib
@@ -10,6 +12,8 @@ from dyn_res_pile_manip_amd.engine import Engine
 from dyn_res_pile_manip_amd.planners import world2cam_affine
 
 N, ns, H = 300, 1024, 10
+if os.environ.get('DRP_NO_PROP3') == '':
+    del os.environ['DRP_NO_PROP3']
 eng = Engine(0)
 eng.set_engine(_lib.ENGINES['fused'])
 eng.load_weights(weights.blob_from_state_dict(weights.random_state_dict(seed=0)), 0.08)
