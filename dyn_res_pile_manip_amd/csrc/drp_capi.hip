@@ -56,6 +56,7 @@ struct drp_ctx {
     bool rev_global_only = false;   // DRP_REV_GLOBAL=1: reversed neighbour lists built in global memory (the N > 3072 path)
     bool self_const = true;         // DRP_NO_SELF_CONST=1: always run the encoder chain on the self slot too
     bool prop3 = true;              // DRP_NO_PROP3=1: one launch per propagation step even for chip-filling batches
+    bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
 
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
@@ -213,10 +214,35 @@ struct StepArgs {
     float* agg_hist = nullptr;      // [3][B*N*64]: aggregated edge effects of every propagation step (training), nullable
     const float* cself = nullptr;   // [B,64] self-edge constant + per-sample validity (fused engine, k_cself)
     const uint8_t* cself_ok = nullptr;
+    bool padded = false;            // training batches: zero-padded (coincident) particles -> plain k_graph
 };
 
 int graph_chunks(int N) { return (N + GRAPH_THREADS - 1) / GRAPH_THREADS; }
+// neighbour lists: x-strip variant for samples of at least two workgroups (below that a wave's range is the whole
+// sample anyway), plain sweep otherwise and for zero-padded batches (coincident particles tie at the cut)
+void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod, size_t prev_stride, const float* actions,
+                  size_t act_stride, float* s_delta, int B, int N, int16_t* nbr_idx, uint8_t* nbr_cnt, int self_first,
+                  bool padded);
 size_t graph_lds(int N) { return (size_t)4 * N * sizeof(float); }
+
+void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod, size_t prev_stride, const float* actions,
+                  size_t act_stride, float* s_delta, int B, int N, int16_t* nbr_idx, uint8_t* nbr_cnt, int self_first,
+                  bool padded) {
+    if (c->graph_strips && !padded && N > GRAPH_THREADS) {
+        // sorted positions and strip starts live in the edge-constant buffer: whatever uses it runs after the lists exist
+        const size_t Np = ((size_t)N + 3) & ~(size_t)3;
+        float4* sorted = reinterpret_cast<float4*>(c->c_edge.p);
+        int* starts = reinterpret_cast<int*>(sorted + (size_t)B * Np);
+        hipLaunchKernelGGL(k_graph_sort, dim3(B), dim3(GRAPH_SORT_THREADS), 0, st, s_prev, prev_mod, prev_stride, actions,
+                           act_stride, s_delta, N, c->cam, sorted, starts);
+        hipLaunchKernelGGL(k_graph_strips, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N), st,
+                           (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), self_first);
+    }
+    else
+        hipLaunchKernelGGL(k_graph, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), graph_lds(N), st, s_prev,
+                           prev_mod, prev_stride, actions, act_stride, s_delta, N, nbr_idx, nbr_cnt, c->cam, c->thr,
+                           graph_chunks(N), self_first);
+}
 
 void launch_aggregate(drp_ctx* c, int B, int N) {
     ProbeScope ps(c, KC_AGGREGATE);
@@ -355,10 +381,8 @@ int run_step(drp_ctx* c, const StepArgs& a) {
     const float* vw = ptr<float>(c->w_valu);
     if (a.build_graph) {
         ProbeScope ps(c, KC_GRAPH);
-        hipLaunchKernelGGL(k_graph, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), graph_lds(N), st, a.s_prev,
-                           a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, N, nbr_idx,
-                           nbr_cnt, c->cam, c->thr, graph_chunks(N),
-                           (c->engine == DRP_ENGINE_FUSED && a.cself != nullptr) ? 1 : 0);
+        launch_graph(c, st, a.s_prev, a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, B, N, nbr_idx, nbr_cnt,
+                     (c->engine == DRP_ENGINE_FUSED && a.cself != nullptr) ? 1 : 0, a.padded);
     }
 #ifdef DRP_HAVE_MFMA
     if (c->engine != DRP_ENGINE_VALU) {
@@ -551,8 +575,10 @@ int drp_create(int device, drp_ctx** out) {
     c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
     c->self_const = getenv("DRP_NO_SELF_CONST") == nullptr;
     c->prop3 = getenv("DRP_NO_PROP3") == nullptr;
+    c->graph_strips = getenv("DRP_NO_GRAPH_STRIPS") == nullptr;
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_graph_strips, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REWARD_LDS(4096)) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reverse_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||
@@ -724,10 +750,8 @@ int drp_build_graph(drp_ctx* c, const float* s_cur, const float* s_delta, int B,
     CHK(h2d(c, c->s_delta, s_delta, (size_t)B * N * 3 * sizeof(float)));
     {
     ProbeScope ps(c, KC_GRAPH);
-    hipLaunchKernelGGL(k_graph, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), graph_lds(N), c->stream,
-                       ptr<float>(c->s_in), B, (size_t)N * 3, (const float*)nullptr, (size_t)0,
-                       ptr<float>(c->s_delta), N, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt),
-                       c->cam, c->thr, graph_chunks(N), 0);
+    launch_graph(c, c->stream, ptr<float>(c->s_in), B, (size_t)N * 3, (const float*)nullptr, (size_t)0,
+                 ptr<float>(c->s_delta), B, N, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), 0, false);
     }
     HIPCHK(c, hipGetLastError());
     CHK(d2h(c, nbr_idx_out, c->nbr_idx.p, (size_t)B * N * DRP_K * sizeof(int16_t)));
@@ -1574,6 +1598,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         a.s_out = states + (size_t)t * N * 3; a.out_stride = hstride;
         a.B = B; a.N = N;
         a.cself = cself; a.cself_ok = cself_ok;
+        a.padded = true;                // collate_fn pads with zero rows: coincident particles
         if (backward) {
             a.eff_hist = eh + (size_t)t * 4 * bn64;
             a.mask_hist = mh + (size_t)t * DRP_PSTEP * bnk * 2;

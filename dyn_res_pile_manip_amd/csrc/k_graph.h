@@ -87,8 +87,8 @@ __device__ __forceinline__ float pair_dis(float xi, float yi, float zi, float xj
 //      instructions per sender, no branch, no divergence.  The list starts at thr, so
 //      senders outside the radius (which can never be edges: adj = (dis - thr < 0) * topk)
 //      leave it unchanged and list[9] ends as min(thr, 10th smallest in-radius distance).
-//   2. senders in ascending index with d <= list[9] and d - thr < 0 are the edges (at most
-//      ten; ties at the cut go to the lower index).
+//   2. senders in ascending index with d - thr < 0 and d < list[9], plus the senders AT list[9]
+//      while slots are left (ties at the cut go to the lower index), are the edges.
 // Both sweeps evaluate the distance with the same expression, so the result is exactly
 // the reference's radius AND top-10 mask.
 // grid = B * ceil(N / GRAPH_THREADS): a workgroup owns GRAPH_THREADS consecutive receivers of
@@ -160,20 +160,245 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
     // and the other senders follow in ascending index.  The sum over a receiver's edges does not
     // depend on their order; the C ABI's drp_build_graph keeps the reference's ascending order.
     const int skip = (self_first && thr > 0.0f) ? i : -1;
-    if (skip >= 0) out[cnt++] = (int16_t)i;
+    // every sender strictly nearer than kth is in; the senders AT kth share the slots that leaves, lowest index
+    // first (exact ties beyond the one that defines kth need coincident particles)
+    int ties_left = DRP_K;
+#pragma unroll
+    for (int q = 0; q < DRP_K - 1; ++q) ties_left -= (best[q] < kth) ? 1 : 0;
+    if (skip >= 0) {
+        out[cnt++] = (int16_t)i;
+        if (!(0.0f < kth)) --ties_left;              // the self loop (distance 0) is itself one of the ties
+    }
     for (j = 0; j + 4 <= N; j += 4) {
         const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
         const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
                              pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (d4[u] <= kth && __fsub_rn(d4[u], thr) < 0.0f && cnt < DRP_K && j + u != skip) out[cnt++] = (int16_t)(j + u);
+            if (d4[u] <= kth && __fsub_rn(d4[u], thr) < 0.0f && cnt < DRP_K && j + u != skip) {
+                if (d4[u] < kth) out[cnt++] = (int16_t)(j + u);
+                else if (ties_left > 0) { out[cnt++] = (int16_t)(j + u); --ties_left; }
+            }
     }
     for (; j < N; ++j) {
         const float4 pj = p4[j];
         const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
-        if (d <= kth && __fsub_rn(d, thr) < 0.0f && cnt < DRP_K && j != skip) out[cnt++] = (int16_t)j;
+        if (d <= kth && __fsub_rn(d, thr) < 0.0f && cnt < DRP_K && j != skip) {
+            if (d < kth) out[cnt++] = (int16_t)j;
+            else if (ties_left > 0) { out[cnt++] = (int16_t)j; --ties_left; }
+        }
     }
     nbr_cnt[(size_t)b * N + i] = (uint8_t)cnt;
     for (int q = cnt; q < DRP_K; ++q) out[q] = -1;
+}
+
+// ---- the same lists with the senders bucketed into x strips --------------------------------------------
+// An edge needs |dx| < radius, so a receiver only has to look at senders whose x is within the radius of
+// its own.  k_graph_sort (one workgroup per sample) writes the sample's displaced positions into 64 fixed
+// strips of x (counting sort: histogram, scan, scatter; 1 cm wide in the camera frame, the ends clamped)
+// and k_graph_strips hands a workgroup 128 CONSECUTIVE receivers of that order, so the receivers of a wave sit
+// in a few neighbouring strips and the wave sweeps one contiguous range of the sorted senders: the strips of
+// its first and last receiver widened by the radius (+ one strip against rounding).  The range is
+// wave-uniform, so the positions still arrive by broadcast LDS reads (per-lane windows do not pay, DESIGN.md
+// 9b), and a workgroup stages only the range its two waves need.  Senders outside the range are farther than
+// the radius in x alone: (dis - thr < 0) is false for them and, being farther than every in-radius sender,
+// they cannot displace one from the ten nearest -- the result is exactly k_graph's.
+//   uniform piles over the +-0.2 workspace: 66 % of the pairs at N = 300, 50 % at N = 1200; a pile narrower
+//   than two radii gains nothing and pays the sort.
+// The order inside a strip is whatever the scatter's atomics produced (one order per sample: that is why the
+// sort is its own launch and not redone by every workgroup); nothing depends on it.  The sweeps meet the
+// senders in strip order, not index order: the (at most ten) chosen indices are staged in LDS and leave
+// through a sorting network in ascending index, as k_graph emits them.  The 10th-nearest distance itself
+// always ties with kth; a SECOND sender at exactly that distance (coincident particles, e.g. zero-padded
+// training rows) takes the slow path that picks the remaining lowest indices one sweep at a time -- the host
+// keeps k_graph for padded batches.
+#define GRAPH_STRIPS 64
+#define GRAPH_STRIP_X0 (-0.32f)
+#define GRAPH_STRIP_INV_W 100.0f
+#define GRAPH_SORT_THREADS 256
+
+__device__ __forceinline__ int graph_strip(float x) {
+    // any monotone map of x is valid; NaN lands in strip 0
+    const float t = __fmul_rn(__fsub_rn(x, GRAPH_STRIP_X0), GRAPH_STRIP_INV_W);
+    return (int)fminf(fmaxf(t, 0.0f), (float)(GRAPH_STRIPS - 1));
+}
+
+__device__ __forceinline__ void sort2(int& a, int& b) {
+    const int lo = min(a, b), hi = max(a, b);
+    a = lo; b = hi;
+}
+
+// sorted[b][Np] = (x, y, z, index) in strip order (Np = N rounded up to 4, the padding 1e18 away),
+// starts[b][GRAPH_STRIPS + 1] = first slot of every strip; also writes s_delta when the push is given.
+__global__ void __launch_bounds__(GRAPH_SORT_THREADS)
+k_graph_sort(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
+             const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
+             DrpCam cam, float4* __restrict__ sorted, int* __restrict__ starts) {
+    __shared__ int cursor[GRAPH_STRIPS];
+    const int b = blockIdx.x, Np = (N + 3) & ~3;
+    const float* s = s_prev + (size_t)(b % prev_mod) * prev_stride;
+    float* sd = s_delta + (size_t)b * N * 3;
+    float4* q4 = sorted + (size_t)b * Np;
+    int* sstart = starts + (size_t)b * (GRAPH_STRIPS + 1);
+    PushFrame f = {};
+    if (actions != nullptr) f = push_frame(cam, actions + (size_t)b * act_stride);
+    auto displaced = [&](int i, float& x, float& y, float& z, bool write_delta) {
+        const float sx = s[i * 3 + 0], sy = s[i * 3 + 1], sz = s[i * 3 + 2];
+        float ox, oy, oz;
+        if (actions != nullptr) {
+            push_delta(f, sx, sy, sz, ox, oy, oz);
+            if (write_delta) {
+                sd[i * 3 + 0] = ox;
+                sd[i * 3 + 1] = oy;
+                sd[i * 3 + 2] = oz;
+            }
+        } else {
+            ox = sd[i * 3 + 0]; oy = sd[i * 3 + 1]; oz = sd[i * 3 + 2];
+        }
+        x = __fadd_rn(sx, ox);                                    // gnn_dyn.py:224
+        y = __fadd_rn(sy, oy);
+        z = __fadd_rn(sz, oz);
+    };
+    if (threadIdx.x < GRAPH_STRIPS) cursor[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += GRAPH_SORT_THREADS) {
+        float x, y, z;
+        displaced(i, x, y, z, false);
+        atomicAdd(&cursor[graph_strip(x)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                       // exclusive scan of the 64 counts by the first wave
+        const int cnt = cursor[threadIdx.x];
+        int v = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(v, o, 64);
+            if ((int)threadIdx.x >= o) v += u;
+        }
+        sstart[threadIdx.x + 1] = v;
+        if (threadIdx.x == 0) sstart[0] = 0;
+        cursor[threadIdx.x] = v - cnt;
+    }
+    if ((int)threadIdx.x < Np - N) q4[N + threadIdx.x] = make_float4(1e18f, 0.0f, 0.0f, __int_as_float(-1));
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += GRAPH_SORT_THREADS) {
+        float x, y, z;
+        displaced(i, x, y, z, true);
+        const int slot = atomicAdd(&cursor[graph_strip(x)], 1);
+        q4[slot] = make_float4(x, y, z, __int_as_float(i));
+    }
+}
+
+#define GRAPH_STRIPS_LDS(N) ((size_t)(((N) + 3) & ~3) * 16 + (GRAPH_STRIPS + 1) * 4 + GRAPH_THREADS * DRP_K * 2)
+
+__global__ void __launch_bounds__(GRAPH_THREADS)
+k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts, int N,
+               int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, float thr, int chunks, int self_first) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Np = (N + 3) & ~3;
+    float4* q4 = reinterpret_cast<float4*>(lds);                 // the staged range of the sorted senders
+    int* sstart = reinterpret_cast<int*>(q4 + Np);               // [GRAPH_STRIPS + 1]
+    int16_t* lst = reinterpret_cast<int16_t*>(sstart + GRAPH_STRIPS + 1);   // [GRAPH_THREADS][DRP_K] chosen indices, unsorted
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const float4* g4 = sorted + (size_t)b * Np;
+    if (threadIdx.x <= GRAPH_STRIPS) sstart[threadIdx.x] = starts[(size_t)b * (GRAPH_STRIPS + 1) + threadIdx.x];
+    const int s_first = chunk * GRAPH_THREADS;
+    const int s_last = min(s_first + GRAPH_THREADS, N) - 1;
+    const float radius = __fsqrt_rn(fmaxf(thr, 0.0f)) * 1.000001f;
+    const int reach = (int)fminf(ceilf(radius * GRAPH_STRIP_INV_W), (float)GRAPH_STRIPS) + 1;
+    // the workgroup's range: strips of its first and last receiver (the order is by strip), widened by the radius
+    const int wg_smin = graph_strip(g4[s_first].x), wg_smax = graph_strip(g4[s_last].x);
+    __syncthreads();
+    const int wlo = sstart[max(wg_smin - reach, 0)] & ~3;
+    const int whi = (sstart[min(wg_smax + reach, GRAPH_STRIPS - 1) + 1] + 3) & ~3;
+    for (int j = wlo + (int)threadIdx.x; j < whi; j += GRAPH_THREADS) q4[j] = g4[j];
+    __syncthreads();
+
+    const int si = s_first + threadIdx.x;
+    const bool valid = si < N;
+    const unsigned long long act = __ballot(valid);
+    if (act == 0) return;
+    const float4 pi = q4[valid ? si : s_last];                    // a receiver is inside its own workgroup's range
+    const int i = __float_as_int(pi.w);
+    const int my_strip = graph_strip(pi.x);
+    const int smin = __builtin_amdgcn_readlane(my_strip, __ffsll((long long)act) - 1);
+    const int smax = __builtin_amdgcn_readlane(my_strip, 63 - __clzll((long long)act));
+    const int jlo = max(sstart[max(smin - reach, 0)] & ~3, wlo);
+    const int jhi = min((sstart[min(smax + reach, GRAPH_STRIPS - 1) + 1] + 3) & ~3, whi);
+
+    float best[DRP_K];
+#pragma unroll
+    for (int q = 0; q < DRP_K; ++q) best[q] = thr;
+    for (int j = jlo; j < jhi; j += 4) {
+        const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
+        const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
+                             pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int q = DRP_K - 1; q > 0; --q) best[q] = __builtin_amdgcn_fmed3f(d4[u], best[q - 1], best[q]);
+            best[0] = min_nonneg(d4[u], best[0]);
+        }
+    }
+    const float kth = best[DRP_K - 1];
+    // second sweep: senders strictly nearer than kth are in; the ones AT kth fill what is left, lowest index first
+    const int skip = (self_first && thr > 0.0f) ? i : -1;
+    int16_t* mine = lst + threadIdx.x * DRP_K;
+    int cnt = 0, ties = 0, min_tie = 0x7fff;
+    for (int j = jlo; j < jhi; j += 4) {
+        const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
+        const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
+                             pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
+        const int o4[4] = {__float_as_int(q0.w), __float_as_int(q1.w), __float_as_int(q2.w), __float_as_int(q3.w)};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool inr = __fsub_rn(d4[u], thr) < 0.0f;
+            if (inr && d4[u] < kth && o4[u] != skip && cnt < DRP_K) mine[cnt++] = (int16_t)o4[u];
+            if (inr && d4[u] == kth && o4[u] != skip) {
+                ++ties;
+                min_tie = min(min_tie, o4[u]);
+            }
+        }
+    }
+    const int room = DRP_K - cnt - (skip >= 0 ? 1 : 0);
+    if (ties == 1 && room > 0) {
+        mine[cnt++] = (int16_t)min_tie;
+    } else if (ties > 1 && room > 0) {
+        // several senders at exactly kth: take the lowest indices among them, one sweep each
+        int last = -1;
+        for (int r = 0; r < room && r < ties; ++r) {
+            int nxt = 0x7fff;
+            for (int j = jlo; j < jhi; ++j) {
+                const float4 q = q4[j];
+                const float d = pair_dis(pi.x, pi.y, pi.z, q.x, q.y, q.z);
+                const int o = __float_as_int(q.w);
+                if (__fsub_rn(d, thr) < 0.0f && d == kth && o != skip && o > last) nxt = min(nxt, o);
+            }
+            mine[cnt++] = (int16_t)nxt;
+            last = nxt;
+        }
+    }
+    if (!valid) return;
+    // ascending index through a 10-input sorting network (29 compare-exchanges); empty slots sort last
+    int v[DRP_K];
+#pragma unroll
+    for (int q = 0; q < DRP_K; ++q) v[q] = (q < cnt) ? (int)mine[q] : 0x7fff;
+#define CE(a, b) sort2(v[a], v[b])
+    CE(0, 5); CE(1, 6); CE(2, 7); CE(3, 8); CE(4, 9);
+    CE(0, 3); CE(1, 4); CE(5, 8); CE(6, 9);
+    CE(0, 2); CE(3, 6); CE(7, 9);
+    CE(0, 1); CE(2, 4); CE(5, 7); CE(8, 9);
+    CE(1, 2); CE(3, 5); CE(4, 6); CE(7, 8);
+    CE(1, 3); CE(2, 5); CE(4, 7); CE(6, 8);
+    CE(2, 3); CE(4, 5); CE(6, 7);
+    CE(3, 4); CE(5, 6);
+#undef CE
+    int16_t* out = nbr_idx + ((size_t)b * N + i) * DRP_K;
+    int w = 0;
+    if (skip >= 0) out[w++] = (int16_t)i;
+#pragma unroll
+    for (int q = 0; q < DRP_K; ++q)
+        if (q < cnt && w < DRP_K) out[w++] = (int16_t)v[q];
+    nbr_cnt[(size_t)b * N + i] = (uint8_t)w;
+    for (int q = w; q < DRP_K; ++q) out[q] = -1;
 }

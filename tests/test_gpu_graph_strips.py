@@ -1,0 +1,83 @@
+"""GPU: the x-strip neighbour build (k_graph_sort + k_graph_strips, samples of more than 128 particles) against
+the plain two-sweep kernel (DRP_NO_GRAPH_STRIPS=1) -- the same lists bit for bit, in both emission orders
+(ascending index through drp_build_graph; self loop first inside the fused engine's rollouts) -- and against
+the reference's own lists through the golden one-step cases elsewhere (tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+from dyn_res_pile_manip_amd import synthetic as syn, weights
+from dyn_res_pile_manip_amd.planners import world2cam_affine
+
+pytestmark = pytest.mark.gpu
+
+
+def _engines(monkeypatch):
+    from dyn_res_pile_manip_amd.engine import Engine
+    blob = weights.blob_from_state_dict(weights.random_state_dict(seed=0))
+    M34 = world2cam_affine(syn.demo_cam_extrinsics())
+    out = {}
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv('DRP_NO_GRAPH_STRIPS', '1')
+        else:
+            monkeypatch.delenv('DRP_NO_GRAPH_STRIPS', raising=False)
+        eng = Engine(0)
+        eng.load_weights(blob, 0.08)
+        eng.set_camera(M34, 24.0, syn.demo_cam_params())
+        out[plain] = eng
+    return out
+
+
+@pytest.mark.parametrize('N,B,kind,scale', [(129, 5, 'uniform', 1.0), (300, 6, 'uniform', 1.0), (300, 4, 'blob', 1.0),
+                                            (515, 3, 'uniform', 3.0), (700, 2, 'blob', 0.3), (1200, 2, 'uniform', 1.0)])
+def test_lists_equal_plain_sweep(monkeypatch, N, B, kind, scale):
+    """Jittered piles: uniform over the workspace, clumped (everything within a radius or two: the strips prune
+    nothing), spread out (most strips empty, particles beyond the clamped end strips)."""
+    engs = _engines(monkeypatch)
+    rng = np.random.default_rng(N)
+    s0, _, _ = syn.make_pile(N, 1, seed=N, kind=kind)
+    s = np.tile(s0, (B, 1, 1)).astype(np.float32)
+    s[..., :2] *= scale
+    s += 0.002 * rng.standard_normal(s.shape).astype(np.float32)
+    sd = (0.004 * rng.standard_normal(s.shape)).astype(np.float32)
+    i0, c0 = engs[False].build_graph(s, sd)
+    i1, c1 = engs[True].build_graph(s, sd)
+    for e in engs.values():
+        e.close()
+    assert np.array_equal(c0, c1)
+    assert np.array_equal(i0, i1)
+    assert c0.max() == 10 or scale > 1.0
+
+
+def test_coincident_particles_tie_at_the_cut(monkeypatch):
+    """Sixty particles on one spot and a few exact duplicates elsewhere: more senders at exactly the 10th
+    distance than slots left -- the lowest indices win in both kernels."""
+    engs = _engines(monkeypatch)
+    N, B = 260, 3
+    s0, _, _ = syn.make_pile(N, 1, seed=5)
+    s = np.tile(s0, (B, 1, 1)).astype(np.float32)
+    s[:, 40:100] = s[:, 40:41]
+    s[1, 200:204] = s[1, 10:11]
+    s[2, 150] = s[2, 7]
+    sd = np.zeros_like(s)
+    i0, c0 = engs[False].build_graph(s, sd)
+    i1, c1 = engs[True].build_graph(s, sd)
+    for e in engs.values():
+        e.close()
+    assert np.array_equal(c0, c1)
+    assert np.array_equal(i0, i1)
+    assert (i0[0, 40:100, :10] < 100).all() and (i0[0, 40:100, 0] == 40).all()
+
+
+def test_rollouts_equal_with_self_loop_first(monkeypatch):
+    """Inside the fused engine the lists start with the self loop; whole rollouts (pushes included) agree bitwise."""
+    engs = _engines(monkeypatch)
+    N, ns, H = 300, 40, 3
+    s0, dens, attr = syn.make_pile(N, 1, seed=2)
+    acts = syn.sample_pushes(ns, H, seed=2)
+    r0, _ = engs[False].rollout(s0, attr, dens, acts)
+    r1, _ = engs[True].rollout(s0, attr, dens, acts)
+    for e in engs.values():
+        e.close()
+    assert np.isfinite(r0).all()
+    assert np.array_equal(r0, r1)
