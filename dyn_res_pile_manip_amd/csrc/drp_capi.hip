@@ -428,7 +428,7 @@ int run_step(drp_ctx* c, const StepArgs& a) {
 int run_reward(drp_ctx* c, const float* state, size_t row_stride, int rows, int N, int normalize,
                float* out) {
     ProbeScope ps(c, KC_REWARD);
-    hipLaunchKernelGGL(k_reward, dim3(rows), dim3(256), (2 * N + 8) * sizeof(float), c->stream, state,
+    hipLaunchKernelGGL(k_reward, dim3(rows), dim3(256), (2 * ((N + 3) & ~3) + 8) * sizeof(float), c->stream, state,
                        row_stride, N, ptr<float>(c->goal_field), c->goal_h, c->goal_w,
                        ptr<float>(c->goal_coor), c->goal_m, c->cam, normalize, out);
     HIPCHK(c, hipGetLastError());

@@ -29,9 +29,10 @@ k_reward(const float* __restrict__ state, size_t row_stride, int N, const float*
          int Hh, int Ww, const float* __restrict__ goal_coor, int M, DrpCam cam, int normalize,
          float* __restrict__ reward_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Na = (N + 3) & ~3;                     // py and the reduction scratch stay 16-B aligned
     float* px = lds;
-    float* py = lds + N;
-    float* red = lds + 2 * N;
+    float* py = lds + Na;
+    float* red = lds + 2 * Na;
     const float* s = state + (size_t)blockIdx.x * row_stride;
     float r1 = 0.0f;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
@@ -61,7 +62,16 @@ k_reward(const float* __restrict__ state, size_t row_stride, int N, const float*
     for (int m = threadIdx.x; m < M; m += blockDim.x) {
         const float gx = goal_coor[m * 2 + 0], gy = goal_coor[m * 2 + 1];
         float best = __builtin_inff();
-        for (int n = 0; n < N; ++n) {
+        int n = 0;
+        for (; n + 4 <= N; n += 4) {                 // four particles per pair of broadcast LDS reads
+            const float4 x4 = *reinterpret_cast<const float4*>(px + n), y4 = *reinterpret_cast<const float4*>(py + n);
+            const float dx0 = gx - x4.x, dy0 = gy - y4.x, dx1 = gx - x4.y, dy1 = gy - y4.y;
+            const float dx2 = gx - x4.z, dy2 = gy - y4.z, dx3 = gx - x4.w, dy3 = gy - y4.w;
+            const float d0 = __fadd_rn(__fmul_rn(dx0, dx0), __fmul_rn(dy0, dy0)), d1 = __fadd_rn(__fmul_rn(dx1, dx1), __fmul_rn(dy1, dy1));
+            const float d2 = __fadd_rn(__fmul_rn(dx2, dx2), __fmul_rn(dy2, dy2)), d3 = __fadd_rn(__fmul_rn(dx3, dx3), __fmul_rn(dy3, dy3));
+            best = fminf(fminf(best, fminf(d0, d1)), fminf(d2, d3));
+        }
+        for (; n < N; ++n) {
             const float dx = gx - px[n], dy = gy - py[n];
             best = fminf(best, __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
         }
