@@ -27,6 +27,7 @@
 #ifdef DRP_HAVE_MFMA
 #include "k_mlp_mfma.h"
 #include "k_mlp_split.h"
+#include "k_mlp_tile16.h"
 #include "k_backward_mfma.h"
 #endif
 
@@ -57,11 +58,12 @@ struct drp_ctx {
     bool self_const = true;         // DRP_NO_SELF_CONST=1: always run the encoder chain on the self slot too
     bool prop3 = true;              // DRP_NO_PROP3=1: one launch per propagation step even for chip-filling batches
     bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
+    bool tile16 = false;            // DRP_TILE16=1: 16-item tiles, three waves per SIMD (km_prop3_t16) where km_prop3 would run
 
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
     float adj_thresh = 0.08f, thr = 0.0064f;
-    DevBuf w_raw, w_valu, w_mfma, w_mfma_bwd, w_split, w_split6;
+    DevBuf w_raw, w_valu, w_mfma, w_mfma_bwd, w_split, w_split6, w_t16, w_t16_6;
     DrpCam cam{};
     DevBuf goal_field, goal_coor, cself;
     unsigned cself_tag = 0;         // bumped by every prepare_cself: who filled c->cself last
@@ -327,7 +329,12 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
 #define PROP3_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
                    a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, pb, \
                    ptr<float>(c->c_node), eff_base, N, B, spw, a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist
-            if (!tape) hipLaunchKernelGGL((km_prop3<false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
+            if (!tape && c->tile16)
+                hipLaunchKernelGGL(km_prop3_t16, grid, dim3(64 * PROP16_WAVES), KM_PROP3_T16_LDS, st, ptr<uint16_t>(c->w_t16),
+                                   ptr<uint16_t>(c->w_t16_6), mw, a.s_prev, a.prev_mod, a.prev_stride, a.attr, a.attr_mod, a.dens,
+                                   a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, pb, ptr<float>(c->c_node),
+                                   eff_base, N, B, spw, a.s_out, a.out_stride, a.cself, a.cself_ok);
+            else if (!tape) hipLaunchKernelGGL((km_prop3<false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
             else hipLaunchKernelGGL((km_prop3<true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
 #undef PROP3_ARGS
         }
@@ -576,6 +583,7 @@ int drp_create(int device, drp_ctx** out) {
     c->self_const = getenv("DRP_NO_SELF_CONST") == nullptr;
     c->prop3 = getenv("DRP_NO_PROP3") == nullptr;
     c->graph_strips = getenv("DRP_NO_GRAPH_STRIPS") == nullptr;
+    c->tile16 = getenv("DRP_TILE16") != nullptr;
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -599,6 +607,7 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_prop<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3_t16, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_T16_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
@@ -618,7 +627,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     DevBuf* bufs[] = {&c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
-                      &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
+                      &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->w_t16, &c->w_t16_6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
                       &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats, &c->cself,
@@ -691,6 +700,11 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
         pack_split6(blob, sp6);
         CHK(h2d(c, c->w_split6, sp6.data(), sp6.size() * sizeof(uint16_t)));
         HIPCHK(c, hipStreamSynchronize(c->stream));     // sp6 too
+        pack_tile16(blob, sp);
+        CHK(h2d(c, c->w_t16, sp.data(), sp.size() * sizeof(uint16_t)));
+        pack_tile16_6(blob, sp6);
+        CHK(h2d(c, c->w_t16_6, sp6.data(), sp6.size() * sizeof(uint16_t)));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));     // m, sp are about to go out of scope
     }
 #endif

@@ -160,3 +160,30 @@ def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch):
         assert np.isfinite(res[False, tag]).all()
         assert np.array_equal(res[False, tag], res[True, tag]), tag
     assert not np.array_equal(res[False, 'uniform'], res[False, 'mixed'])
+
+
+def test_sixteen_item_tiles_agree(monkeypatch):
+    """DRP_TILE16=1: the experimental propagation kernel on 16-receiver tiles (three waves per SIMD,
+    km_prop3_t16) against the default 32-receiver tiles -- the same arithmetic per item in another summation
+    order: agreement to a few ulp of the positions on the first step."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    blob = weights.blob_from_state_dict(weights.random_state_dict(seed=0))
+    M34 = world2cam_affine(syn.demo_cam_extrinsics())
+    for N, ns, H in ((300, 512, 2), (70, 700, 2)):
+        s0, dens, attr = syn.make_pile(N, 1, seed=1)
+        acts = syn.sample_pushes(ns, H, seed=1)
+        res = {}
+        for t16 in (False, True):
+            if t16:
+                monkeypatch.setenv('DRP_TILE16', '1')
+            else:
+                monkeypatch.delenv('DRP_TILE16', raising=False)
+            eng = Engine(0)
+            eng.load_weights(blob, 0.08)
+            eng.set_camera(M34, 24.0, syn.demo_cam_params())
+            res[t16], _ = eng.rollout(s0, attr, dens, acts)
+            eng.close()
+        disp = np.abs(res[False][:, 0] - s0).max()
+        assert np.isfinite(res[True]).all()
+        assert np.abs(res[False][:, 0] - res[True][:, 0]).max() < 1e-4 * disp
+        assert np.median(np.abs(res[False] - res[True]).reshape(ns, -1).max(1)) < 5e-7
