@@ -341,11 +341,19 @@ k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts
         }
     }
     const float kth = best[DRP_K - 1];
-    // second sweep: senders strictly nearer than kth are in; the ones AT kth fill what is left, lowest index first
+    // second sweep: senders strictly nearer than kth are in; the ones AT kth fill what is left, lowest index first.
+    // Nothing farther than sqrt(kth) is emitted, so the sweep narrows to the strips within the wave's largest
+    // 10th-nearest distance (dense piles: a quarter of the radius)
+    float kmax = valid ? kth : 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kmax = fmaxf(kmax, __shfl_xor(kmax, o, 64));
+    const int reach2 = min(reach, (int)ceilf(__fsqrt_rn(fmaxf(kmax, 0.0f)) * 1.000001f * GRAPH_STRIP_INV_W) + 1);
+    const int jlo2 = max(sstart[max(smin - reach2, 0)] & ~3, jlo);
+    const int jhi2 = min((sstart[min(smax + reach2, GRAPH_STRIPS - 1) + 1] + 3) & ~3, jhi);
     const int skip = (self_first && thr > 0.0f) ? i : -1;
     int16_t* mine = lst + threadIdx.x * DRP_K;
     int cnt = 0, ties = 0, min_tie = 0x7fff;
-    for (int j = jlo; j < jhi; j += 4) {
+    for (int j = jlo2; j < jhi2; j += 4) {
         const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
         const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
                              pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
@@ -368,7 +376,7 @@ k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts
         int last = -1;
         for (int r = 0; r < room && r < ties; ++r) {
             int nxt = 0x7fff;
-            for (int j = jlo; j < jhi; ++j) {
+            for (int j = jlo2; j < jhi2; ++j) {
                 const float4 q = q4[j];
                 const float d = pair_dis(pi.x, pi.y, pi.z, q.x, q.y, q.z);
                 const int o = __float_as_int(q.w);
