@@ -329,15 +329,37 @@ k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts
     float best[DRP_K];
 #pragma unroll
     for (int q = 0; q < DRP_K; ++q) best[q] = thr;
-    for (int j = jlo; j < jhi; j += 4) {
-        const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
-        const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
-                             pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
+    auto sweep1 = [&](int ja, int jb) {
+        for (int j = ja; j < jb; j += 4) {
+            const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
+            const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
+                                 pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int q = DRP_K - 1; q > 0; --q) best[q] = __builtin_amdgcn_fmed3f(d4[u], best[q - 1], best[q]);
-            best[0] = min_nonneg(d4[u], best[0]);
+                for (int q = DRP_K - 1; q > 0; --q) best[q] = __builtin_amdgcn_fmed3f(d4[u], best[q - 1], best[q]);
+                best[0] = min_nonneg(d4[u], best[0]);
+            }
+        }
+    };
+    // first sweep in two stages: the strips within half the radius give a provisional 10th-nearest distance (an upper
+    // bound of the final one: more candidates can only lower it); a sender that could still enter the list is nearer
+    // than that in x, so the stage that follows only covers the strips within the wave's largest provisional distance
+    // -- none at all in a dense pile.  The list of the ten smallest does not depend on the order of insertion.
+    const int reach_a = (reach + 1) >> 1;
+    const int ja = max(sstart[max(smin - reach_a, 0)] & ~3, jlo);
+    const int jb = min((sstart[min(smax + reach_a, GRAPH_STRIPS - 1) + 1] + 3) & ~3, jhi);
+    sweep1(ja, jb);
+    {
+        float kprov = valid ? best[DRP_K - 1] : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kprov = fmaxf(kprov, __shfl_xor(kprov, o, 64));
+        const int reach_b = min(reach, (int)ceilf(__fsqrt_rn(fmaxf(kprov, 0.0f)) * 1.000001f * GRAPH_STRIP_INV_W) + 1);
+        if (reach_b > reach_a) {
+            const int jl = max(sstart[max(smin - reach_b, 0)] & ~3, jlo);
+            const int jh = min((sstart[min(smax + reach_b, GRAPH_STRIPS - 1) + 1] + 3) & ~3, jhi);
+            sweep1(jl, ja);
+            sweep1(jb, jh);
         }
     }
     const float kth = best[DRP_K - 1];
