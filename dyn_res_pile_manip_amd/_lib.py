@@ -77,6 +77,9 @@ SIGNATURES = {
     'drp_mpc_partials': (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     'drp_mpc_update': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p]),
     'drp_mpc_update_device': (ctypes.c_int, [ctypes.c_void_p]),
+    'drp_mpc_elite': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p]),
+    'drp_mpc_update_elite': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p]),
+    'drp_mpc_update_elite_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'drp_mpc_get': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                    c_double_p]),
     'drp_fps': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

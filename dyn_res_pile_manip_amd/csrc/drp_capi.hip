@@ -76,7 +76,7 @@ struct drp_ctx {
     // MPC state
     bool mpc_on = false;
     drp_mpc_params mpc{};
-    DevBuf nominal, noise, partials, gathered, stats;
+    DevBuf nominal, noise, partials, gathered, stats, elite, elite_all;
     int n_ranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
 
@@ -630,7 +630,7 @@ void drp_destroy(drp_ctx* c) {
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->w_t16, &c->w_t16_6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
-                      &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats, &c->cself,
+                      &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats, &c->elite, &c->elite_all, &c->cself,
                       &c->px_depth, &c->px_mask, &c->px_blk, &c->px_bmin, &c->px_bmax, &c->px_grid, &c->px_pcd, &c->px_keys,
                       &c->px_cellcnt, &c->px_cellfill, &c->px_celloff, &c->px_list, &c->px_down, &c->px_down32, &c->px_init,
                       &c->px_dist, &c->px_chosen, &c->px_pts, &c->px_r, &c->px_rr, &c->px_out,
@@ -968,6 +968,74 @@ int drp_mpc_update_device(drp_ctx* c) {
         return launch_update(c, ptr<double>(c->gathered), c->n_ranks);
     }
     return launch_update(c, ptr<double>(c->partials), 1);
+}
+
+// ---- elite (CEM-style) update: nominal = mean of the k best sequences over all ranks
+static int elite_check(drp_ctx* c, int k) {
+    if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    if (k < 1 || k > 1024) return fail(c, DRP_EINVAL, "elite size %d outside 1..1024", k);
+    if (4 * c->mpc.n_look_ahead > 256) return fail(c, DRP_EINVAL, "elite update supports horizons up to 64");
+    return DRP_OK;
+}
+
+static int launch_elite_local(drp_ctx* c, int k) {
+    const drp_mpc_params& p = c->mpc;
+    const int H = p.n_look_ahead;
+    CHK(ensure(c, c->elite, (size_t)k * (2 + 4 * H) * sizeof(double)));
+    ProbeScope ps(c, KC_MPPI);
+    hipLaunchKernelGGL(k_elite_local, dim3(1), dim3(256), 0, c->stream, ptr<float>(c->rewards) + (H - 1), H,
+                       ptr<float>(c->actions), p.n_sample, p.n_batch, H, k, p.sample_offset, ptr<double>(c->elite));
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+static int launch_elite_update(drp_ctx* c, const double* dev_records, int n_ranks, int k) {
+    ProbeScope ps(c, KC_MPPI);
+    hipLaunchKernelGGL(k_elite_update, dim3(1), dim3(256), 0, c->stream, dev_records, n_ranks, k, c->mpc.n_look_ahead,
+                       ptr<double>(c->nominal), ptr<double>(c->stats) + 6);
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+int drp_mpc_elite(drp_ctx* c, int k, double* out) {
+    CHK(elite_check(c, k));
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(launch_elite_local(c, k));
+    if (out) {
+        CHK(d2h(c, out, c->elite.p, (size_t)k * (2 + 4 * c->mpc.n_look_ahead) * sizeof(double)));
+        return drp_sync(c);
+    }
+    return DRP_OK;
+}
+
+int drp_mpc_update_elite(drp_ctx* c, const double* records, int n_ranks, int k, double* nominal_out) {
+    CHK(elite_check(c, k));
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!records || n_ranks <= 0) return fail(c, DRP_EINVAL, "bad elite records");
+    const size_t bytes = (size_t)n_ranks * k * (2 + 4 * c->mpc.n_look_ahead) * sizeof(double);
+    CHK(ensure(c, c->elite_all, bytes));
+    CHK(h2d(c, c->elite_all, records, bytes));
+    CHK(launch_elite_update(c, ptr<double>(c->elite_all), n_ranks, k));
+    if (nominal_out) {
+        CHK(d2h(c, nominal_out, c->nominal.p, (size_t)c->mpc.n_look_ahead * 4 * sizeof(double)));
+        return drp_sync(c);
+    }
+    return DRP_OK;
+}
+
+int drp_mpc_update_elite_device(drp_ctx* c, int k) {
+    CHK(elite_check(c, k));
+    // reward statistics (mean, std, max, argmax) as in the softmax update; its nominal is then replaced
+    CHK(drp_mpc_update_device(c));
+    CHK(launch_elite_local(c, k));
+    const int rec = k * (2 + 4 * c->mpc.n_look_ahead);
+    if (c->comm && c->n_ranks > 1) {
+        CHK(ensure(c, c->elite_all, (size_t)rec * sizeof(double) * c->n_ranks));
+        ncclResult_t r = ncclAllGather(c->elite.p, c->elite_all.p, rec, ncclDouble, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", ncclGetErrorString(r));
+        return launch_elite_update(c, ptr<double>(c->elite_all), c->n_ranks, k);
+    }
+    return launch_elite_update(c, ptr<double>(c->elite), 1, k);
 }
 
 int drp_mpc_get(drp_ctx* c, float* actions, float* rewards, float* rewards_all, float* states,

@@ -188,3 +188,97 @@ __global__ void k_mppi_update(const double* __restrict__ partials, int n_ranks, 
         stats_out[5] = m;
     }
 }
+
+
+// ---- elite update (cross-entropy-method style) ------------------------------------------------
+// Not in the reference (planners.py has neither CEM nor a working sampling planner; SURVEY.md section 8e
+// names it as the other form of the one exchange): the new nominal sequence is the MEAN of the k best
+// samples' sequences.  Order: higher reward first, ties to the lower global sample index, so every rank
+// count gives the same elite.  A rank contributes its k best as records
+//     [reward, global sample index, act[4H]]            (2 + 4H doubles each, best first;
+//                                                        reward = -inf pads a rank with fewer samples)
+// and the combine picks the k best of all ranks' records.  Selection = k rounds of "best key after the last
+// pick" over <= a few thousand keys: no sort, no scratch.
+__device__ __forceinline__ bool elite_before(double ra, double ia, double rb, double ib) {
+    return ra > rb || (ra == rb && ia < ib);
+}
+
+// best (r, i) over the block; every thread returns it.  red: >= 2 * 4 doubles of LDS
+__device__ __forceinline__ void block_best(double& r, double& i, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double r2 = __shfl_xor(r, o, 64), i2 = __shfl_xor(i, o, 64);
+        if (elite_before(r2, i2, r, i)) { r = r2; i = i2; }
+    }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[2 * wave] = r; red[2 * wave + 1] = i; }
+    __syncthreads();
+    r = red[0]; i = red[1];
+    for (int w = 1; w < nw; ++w)
+        if (elite_before(red[2 * w], red[2 * w + 1], r, i)) { r = red[2 * w]; i = red[2 * w + 1]; }
+}
+
+__global__ void __launch_bounds__(256)
+k_elite_local(const float* __restrict__ reward, int reward_stride, const float* __restrict__ actions,
+              int n_sample, int n_batch, int H, int k, uint64_t sample_offset, double* __restrict__ out) {
+    __shared__ double red[8];
+    const int HJ = 4 * H, REC = 2 + HJ;
+    double last_r = __builtin_inf(), last_i = -1.0;              // everything comes after (+inf, -1)
+    for (int e = 0; e < k; ++e) {
+        double br = -__builtin_inf(), bi = 1e300;
+        for (int s = threadIdx.x; s < n_sample; s += blockDim.x) {
+            double r = 0.0;
+            for (int c = 0; c < n_batch; ++c) r += (double)reward[((size_t)s * n_batch + c) * reward_stride];
+            r /= (double)n_batch;
+            const double gi = (double)s + (double)sample_offset;
+            if (elite_before(last_r, last_i, r, gi) && elite_before(r, gi, br, bi)) { br = r; bi = gi; }
+        }
+        block_best(br, bi, red);
+        double* o = out + (size_t)e * REC;
+        const bool found = bi < 1e299;
+        if (threadIdx.x == 0) { o[0] = found ? br : -__builtin_inf(); o[1] = found ? bi : -1.0; }
+        const int s = found ? (int)(bi - (double)sample_offset) : 0;
+        for (int j = threadIdx.x; j < HJ; j += blockDim.x)
+            o[2 + j] = found ? (double)actions[((size_t)s * n_batch) * HJ + j] : 0.0;
+        if (found) { last_r = br; last_i = bi; }
+        else { last_r = -__builtin_inf(); last_i = 1e300; }     // nothing left: the remaining records are padding
+    }
+}
+
+// records [n_ranks][k][2+4H] -> nominal = mean of the k best sequences; elite_out: [0] elite size, [1] worst elite reward
+__global__ void __launch_bounds__(256)
+k_elite_update(const double* __restrict__ recs, int n_ranks, int k, int H, double* __restrict__ nominal,
+               double* __restrict__ elite_out) {
+    __shared__ double red[8];
+    const int HJ = 4 * H, REC = 2 + HJ, total = n_ranks * k;
+    double last_r = __builtin_inf(), last_i = -1.0;
+    double acc = 0.0;                                            // thread j < 4H: sum of the elite's action j
+    int taken = 0;
+    double worst = 0.0;
+    for (int e = 0; e < k; ++e) {
+        double br = -__builtin_inf(), bi = 1e300;
+        for (int q = threadIdx.x; q < total; q += blockDim.x) {
+            const double r = recs[(size_t)q * REC], gi = recs[(size_t)q * REC + 1];
+            if (gi >= 0.0 && elite_before(last_r, last_i, r, gi) && elite_before(r, gi, br, bi)) { br = r; bi = gi; }
+        }
+        block_best(br, bi, red);
+        if (!(bi < 1e299)) break;
+        // the record that holds the pick (global indices are unique across ranks)
+        int where = -1;
+        for (int q = threadIdx.x; q < total; q += blockDim.x)
+            if (recs[(size_t)q * REC + 1] == bi && recs[(size_t)q * REC] == br) where = q;
+        double w = (double)where, dummy = (where >= 0) ? 0.0 : 1.0;
+        {   // broadcast the (single) holder's position: best = highest `where`
+            double wr = w, wi = dummy;
+            block_best(wr, wi, red);
+            where = (int)wr;
+        }
+        if ((int)threadIdx.x < HJ) acc += recs[(size_t)where * REC + 2 + threadIdx.x];   // 4H <= blockDim (host checks)
+        ++taken;
+        worst = br;
+        last_r = br; last_i = bi;
+    }
+    if ((int)threadIdx.x < HJ && taken > 0) nominal[threadIdx.x] = acc / (double)taken;
+    if (threadIdx.x == 0 && elite_out != nullptr) { elite_out[0] = (double)taken; elite_out[1] = worst; }
+}

@@ -220,6 +220,21 @@ class Engine(object):
     def mpc_update_device(self):
         self._ck(self.lib.drp_mpc_update_device(self.h))
 
+    # elite (CEM-style) update: nominal = mean of the k best sequences (not in the reference; include/drp.h)
+    def mpc_elite(self, k, fetch=True):
+        out = np.empty((int(k), 2 + 4 * self.H), dtype=np.float64) if fetch else None
+        self._ck(self.lib.drp_mpc_elite(self.h, int(k), _dp(out) if fetch else None))
+        return out
+
+    def mpc_update_elite(self, records, k):
+        records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, int(k), 2 + 4 * self.H)
+        nominal = np.empty((self.H, 4), dtype=np.float64)
+        self._ck(self.lib.drp_mpc_update_elite(self.h, _dp(records), records.shape[0], int(k), _dp(nominal)))
+        return nominal
+
+    def mpc_update_elite_device(self, k):
+        self._ck(self.lib.drp_mpc_update_elite_device(self.h, int(k)))
+
     def mpc_get(self, actions=False, rewards=False, rewards_all=False, states=False, nominal=False):
         B = self.ns * self.nb
         a = np.empty((B, self.H, 4), np.float32) if actions else None

@@ -315,7 +315,11 @@ class PlannerGD(Planner):
                 eng.mpc_sample(i)
                 eng.mpc_rollout(False)
                 t1 = time.perf_counter()
-                eng.mpc_update_device()
+                if mpc_type == 'CEM':
+                    # elite update (not in the reference): mean of the n_elite best sequences
+                    eng.mpc_update_elite_device(int(cfg.get('cem', {}).get('n_elite', max(1, n_sample // 10))))
+                else:
+                    eng.mpc_update_device()
                 got = eng.mpc_get(rewards=True, actions=True)
                 t2 = time.perf_counter()
                 rollout_time += (t1 - t0) * 1e3

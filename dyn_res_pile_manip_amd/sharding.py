@@ -76,3 +76,36 @@ def allgather_records(record, group=None):
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t, group=group)
     return torch.stack(out).cpu().numpy()
+
+
+# ---- elite (CEM-style) update: nominal = mean of the k best sequences over all ranks -----------------
+# Not in the reference; SURVEY.md section 8e names it as the other form of the exchange.  A rank's record
+# block is its k best samples as [reward, global sample index, act[4H]], best first (higher reward, ties to
+# the lower index; reward -inf / index -1 pad a short rank).  Host mirrors of k_elite_local / k_elite_update.
+def elite_record_size(H):
+    return 2 + 4 * H
+
+
+def make_elite_records(rewards, act_seqs, k, sample_offset=0):
+    r = np.asarray(rewards, dtype=np.float64)
+    a = np.asarray(act_seqs, dtype=np.float64)
+    H = a.shape[1]
+    order = np.lexsort((np.arange(r.size), -r))          # reward descending, index ascending; NaN rewards last
+    order = [int(i) for i in order if not np.isnan(r[i])][:k]
+    rec = np.zeros((k, elite_record_size(H)), dtype=np.float64)
+    rec[:, 0], rec[:, 1] = -np.inf, -1.0
+    for e, i in enumerate(order):
+        rec[e, 0], rec[e, 1] = r[i], float(i + sample_offset)
+        rec[e, 2:] = a[i].ravel()
+    return rec
+
+
+def combine_elite_records(records, k):
+    """[n_ranks, k, 2+4H] -> nominal [H,4] (mean of the k best of all records), elite size, worst elite reward."""
+    rec = np.asarray(records, dtype=np.float64)
+    rec = rec.reshape(-1, rec.shape[-1])
+    rec = rec[rec[:, 1] >= 0.0]
+    order = np.lexsort((rec[:, 1], -rec[:, 0]))[:k]
+    H = (rec.shape[1] - 2) // 4
+    el = rec[order]
+    return el[:, 2:].mean(0).reshape(H, 4), len(order), float(el[-1, 0])

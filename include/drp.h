@@ -163,6 +163,17 @@ int drp_mpc_partials(drp_ctx* ctx, double* out /* [6+4H], nullable */);
 int drp_mpc_update(drp_ctx* ctx, const double* partials, int n_ranks, double* nominal_out);
 /* partials -> (RCCL all-gather if a communicator is attached) -> update, no host hop */
 int drp_mpc_update_device(drp_ctx* ctx);
+/* Elite (cross-entropy-method style) update -- NOT in the reference (planners.py has no CEM; SURVEY.md section 8e
+ * lists it as the other form of the planner's one exchange): the new nominal sequence is the mean of the k best
+ * samples' sequences, higher final-step reward first, ties to the lower global sample index.
+ * drp_mpc_elite: this rank's k best as records [reward, global sample index, act[4H]] (2 + 4H doubles each, best
+ * first; reward = -inf and index = -1 pad a rank with fewer than k samples).
+ * drp_mpc_update_elite: combine n_ranks x k records (host transport) into the nominal sequence.
+ * drp_mpc_update_elite_device: statistics as drp_mpc_update_device, then local elite -> RCCL all-gather when a
+ * communicator is attached -> combine, no host hop.  1 <= k <= 1024, horizons up to 64. */
+int drp_mpc_elite(drp_ctx* ctx, int k, double* out /* [k][2+4H], nullable */);
+int drp_mpc_update_elite(drp_ctx* ctx, const double* records, int n_ranks, int k, double* nominal_out /* [H][4], nullable */);
+int drp_mpc_update_elite_device(drp_ctx* ctx, int k);
 int drp_mpc_get(drp_ctx* ctx, float* actions /*[B,H,4]*/, float* rewards /*[B] final*/,
                 float* rewards_all /*[B,H]*/, float* states /*[B,H,N,3]*/, double* nominal);
 

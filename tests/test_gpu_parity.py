@@ -298,3 +298,55 @@ def test_fused_self_edge_constant(ctx, attr_kind):
         prev = ref[:, t]
     idx = ctx.debug_fetch('nbr_idx', (ns * nb, N, 10), np.int16)
     assert (idx[..., 0] == np.arange(N)[None, :]).all()              # self loop in slot 0 on this engine
+
+
+def test_elite_update_two_shards_and_device_path(ctx, golden):
+    """Elite (CEM-style) update -- an extension, not in the reference (include/drp.h): the nominal sequence
+    becomes the mean of the k best samples' sequences.  One rank with all 64 samples == two ranks' records
+    combined (on the device and by the host mirror in sharding.py) == the communicator-free and the
+    one-rank-communicator device paths; a short rank pads; ties go to the lower global index."""
+    from dyn_res_pile_manip_amd import sharding
+    g = golden.mppi
+    acts = g['opt_act_seqs'][:, :, 0, :].astype(np.float32)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('disc'))
+    N, k = 16, 12
+    ctx.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+    s0, dens, attr = syn.make_pile(N, 1, seed=1)
+    lo, hi = syn.action_limits()
+    kw = dict(sigma=0.6, beta_filter=0.7, reward_weight=0.1, act_lo=lo, act_hi=hi)
+    ctx.mpc_begin(s0, attr, dens, g['nominal'], n_sample=64, **kw)
+    ctx.mpc_set_actions(acts)
+    ctx.mpc_rollout()
+    r_full = ctx.mpc_get(rewards=True)['rewards']
+    full = ctx.mpc_elite(k)
+    host_full = sharding.make_elite_records(r_full, acts, k)
+    np.testing.assert_array_equal(full, host_full)
+    assert (np.diff(full[:, 0]) <= 0).all()
+    want = ctx.mpc_update_elite(full, k)
+    order = np.lexsort((np.arange(64), -r_full.astype(np.float64)))[:k]
+    np.testing.assert_allclose(want, acts[order].astype(np.float64).mean(0), rtol=1e-12, atol=1e-12)
+    # the device path (statistics + elite), without and with a one-rank communicator
+    ctx.mpc_update_elite_device(k)
+    np.testing.assert_array_equal(ctx.mpc_get(nominal=True)['nominal'], want)
+    assert ctx.mpc_stats()['argmax'] == int(np.argmax(r_full))
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    try:
+        ctx.mpc_update_elite_device(k)
+        np.testing.assert_array_equal(ctx.mpc_get(nominal=True)['nominal'], want)
+    finally:
+        ctx._ck(ctx.lib.drp_comm_destroy(ctx.h))
+    # two shards of 40 + 24 samples, the second shorter than... no: a third "rank" of 5 samples pads its records
+    recs = []
+    for lo_s, hi_s in ((0, 40), (40, 59), (59, 64)):
+        ctx.mpc_begin(s0, attr, dens, g['nominal'], n_sample=hi_s - lo_s, sample_offset=lo_s, **kw)
+        ctx.mpc_set_actions(acts[lo_s:hi_s])
+        ctx.mpc_rollout()
+        rec = ctx.mpc_elite(k)
+        np.testing.assert_array_equal(rec, sharding.make_elite_records(r_full[lo_s:hi_s], acts[lo_s:hi_s], k, lo_s))
+        recs.append(rec)
+    assert recs[2][5:, 1].max() == -1.0 and np.isneginf(recs[2][5:, 0]).all()
+    got = ctx.mpc_update_elite(np.stack(recs), k)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    nominal, n_el, worst = sharding.combine_elite_records(np.stack(recs), k)
+    np.testing.assert_allclose(nominal, want, rtol=1e-12, atol=1e-12)
+    assert n_el == k and worst == float(r_full[order[-1]])

@@ -131,6 +131,30 @@ def test_trajectory_optimization_contract(stack, golden):
     assert res['reward'][0] >= cand_best - 1e-3
 
 
+def test_planner_with_elite_update(stack, golden):
+    """mpc_type 'CEM' (an extension: the sampling planner's update is the mean of the n_elite best sequences
+    instead of the softmax mean): same call, same dict; not worse than the best initial candidate."""
+    config, env, model, planner = stack
+    g = golden.gd_planner
+    s, dens, attr, act_seq = g['s_cur'], g['dens'], g['attr'], g['act_seq']
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    old = dict(config['mpc'])
+    config['mpc']['mpc_type'] = 'CEM'
+    config['mpc']['cem'] = {'n_elite': 8}
+    try:
+        np.random.seed(0)
+        res = planner.trajectory_optimization_ptcl_multi_traj(
+            s, dens, attr, obs_goal, model, act_seq, np.zeros(1), n_sample=64, n_look_ahead=1,
+            n_update_iter=6, action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=1e9)
+    finally:
+        config['mpc'].clear()
+        config['mpc'].update(old)
+    assert res['action_sequence'].shape == (1, 4) and res['rew_mean'].shape == (1, 6)
+    assert np.isfinite(res['reward']).all()
+    assert res['reward'][0] >= res['rew_mean'][0, 0] - 1e-3
+
+
 def test_device_fps_equals_fps_np(stack):
     """utils.py:451-466 as used at planners.py:620-624: same points in the same order."""
     from oracle.particles import fps_np

@@ -47,8 +47,13 @@ def _worker(rank, world, port, out_dir):
     rec = sharding.make_record(0.1, r, acts[lo:hi], sample_offset=lo)
     allrec = sharding.allgather_records(rec)
     nominal, stats = sharding.combine_records(allrec, ns_total)
+    # the elite (CEM-style) form of the exchange: k best per rank, all-gathered, re-selected
+    k = 4
+    erec = sharding.make_elite_records(r, acts[lo:hi], k, sample_offset=lo)
+    eall = sharding.allgather_records(erec.ravel()).reshape(world, k, -1)
+    e_nominal, e_n, e_worst = sharding.combine_elite_records(eall, k)
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), nominal=nominal, r=r, lo=lo, hi=hi,
-             mean=stats['mean'], std=stats['std'], argmax=stats['argmax'])
+             mean=stats['mean'], std=stats['std'], argmax=stats['argmax'], e_nominal=e_nominal, e_n=e_n, e_worst=e_worst)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,6 +74,11 @@ def test_two_rank_mppi_update_equals_single_rank(tmp_path):
     np.testing.assert_allclose(got[0]['mean'], r_all.astype(np.float64).mean(), rtol=1e-12)
     np.testing.assert_allclose(got[0]['std'], r_all.astype(np.float64).std(ddof=1), rtol=1e-9)
     assert int(got[0]['argmax']) == int(np.argmax(r_all))
+    # elite update: mean of the 4 best of all 10 samples, whichever rank held them
+    np.testing.assert_array_equal(got[0]['e_nominal'], got[1]['e_nominal'])
+    best = np.lexsort((np.arange(10), -r_all.astype(np.float64)))[:4]
+    np.testing.assert_allclose(got[0]['e_nominal'], acts[best].astype(np.float64).mean(0), rtol=1e-12, atol=1e-12)
+    assert int(got[0]['e_n']) == 4 and float(got[0]['e_worst']) == float(r_all[best[-1]])
 
 
 def test_shard_range_covers_everything():
