@@ -46,6 +46,10 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=64)
     ap.add_argument('--no-alt', action='store_true', help='skip the fp32-MFMA engine comparison run')
+    ap.add_argument('--update', choices=['mppi', 'elite'], default='mppi',
+                    help='the planner update that ends an iteration: softmax-weighted mean (the reference\'s optimize_action) '
+                         'or the mean of the --elite best sequences; either is one small RCCL all-gather when sharded')
+    ap.add_argument('--elite', type=int, default=64)
     return ap.parse_args()
 
 
@@ -139,7 +143,10 @@ def main():
     def step():
         eng.mpc_sample(it[0])
         eng.mpc_rollout(False)
-        eng.mpc_update_device()
+        if args.update == 'elite':
+            eng.mpc_update_elite_device(args.elite)
+        else:
+            eng.mpc_update_device()
         it[0] += 1
 
     def fence():
@@ -256,7 +263,8 @@ def main():
             'config': {'workload': '%d-particle pile, %d MPPI samples per GPU, %d-step horizon '
                                    '(BASELINE configs[%d])' % (N, ns, H, 1 if world == 1 else 2),
                        'n_particles': N, 'n_sample_per_gpu': ns, 'n_look_ahead': H, 'engine': engine,
-                       'mean_in_degree': kbar, 'parallelism': 'samples sharded x%d' % world},
+                       'mean_in_degree': kbar, 'parallelism': 'samples sharded x%d' % world,
+                       'update': 'softmax mean (optimize_action)' if args.update == 'mppi' else 'mean of the %d best (elite)' % args.elite},
             'roofline': roof,
             'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items()},
         }

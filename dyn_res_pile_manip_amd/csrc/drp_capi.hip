@@ -586,6 +586,8 @@ int drp_create(int device, drp_ctx** out) {
     c->tile16 = getenv("DRP_TILE16") != nullptr;
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_elite_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REWARD_LDS(4096)) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_EDGE_ENCODE_LDS) != hipSuccess ||
@@ -974,24 +976,41 @@ int drp_mpc_update_device(drp_ctx* c) {
 static int elite_check(drp_ctx* c, int k) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
     if (k < 1 || k > 1024) return fail(c, DRP_EINVAL, "elite size %d outside 1..1024", k);
-    if (4 * c->mpc.n_look_ahead > 256) return fail(c, DRP_EINVAL, "elite update supports horizons up to 64");
+    if ((size_t)c->mpc.n_sample * 16 + (size_t)k * 4 > 150 * 1024)
+        return fail(c, DRP_EINVAL, "elite update supports up to 9 000 samples per rank");
     return DRP_OK;
 }
+
+static int pow2_at_least(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 static int launch_elite_local(drp_ctx* c, int k) {
     const drp_mpc_params& p = c->mpc;
     const int H = p.n_look_ahead;
     CHK(ensure(c, c->elite, (size_t)k * (2 + 4 * H) * sizeof(double)));
+    // sort path while keys + indices + positions of 2^m >= n_sample entries fit in LDS; k dependent rounds otherwise
+    int n2 = pow2_at_least(p.n_sample);
+    size_t lds = (size_t)n2 * 20;
+    if (lds > 150 * 1024 || k > n2) { n2 = 0; lds = (size_t)p.n_sample * 16 + (size_t)k * 4; }
     ProbeScope ps(c, KC_MPPI);
-    hipLaunchKernelGGL(k_elite_local, dim3(1), dim3(256), 0, c->stream, ptr<float>(c->rewards) + (H - 1), H,
-                       ptr<float>(c->actions), p.n_sample, p.n_batch, H, k, p.sample_offset, ptr<double>(c->elite));
+    hipLaunchKernelGGL(k_elite_local, dim3(1), dim3(256), lds, c->stream, ptr<float>(c->rewards) + (H - 1), H,
+                       ptr<float>(c->actions), p.n_sample, p.n_batch, H, k, p.sample_offset, n2, ptr<double>(c->elite));
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
 
 static int launch_elite_update(drp_ctx* c, const double* dev_records, int n_ranks, int k) {
+    const int HJ = 4 * c->mpc.n_look_ahead, total = n_ranks * k;
+    int n2 = pow2_at_least(total);
+    size_t lds = (size_t)n2 * 16 + (size_t)((n2 + 1) / 2) * 8 + (size_t)k * HJ * 8;    // keys, indices, positions, k sequences
+    if (lds > 150 * 1024) {
+        n2 = 0;
+        size_t lds_d = (size_t)total * 2;
+        if (lds_d < (size_t)k * HJ) lds_d = (size_t)k * HJ;
+        lds = lds_d * 8 + (size_t)k * 4;
+        if (lds > 150 * 1024) return fail(c, DRP_EINVAL, "too many elite records (%d ranks x %d, horizon %d)", n_ranks, k, c->mpc.n_look_ahead);
+    }
     ProbeScope ps(c, KC_MPPI);
-    hipLaunchKernelGGL(k_elite_update, dim3(1), dim3(256), 0, c->stream, dev_records, n_ranks, k, c->mpc.n_look_ahead,
+    hipLaunchKernelGGL(k_elite_update, dim3(1), dim3(256), lds, c->stream, dev_records, n_ranks, k, c->mpc.n_look_ahead, n2,
                        ptr<double>(c->nominal), ptr<double>(c->stats) + 6);
     HIPCHK(c, hipGetLastError());
     return DRP_OK;

@@ -203,82 +203,190 @@ __device__ __forceinline__ bool elite_before(double ra, double ia, double rb, do
     return ra > rb || (ra == rb && ia < ib);
 }
 
-// best (r, i) over the block; every thread returns it.  red: >= 2 * 4 doubles of LDS
-__device__ __forceinline__ void block_best(double& r, double& i, double* red) {
+// best (r, i) over a wave; every lane returns it, and `owner` = a lane that holds it
+__device__ __forceinline__ void wave_best(double& r, double& i, int& owner) {
+    owner = threadIdx.x & 63;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const double r2 = __shfl_xor(r, o, 64), i2 = __shfl_xor(i, o, 64);
-        if (elite_before(r2, i2, r, i)) { r = r2; i = i2; }
+        const int w2 = __shfl_xor(owner, o, 64);
+        if (elite_before(r2, i2, r, i)) { r = r2; i = i2; owner = w2; }
     }
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { red[2 * wave] = r; red[2 * wave + 1] = i; }
-    __syncthreads();
-    r = red[0]; i = red[1];
-    for (int w = 1; w < nw; ++w)
-        if (elite_before(red[2 * w], red[2 * w + 1], r, i)) { r = red[2 * w]; i = red[2 * w + 1]; }
 }
 
+// k picks out of n keys (key[q] = reward, idx[q] = global index or < 0 for padding) held in LDS, by ONE wave:
+// every lane caches the best of its strided share, a round is one shuffle reduction, and only the lane that owned
+// the pick rescans its share.  The picked positions go to pick[0..k) (or -1), in order.  Destroys key[].
+__device__ __forceinline__ void wave_select(double* key, const double* idx, int n, int k, int* pick) {
+    const int lane = threadIdx.x & 63;
+    auto rescan = [&](double& br, double& bi, int& bq) {
+        br = -__builtin_inf(); bi = 1e300; bq = -1;
+        for (int q = lane; q < n; q += 64) {
+            const double r = key[q], gi = idx[q];
+            if (gi >= 0.0 && r == r && elite_before(r, gi, br, bi)) { br = r; bi = gi; bq = q; }
+        }
+    };
+    double br, bi;
+    int bq;
+    rescan(br, bi, bq);
+    for (int e = 0; e < k; ++e) {
+        double r = br, i = bi;
+        int owner;
+        wave_best(r, i, owner);
+        const bool found = i < 1e299;
+        const int q = __shfl(bq, owner, 64);
+        if (lane == 0) pick[e] = found ? q : -1;
+        if (found && lane == owner) {
+            key[bq] = __builtin_nan("");         // taken
+            rescan(br, bi, bq);
+        }
+    }
+}
+
+// all keys best first, by the whole workgroup: bitonic network over n2 = 2^m >= n entries in LDS (padding: idx < 0).
+// src[] travels with the keys (the entry's original position).  ~m(m+1)/2 barriers instead of k dependent rounds.
+__device__ __forceinline__ bool elite_before_pad(double ra, double ia, double rb, double ib) {
+    // padding (idx < 0) and NaN rewards sort last
+    const bool va = ia >= 0.0 && ra == ra, vb = ib >= 0.0 && rb == rb;
+    if (va != vb) return va;
+    if (!va) return false;
+    return elite_before(ra, ia, rb, ib);
+}
+__device__ __forceinline__ void block_sort_best_first(double* key, double* idx, int* src, int n2) {
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
+                const int a = 2 * t - (t & (stride - 1)), b = a + stride;
+                const bool up = (a & size) == 0;
+                const double ra = key[a], ia = idx[a], rb = key[b], ib = idx[b];
+                const bool swap = up ? elite_before_pad(rb, ib, ra, ia) : elite_before_pad(ra, ia, rb, ib);
+                if (swap) {
+                    key[a] = rb; idx[a] = ib; key[b] = ra; idx[b] = ia;
+                    const int sa = src[a]; src[a] = src[b]; src[b] = sa;
+                }
+            }
+        }
+    __syncthreads();
+}
+
+// this rank's k best samples as records [reward, global index, act[4H]]; dynamic LDS: 2 * n_sample doubles + k ints
 __global__ void __launch_bounds__(256)
 k_elite_local(const float* __restrict__ reward, int reward_stride, const float* __restrict__ actions,
-              int n_sample, int n_batch, int H, int k, uint64_t sample_offset, double* __restrict__ out) {
-    __shared__ double red[8];
+              int n_sample, int n_batch, int H, int k, uint64_t sample_offset, int n2 /* 2^m >= n_sample: sort path; 0: k rounds */,
+              double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double el_lds[];
+    const int cap = n2 > 0 ? n2 : n_sample;
+    double* key = el_lds;
+    double* idx = key + cap;
+    int* pick = reinterpret_cast<int*>(idx + cap);
     const int HJ = 4 * H, REC = 2 + HJ;
-    double last_r = __builtin_inf(), last_i = -1.0;              // everything comes after (+inf, -1)
-    for (int e = 0; e < k; ++e) {
-        double br = -__builtin_inf(), bi = 1e300;
-        for (int s = threadIdx.x; s < n_sample; s += blockDim.x) {
-            double r = 0.0;
+    for (int s = threadIdx.x; s < n_sample; s += blockDim.x) {
+        double r = 0.0;
+        for (int c = 0; c < n_batch; ++c) r += (double)reward[((size_t)s * n_batch + c) * reward_stride];
+        key[s] = r / (double)n_batch;
+        idx[s] = (double)s + (double)sample_offset;
+    }
+    if (n2 > 0) {
+        // sort path: LDS holds n2 keys, indices and positions (the host picks it when they fit)
+        int* src = reinterpret_cast<int*>(idx + n2);
+        for (int s = threadIdx.x; s < n2; s += blockDim.x) {
+            src[s] = s;
+            if (s >= n_sample) { key[s] = 0.0; idx[s] = -1.0; }
+        }
+        block_sort_best_first(key, idx, src, n2);
+        for (int e = threadIdx.x; e < k; e += blockDim.x) {
+            const bool ok = e < n2 && idx[e] >= 0.0 && key[e] == key[e];
+            out[(size_t)e * REC] = ok ? key[e] : -__builtin_inf();
+            out[(size_t)e * REC + 1] = ok ? idx[e] : -1.0;
+        }
+        for (int t = threadIdx.x; t < k * HJ; t += blockDim.x) {
+            const int e = t / HJ, j = t - e * HJ;
+            const bool ok = e < n2 && idx[e] >= 0.0 && key[e] == key[e];
+            out[(size_t)e * REC + 2 + j] = ok ? (double)actions[((size_t)src[e] * n_batch) * HJ + j] : 0.0;
+        }
+        return;
+    }
+    __syncthreads();
+    // the selection consumes key[]: keep the rewards of the picks
+    if (threadIdx.x < 64) wave_select(key, idx, n_sample, k, pick);
+    __syncthreads();
+    for (int e = threadIdx.x; e < k; e += blockDim.x) {
+        const int s = pick[e];
+        double r = 0.0;
+        if (s >= 0) {
             for (int c = 0; c < n_batch; ++c) r += (double)reward[((size_t)s * n_batch + c) * reward_stride];
             r /= (double)n_batch;
-            const double gi = (double)s + (double)sample_offset;
-            if (elite_before(last_r, last_i, r, gi) && elite_before(r, gi, br, bi)) { br = r; bi = gi; }
         }
-        block_best(br, bi, red);
-        double* o = out + (size_t)e * REC;
-        const bool found = bi < 1e299;
-        if (threadIdx.x == 0) { o[0] = found ? br : -__builtin_inf(); o[1] = found ? bi : -1.0; }
-        const int s = found ? (int)(bi - (double)sample_offset) : 0;
-        for (int j = threadIdx.x; j < HJ; j += blockDim.x)
-            o[2 + j] = found ? (double)actions[((size_t)s * n_batch) * HJ + j] : 0.0;
-        if (found) { last_r = br; last_i = bi; }
-        else { last_r = -__builtin_inf(); last_i = 1e300; }     // nothing left: the remaining records are padding
+        out[(size_t)e * REC] = (s >= 0) ? r : -__builtin_inf();
+        out[(size_t)e * REC + 1] = (s >= 0) ? idx[s] : -1.0;
+    }
+    for (int t = threadIdx.x; t < k * HJ; t += blockDim.x) {       // all picks' sequences at once
+        const int e = t / HJ, j = t - e * HJ, s = pick[e];
+        out[(size_t)e * REC + 2 + j] = (s >= 0) ? (double)actions[((size_t)s * n_batch) * HJ + j] : 0.0;
     }
 }
 
-// records [n_ranks][k][2+4H] -> nominal = mean of the k best sequences; elite_out: [0] elite size, [1] worst elite reward
+// records [n_ranks][k][2+4H] -> nominal = mean of the k best sequences (summed in pick order);
+// elite_out: [0] elite size, [1] worst elite reward.  dynamic LDS: max(2 * n_ranks * k, k * 4H) doubles + k ints
 __global__ void __launch_bounds__(256)
-k_elite_update(const double* __restrict__ recs, int n_ranks, int k, int H, double* __restrict__ nominal,
-               double* __restrict__ elite_out) {
-    __shared__ double red[8];
+k_elite_update(const double* __restrict__ recs, int n_ranks, int k, int H, int n2 /* 2^m >= n_ranks * k: sort path; 0: k rounds */,
+               double* __restrict__ nominal, double* __restrict__ elite_out) {
+    extern __shared__ __attribute__((aligned(16))) double el_lds[];
     const int HJ = 4 * H, REC = 2 + HJ, total = n_ranks * k;
-    double last_r = __builtin_inf(), last_i = -1.0;
-    double acc = 0.0;                                            // thread j < 4H: sum of the elite's action j
-    int taken = 0;
-    double worst = 0.0;
-    for (int e = 0; e < k; ++e) {
-        double br = -__builtin_inf(), bi = 1e300;
-        for (int q = threadIdx.x; q < total; q += blockDim.x) {
-            const double r = recs[(size_t)q * REC], gi = recs[(size_t)q * REC + 1];
-            if (gi >= 0.0 && elite_before(last_r, last_i, r, gi) && elite_before(r, gi, br, bi)) { br = r; bi = gi; }
-        }
-        block_best(br, bi, red);
-        if (!(bi < 1e299)) break;
-        // the record that holds the pick (global indices are unique across ranks)
-        int where = -1;
-        for (int q = threadIdx.x; q < total; q += blockDim.x)
-            if (recs[(size_t)q * REC + 1] == bi && recs[(size_t)q * REC] == br) where = q;
-        double w = (double)where, dummy = (where >= 0) ? 0.0 : 1.0;
-        {   // broadcast the (single) holder's position: best = highest `where`
-            double wr = w, wi = dummy;
-            block_best(wr, wi, red);
-            where = (int)wr;
-        }
-        if ((int)threadIdx.x < HJ) acc += recs[(size_t)where * REC + 2 + threadIdx.x];   // 4H <= blockDim (host checks)
-        ++taken;
-        worst = br;
-        last_r = br; last_i = bi;
+    double* key = el_lds;
+    double* idx = key + (n2 > 0 ? n2 : total);
+    int* pick = reinterpret_cast<int*>(el_lds + max(2 * total, k * HJ));     // behind whichever use of el_lds is larger
+    for (int q = threadIdx.x; q < total; q += blockDim.x) {
+        key[q] = recs[(size_t)q * REC];
+        idx[q] = recs[(size_t)q * REC + 1];
     }
-    if ((int)threadIdx.x < HJ && taken > 0) nominal[threadIdx.x] = acc / (double)taken;
-    if (threadIdx.x == 0 && elite_out != nullptr) { elite_out[0] = (double)taken; elite_out[1] = worst; }
+    if (n2 > 0) {
+        int* src = reinterpret_cast<int*>(el_lds + 2 * n2);
+        for (int q = threadIdx.x; q < n2; q += blockDim.x) {
+            src[q] = q;
+            if (q >= total) { key[q] = 0.0; idx[q] = -1.0; }
+        }
+        block_sort_best_first(key, idx, src, n2);
+        int taken = 0;
+        for (int e = 0; e < k && e < n2; ++e) taken += (idx[e] >= 0.0 && key[e] == key[e]) ? 1 : 0;
+        double* seq = el_lds + 2 * n2 + (n2 + 1) / 2;             // behind keys, indices and positions
+        for (int t = threadIdx.x; t < taken * HJ; t += blockDim.x) {
+            const int e = t / HJ, j = t - e * HJ;
+            seq[t] = recs[(size_t)src[e] * REC + 2 + j];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < HJ; j += blockDim.x) {
+            double acc = 0.0;
+            for (int e = 0; e < taken; ++e) acc += seq[e * HJ + j];
+            if (taken > 0) nominal[j] = acc / (double)taken;
+        }
+        if (threadIdx.x == 0 && elite_out != nullptr) {
+            elite_out[0] = (double)taken;
+            elite_out[1] = (taken > 0) ? key[taken - 1] : 0.0;
+        }
+        return;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) wave_select(key, idx, total, k, pick);
+    __syncthreads();
+    int taken = 0;
+    for (int e = 0; e < k; ++e) taken += (pick[e] >= 0) ? 1 : 0;
+    // the picked sequences into LDS (all loads in flight at once), then one thread per action sums them in pick order
+    double* seq = el_lds;                            // key[] and idx[] are dead
+    __syncthreads();
+    for (int t = threadIdx.x; t < k * HJ; t += blockDim.x) {
+        const int e = t / HJ, j = t - e * HJ;
+        seq[t] = (pick[e] >= 0) ? recs[(size_t)pick[e] * REC + 2 + j] : 0.0;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < HJ; j += blockDim.x) {
+        double acc = 0.0;
+        for (int e = 0; e < taken; ++e) acc += seq[e * HJ + j];
+        if (taken > 0) nominal[j] = acc / (double)taken;
+    }
+    if (threadIdx.x == 0 && elite_out != nullptr) {
+        elite_out[0] = (double)taken;
+        elite_out[1] = (taken > 0) ? recs[(size_t)pick[taken - 1] * REC] : 0.0;
+    }
 }

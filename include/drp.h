@@ -170,7 +170,7 @@ int drp_mpc_update_device(drp_ctx* ctx);
  * first; reward = -inf and index = -1 pad a rank with fewer than k samples).
  * drp_mpc_update_elite: combine n_ranks x k records (host transport) into the nominal sequence.
  * drp_mpc_update_elite_device: statistics as drp_mpc_update_device, then local elite -> RCCL all-gather when a
- * communicator is attached -> combine, no host hop.  1 <= k <= 1024, horizons up to 64. */
+ * communicator is attached -> combine, no host hop.  1 <= k <= 1024, up to 9 000 samples per rank. */
 int drp_mpc_elite(drp_ctx* ctx, int k, double* out /* [k][2+4H], nullable */);
 int drp_mpc_update_elite(drp_ctx* ctx, const double* records, int n_ranks, int k, double* nominal_out /* [H][4], nullable */);
 int drp_mpc_update_elite_device(drp_ctx* ctx, int k);

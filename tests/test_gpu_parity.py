@@ -350,3 +350,28 @@ def test_elite_update_two_shards_and_device_path(ctx, golden):
     nominal, n_el, worst = sharding.combine_elite_records(np.stack(recs), k)
     np.testing.assert_allclose(nominal, want, rtol=1e-12, atol=1e-12)
     assert n_el == k and worst == float(r_full[order[-1]])
+
+
+def test_elite_of_many_samples_takes_the_round_path(ctx):
+    """5 000 samples on one rank: their keys no longer fit the LDS sort, the k-rounds selection runs instead --
+    the same records as the host mirror, and the same nominal."""
+    from dyn_res_pile_manip_amd import sharding
+    N, ns, H, k = 8, 5000, 2, 40
+    obs_goal = syn.goal_distance_image(syn.goal_mask('disc'))
+    ctx.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+    s0, dens, attr = syn.make_pile(N, 1, seed=4)
+    lo, hi = syn.action_limits()
+    acts = syn.sample_pushes(ns, H, seed=4)
+    acts[100] = acts[7]                      # an exact tie between two samples: the lower index wins
+    ctx.mpc_begin(s0, attr, dens, syn.nominal_pushes(H, seed=4), n_sample=ns, sigma=0.6, beta_filter=0.7,
+                  reward_weight=0.1, act_lo=lo, act_hi=hi)
+    ctx.mpc_set_actions(acts)
+    ctx.mpc_rollout()
+    r = ctx.mpc_get(rewards=True)['rewards']
+    assert r[100] == r[7]
+    rec = ctx.mpc_elite(k)
+    np.testing.assert_array_equal(rec, sharding.make_elite_records(r, acts, k))
+    nominal = ctx.mpc_update_elite(rec, k)
+    want, n_el, _ = sharding.combine_elite_records(rec[None], k)
+    np.testing.assert_allclose(nominal, want, rtol=1e-12, atol=1e-12)
+    assert n_el == k
