@@ -221,12 +221,18 @@ def main():
             # chip-filling batches): told apart by the launches the probe counted
             psteps = max(1, int(round(3.0 * H * args.steps / max(dom_n, 1))))
             mfmas = psteps * tiles * (slots_per_tile * 78 + (2 * 144 + 96) / 3.0)
-            work = mfmas * 32768.0
             alg = psteps * B * N * (kbar * FLOP_PER_EDGE_ENCODE + 2 * 64 * 64 * (1 + 2 * 2 / 3.0 + 1 / 3.0))
+            # the particle encoder runs as the first phase of km_prop3 when no launch of its own was counted:
+            # 12 + 4 x 48 bf16 MFMAs per tile (first layer + four 64x64 products on the 6-term split)
+            encoder_inside = psteps == 3 and per_class['node_encode'][1] == 0
+            if encoder_inside:
+                mfmas += tiles * 204
+                alg += B * N * FLOP_PER_NODE['node_encode'] + B * N * 2 * 2 * 64 * 64
+            work = mfmas * 32768.0
             roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                     'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
                     'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile,
-                    'propagation_steps_per_launch': psteps}
+                    'propagation_steps_per_launch': psteps, 'particle_encoder_in_launch': bool(encoder_inside)}
         elif dominant == 'aggregate':
             work = B * N * (2 * kbar + 2) * 256.0
             roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}

@@ -58,6 +58,7 @@ struct drp_ctx {
     bool self_const = true;         // DRP_NO_SELF_CONST=1: always run the encoder chain on the self slot too
     bool prop3 = true;              // DRP_NO_PROP3=1: one launch per propagation step even for chip-filling batches
     bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
+    bool prop3e = true;             // DRP_NO_PROP3E=1: the particle encoder stays its own launch in front of km_prop3
     bool tile16 = false;            // DRP_TILE16=1: 16-item tiles, three waves per SIMD (km_prop3_t16) where km_prop3 would run
 
     // model constants
@@ -284,7 +285,13 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     const bool tape = a.eff_hist != nullptr;
     if (tape && c->engine != DRP_ENGINE_FUSED) return fail(c, DRP_ESTATE, "the backward tape is written by the fused engine");
     float* eff0 = tape ? a.eff_hist : ptr<float>(c->eff);
-    {
+    // chip-filling batches on the fused engine: the three propagation steps are one launch (km_prop3), and the
+    // particle encoder is its first phase unless switched off
+    const int tps3 = (N + 31) / 32;
+    const int spw = (int)((B + c->n_cu - 1) / c->n_cu);
+    const bool prop3 = c->engine == DRP_ENGINE_FUSED && c->prop3 && B >= c->n_cu && (long)spw * tps3 >= PROP_WAVES;
+    const bool phase_e = prop3 && c->prop3e && !(c->tile16 && !tape);
+    if (!phase_e) {
         ProbeScope ps(c, KC_NODE_ENCODE);
         if (c->engine == DRP_ENGINE_FUSED)
             hipLaunchKernelGGL(km_node_encode_split, dim3(mfma_grid(c, node_tiles)), blk, KM_NODE_SPLIT_LDS, st,
@@ -317,9 +324,6 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
         // PROP_WAVES tiles per step; otherwise one launch per step with the tiles of all samples dealt over the chip
         float* pa = ptr<float>(c->proj);
         float* pb = ptr<float>(c->proj2);
-        const int tps = (N + 31) / 32;
-        const int spw = (int)((B + c->n_cu - 1) / c->n_cu);
-        const bool prop3 = c->prop3 && B >= c->n_cu && (long)spw * tps >= PROP_WAVES;
         if (prop3) {
             ProbeScope ps(c, KC_PROP);
             const dim3 grid((unsigned)((B + spw - 1) / spw)), pblk(64 * PROP_WAVES);
@@ -328,7 +332,8 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             float* agg_hist = tape ? a.agg_hist : nullptr;
 #define PROP3_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
                    a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, pb, \
-                   ptr<float>(c->c_node), eff_base, N, B, spw, a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist
+                   ptr<float>(c->c_node), eff_base, N, B, spw, phase_e ? (const float*)ptr<float>(c->s_delta) : (const float*)nullptr, \
+                   a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist
             if (!tape && c->tile16)
                 hipLaunchKernelGGL(km_prop3_t16, grid, dim3(64 * PROP16_WAVES), KM_PROP3_T16_LDS, st, ptr<uint16_t>(c->w_t16),
                                    ptr<uint16_t>(c->w_t16_6), mw, a.s_prev, a.prev_mod, a.prev_stride, a.attr, a.attr_mod, a.dens,
@@ -584,6 +589,7 @@ int drp_create(int device, drp_ctx** out) {
     c->prop3 = getenv("DRP_NO_PROP3") == nullptr;
     c->graph_strips = getenv("DRP_NO_GRAPH_STRIPS") == nullptr;
     c->tile16 = getenv("DRP_TILE16") != nullptr;
+    c->prop3e = getenv("DRP_NO_PROP3E") == nullptr;
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||

@@ -373,6 +373,33 @@ __device__ __forceinline__ void mfma_layer64_split6(const bf16x8* __restrict__ w
     }
 }
 
+// first layer of the particle encoder on the 6-term split (km_node_encode_split, and km_prop3's phase E)
+__device__ __forceinline__ void mfma_layer8_split6(const bf16x8* __restrict__ wp, const float (&x)[8], int h, Frag& acc, int lane) {
+    bf16x8 b0, b1, b2;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const float v = (h == 0) ? x[jj] : 0.0f;
+        const __bf16 hi = (__bf16)v;
+        const float r1 = v - (float)hi;
+        const __bf16 mid = (__bf16)r1;
+        b0[jj] = hi;
+        b1[jj] = mid;
+        b2[jj] = (__bf16)(r1 - (float)mid);
+    }
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+        const bf16x8 w0 = wp[(0 * 2 + ob) * 64 + lane];
+        const bf16x8 w1 = wp[(1 * 2 + ob) * 64 + lane];
+        const bf16x8 w2 = wp[(2 * 2 + ob) * 64 + lane];
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b0, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b2, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b1, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b0, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b1, acc.v[ob], 0, 0, 0);
+        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b0, acc.v[ob], 0, 0, 0);
+    }
+}
+
 #ifndef PROP_WAVES
 #define PROP_WAVES 8
 #endif
@@ -805,8 +832,9 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
          const float* __restrict__ s_cur, int s_mod, size_t s_stride,
          const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
          const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
-         float* __restrict__ proj_a, float* __restrict__ proj_b, const float* __restrict__ c_node,
+         float* __restrict__ proj_a, float* __restrict__ proj_b, float* __restrict__ c_node,
          float* __restrict__ eff /* !TAPE: in place; TAPE: effect history [4][B*N,64] */, int N, int B, int spw,
+         const float* __restrict__ s_delta /* not null: the particle encoder runs here first (phase E) */,
          float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself, const uint8_t* __restrict__ cself_ok,
          unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -816,7 +844,17 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     float* wsp_f = lds;
     float* w6_f = wsp_f + S_TOTAL * 4;               // AGG | RPR | RPS | PR0
     float* rows = w6_f + 4 * 1536 * 4;               // b2,b4,b_rp,wd_rp | b_pr0, w_pr1[3], b_pr1
-    lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
+    float* pe0_f = rows + 520;                       // phase E: first layer of the particle encoder, then b_pe2, b_pp, wd_pp
+    float* rows_e = pe0_f + 384 * 4;
+    const bool phase_e = s_delta != nullptr;
+    if (phase_e) {
+        // the particle encoder's two 64x64 layers borrow the edge chain's region; W_r and W_s are resident anyway
+        lds_fill(wsp_f, reinterpret_cast<const float*>(sw6) + S6_PE2 * 4, 2 * 1536 * 4);
+        lds_fill(pe0_f, reinterpret_cast<const float*>(sw6) + S6_PE0 * 4, 384 * 4);
+        lds_fill(rows_e, mw + R_PE2_B, 192);
+    } else {
+        lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
+    }
     lds_fill(w6_f, reinterpret_cast<const float*>(sw6) + S6_AGG * 4, 4 * 1536 * 4);   // S6_AGG, RPR, RPS, PR0 are consecutive
     lds_fill(rows, mw + R_RE2_B, 256);
     lds_fill(rows + 256, mw + R_PR0_B, 260);
@@ -827,6 +865,50 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     const int tps = (N + 31) >> 5;
     const int b0 = blockIdx.x * spw, nb = min(spw, B - b0);
     const int wg_tiles = (nb > 0 ? nb : 0) * tps;
+    if (phase_e) {
+        // ---- phase E: km_node_encode_split's tile over this workgroup's samples (same arithmetic, same order)
+        const bf16x8* wpe2 = reinterpret_cast<const bf16x8*>(wsp_f);
+        const bf16x8* wrs = reinterpret_cast<const bf16x8*>(w6_f) + 1536;
+        const bf16x8* wpe0 = reinterpret_cast<const bf16x8*>(pe0_f);
+        const int j = lane & 31, h = lane >> 5;
+        for (int li = wave; li < wg_tiles;) {
+            asm volatile("" ::: "memory");
+            const int m = li / tps, t = li - m * tps, b = b0 + m;
+            const int i = min(t * 32 + j, N - 1);
+            const bool live = (t * 32 + j) < N;
+            const size_t row = (size_t)b * N + i;
+            const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+            const float* sd = s_delta + row * 3;
+            float x[8] = {sd[0], sd[1], sd[2], attr[(size_t)(b % attr_mod) * N + i], d, 1.0f, 0.0f, 0.0f};
+            Frag a, pe, c;
+            FragB6 f6;
+            frag_zero(a);
+            mfma_layer8_split6(wpe0, x, h, a, lane);
+            frag_relu(a);
+            split_frag6(a, f6);
+            frag_from_row(rows_e + 0, h, pe);
+            mfma_layer64_split6(wpe2, f6, pe, lane);
+            frag_relu(pe);
+            if (live) frag_to_row(eff + row * 64, h, pe);          // TAPE: slot 0 of the effect history
+            split_frag6(pe, f6);
+            frag_bias_dens(rows_e + 64, rows_e + 128, d, h, c);
+            mfma_layer64_split6(wpe2 + 1536, f6, c, lane);
+            if (live) frag_to_row(c_node + row * 64, h, c);
+            frag_zero(c);
+            mfma_layer64_split6(wrs, f6, c, lane);
+            if (live) frag_to_row(proj_a + row * 128, h, c);
+            frag_zero(c);
+            mfma_layer64_split6(wrs + 1536, f6, c, lane);
+            if (live) frag_to_row(proj_a + row * 128 + 64, h, c);
+            int q = 0;
+            if (lane == 0) q = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            li = __builtin_amdgcn_readfirstlane(q);
+        }
+        __syncthreads();                                 // the encoder's rows of this workgroup's samples are written
+        lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
+        if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
+        __syncthreads();
+    }
     auto decode = [&](int li) {
         TileId id;
         id.valid = li < wg_tiles;
@@ -876,38 +958,12 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     }
 #endif
 }
-#define KM_PROP3_LDS ((size_t)(S_TOTAL * 4 + 4 * 1536 * 4 + 256 + 260 + 4) * sizeof(float))
+#define KM_PROP3_LDS ((size_t)(S_TOTAL * 4 + 4 * 1536 * 4 + 256 + 260 + 4 + 384 * 4 + 192) * sizeof(float))
 
 
 // ---- particle encoder, node constant and first projections on the 6-term split --------------
 // Same contract as km_node_encode (k_mlp_mfma.h); outputs go straight from the accumulator
 // layout to their rows (no LDS transposition tiles: LDS holds the 126 KB of packed weights).
-__device__ __forceinline__ void mfma_layer8_split6(const bf16x8* __restrict__ wp, const float (&x)[8], int h, Frag& acc, int lane) {
-    bf16x8 b0, b1, b2;
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-        const float v = (h == 0) ? x[jj] : 0.0f;
-        const __bf16 hi = (__bf16)v;
-        const float r1 = v - (float)hi;
-        const __bf16 mid = (__bf16)r1;
-        b0[jj] = hi;
-        b1[jj] = mid;
-        b2[jj] = (__bf16)(r1 - (float)mid);
-    }
-#pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-        const bf16x8 w0 = wp[(0 * 2 + ob) * 64 + lane];
-        const bf16x8 w1 = wp[(1 * 2 + ob) * 64 + lane];
-        const bf16x8 w2 = wp[(2 * 2 + ob) * 64 + lane];
-        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b0, acc.v[ob], 0, 0, 0);
-        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b2, acc.v[ob], 0, 0, 0);
-        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b1, acc.v[ob], 0, 0, 0);
-        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b0, acc.v[ob], 0, 0, 0);
-        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b1, acc.v[ob], 0, 0, 0);
-        acc.v[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b0, acc.v[ob], 0, 0, 0);
-    }
-}
-
 __global__ void __launch_bounds__(64 * MFMA_WAVES)
 km_node_encode_split(const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
                      const float* __restrict__ s_delta, const float* __restrict__ attr, int attr_mod,
