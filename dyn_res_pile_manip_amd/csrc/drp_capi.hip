@@ -197,7 +197,10 @@ int ensure_step_ws(drp_ctx* c, int B, int N) {
     CHK(ensure(c, c->agg, bn * 64 * sizeof(float)));
     CHK(ensure(c, c->proj, bn * 128 * sizeof(float)));
     CHK(ensure(c, c->proj2, bn * 128 * sizeof(float)));
-    CHK(ensure(c, c->c_edge, bn * DRP_K * 64 * sizeof(float)));
+    // edge constants [B,N,10,64] for the engines that materialise them; the fused engine only parks the graph build's
+    // sorted positions and strip starts there (launch_graph)
+    const size_t graph_scratch = (size_t)B * (((size_t)N + 3) & ~(size_t)3) * 16 + (size_t)B * (GRAPH_STRIPS + 1) * sizeof(int);
+    CHK(ensure(c, c->c_edge, c->engine == DRP_ENGINE_FUSED ? graph_scratch : bn * DRP_K * 64 * sizeof(float)));
     c->lastB = B;
     c->lastN = N;
     return DRP_OK;
