@@ -44,7 +44,7 @@ def parse():
     ap.add_argument('--horizon', type=int, default=10)
     ap.add_argument('--engine', default=os.environ.get('DRP_ENGINE', 'auto'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-samples', type=int, default=64)
+    ap.add_argument('--cpu-samples', type=int, default=128)
     ap.add_argument('--no-alt', action='store_true', help='skip the fp32-MFMA engine comparison run')
     ap.add_argument('--update', choices=['mppi', 'elite'], default='mppi',
                     help='the planner update that ends an iteration: softmax-weighted mean (the reference\'s optimize_action) '
