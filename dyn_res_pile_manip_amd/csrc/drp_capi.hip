@@ -241,8 +241,14 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
         int* starts = reinterpret_cast<int*>(sorted + (size_t)B * Np);
         hipLaunchKernelGGL(k_graph_sort, dim3(B), dim3(GRAPH_SORT_THREADS), 0, st, s_prev, prev_mod, prev_stride, actions,
                            act_stride, s_delta, N, c->cam, sorted, starts);
-        hipLaunchKernelGGL(k_graph_strips, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N), st,
-                           (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), self_first);
+        if (N >= 800) {
+            const int chunks = (N + 255) / 256;
+            hipLaunchKernelGGL(k_graph_strips<256>, dim3(B * chunks), dim3(256), GRAPH_STRIPS_LDS(N, 256), st,
+                               (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, chunks, self_first);
+        } else {
+            hipLaunchKernelGGL(k_graph_strips<GRAPH_THREADS>, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N, GRAPH_THREADS), st,
+                               (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), self_first);
+        }
     }
     else
         hipLaunchKernelGGL(k_graph, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), graph_lds(N), st, s_prev,
@@ -597,7 +603,8 @@ int drp_create(int device, drp_ctx** out) {
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_graph_strips, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_graph_strips<GRAPH_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_graph_strips<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REWARD_LDS(4096)) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reverse_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||
