@@ -8,9 +8,14 @@ Workload at N=1: BASELINE.json configs[1] -- 300-particle pile, 1024 MPPI sample
 10-step horizon (inputs resident in HBM).  With --gpus N the sample axis is sharded,
 1024 samples per GPU (weak scaling, configs[2] at N=8).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4-50|c4-150|c4-300|c4-600|c5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
+
+--config selects a BASELINE.json workload (default c2 at one GPU, c3 = the same per-GPU share under
+--gpus N); c5 is the strong-scaling one (4096 samples in total).  --force-comm (under the launcher with
+one process) attaches a one-rank RCCL communicator and runs the update through ncclAllGather.
+tools/scale.sh runs the 1/2/4/8-GPU series of c3 and c5.
 """
 import argparse
 import json
@@ -26,6 +31,16 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3      # dense fp32 (vector == f32-input MFMA rate)
 PEAK_BF16_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA (same rate)
+# BASELINE.json configs -> (particles, samples, horizon, samples are per GPU (weak) or in total (strong), label)
+CONFIGS = {
+    'c2': (300, 1024, 10, 'weak', 'BASELINE configs[1]: 300-particle pile, 1024 MPPI samples, 10-step horizon, 1 GPU'),
+    'c3': (300, 1024, 10, 'weak', 'BASELINE configs[2]: 300-particle pile, 8192 MPPI samples at 8 GPUs (1024 per GPU), 10-step horizon, RCCL exchange'),
+    'c4-50': (50, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 50 particles x 1024 samples x 10 steps'),
+    'c4-150': (150, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 150 particles x 1024 samples x 10 steps'),
+    'c4-300': (300, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 300 particles x 1024 samples x 10 steps'),
+    'c4-600': (600, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 600 particles x 1024 samples x 10 steps'),
+    'c5': (1200, 4096, 20, 'strong', 'BASELINE configs[4]: 1200-particle dense pile, 4096 samples in total, 20-step horizon'),
+}
 KERNEL_CLASSES = ['graph', 'node_encode', 'edge_encode', 'project', 'aggregate', 'update',
                   'predict', 'reward', 'mppi', 'prop']
 # algorithmic work of one LAUNCH of each class, per particle (node) or per edge
@@ -39,18 +54,56 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--particles', type=int, default=300)
-    ap.add_argument('--samples', type=int, default=1024, help='MPPI samples per GPU')
-    ap.add_argument('--horizon', type=int, default=10)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default=None, help='a BASELINE.json workload (default: c2 / c3)')
+    ap.add_argument('--particles', type=int, default=None)
+    ap.add_argument('--samples', type=int, default=None, help='MPPI samples per GPU (weak scaling)')
+    ap.add_argument('--samples-total', type=int, default=None, help='MPPI samples over all GPUs (strong scaling)')
+    ap.add_argument('--horizon', type=int, default=None)
+    ap.add_argument('--force-comm', action='store_true',
+                    help='one process: still attach an RCCL communicator (ncclCommInitRank with one rank, the id broadcast '
+                         'through torch.distributed) and run the update through ncclAllGather')
     ap.add_argument('--engine', default=os.environ.get('DRP_ENGINE', 'auto'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-samples', type=int, default=128)
+    ap.add_argument('--cpu-samples', type=int, default=None, help='samples of the CPU baseline (default: about 10 s of host work)')
     ap.add_argument('--no-alt', action='store_true', help='skip the fp32-MFMA engine comparison run')
     ap.add_argument('--update', choices=['mppi', 'elite'], default='mppi',
                     help='the planner update that ends an iteration: softmax-weighted mean (the reference\'s optimize_action) '
                          'or the mean of the --elite best sequences; either is one small RCCL all-gather when sharded')
     ap.add_argument('--elite', type=int, default=64)
-    return ap.parse_args()
+    args = ap.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        args.gpus = world
+    cfg = args.config or ('c2' if args.gpus == 1 else 'c3')
+    N, ns, H, scaling, label = CONFIGS[cfg]
+    custom = any(v is not None for v in (args.particles, args.samples, args.samples_total, args.horizon))
+    args.particles = args.particles or N
+    args.horizon = args.horizon or H
+    if args.samples_total is not None:
+        scaling, ns = 'strong', args.samples_total
+    elif args.samples is not None:
+        scaling, ns = 'weak', args.samples
+    args.scaling = scaling
+    args.samples_total_job = ns if scaling == 'strong' else ns * args.gpus
+    if custom:
+        label = 'custom: %d particles x %d samples (%s) x %d steps' % (
+            args.particles, ns, 'in total' if scaling == 'strong' else 'per GPU', args.horizon)
+    args.workload = label
+    if args.cpu_samples is None:
+        # about 10 s of host work for the dense formulation: its cost per sample grows with N^2
+        args.cpu_samples = int(min(1024, max(4, 128 * (300.0 / args.particles) ** 2 * 10.0 / args.horizon)))
+    args.config_name = cfg if not custom else 'custom'
+    return args
+
+
+def host_cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
 
 
 def cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam):
@@ -90,8 +143,9 @@ def cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam):
         od.optimize_action(acts, r.numpy(), 0.1)
         dt = time.perf_counter() - t0
     return {'value': ns * N * H / dt, 'unit': 'particle-steps/s', 'cores': cores, 'kind': 'port',
+            'cpu_model': host_cpu_model(), 'host_threads_available': avail,
             'sample': '%d samples x %d particles x %d steps, oracle/propnet_dense.py (dense '
-                      'Rr/Rs PyTorch fp32, %d of %d host threads), %.1f s' % (ns, N, H, cores, avail, dt)}
+                      'Rr/Rs PyTorch fp32, %d of %d host threads of %s), %.1f s' % (ns, N, H, cores, avail, host_cpu_model(), dt)}
 
 
 def main():
@@ -99,8 +153,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if args.force_comm:
+        os.environ['DRP_COMM_ALWAYS'] = '1'          # read at drp_create
     import torch
     import torch.distributed as dist
     from dyn_res_pile_manip_amd import synthetic as syn, weights, _lib
@@ -108,12 +162,17 @@ def main():
     from dyn_res_pile_manip_amd.planners import world2cam_affine
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_comm = world > 1 or args.force_comm
+    if use_comm:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local_rank))
 
-    N, ns, H = args.particles, args.samples, args.horizon
+    from dyn_res_pile_manip_amd.sharding import shard_range
+    N, H = args.particles, args.horizon
+    s_lo, s_hi = shard_range(args.samples_total_job, rank, world)      # this rank's contiguous block of samples
+    ns = s_hi - s_lo
     eng = Engine(local_rank)
     engine = args.engine
     if engine == 'auto':
@@ -132,8 +191,8 @@ def main():
     lo, hi = syn.action_limits()
     nominal = syn.nominal_pushes(H, seed=0)
     eng.mpc_begin(s0, attr, dens, nominal, n_sample=ns, sigma=0.3 * 24 / 12.0, beta_filter=0.7,
-                  reward_weight=0.1, act_lo=lo, act_hi=hi, seed=1234, sample_offset=rank * ns)
-    if world > 1:
+                  reward_weight=0.1, act_lo=lo, act_hi=hi, seed=1234, sample_offset=s_lo)
+    if use_comm:
         uid = [eng.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(uid[0], rank, world)
@@ -152,7 +211,7 @@ def main():
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_comm:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -189,27 +248,57 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # the same K steps on the pure-fp32 MFMA engine (bit-for-bit an fp32 fma chain), for reference
-    alt = None
+    # per-iteration times (each iteration synchronised; SURVEY.md 8d asks for the median): a second pass, so the
+    # contract's K back-to-back iterations above stay un-synchronised
+    per_iter = []
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        step()
+        eng.sync()
+        per_iter.append(time.perf_counter() - t1)
+    fence()
+    med = float(np.median(per_iter))
+    if world > 1:
+        t = torch.tensor([med], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        med = float(t.item())
+
+    # the same K steps on the pure-fp32 MFMA engine (bit-for-bit an fp32 fma chain), for reference; its un-fused
+    # pipeline has the segmented sum ("scatter-add") as a kernel of its own, timed here with the HIP-event probe
+    alt, scatter = None, None
     if engine != 'mfma' and not args.no_alt:
         eng.set_engine(_lib.ENGINES['mfma'])
         for _ in range(2):
             step()
+        eng.probe_begin('aggregate')
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
         dta = time.perf_counter() - t0
+        agg_ms, agg_n = eng.probe_read()
+        eng.probe_begin(None)
+        kbar_alt = float(eng.debug_fetch('nbr_cnt', (ns, N), np.uint8).mean())
+        if agg_n > 0:
+            # per receiver and propagation step, own row + K sender rows + K edge-constant rows read,
+            # one row written, 256 B each
+            agg_bytes = ns * N * (2 * kbar_alt + 2) * 256.0
+            agg_s = agg_ms / agg_n * 1e-3
+            scatter = {'kernel': 'k_aggregate (engine mfma: segmented sum over the receiver-major lists)', 'bound': 'hbm',
+                       'achieved': agg_bytes / agg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                       'frac': agg_bytes / agg_s / 1e9 / PEAK_HBM_GBS, 'avg_launch_ms': agg_s * 1e3, 'launches': agg_n,
+                       'algorithmic_bytes_per_launch': agg_bytes, 'mean_in_degree': kbar_alt,
+                       'traffic': None, 'traffic_source': None}
         if world > 1:
             t = torch.tensor([dta], dtype=torch.float64, device='cuda')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dta = float(t.item())
-        alt = {'engine': 'mfma', 'dtype': 'f32', 'value': world * ns * N * H * args.steps / dta,
+        alt = {'engine': 'mfma', 'dtype': 'f32', 'value': args.samples_total_job * N * H * args.steps / dta,
                'ms_per_step': dta / args.steps * 1e3}
         eng.set_engine(_lib.ENGINES[engine])
     if rank == 0:
-        total = world * ns * N * H * args.steps
+        total = args.samples_total_job * N * H * args.steps
         avg_s = dom_ms / max(dom_n, 1) * 1e-3
         B = ns
         tiles = B * ((N + 31) // 32)
@@ -252,28 +341,37 @@ def main():
         # HBM-side bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 +
         # WRITE_SIZE, profiles/summarize_pmc.py); collected on this same workload
         roof['traffic'] = None
+        roof['traffic_source'] = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath) and (N, ns) == (300, 1024):
             try:
+                tj = json.load(open(tpath))
                 tkey = 'prop3' if (dominant == 'prop' and roof.get('propagation_steps_per_launch') == 3) else dominant
-                roof['traffic'] = json.load(open(tpath))[engine][tkey]['hbm_bytes_per_launch']
+                roof['traffic'] = tj[engine][tkey]['hbm_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/traffic.json (builder-side rocprofv3 --pmc passes of this command, not measured in this run)'
+                if scatter is not None:
+                    scatter['traffic'] = tj['mfma']['aggregate']['hbm_bytes_per_launch']
+                    scatter['traffic_source'] = roof['traffic_source']
             except Exception:
                 pass
         out = {
             'metric': 'MPC rollout-steps/sec (samples x particles x steps/sec)',
             'value': total / dt, 'unit': 'particle-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None,
+            'scaling': args.scaling, 'vs_baseline': None,
+            'ms_per_step_median': med * 1e3, 'value_median': args.samples_total_job * N * H / med,
             'dtype': 'f32' if engine in ('valu', 'mfma') else 'f32 (MLP products as split fp16 / bf16 MFMA terms, fp32 accumulate)',
             'data': 'synthetic',
-            'config': {'workload': '%d-particle pile, %d MPPI samples per GPU, %d-step horizon '
-                                   '(BASELINE configs[%d])' % (N, ns, H, 1 if world == 1 else 2),
-                       'n_particles': N, 'n_sample_per_gpu': ns, 'n_look_ahead': H, 'engine': engine,
+            'config': {'workload': args.workload, 'name': args.config_name,
+                       'n_particles': N, 'n_sample_per_gpu': ns, 'n_sample_total': args.samples_total_job,
+                       'n_look_ahead': H, 'engine': engine,
+                       'communicator': ('rccl, %d rank%s' % (world, '' if world == 1 else 's')) if use_comm else None,
                        'mean_in_degree': kbar, 'parallelism': 'samples sharded x%d' % world,
                        'update': 'softmax mean (optimize_action)' if args.update == 'mppi' else 'mean of the %d best (elite)' % args.elite},
             'roofline': roof,
             'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items()},
         }
+        out['roofline_scatter'] = scatter
         out['alt_engine'] = alt
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam)
@@ -281,7 +379,7 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_comm:
         dist.destroy_process_group()
 
 

@@ -20,6 +20,7 @@ ENGINE_SPLIT = 2
 ENGINE_FUSED = 3
 TRAIN_MODES = {'eval': 0, 'grad': 1, 'update': 2}
 DIST_TRANSFORMS = {'cv5': 0, 'exact': 1}
+NOISE_TYPES = {'normal': 0, 'uniform': 1, 'total_rand': 2}
 ENGINES = {'valu': ENGINE_VALU, 'mfma': ENGINE_MFMA, 'split': ENGINE_SPLIT, 'fused': ENGINE_FUSED}
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -35,7 +36,8 @@ class MpcParams(ctypes.Structure):
                 ('sigma', ctypes.c_double), ('beta_filter', ctypes.c_double),
                 ('reward_weight', ctypes.c_double),
                 ('act_lo', ctypes.c_float * 4), ('act_hi', ctypes.c_float * 4),
-                ('seed', ctypes.c_uint64), ('sample_offset', ctypes.c_uint64)]
+                ('seed', ctypes.c_uint64), ('sample_offset', ctypes.c_uint64),
+                ('noise_type', ctypes.c_int), ('reserved', ctypes.c_int)]
 
 
 # name -> (restype, argtypes); exactly the symbols include/drp.h declares
@@ -112,6 +114,7 @@ SIGNATURES = {
     'drp_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'drp_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'drp_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'drp_comm_allgather': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'drp_probe_begin': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     'drp_probe_read': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_long)]),
     'drp_debug_fetch': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p,

@@ -24,12 +24,9 @@
 #include "k_particles.h"
 #include "k_goal.h"
 #include "k_train.h"
-#ifdef DRP_HAVE_MFMA
 #include "k_mlp_mfma.h"
 #include "k_mlp_split.h"
-#include "k_mlp_tile16.h"
 #include "k_backward_mfma.h"
-#endif
 
 namespace {
 
@@ -58,13 +55,13 @@ struct drp_ctx {
     bool self_const = true;         // DRP_NO_SELF_CONST=1: always run the encoder chain on the self slot too
     bool prop3 = true;              // DRP_NO_PROP3=1: one launch per propagation step even for chip-filling batches
     bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
+    bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
     bool prop3e = true;             // DRP_NO_PROP3E=1: the particle encoder stays its own launch in front of km_prop3
-    bool tile16 = false;            // DRP_TILE16=1: 16-item tiles, three waves per SIMD (km_prop3_t16) where km_prop3 would run
 
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
     float adj_thresh = 0.08f, thr = 0.0064f;
-    DevBuf w_raw, w_valu, w_mfma, w_mfma_bwd, w_split, w_split6, w_t16, w_t16_6;
+    DevBuf w_raw, w_valu, w_mfma, w_mfma_bwd, w_split, w_split6;
     DrpCam cam{};
     DevBuf goal_field, goal_coor, cself;
     unsigned cself_tag = 0;         // bumped by every prepare_cself: who filled c->cself last
@@ -77,7 +74,7 @@ struct drp_ctx {
     // MPC state
     bool mpc_on = false;
     drp_mpc_params mpc{};
-    DevBuf nominal, noise, partials, gathered, stats, elite, elite_all;
+    DevBuf nominal, noise, partials, gathered, stats, elite, elite_all, xchg;
     int n_ranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
 
@@ -275,7 +272,6 @@ void launch_aggregate(drp_ctx* c, int B, int N) {
                            ptr<float>(c->agg), chunks);
 }
 
-#ifdef DRP_HAVE_MFMA
 int mfma_grid(drp_ctx* c, long ntiles) {
     long blocks = (ntiles + MFMA_WAVES - 1) / MFMA_WAVES;
     long cap = (long)c->n_cu;
@@ -299,7 +295,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     const int tps3 = (N + 31) / 32;
     const int spw = (int)((B + c->n_cu - 1) / c->n_cu);
     const bool prop3 = c->engine == DRP_ENGINE_FUSED && c->prop3 && B >= c->n_cu && (long)spw * tps3 >= PROP_WAVES;
-    const bool phase_e = prop3 && c->prop3e && !(c->tile16 && !tape);
+    const bool phase_e = prop3 && c->prop3e;
     if (!phase_e) {
         ProbeScope ps(c, KC_NODE_ENCODE);
         if (c->engine == DRP_ENGINE_FUSED)
@@ -343,12 +339,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                    a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, pb, \
                    ptr<float>(c->c_node), eff_base, N, B, spw, phase_e ? (const float*)ptr<float>(c->s_delta) : (const float*)nullptr, \
                    a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist
-            if (!tape && c->tile16)
-                hipLaunchKernelGGL(km_prop3_t16, grid, dim3(64 * PROP16_WAVES), KM_PROP3_T16_LDS, st, ptr<uint16_t>(c->w_t16),
-                                   ptr<uint16_t>(c->w_t16_6), mw, a.s_prev, a.prev_mod, a.prev_stride, a.attr, a.attr_mod, a.dens,
-                                   a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, pb, ptr<float>(c->c_node),
-                                   eff_base, N, B, spw, a.s_out, a.out_stride, a.cself, a.cself_ok);
-            else if (!tape) hipLaunchKernelGGL((km_prop3<false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
+            if (!tape) hipLaunchKernelGGL((km_prop3<false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
             else hipLaunchKernelGGL((km_prop3<true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
 #undef PROP3_ARGS
         }
@@ -390,7 +381,6 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     }
     return DRP_OK;
 }
-#endif
 
 // One predict_one_step (model/gnn_dyn.py:209-254) [+ gen_s_delta, planners.py:346] for B samples.
 int run_step(drp_ctx* c, const StepArgs& a) {
@@ -405,14 +395,12 @@ int run_step(drp_ctx* c, const StepArgs& a) {
         launch_graph(c, st, a.s_prev, a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, B, N, nbr_idx, nbr_cnt,
                      (c->engine == DRP_ENGINE_FUSED && a.cself != nullptr) ? 1 : 0, a.padded);
     }
-#ifdef DRP_HAVE_MFMA
     if (c->engine != DRP_ENGINE_VALU) {
         int rc = run_step_mfma(c, a);
         if (rc != DRP_OK) return rc;
         HIPCHK(c, hipGetLastError());
         return DRP_OK;
     }
-#endif
     {
         ProbeScope ps(c, KC_NODE_ENCODE);
         hipLaunchKernelGGL(k_node_encode<8>, dim3(B), dim3(256), 0, st, vw, s_delta, a.attr,
@@ -462,7 +450,6 @@ int run_reward(drp_ctx* c, const float* state, size_t row_stride, int rows, int 
 int prepare_cself(drp_ctx* c, int attr_mod, int N, int B, const float** cself, const uint8_t** cself_ok) {
     *cself = nullptr;
     *cself_ok = nullptr;
-#ifdef DRP_HAVE_MFMA
     if (c->engine == DRP_ENGINE_FUSED && c->self_const) {
         CHK(ensure(c, c->cself, (size_t)B * 64 * sizeof(float) + (size_t)B));
         float* cs = ptr<float>(c->cself);
@@ -473,7 +460,6 @@ int prepare_cself(drp_ctx* c, int attr_mod, int N, int B, const float** cself, c
         *cself_ok = ok;
         ++c->cself_tag;
     }
-#endif
     return DRP_OK;
 }
 
@@ -564,6 +550,11 @@ void launch_wgrad(drp_ctx* c, const float* g, int ldg, const float* x, int ldx, 
                        db, dwd);
 }
 
+// The one-shot entry points stage their inputs in the buffers the planner sessions keep their state in
+// (s_in, attr, dens, actions, states): a session interrupted by one of them is over -- its next call returns
+// DRP_ESTATE instead of results computed from overwritten inputs.
+void end_sessions(drp_ctx* c) { c->mpc_on = false; c->gd_on = false; }
+
 int check_bn(drp_ctx* c, int B, int N) {
     if (B <= 0 || N <= 0 || N > 4096) return fail(c, DRP_EINVAL, "bad shape B=%d N=%d (N <= 4096)", B, N);
     return DRP_OK;
@@ -597,8 +588,8 @@ int drp_create(int device, drp_ctx** out) {
     c->self_const = getenv("DRP_NO_SELF_CONST") == nullptr;
     c->prop3 = getenv("DRP_NO_PROP3") == nullptr;
     c->graph_strips = getenv("DRP_NO_GRAPH_STRIPS") == nullptr;
-    c->tile16 = getenv("DRP_TILE16") != nullptr;
     c->prop3e = getenv("DRP_NO_PROP3E") == nullptr;
+    c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -614,7 +605,6 @@ int drp_create(int device, drp_ctx** out) {
         delete c;
         return fail(nullptr, DRP_EHIP, "hipFuncSetAttribute (dynamic LDS size of k_graph, kb_edge_encode, kb_reverse_lists or k_aggregate_lds) failed");
     }
-#ifdef DRP_HAVE_MFMA
     // the MFMA kernels keep packed weights + per-wave transposition tiles in LDS (> 64 KiB)
     if (hipFuncSetAttribute((const void*)km_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_node_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_LDS) != hipSuccess ||
@@ -625,7 +615,6 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_prop<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3_t16, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_T16_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
@@ -634,7 +623,6 @@ int drp_create(int device, drp_ctx** out) {
         return fail(nullptr, DRP_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     }
     c->engine = DRP_ENGINE_FUSED;
-#endif
     *out = c;
     return DRP_OK;
 }
@@ -645,10 +633,10 @@ void drp_destroy(drp_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     DevBuf* bufs[] = {&c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
-                      &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->w_t16, &c->w_t16_6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
+                      &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
-                      &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats, &c->elite, &c->elite_all, &c->cself,
+                      &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats, &c->elite, &c->elite_all, &c->xchg, &c->cself,
                       &c->px_depth, &c->px_mask, &c->px_blk, &c->px_bmin, &c->px_bmax, &c->px_grid, &c->px_pcd, &c->px_keys,
                       &c->px_cellcnt, &c->px_cellfill, &c->px_celloff, &c->px_list, &c->px_down, &c->px_down32, &c->px_init,
                       &c->px_dist, &c->px_chosen, &c->px_pts, &c->px_r, &c->px_rr, &c->px_out,
@@ -674,12 +662,10 @@ int drp_sync(drp_ctx* c) {
 int drp_set_engine(drp_ctx* c, int engine) {
     if (!c) return DRP_EINVAL;
     if (engine == DRP_ENGINE_VALU) { c->engine = engine; return DRP_OK; }
-#ifdef DRP_HAVE_MFMA
     if (engine == DRP_ENGINE_MFMA || engine == DRP_ENGINE_SPLIT || engine == DRP_ENGINE_FUSED) {
         c->engine = engine;
         return DRP_OK;
     }
-#endif
     return fail(c, DRP_EINVAL, "engine %d not available in this build", engine);
 }
 
@@ -702,7 +688,6 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
     pack_valu(blob, v);
     CHK(h2d(c, c->w_raw, blob, n_floats * sizeof(float)));
     CHK(h2d(c, c->w_valu, v.data(), v.size() * sizeof(float)));
-#ifdef DRP_HAVE_MFMA
     {
         std::vector<float> m;
         pack_mfma(blob, m);
@@ -718,14 +703,8 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
         pack_split6(blob, sp6);
         CHK(h2d(c, c->w_split6, sp6.data(), sp6.size() * sizeof(uint16_t)));
         HIPCHK(c, hipStreamSynchronize(c->stream));     // sp6 too
-        pack_tile16(blob, sp);
-        CHK(h2d(c, c->w_t16, sp.data(), sp.size() * sizeof(uint16_t)));
-        pack_tile16_6(blob, sp6);
-        CHK(h2d(c, c->w_t16_6, sp6.data(), sp6.size() * sizeof(uint16_t)));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));     // m, sp are about to go out of scope
     }
-#endif
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->w_host.assign(blob, blob + n_floats);
     c->adj_thresh = adj_thresh;
@@ -761,6 +740,7 @@ int drp_gen_s_delta(drp_ctx* c, const float* s_cur, const float* action, int B, 
     CHK(check_bn(c, B, N));
     if (!s_cur || !action || !out) return fail(c, DRP_EINVAL, "null buffer");
     HIPCHK(c, hipSetDevice(c->device));
+    end_sessions(c);
     CHK(h2d(c, c->s_in, s_cur, (size_t)B * N * 3 * sizeof(float)));
     CHK(h2d(c, c->actions, action, (size_t)B * 4 * sizeof(float)));
     CHK(ensure(c, c->s_delta, (size_t)B * N * 3 * sizeof(float)));
@@ -777,6 +757,7 @@ int drp_build_graph(drp_ctx* c, const float* s_cur, const float* s_delta, int B,
     CHK(check_bn(c, B, N));
     if (!s_cur || !s_delta || !nbr_idx_out || !nbr_cnt_out) return fail(c, DRP_EINVAL, "null buffer");
     HIPCHK(c, hipSetDevice(c->device));
+    end_sessions(c);
     CHK(ensure_step_ws(c, B, N));
     CHK(h2d(c, c->s_in, s_cur, (size_t)B * N * 3 * sizeof(float)));
     CHK(h2d(c, c->s_delta, s_delta, (size_t)B * N * 3 * sizeof(float)));
@@ -798,6 +779,7 @@ static int step_common(drp_ctx* c, const float* a_cur, const float* s_cur, const
     CHK(check_bn(c, B, N));
     if (!a_cur || !s_cur || !s_delta || !dens || !s_pred_out) return fail(c, DRP_EINVAL, "null buffer");
     HIPCHK(c, hipSetDevice(c->device));
+    end_sessions(c);
     CHK(ensure_step_ws(c, B, N));
     const size_t bn = (size_t)B * N;
     CHK(h2d(c, c->s_in, s_cur, bn * 3 * sizeof(float)));
@@ -842,6 +824,7 @@ int drp_rollout(drp_ctx* c, const float* s0, const float* attr, const float* den
     if (nb <= 0 || H <= 0 || B % nb != 0)
         return fail(c, DRP_EINVAL, "bad rollout shape nb=%d B=%d H=%d (B must be a multiple of nb)", nb, B, H);
     HIPCHK(c, hipSetDevice(c->device));
+    end_sessions(c);
     CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
     CHK(h2d(c, c->attr, attr, (size_t)nb * N * sizeof(float)));
     CHK(h2d(c, c->dens, dens, (size_t)nb * sizeof(float)));
@@ -871,6 +854,8 @@ int drp_mpc_begin(drp_ctx* c, const drp_mpc_params* p, const float* s0, const fl
     if (!p || !s0 || !attr || !dens || !nominal) return fail(c, DRP_EINVAL, "null argument");
     if (p->n_batch <= 0 || p->n_sample <= 0 || p->n_look_ahead <= 0 || p->n_look_ahead > 64)
         return fail(c, DRP_EINVAL, "bad mpc shape");
+    if (p->noise_type < DRP_NOISE_NORMAL || p->noise_type > DRP_NOISE_TOTAL_RAND)
+        return fail(c, DRP_EINVAL, "bad noise_type %d", p->noise_type);
     const int nb = p->n_batch, N = p->n_particles, H = p->n_look_ahead, B = p->n_sample * nb;
     CHK(check_bn(c, B, N));
     HIPCHK(c, hipSetDevice(c->device));
@@ -889,6 +874,7 @@ int drp_mpc_begin(drp_ctx* c, const drp_mpc_params* p, const float* s0, const fl
     CHK(ensure(c, c->scratch, (size_t)B * sizeof(float)));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->mpc_on = true;
+    c->gd_on = false;
     return DRP_OK;
 }
 
@@ -906,7 +892,7 @@ int drp_mpc_sample(drp_ctx* c, const float* noise, uint64_t iteration) {
                        ptr<double>(c->nominal), dnoise, p.n_sample, p.n_batch, p.n_look_ahead, p.sigma,
                        p.beta_filter, make_float4(p.act_lo[0], p.act_lo[1], p.act_lo[2], p.act_lo[3]),
                        make_float4(p.act_hi[0], p.act_hi[1], p.act_hi[2], p.act_hi[3]), p.seed,
-                       p.sample_offset, iteration, ptr<float>(c->actions));
+                       p.sample_offset, iteration, p.noise_type, ptr<float>(c->actions));
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
@@ -928,13 +914,13 @@ int drp_mpc_rollout(drp_ctx* c, int reward_all_steps) {
                        reward_all_steps != 0, reward_all_steps == 0);
 }
 
-static int launch_partials(drp_ctx* c) {
+static int launch_partials(drp_ctx* c, double* out) {
     const drp_mpc_params& p = c->mpc;
     const int H = p.n_look_ahead;
     ProbeScope ps(c, KC_MPPI);
     hipLaunchKernelGGL(k_mppi_partials, dim3(4 * H + 1), dim3(256), 0, c->stream,
                        ptr<float>(c->rewards) + (H - 1), H, ptr<float>(c->actions), p.n_sample, p.n_batch,
-                       H, p.reward_weight, p.sample_offset, ptr<double>(c->partials));
+                       H, p.reward_weight, p.sample_offset, out);
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
@@ -942,7 +928,7 @@ static int launch_partials(drp_ctx* c) {
 int drp_mpc_partials(drp_ctx* c, double* out) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
     HIPCHK(c, hipSetDevice(c->device));
-    CHK(launch_partials(c));
+    CHK(launch_partials(c, ptr<double>(c->partials)));
     if (out) {
         CHK(d2h(c, out, c->partials.p, (size_t)(6 + 4 * c->mpc.n_look_ahead) * sizeof(double)));
         return drp_sync(c);
@@ -950,11 +936,11 @@ int drp_mpc_partials(drp_ctx* c, double* out) {
     return DRP_OK;
 }
 
-static int launch_update(drp_ctx* c, const double* dev_partials, int n_ranks) {
+static int launch_update(drp_ctx* c, const double* dev_partials, int n_ranks, int rank_stride = 0) {
     const drp_mpc_params& p = c->mpc;
     ProbeScope ps(c, KC_MPPI);
     hipLaunchKernelGGL(k_mppi_update, dim3(1), dim3(128), 0, c->stream, dev_partials, n_ranks,
-                       p.n_look_ahead, (double)p.n_sample * (double)n_ranks, ptr<double>(c->nominal),
+                       rank_stride > 0 ? rank_stride : 6 + 4 * p.n_look_ahead, p.n_look_ahead, (double)p.n_sample * (double)n_ranks, ptr<double>(c->nominal),
                        ptr<double>(c->stats));
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
@@ -977,9 +963,9 @@ int drp_mpc_update(drp_ctx* c, const double* partials, int n_ranks, double* nomi
 int drp_mpc_update_device(drp_ctx* c) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
     HIPCHK(c, hipSetDevice(c->device));
-    CHK(launch_partials(c));
+    CHK(launch_partials(c, ptr<double>(c->partials)));
     const int rec = 6 + 4 * c->mpc.n_look_ahead;
-    if (c->comm && c->n_ranks > 1) {
+    if (c->comm && (c->n_ranks > 1 || c->comm_always)) {
         CHK(ensure(c, c->gathered, (size_t)rec * sizeof(double) * c->n_ranks));
         ncclResult_t r = ncclAllGather(c->partials.p, c->gathered.p, rec, ncclDouble, c->comm, c->stream);
         if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", ncclGetErrorString(r));
@@ -999,23 +985,23 @@ static int elite_check(drp_ctx* c, int k) {
 
 static int pow2_at_least(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
-static int launch_elite_local(drp_ctx* c, int k) {
+static int launch_elite_local(drp_ctx* c, int k, double* out) {
     const drp_mpc_params& p = c->mpc;
     const int H = p.n_look_ahead;
-    CHK(ensure(c, c->elite, (size_t)k * (2 + 4 * H) * sizeof(double)));
     // sort path while keys + indices + positions of 2^m >= n_sample entries fit in LDS; k dependent rounds otherwise
     int n2 = pow2_at_least(p.n_sample);
     size_t lds = (size_t)n2 * 20;
     if (lds > 150 * 1024 || k > n2) { n2 = 0; lds = (size_t)p.n_sample * 16 + (size_t)k * 4; }
     ProbeScope ps(c, KC_MPPI);
     hipLaunchKernelGGL(k_elite_local, dim3(1), dim3(256), lds, c->stream, ptr<float>(c->rewards) + (H - 1), H,
-                       ptr<float>(c->actions), p.n_sample, p.n_batch, H, k, p.sample_offset, n2, ptr<double>(c->elite));
+                       ptr<float>(c->actions), p.n_sample, p.n_batch, H, k, p.sample_offset, n2, out);
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
 
-static int launch_elite_update(drp_ctx* c, const double* dev_records, int n_ranks, int k) {
+static int launch_elite_update(drp_ctx* c, const double* dev_records, int n_ranks, int k, int rank_stride = 0) {
     const int HJ = 4 * c->mpc.n_look_ahead, total = n_ranks * k;
+    if (rank_stride <= 0) rank_stride = k * (2 + HJ);
     int n2 = pow2_at_least(total);
     size_t lds = (size_t)n2 * 16 + (size_t)((n2 + 1) / 2) * 8 + (size_t)k * HJ * 8;    // keys, indices, positions, k sequences
     if (lds > 150 * 1024) {
@@ -1026,7 +1012,7 @@ static int launch_elite_update(drp_ctx* c, const double* dev_records, int n_rank
         if (lds > 150 * 1024) return fail(c, DRP_EINVAL, "too many elite records (%d ranks x %d, horizon %d)", n_ranks, k, c->mpc.n_look_ahead);
     }
     ProbeScope ps(c, KC_MPPI);
-    hipLaunchKernelGGL(k_elite_update, dim3(1), dim3(256), lds, c->stream, dev_records, n_ranks, k, c->mpc.n_look_ahead, n2,
+    hipLaunchKernelGGL(k_elite_update, dim3(1), dim3(256), lds, c->stream, dev_records, n_ranks, rank_stride, k, c->mpc.n_look_ahead, n2,
                        ptr<double>(c->nominal), ptr<double>(c->stats) + 6);
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
@@ -1035,7 +1021,8 @@ static int launch_elite_update(drp_ctx* c, const double* dev_records, int n_rank
 int drp_mpc_elite(drp_ctx* c, int k, double* out) {
     CHK(elite_check(c, k));
     HIPCHK(c, hipSetDevice(c->device));
-    CHK(launch_elite_local(c, k));
+    CHK(ensure(c, c->elite, (size_t)k * (2 + 4 * c->mpc.n_look_ahead) * sizeof(double)));
+    CHK(launch_elite_local(c, k, ptr<double>(c->elite)));
     if (out) {
         CHK(d2h(c, out, c->elite.p, (size_t)k * (2 + 4 * c->mpc.n_look_ahead) * sizeof(double)));
         return drp_sync(c);
@@ -1060,17 +1047,27 @@ int drp_mpc_update_elite(drp_ctx* c, const double* records, int n_ranks, int k, 
 
 int drp_mpc_update_elite_device(drp_ctx* c, int k) {
     CHK(elite_check(c, k));
-    // reward statistics (mean, std, max, argmax) as in the softmax update; its nominal is then replaced
-    CHK(drp_mpc_update_device(c));
-    CHK(launch_elite_local(c, k));
-    const int rec = k * (2 + 4 * c->mpc.n_look_ahead);
-    if (c->comm && c->n_ranks > 1) {
-        CHK(ensure(c, c->elite_all, (size_t)rec * sizeof(double) * c->n_ranks));
-        ncclResult_t r = ncclAllGather(c->elite.p, c->elite_all.p, rec, ncclDouble, c->comm, c->stream);
+    HIPCHK(c, hipSetDevice(c->device));
+    // One message per rank and iteration: [statistics record (6 + 4H) | k elite records (2 + 4H each)],
+    // written side by side by the two local kernels, all-gathered with ONE RCCL call, read in place by the
+    // two combine kernels (the softmax combine supplies mean / std / max / argmax; its nominal is then replaced
+    // by the elite mean).
+    const int H = c->mpc.n_look_ahead, rec_s = 6 + 4 * H, rec_e = k * (2 + 4 * H), msg = rec_s + rec_e;
+    CHK(ensure(c, c->elite, (size_t)msg * sizeof(double)));
+    double* mine = ptr<double>(c->elite);
+    CHK(launch_partials(c, mine));
+    CHK(launch_elite_local(c, k, mine + rec_s));
+    const double* all = mine;
+    int n_ranks = 1;
+    if (c->comm && (c->n_ranks > 1 || c->comm_always)) {
+        CHK(ensure(c, c->elite_all, (size_t)msg * sizeof(double) * c->n_ranks));
+        ncclResult_t r = ncclAllGather(c->elite.p, c->elite_all.p, msg, ncclDouble, c->comm, c->stream);
         if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", ncclGetErrorString(r));
-        return launch_elite_update(c, ptr<double>(c->elite_all), c->n_ranks, k);
+        all = ptr<double>(c->elite_all);
+        n_ranks = c->n_ranks;
     }
-    return launch_elite_update(c, ptr<double>(c->elite), 1, k);
+    CHK(launch_update(c, all, n_ranks, msg));
+    return launch_elite_update(c, all + rec_s, n_ranks, k, msg);
 }
 
 int drp_mpc_get(drp_ctx* c, float* actions, float* rewards, float* rewards_all, float* states,
@@ -1588,9 +1585,6 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     if (!s0 || !attr || !dens || !actions || !act_lo || !act_hi) return fail(c, DRP_EINVAL, "null argument");
     if (H < 1 || H > 64) return fail(c, DRP_EINVAL, "bad horizon H=%d", H);
     if (nb <= 0 || B % nb != 0) return fail(c, DRP_EINVAL, "B must be a multiple of n_batch");
-#ifndef DRP_HAVE_MFMA
-    return fail(c, DRP_ESTATE, "built without the MFMA engine");
-#endif
     HIPCHK(c, hipSetDevice(c->device));
     const size_t bn = (size_t)B * N;
     CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
@@ -1890,9 +1884,6 @@ int drp_train_begin(drp_ctx* c, int n_rollout, double lr, double beta1) {
     CHK(need(c, true, false, false));
     if (n_rollout < 1 || n_rollout > 64 || !(lr > 0.0) || !(beta1 >= 0.0 && beta1 < 1.0))
         return fail(c, DRP_EINVAL, "bad training arguments n_rollout=%d lr=%g beta1=%g", n_rollout, lr, beta1);
-#ifndef DRP_HAVE_MFMA
-    return fail(c, DRP_ESTATE, "built without the MFMA engine");
-#endif
     HIPCHK(c, hipSetDevice(c->device));
     CHK(ensure(c, c->tr_grad, (size_t)W_TOTAL * sizeof(float)));
     CHK(ensure(c, c->tr_m, (size_t)W_TOTAL * sizeof(float)));
@@ -1919,6 +1910,7 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         if (particle_nums[b] <= 0 || particle_nums[b] > N)
             return fail(c, DRP_EINVAL, "particle_nums[%d]=%d outside 1..%d", b, particle_nums[b], N);
     HIPCHK(c, hipSetDevice(c->device));
+    end_sessions(c);
     const int H = c->tr_nroll;
     const size_t bn = (size_t)B * N, bn64 = bn * 64, bnk = bn * DRP_K;
     const bool backward = mode != DRP_TRAIN_EVAL;
@@ -2023,6 +2015,23 @@ int drp_comm_init(drp_ctx* c, const char* id128, int rank, int n_ranks) {
     c->rank = rank;
     c->n_ranks = n_ranks;
     return DRP_OK;
+}
+
+int drp_comm_allgather(drp_ctx* c, const void* send, size_t bytes, void* recv) {
+    if (!c || !send || !recv || bytes == 0) return fail(c, DRP_EINVAL, "bad all-gather arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->comm || (c->n_ranks <= 1 && !c->comm_always)) {
+        memcpy(recv, send, bytes);
+        return DRP_OK;
+    }
+    CHK(ensure(c, c->xchg, bytes * (size_t)(c->n_ranks + 1)));
+    char* dsend = static_cast<char*>(c->xchg.p);
+    char* drecv = dsend + bytes;
+    HIPCHK(c, hipMemcpyAsync(dsend, send, bytes, hipMemcpyHostToDevice, c->stream));
+    ncclResult_t r = ncclAllGather(dsend, drecv, bytes, ncclChar, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", ncclGetErrorString(r));
+    CHK(d2h(c, recv, drecv, bytes * (size_t)c->n_ranks));
+    return drp_sync(c);
 }
 
 int drp_comm_destroy(drp_ctx* c) {

@@ -1,7 +1,7 @@
 // Sampling-MPC bookkeeping on the device: action sampling and the softmax-weighted
 // update, written so the sample axis can be sharded over GPUs.
 //
-//   sample_action_sequences   planners.py:69-190  (noise_type 'normal')
+//   sample_action_sequences   planners.py:69-190  (noise_type 'normal', 'uniform', 'total_rand')
 //   optimize_action           planners.py:549-561
 //
 // Both are dead code in the reference (nothing calls them; the live planner is gradient
@@ -41,12 +41,14 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
 // One thread per sample: temporally filtered Gaussian residual added to the nominal
 // sequence, clipped to the action box; written to all n_batch rows of the sample
 // (row = sample * n_batch + batch, planners.py:661-662).
-//   noise: null -> Philox normals keyed by (seed; global sample, t, iteration),
-//          else [n_sample,H,4] standard normal draws from the host.
+//   noise: null -> Philox draws keyed by (seed; global sample, t, iteration),
+//          else [n_sample,H,4] draws from the host (standard normal / U(-1,1) / U[0,1) by noise_type).
+//   noise_type (planners.py:116-135,169-175): 0 'normal' N(0, sigma); 1 'uniform' U(-sigma, sigma);
+//          2 'total_rand': no residual, the push is drawn uniformly from the clip box.
 __global__ void k_mppi_sample(const double* __restrict__ nominal, const float* __restrict__ noise,
                               int n_sample, int n_batch, int H, double sigma, double beta, float4 lo,
                               float4 hi, uint64_t seed, uint64_t sample_offset, uint64_t iteration,
-                              float* __restrict__ actions) {
+                              int noise_type, float* __restrict__ actions) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_sample) return;
     const float lo_[4] = {lo.x, lo.y, lo.z, lo.w}, hi_[4] = {hi.x, hi.y, hi.z, hi.w};
@@ -60,14 +62,24 @@ __global__ void k_mppi_sample(const double* __restrict__ nominal, const float* _
             const uint64_t gs = sample_offset + (uint64_t)s;
             uint32_t ctr[4] = {(uint32_t)gs, (uint32_t)(gs >> 32), (uint32_t)t, (uint32_t)iteration};
             philox4x32(ctr, seed);
-            box_muller(ctr[0], ctr[1], n[0], n[1]);
-            box_muller(ctr[2], ctr[3], n[2], n[3]);
+            if (noise_type == 0) {
+                box_muller(ctr[0], ctr[1], n[0], n[1]);
+                box_muller(ctr[2], ctr[3], n[2], n[3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float u = (float)(ctr[c] >> 8) * 5.9604644775390625e-08f;      // [0,1), 24 bits
+                    n[c] = (noise_type == 1) ? 2.0f * u - 1.0f : u;
+                }
+            }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            resid[c] = beta * (sigma * (double)n[c]) + resid[c] * (1.0 - beta);
+            const double z = (noise_type == 2) ? 0.0 : sigma * (double)n[c];
+            resid[c] = beta * z + resid[c] * (1.0 - beta);
             double a = nominal[t * 4 + c] + resid[c];
             a = fmin(fmax(a, (double)lo_[c]), (double)hi_[c]);
+            if (noise_type == 2) a = (double)lo_[c] + (double)n[c] * ((double)hi_[c] - (double)lo_[c]);
             for (int j = 0; j < n_batch; ++j)
                 actions[(((size_t)s * n_batch + j) * H + t) * 4 + c] = (float)a;
         }
@@ -154,12 +166,14 @@ k_mppi_partials(const float* __restrict__ reward, int reward_stride, const float
     }
 }
 
-// Combine n_ranks partial records into the new nominal sequence (and global stats).
+// Combine n_ranks partial records into the new nominal sequence (and global stats).  Rank g's record
+// starts at partials + g * rank_stride (>= 6 + 4H doubles: the elite form of the exchange packs a rank's
+// statistics record and its elite block into one all-gathered message).
 //   stats_out: [0] mean r  [1] unbiased std r  [2] max r  [3] argmax  [4] Z  [5] m
-__global__ void k_mppi_update(const double* __restrict__ partials, int n_ranks, int H,
+__global__ void k_mppi_update(const double* __restrict__ partials, int n_ranks, int rank_stride, int H,
                               double n_sample_total, double* __restrict__ nominal,
                               double* __restrict__ stats_out) {
-    const int HJ = 4 * H, REC = 6 + HJ;
+    const int HJ = 4 * H, REC = rank_stride;
     double m = -__builtin_inf();
     for (int g = 0; g < n_ranks; ++g) m = fmax(m, partials[(size_t)g * REC]);
     double Z = 0.0;
@@ -327,19 +341,21 @@ k_elite_local(const float* __restrict__ reward, int reward_stride, const float* 
     }
 }
 
-// records [n_ranks][k][2+4H] -> nominal = mean of the k best sequences (summed in pick order);
+// records [n_ranks][k][2+4H] (rank g's block at recs + g * rank_stride doubles) -> nominal = mean of the k best
+// sequences (summed in pick order);
 // elite_out: [0] elite size, [1] worst elite reward.  dynamic LDS: max(2 * n_ranks * k, k * 4H) doubles + k ints
 __global__ void __launch_bounds__(256)
-k_elite_update(const double* __restrict__ recs, int n_ranks, int k, int H, int n2 /* 2^m >= n_ranks * k: sort path; 0: k rounds */,
+k_elite_update(const double* __restrict__ recs, int n_ranks, int rank_stride, int k, int H, int n2 /* 2^m >= n_ranks * k: sort path; 0: k rounds */,
                double* __restrict__ nominal, double* __restrict__ elite_out) {
     extern __shared__ __attribute__((aligned(16))) double el_lds[];
     const int HJ = 4 * H, REC = 2 + HJ, total = n_ranks * k;
+    auto rec_at = [&](int q) { return recs + (size_t)(q / k) * rank_stride + (size_t)(q % k) * REC; };
     double* key = el_lds;
     double* idx = key + (n2 > 0 ? n2 : total);
     int* pick = reinterpret_cast<int*>(el_lds + max(2 * total, k * HJ));     // behind whichever use of el_lds is larger
     for (int q = threadIdx.x; q < total; q += blockDim.x) {
-        key[q] = recs[(size_t)q * REC];
-        idx[q] = recs[(size_t)q * REC + 1];
+        key[q] = rec_at(q)[0];
+        idx[q] = rec_at(q)[1];
     }
     if (n2 > 0) {
         int* src = reinterpret_cast<int*>(el_lds + 2 * n2);
@@ -353,7 +369,7 @@ k_elite_update(const double* __restrict__ recs, int n_ranks, int k, int H, int n
         double* seq = el_lds + 2 * n2 + (n2 + 1) / 2;             // behind keys, indices and positions
         for (int t = threadIdx.x; t < taken * HJ; t += blockDim.x) {
             const int e = t / HJ, j = t - e * HJ;
-            seq[t] = recs[(size_t)src[e] * REC + 2 + j];
+            seq[t] = rec_at(src[e])[2 + j];
         }
         __syncthreads();
         for (int j = threadIdx.x; j < HJ; j += blockDim.x) {
@@ -377,7 +393,7 @@ k_elite_update(const double* __restrict__ recs, int n_ranks, int k, int H, int n
     __syncthreads();
     for (int t = threadIdx.x; t < k * HJ; t += blockDim.x) {
         const int e = t / HJ, j = t - e * HJ;
-        seq[t] = (pick[e] >= 0) ? recs[(size_t)pick[e] * REC + 2 + j] : 0.0;
+        seq[t] = (pick[e] >= 0) ? rec_at(pick[e])[2 + j] : 0.0;
     }
     __syncthreads();
     for (int j = threadIdx.x; j < HJ; j += blockDim.x) {
@@ -387,6 +403,6 @@ k_elite_update(const double* __restrict__ recs, int n_ranks, int k, int H, int n
     }
     if (threadIdx.x == 0 && elite_out != nullptr) {
         elite_out[0] = (double)taken;
-        elite_out[1] = (taken > 0) ? recs[(size_t)pick[taken - 1] * REC] : 0.0;
+        elite_out[1] = (taken > 0) ? rec_at(pick[taken - 1])[0] : 0.0;
     }
 }

@@ -175,7 +175,7 @@ class Engine(object):
 
     # ---- device-resident MPPI -----------------------------------------------------
     def mpc_begin(self, s0, attr, dens, nominal, n_sample, sigma, beta_filter, reward_weight,
-                  act_lo, act_hi, seed=0, sample_offset=0):
+                  act_lo, act_hi, seed=0, sample_offset=0, noise_type='normal'):
         s0, attr, dens = _f32(s0), _f32(attr), _f32(dens)
         nominal = np.ascontiguousarray(nominal, dtype=np.float64)
         nb, N, _ = s0.shape
@@ -187,6 +187,7 @@ class Engine(object):
             p.act_lo[i] = float(act_lo[i])
             p.act_hi[i] = float(act_hi[i])
         p.seed, p.sample_offset = int(seed), int(sample_offset)
+        p.noise_type, p.reserved = L.NOISE_TYPES[noise_type], 0
         self._ck(self.lib.drp_mpc_begin(self.h, ctypes.byref(p), _fp(s0), _fp(attr), _fp(dens),
                                         _dp(nominal)))
         self.H, self.nb, self.N, self.ns = H, nb, N, int(n_sample)
@@ -411,6 +412,15 @@ class Engine(object):
 
     def comm_init(self, uid, rank, n_ranks):
         self._ck(self.lib.drp_comm_init(self.h, uid, int(rank), int(n_ranks)))
+        self._n_ranks = int(n_ranks)
+
+    def comm_allgather(self, arr):
+        """All-gather one host array per rank over the context's communicator -> [n_ranks, *arr.shape]."""
+        arr = np.ascontiguousarray(arr)
+        out = np.empty((getattr(self, '_n_ranks', 1),) + arr.shape, arr.dtype)
+        self._ck(self.lib.drp_comm_allgather(self.h, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes,
+                                             out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     # ---- measurement ------------------------------------------------------------------
     def sync(self):

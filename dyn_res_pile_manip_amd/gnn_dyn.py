@@ -94,10 +94,15 @@ class PropNetDiffDenModel(object):
         return self
 
     def state_dict(self):
+        """The current weights under the reference's keys, as torch tensors: what
+        `torch.save(model.state_dict(), 'net_best.pth')` (train/train_gnn_dyn.py:214-215,226) must write
+        for the reference's `load_state_dict` / visualize_mpc.py:36-41 to read it back."""
         if self._blob is None:
             raise RuntimeError('no weights loaded')
         self._blob = self.engine.get_weights()       # training updates them on the device
-        return _weights.state_dict_from_blob(self._blob)
+        import torch
+        from collections import OrderedDict
+        return OrderedDict((k, torch.from_numpy(v)) for k, v in _weights.state_dict_from_blob(self._blob).items())
 
     def train(self, mode=True):
         self.training = bool(mode)

@@ -2,12 +2,14 @@
 the HIP engine through the C ABI.
 
 Same method names, argument orders and return structures as the reference
-(SURVEY.md 8b); tensors may be torch tensors or numpy arrays.  The optimiser inside
-`trajectory_optimization_ptcl_multi_traj` is the sampling planner (MPPI) built from
-the reference's own `sample_action_sequences` / `optimize_action` definitions
-(planners.py:69-190, :549-561): forward-only, which is what shards over GPUs.  The
-reference's live gradient-descent loop (planners.py:674-764) needs reverse-mode
-kernels and is the next scope row.
+(SURVEY.md 8b); tensors may be torch tensors or numpy arrays.
+`trajectory_optimization_ptcl_multi_traj` runs, by `config['mpc']['mpc_type']`:
+  'GD'   the reference's live loop (planners.py:661-764): rollout, reward, reverse mode, Adam and
+         the clip box on the device (drp_gd_step), for exactly the iteration count the reference
+         runs (planners.py:679-682);
+  'MPPI' the sampling planner built from the reference's own (dead-code) sampler and update
+         (planners.py:69-190, :549-561): forward-only, the form that shards over GPUs;
+  'CEM'  elite selection instead of the softmax update (not in the reference).
 """
 import time
 
@@ -20,9 +22,21 @@ DEBUG = False
 
 def particle_num_to_iter_time(particle_num):
     """planners.py:25-28: the reference's fitted ms per GD iteration at batch 300 on its
-    (unstated) GPU.  Kept for callers; the planner below measures its own iteration time."""
+    (unstated) GPU.  The GD planner divides its time budget by it (gd_iteration_count)."""
     t = (2969.3971 - 69.923244 * particle_num + 1.8509846 * particle_num ** 2) / 200.
     return max(int(t), 1)
+
+
+def gd_iteration_count(n_update_iter, time_lim_ms, particle_num):
+    """planners.py:590,679-682: the GD loop runs min(n_update_iter, int(time_lim / model)) iterations,
+    the budget in ms divided by the fitted per-iteration time -- a function of the arguments only (the
+    reference's wall-clock check is commented out, planners.py:765-767).  The arithmetic is the
+    reference's, (time_lim / 1000) * 1000 / model, so the truncation falls where it does there.
+    time_lim = inf (the signature's default) overflows int() in the reference; here it means no bound."""
+    if np.isinf(time_lim_ms):
+        return int(n_update_iter)
+    bound = int((time_lim_ms / 1000.0) * 1000.0 / particle_num_to_iter_time(particle_num))
+    return min(int(n_update_iter), bound)
 
 
 def world2cam_affine(cam_extrinsic):
@@ -73,28 +87,35 @@ class PlannerGD(Planner):
     def _set_goal(self, eng, obs_goal, goal_coor=None, max_goal_pts=None):
         """Install the reward's constants on the device, once per (goal image, goal pixels):
         goal_coor given -> field from the image + the caller's pixels; None -> the image also
-        yields the farthest-point subsample of its goal pixels (planners.py:620-624)."""
+        yields the farthest-point subsample of its goal pixels (planners.py:620-624).  The cache key is
+        a digest of the arrays' CONTENT (two goals of equal shape and sum are different goals) and
+        the engine object itself, kept alive by the key."""
+        import hashlib
         from . import flex_rewards
         g, _ = _to_np(obs_goal)
+        g = np.ascontiguousarray(g, dtype=np.float32)
         mode = flex_rewards.DIST_TRANSFORM
+        dig = hashlib.blake2b(g.tobytes(), digest_size=16)
         if goal_coor is None:
-            key = (id(eng), mode, g.shape, float(g.sum()), int(max_goal_pts))
-            if key != self._goal_key:
+            key = (eng, mode, g.shape, dig.digest(), int(max_goal_pts))
+            if self._goal_key is None or key[1:] != self._goal_key[1:] or key[0] is not self._goal_key[0]:
                 eng.set_goal_image(g, max_goal_pts, 0, mode)
                 self._goal_key = key
             return
         gc, _ = _to_np(goal_coor)
-        key = (id(eng), mode, g.shape, float(g.sum()), gc.shape, float(gc.sum()))
-        if key != self._goal_key:
+        gc = np.ascontiguousarray(gc, dtype=np.float32)
+        dig.update(gc.tobytes())
+        key = (eng, mode, g.shape, dig.digest(), gc.shape)
+        if self._goal_key is None or key[1:] != self._goal_key[1:] or key[0] is not self._goal_key[0]:
             eng.set_goal(flex_rewards.goal_field(g, eng), gc)
             self._goal_key = key
 
-    def _clip_box(self):
-        """planners.py:151-167 for cvx region 0."""
+    def _clip_box(self, cvx_l=0):
+        """planners.py:151-167: the clip box of convex region `cvx_l`."""
         r = self.env.cvx_region
-        xd, yd = r[0, 1] - r[0, 0], r[0, 3] - r[0, 2]
-        lo = np.array([r[0, 0], r[0, 2], r[0, 0] + xd * 0.15, r[0, 2] + yd * 0.15])
-        hi = np.array([r[0, 1], r[0, 3], r[0, 1] - xd * 0.15, r[0, 3] - yd * 0.15])
+        xd, yd = r[cvx_l, 1] - r[cvx_l, 0], r[cvx_l, 3] - r[cvx_l, 2]
+        lo = np.array([r[cvx_l, 0], r[cvx_l, 2], r[cvx_l, 0] + xd * 0.15, r[cvx_l, 2] + yd * 0.15])
+        hi = np.array([r[cvx_l, 1], r[cvx_l, 3], r[cvx_l, 1] - xd * 0.15, r[cvx_l, 3] - yd * 0.15])
         return lo, hi
 
     # ---- planners.py:69-190 ---------------------------------------------------------
@@ -107,7 +128,7 @@ class PlannerGD(Planner):
         dim3 = init_act_seq.ndim == 3
         act_seqs = np.stack([init_act_seq] * n_sample)
         resid = np.zeros((n_sample,) + init_act_seq.shape[1:])
-        lo, hi = self._clip_box()
+        lo, hi = self._clip_box(0)
         for i in range(self.n_his - 1, init_act_seq.shape[0]):
             if noise_type == 'normal':
                 sigma = self.config['mpc']['sigma'] * self.global_scale / 12.0
@@ -122,9 +143,11 @@ class PlannerGD(Planner):
             resid = beta * noise + resid * (1. - beta)
             act_seqs[:, i] += resid
             if dim3:
-                act_seqs[:, i, 0] = np.clip(act_seqs[:, i, 0], lo, hi)
+                act_seqs[:, i, 0] = np.clip(act_seqs[:, i, 0], lo, hi)       # region 0 (planners.py:161)
             else:
-                act_seqs[:, i] = np.clip(act_seqs[:, i], lo, hi)
+                # the step's label selects the convex region (planners.py:152)
+                lo_l, hi_l = self._clip_box(int(init_act_label_seq[i]))
+                act_seqs[:, i] = np.clip(act_seqs[:, i], lo_l, hi_l)
             if noise_type == 'total_rand':
                 act_seqs[:, i, 0] = np.random.uniform(lo, hi, (n_sample, self.action_dim))
         return act_seqs
@@ -207,14 +230,28 @@ class PlannerGD(Planner):
                                                 rollout_best_action_sequence=True, reward_params=None,
                                                 funnel_dist=None, distractor_df_fn=None, gd_loop=1,
                                                 time_lim=float('inf'), goal_coor=None, seed=None,
-                                                comm=None):
-        """Same contract as the reference (returned dict keys, shapes, voting rule); the
-        inner optimiser is MPPI.  `act_seq` [n_look_ahead, traj_num, 4] seeds iteration 0:
-        its traj_num candidates are scored and the best becomes the nominal sequence that
-        the following iterations perturb with `n_sample` filtered-noise samples.
-        Extra keyword arguments (not in the reference): goal_coor to skip the host-side
-        farthest-point subsample, seed for the device sampler, comm=(rank, n_ranks, uid)
-        to shard samples over GPUs."""
+                                                comm=None, noise_type='normal', wallclock_limit=False):
+        """Same contract as the reference (arguments, returned dict keys and shapes, voting rule).
+
+        mpc_type 'GD' (the reference's live path): the traj_num x n_batch pushes of `act_seq` are
+        independent Adam problems; the loop runs gd_iteration_count(n_update_iter, time_lim, N)
+        iterations -- the reference's count, a function of the arguments only (planners.py:679-682);
+        gd_loop only sizes rew_mean / rew_std (planners.py:647-648).
+        mpc_type 'MPPI' / 'CEM': `act_seq` [n_look_ahead, traj_num, 4] seeds iteration 0 (its
+        candidates are scored, the best becomes the nominal sequence), iterations 1..n_update_iter-1
+        perturb the nominal with `n_sample` filtered-noise samples (`noise_type` as in
+        sample_action_sequences) and update it.
+
+        Extra keyword arguments (not in the reference):
+          goal_coor        goal pixels given by the caller (skips the farthest-point subsample);
+          seed             key of the device sampler (default: drawn from numpy's global generator);
+          comm             shard the sample axis (MPPI / CEM) or the trajectories (GD) over ranks:
+                           a sharding.RcclComm / sharding.TorchComm, or the tuple (rank, n_ranks, uid).
+                           Every rank gets the same action_sequence / reward / rew_mean / rew_std;
+                           action_full and reward_full are the rank's own shard;
+          wallclock_limit  True: additionally stop when the measured time exceeds time_lim (the check the
+                           reference has commented out, planners.py:765-767); single rank only."""
+        from . import sharding
         assert type(state_cur_np) == np.ndarray and state_cur_np.ndim == 3
         assert state_cur_np.shape[0] == state_param.shape[0] and state_cur_np.shape[2] == 3
         assert type(obs_goal) == np.ndarray and obs_goal.ndim == 2
@@ -223,6 +260,9 @@ class PlannerGD(Planner):
         assert act_seq.shape[0] == n_look_ahead
         if distractor_df_fn is not None:
             raise NotImplementedError('distractor rewards are unused on the live path')
+        comm = sharding.as_comm(comm)
+        if comm is not None and wallclock_limit:
+            raise ValueError('wallclock_limit would stop the ranks at different iterations')
         start = time.time()
         self.particle_num = N = state_cur_np.shape[1]
         n_batch = state_cur_np.shape[0]
@@ -230,105 +270,130 @@ class PlannerGD(Planner):
         traj_num = int(act_seq.shape[1])
         eng = self._bind(model_dy)
         self._eng = eng
+        rank, n_ranks = (comm.rank, comm.n_ranks) if comm is not None else (0, 1)
+        if comm is not None:
+            comm.attach(eng)
 
         obs_goal = obs_goal.astype(np.float32)
         # planners.py:620-624 + env/flex_rewards.py:172-177: goal pixels (col,row), their
         # farthest-point subsample to 5N and the distance field, all on the device
         self._set_goal(eng, obs_goal, goal_coor, max_goal_pts=N * 5)
 
-        lo, hi = self._clip_box()
+        lo, hi = self._clip_box(0)
         cfg = self.config['mpc']
-        sigma = cfg['sigma'] * self.global_scale / 12.0
-        rank, n_ranks = 0, 1
+        if noise_type == 'uniform':
+            sigma = 2.0 * self.global_scale / 12.0                  # planners.py:124
+        else:
+            sigma = cfg['sigma'] * self.global_scale / 12.0         # planners.py:116
         if seed is None:
             seed = int(np.random.randint(0, 2 ** 31 - 1))
+            if comm is not None:                                     # every rank samples with rank 0's key
+                seed = int(comm.allgather(np.array([seed], dtype=np.int64))[0, 0])
 
         max_reward = -np.inf * np.ones(n_batch, dtype=np.float32)
         max_reward_traj_idx = np.zeros(n_batch, dtype=np.int64)
         best_actions_of_samples = np.zeros((n_batch, H, self.action_dim), dtype=np.float32)
-        n_iter = int(n_update_iter) * int(gd_loop)
-        rew_mean = np.zeros((1, n_iter), dtype=np.float32)
-        rew_std = np.zeros((1, n_iter), dtype=np.float32)
+        rew_mean = np.zeros((1, int(n_update_iter) * int(gd_loop)), dtype=np.float32)
+        rew_std = np.zeros((1, int(n_update_iter) * int(gd_loop)), dtype=np.float32)
         rollout_time = 0.0
         optim_time = 0.0
         time_lim_s = time_lim / 1000.0
 
-        def aggregate(rewards, actions, ns):
-            # planners.py:721-727: per-column running max / argmax / best action
-            r = rewards.reshape(ns, n_batch)
-            cur_max = r.max(0)
-            idx = r.argmax(0)
+        def aggregate(it, rewards, actions, ns, index_offset=0, exchange=False):
+            """planners.py:721-727,736-738: per-column running max / argmax / best pushes, and the
+            iteration's reward mean / std over column 0.  exchange: the rows are this rank's shard."""
+            if exchange:
+                rec = sharding.make_column_record(rewards, actions, n_batch, index_offset)
+                mean, std, cur_max, idx, acts = sharding.combine_column_records(comm.allgather(rec), n_batch)
+                acts = acts.reshape(n_batch, H, self.action_dim)
+            else:
+                r = rewards.reshape(ns, n_batch)
+                cur_max, idx = r.max(0), r.argmax(0)
+                acts = [actions[idx[j] * n_batch + j] for j in range(n_batch)]
+                idx = idx + index_offset
+                mean = r[:, 0].mean()
+                std = r[:, 0].std(ddof=1) if ns > 1 else 0.0
             for j in range(n_batch):
                 if cur_max[j] > max_reward[j]:
                     max_reward[j] = cur_max[j]
                     max_reward_traj_idx[j] = idx[j]
-                    best_actions_of_samples[j] = actions[idx[j] * n_batch + j]
-            return r
+                    best_actions_of_samples[j] = acts[j]
+            if it < rew_mean.shape[1]:
+                rew_mean[0, it], rew_std[0, it] = mean, std
 
         mpc_type = cfg.get('mpc_type', 'MPPI')
         i = 0
+        sharded = comm is not None and n_ranks > 1
         if mpc_type == 'GD':
             # the reference's live loop (planners.py:661-764): every trajectory x batch column is an
             # independent Adam problem on its own push; rollout, reward, backward, Adam and the clip all
             # run on the device
             assert n_sample == traj_num, 'GD optimises the traj_num given trajectories (n_sample == traj_num)'
-            cand = np.repeat(act_seq.transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)   # [traj*nb,H,4]
-            eng.gd_begin(state_cur_np, attr_cur_np, state_param, cand, cfg['gd']['lr'], lo, hi)
-            reward_seqs = np.zeros((traj_num * n_batch,), np.float32)
+            n_iter = gd_iteration_count(n_update_iter, time_lim, N)
+            if n_iter < 1:
+                # the reference reaches its return statement with the loop variable unbound (planners.py:870)
+                raise ValueError('time_lim %.3g ms admits no iteration at %d particles (%d ms each, planners.py:25-28)'
+                                 % (time_lim, N, particle_num_to_iter_time(N)))
+            t_lo, t_hi = sharding.shard_range(traj_num, rank, n_ranks)
+            cand = np.repeat(act_seq[:, t_lo:t_hi].transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)
+            eng.gd_begin(state_cur_np, attr_cur_np, state_param, cand, cfg['gd']['lr'], lo, hi)   # [traj*nb,H,4]
+            reward_seqs = np.zeros((cand.shape[0],), np.float32)
             act_seqs_last = cand
             for i in range(n_iter):
-                before = eng.gd_actions() if i == 0 else act_seqs_last
+                before = act_seqs_last
                 t0 = time.perf_counter()
                 reward_seqs = eng.gd_step()
                 act_seqs_last = eng.gd_actions()
                 optim_time += (time.perf_counter() - t0) * 1e3
-                r = aggregate(reward_seqs, before, traj_num)       # rewards belong to the pre-update pushes
-                rew_mean[0, i] = r[:, 0].mean()
-                rew_std[0, i] = r[:, 0].std(ddof=1) if traj_num > 1 else 0.0
-                if (time.time() - start) > time_lim_s:
+                # the rewards belong to the pushes before the update
+                aggregate(i, reward_seqs, before, t_hi - t_lo, index_offset=t_lo, exchange=sharded)
+                if wallclock_limit and (time.time() - start) > time_lim_s:
                     break
             nominal = None
         else:
-            # iteration 0: score the traj_num candidates
+            n_iter = int(n_update_iter)
+            mp = dict(sigma=sigma, beta_filter=cfg['mppi']['beta_filter'], reward_weight=cfg['mppi']['reward_weight'],
+                      act_lo=lo, act_hi=hi, seed=seed, noise_type=noise_type)
+            # iteration 0: every rank scores all traj_num candidates (identical everywhere, no exchange)
             cand = np.repeat(act_seq.transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)  # [traj*nb,H,4]
-            eng.mpc_begin(state_cur_np, attr_cur_np, state_param, act_seq[:, 0, :], n_sample=traj_num,
-                          sigma=sigma, beta_filter=cfg['mppi']['beta_filter'],
-                          reward_weight=cfg['mppi']['reward_weight'], act_lo=lo, act_hi=hi, seed=seed)
+            eng.mpc_begin(state_cur_np, attr_cur_np, state_param, act_seq[:, 0, :], n_sample=traj_num, **mp)
             eng.mpc_set_actions(cand)
             t0 = time.perf_counter()
             eng.mpc_rollout(False)
             got = eng.mpc_get(rewards=True)
             rollout_time += (time.perf_counter() - t0) * 1e3
-            r0 = aggregate(got['rewards'], cand, traj_num)
+            aggregate(0, got['rewards'], cand, traj_num)
             reward_seqs = got['rewards'].copy()
             act_seqs_last = cand
+            r0 = reward_seqs.reshape(traj_num, n_batch)
             nominal = act_seq[:, int(np.argmax(r0.mean(1))), :].astype(np.float64)
-            if n_iter > 0:
-                rew_mean[0, 0] = r0[:, 0].mean()
-                rew_std[0, 0] = r0[:, 0].std(ddof=1) if traj_num > 1 else 0.0
+            s_lo, s_hi = sharding.shard_range(n_sample, rank, n_ranks)
+            ns_loc = s_hi - s_lo
             if n_iter > 1:
-                eng.mpc_begin(state_cur_np, attr_cur_np, state_param, nominal, n_sample=n_sample,
-                              sigma=sigma, beta_filter=cfg['mppi']['beta_filter'],
-                              reward_weight=cfg['mppi']['reward_weight'], act_lo=lo, act_hi=hi, seed=seed)
+                eng.mpc_begin(state_cur_np, attr_cur_np, state_param, nominal, n_sample=ns_loc, sample_offset=s_lo, **mp)
+            k_elite = int(cfg.get('cem', {}).get('n_elite', max(1, n_sample // 10)))
             for i in range(1, n_iter):
                 t0 = time.perf_counter()
                 eng.mpc_sample(i)
                 eng.mpc_rollout(False)
                 t1 = time.perf_counter()
-                if mpc_type == 'CEM':
-                    # elite update (not in the reference): mean of the n_elite best sequences
-                    eng.mpc_update_elite_device(int(cfg.get('cem', {}).get('n_elite', max(1, n_sample // 10))))
+                if comm is None or comm.device_update:
+                    # partials -> [one RCCL all-gather] -> combine, on the stream
+                    if mpc_type == 'CEM':
+                        eng.mpc_update_elite_device(k_elite)   # elite update (not in the reference)
+                    else:
+                        eng.mpc_update_device()
+                elif mpc_type == 'CEM':
+                    eng.mpc_update_elite(comm.allgather(eng.mpc_elite(k_elite)), k_elite)
                 else:
-                    eng.mpc_update_device()
+                    eng.mpc_update(comm.allgather(eng.mpc_partials()))
                 got = eng.mpc_get(rewards=True, actions=True)
                 t2 = time.perf_counter()
                 rollout_time += (t1 - t0) * 1e3
                 optim_time += (t2 - t1) * 1e3
-                r = aggregate(got['rewards'], got['actions'], n_sample)
+                aggregate(i, got['rewards'], got['actions'], ns_loc, index_offset=s_lo, exchange=sharded)
                 reward_seqs, act_seqs_last = got['rewards'], got['actions']
-                rew_mean[0, i] = r[:, 0].mean()
-                rew_std[0, i] = r[:, 0].std(ddof=1) if n_sample > 1 else 0.0
-                if (time.time() - start) > time_lim_s:
+                if wallclock_limit and (time.time() - start) > time_lim_s:
                     break
             if n_iter > 1:
                 nominal = eng.mpc_get(nominal=True)['nominal']

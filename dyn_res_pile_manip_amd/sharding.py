@@ -7,11 +7,12 @@ softmax-weighted update (planners.py:549-561): every rank contributes the record
     [m, Z, A[H*4], sum r, sum r^2, max r, argmax]          (6 + 4H doubles)
 and the combined mean is  sum_g A_g e^(m_g - M) / sum_g Z_g e^(m_g - M),  M = max_g m_g.
 
-Two transports for that record:
-  * on the device: drp_mpc_update_device() all-gathers it with RCCL (xGMI) and runs the
-    combine kernel -- no host hop (bench.py, one fused collective per iteration);
-  * through torch.distributed (`allgather_records`): any backend, used by the planner when
-    it is handed a process group, and by the gloo tests on CPU.
+Two transports for that record, both behind the `comm=` argument of
+`PlannerGD.trajectory_optimization_ptcl_multi_traj`:
+  * `RcclComm`: drp_mpc_update_device() all-gathers it with RCCL (xGMI) and runs the combine
+    kernel -- no host hop, one collective per iteration (bench.py uses the same entry point);
+  * `TorchComm`: through torch.distributed (`allgather_records`), any backend -- the world-2
+    gloo tests on CPU, and two processes sharing one GPU in tests/test_gpu_sharded_planner.py.
 `combine_records` is the host mirror of the combine kernel (k_mppi_update).
 """
 import numpy as np
@@ -109,3 +110,82 @@ def combine_elite_records(records, k):
     H = (rec.shape[1] - 2) // 4
     el = rec[order]
     return el[:, 2:].mean(0).reshape(H, 4), len(order), float(el[-1, 0])
+
+
+# ---- what the planner is handed to shard its sample axis (comm=) ---------------------------------
+class RcclComm(object):
+    """One rank of an RCCL communicator attached to the engine's context: the planner's update runs as
+    drp_mpc_update_device / drp_mpc_update_elite_device (partials -> ncclAllGather -> combine on the
+    stream), its bookkeeping record travels through drp_comm_allgather.  `uid` = the 128-byte
+    ncclUniqueId every rank received from rank 0 (Engine.comm_unique_id())."""
+    device_update = True
+
+    def __init__(self, uid, rank, n_ranks):
+        self.uid, self.rank, self.n_ranks = uid, int(rank), int(n_ranks)
+        self._eng = None
+
+    def attach(self, eng):
+        if self._eng is not eng:
+            eng.comm_init(self.uid, self.rank, self.n_ranks)
+            self._eng = eng
+
+    def allgather(self, arr):
+        return self._eng.comm_allgather(arr)
+
+
+class TorchComm(object):
+    """Host transport over a torch.distributed process group (gloo or nccl): the planner fetches its
+    rank's record (drp_mpc_partials / drp_mpc_elite), all-gathers it here and uploads the gathered
+    records to the combine kernel (drp_mpc_update / drp_mpc_update_elite)."""
+    device_update = False
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.rank, self.n_ranks = dist.get_rank(group), dist.get_world_size(group)
+
+    def attach(self, eng):
+        pass
+
+    def allgather(self, arr):
+        return allgather_records(arr, self.group).reshape((self.n_ranks,) + np.shape(arr))
+
+
+def as_comm(comm):
+    """None | RcclComm | TorchComm | the documented tuple (rank, n_ranks, uid) -> a comm object or None."""
+    if comm is None or hasattr(comm, 'allgather'):
+        return comm
+    rank, n_ranks, uid = comm
+    return RcclComm(uid, rank, n_ranks)
+
+
+# The planner's per-iteration bookkeeping (planners.py:721-727,736-738) over a sharded sample axis: every rank
+# reduces its own samples to one record
+#     [n, sum r, sum r^2 of column 0 | per batch column: max r, global index of the first sample attaining it,
+#      that sample's pushes (4H)]
+# and folds the gathered records in rank order -- ranks own ascending index ranges, so "first maximum"
+# (torch.max's rule) is the lowest rank attaining the column maximum.
+def make_column_record(rewards, actions, n_batch, index_offset):
+    """rewards [ns*n_batch] (row = sample * n_batch + column), actions [ns*n_batch, H, 4] -> float64 record."""
+    r = np.asarray(rewards, dtype=np.float64).reshape(-1, n_batch)
+    a = np.asarray(actions, dtype=np.float64).reshape(r.shape[0], n_batch, -1)
+    rec = np.empty(3 + n_batch * (2 + a.shape[2]), dtype=np.float64)
+    rec[0], rec[1], rec[2] = r.shape[0], r[:, 0].sum(), (r[:, 0] * r[:, 0]).sum()
+    body = rec[3:].reshape(n_batch, 2 + a.shape[2])
+    idx = r.argmax(0)
+    for j in range(n_batch):
+        body[j, 0], body[j, 1] = r[idx[j], j], float(idx[j] + index_offset)
+        body[j, 2:] = a[idx[j], j]
+    return rec
+
+
+def combine_column_records(records, n_batch):
+    """[n_ranks, record] -> (mean, unbiased std of column 0; per column: max, global argmax, pushes [n_batch, 4H])."""
+    rec = np.asarray(records, dtype=np.float64)
+    n, s1, s2 = rec[:, 0].sum(), rec[:, 1].sum(), rec[:, 2].sum()
+    mean = s1 / n
+    std = float(np.sqrt(max((s2 - s1 * mean) / (n - 1.0), 0.0))) if n > 1 else 0.0
+    body = rec[:, 3:].reshape(rec.shape[0], n_batch, -1)
+    g = body[:, :, 0].argmax(0)                       # first rank attaining the column maximum
+    cols = np.arange(n_batch)
+    return mean, std, body[g, cols, 0], body[g, cols, 1].astype(np.int64), body[g, cols, 2:]

@@ -19,24 +19,35 @@ def _np(x, dtype=np.float32):
     return np.asarray(x, dtype=dtype)
 
 
+class PaddedBatch(tuple):
+    """What `collate_fn` returns: the reference's 6-tuple (states, states_delta, attr, particle_num,
+    particle_den, color_imgs), plus the ragged layout it was built from."""
+    offsets = None          # [B+1] running particle offset of each sample in the concatenated cloud
+
+
 def collate_fn(data):
-    """List of (states [T,n,3], states_delta [T-1,n,3], attrs [T,n], particle_num, particle_den,
-    color_imgs) -> zero-padded arrays, as train/train_gnn_dyn.py:20-45 (numpy instead of torch)."""
-    states, states_delta, attrs, particle_num, particle_den, color_imgs = zip(*data)
-    max_len = max(particle_num)
-    batch_size = len(data)
-    n_time, _, n_dim = _np(states[0]).shape
-    states_tensor = np.zeros((batch_size, n_time, max_len, n_dim), dtype=np.float32)
-    states_delta_tensor = np.zeros((batch_size, n_time - 1, max_len, n_dim), dtype=np.float32)
-    attr = np.zeros((batch_size, n_time, max_len), dtype=np.float32)
-    particle_num_tensor = np.asarray(particle_num, dtype=np.int32)
-    particle_den_tensor = np.asarray(particle_den, dtype=np.float32)
-    for i in range(batch_size):
-        states_tensor[i, :, :particle_num[i], :] = _np(states[i])
-        states_delta_tensor[i, :, :particle_num[i], :] = _np(states_delta[i])
-        attr[i, :, :particle_num[i]] = _np(attrs[i])
-    imgs = None if color_imgs[0] is None else np.asarray(color_imgs, dtype=np.float32)
-    return states_tensor, states_delta_tensor, attr, particle_num_tensor, particle_den_tensor, imgs
+    """Contract of train/train_gnn_dyn.py:20-45: samples with different particle counts become one batch
+    zero-padded to the largest count -- states [B,T,n_max,3], states_delta [B,T-1,n_max,3], attr [B,T,n_max],
+    particle_num [B] int32, particle_den [B] float32, color_imgs.
+
+    Built as one ragged pack instead of a per-sample copy loop: the samples' particle axes are concatenated
+    ([T, sum n, 3]), every particle gets its (sample, slot) address from the running offsets, and a single
+    fancy-indexed store per field places the whole batch.  The offsets stay on the result (`.offsets`)."""
+    counts = np.fromiter((int(d[3]) for d in data), dtype=np.int64, count=len(data))
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    B, n_max = len(data), int(counts.max())
+    owner = np.repeat(np.arange(B), counts)                      # sample of every packed particle
+    slot = np.arange(offsets[-1]) - offsets[owner]               # its index inside that sample
+    def pack(field, time_axis_len=None):
+        cloud = np.concatenate([_np(d[field]) for d in data], axis=1)           # [T, sum n(, 3)]
+        out = np.zeros((B, cloud.shape[0], n_max) + cloud.shape[2:], dtype=np.float32)
+        out[owner, :, slot] = np.moveaxis(cloud, 1, 0)
+        return out
+    imgs = None if data[0][5] is None else np.stack([np.asarray(d[5], dtype=np.float32) for d in data])
+    batch = PaddedBatch((pack(0), pack(1), pack(2), counts.astype(np.int32),
+                         np.asarray([d[4] for d in data], dtype=np.float32), imgs))
+    batch.offsets = offsets
+    return batch
 
 
 class DeviceAdam(object):

@@ -98,7 +98,9 @@ int drp_distance_transform(drp_ctx* ctx, const uint8_t* src, int h, int w, int m
 int drp_set_goal_image(drp_ctx* ctx, const float* obs_goal, int h, int w, int mode, int max_goal_pts,
                        int fps_init, float* field_out, float* goal_coor_out, int* m_out);
 
-/* ---- single operations on host buffers (unit parity with the reference) -------- */
+/* ---- single operations on host buffers (unit parity with the reference) --------
+ * These stage their inputs in the buffers the drp_mpc_* / drp_gd_* sessions keep their state in: calling one of
+ * them ends a running session (its next call returns DRP_ESTATE; begin again). */
 /* PlannerGD.gen_s_delta (planners.py:211-257). s_cur [B,N,3], action [B,4] -> [B,N,3] */
 int drp_gen_s_delta(drp_ctx* ctx, const float* s_cur, const float* action, int B, int N,
                     float* s_delta_out);
@@ -147,11 +149,17 @@ typedef struct drp_mpc_params {
     float act_hi[4];
     uint64_t seed;        /* Philox key */
     uint64_t sample_offset; /* first global sample index of this rank (Philox counter) */
+    int noise_type;       /* DRP_NOISE_*: the sampler's noise_type argument (planners.py:75,116-135,169-175) */
+    int reserved;         /* 0 */
 } drp_mpc_params;
+#define DRP_NOISE_NORMAL 0      /* N(0, sigma)                                                  */
+#define DRP_NOISE_UNIFORM 1     /* U(-sigma, sigma); the caller passes sigma = 2 global_scale / 12 */
+#define DRP_NOISE_TOTAL_RAND 2  /* no residual: every push drawn uniformly from the clip box   */
 
 int drp_mpc_begin(drp_ctx* ctx, const drp_mpc_params* p, const float* s0, const float* attr,
                   const float* dens, const double* nominal /* [H,4] */);
-/* noise: NULL -> device Philox normals; else host [B,H,4] standard-normal draws. */
+/* noise: NULL -> device Philox draws; else host [n_sample,H,4] draws: standard normal (DRP_NOISE_NORMAL),
+ * U(-1,1) (DRP_NOISE_UNIFORM) or U[0,1) (DRP_NOISE_TOTAL_RAND). */
 int drp_mpc_sample(drp_ctx* ctx, const float* noise, uint64_t iteration);
 int drp_mpc_set_actions(drp_ctx* ctx, const float* actions /* [B,H,4] */);
 int drp_mpc_rollout(drp_ctx* ctx, int reward_all_steps);
@@ -169,8 +177,10 @@ int drp_mpc_update_device(drp_ctx* ctx);
  * drp_mpc_elite: this rank's k best as records [reward, global sample index, act[4H]] (2 + 4H doubles each, best
  * first; reward = -inf and index = -1 pad a rank with fewer than k samples).
  * drp_mpc_update_elite: combine n_ranks x k records (host transport) into the nominal sequence.
- * drp_mpc_update_elite_device: statistics as drp_mpc_update_device, then local elite -> RCCL all-gather when a
- * communicator is attached -> combine, no host hop.  1 <= k <= 1024, up to 9 000 samples per rank. */
+ * drp_mpc_update_elite_device: the rank's statistics record (as drp_mpc_update_device) and its k elite records
+ * travel as ONE message, [6 + 4H | k (2 + 4H)] doubles, in ONE RCCL all-gather per iteration when a communicator is
+ * attached, and both combines read the gathered messages in place; no host hop.  1 <= k <= 1024, up to 9 000
+ * samples per rank. */
 int drp_mpc_elite(drp_ctx* ctx, int k, double* out /* [k][2+4H], nullable */);
 int drp_mpc_update_elite(drp_ctx* ctx, const double* records, int n_ranks, int k, double* nominal_out /* [H][4], nullable */);
 int drp_mpc_update_elite_device(drp_ctx* ctx, int k);
@@ -269,6 +279,11 @@ int drp_gd_get(drp_ctx* ctx, float* actions_out);
 int drp_comm_unique_id(char* id128);                       /* ncclGetUniqueId */
 int drp_comm_init(drp_ctx* ctx, const char* id128, int rank, int n_ranks);
 int drp_comm_destroy(drp_ctx* ctx);
+/* All-gather of one host buffer per rank over the context's communicator (upload, ncclAllGather, download):
+ * recv [n_ranks][bytes] in rank order.  Without a communicator (or one rank) it copies send to recv.  The planner
+ * mirror uses it for its per-iteration bookkeeping record (per-column best reward / index / pushes,
+ * planners.py:721-727) when the sample axis is sharded; the update itself stays on the device. */
+int drp_comm_allgather(drp_ctx* ctx, const void* send, size_t bytes, void* recv);
 
 /* ---- measurement / debugging ----------------------------------------------------- */
 /* HIP-event timing of one kernel class on the context's stream.  name: "graph",

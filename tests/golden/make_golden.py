@@ -362,6 +362,93 @@ def main():
         gr[name + '/grad_act'] = a_t.grad.numpy()
     np.savez_compressed(os.path.join(HERE, 'grad.npz'), **gr)
 
+    # ---- the GD planner with a BINDING time budget (a14, a15; planners.py:590,679-682) -------------
+    # N = 40 -> particle_num_to_iter_time = 15 ms; time_lim = 50 ms -> int(50 / 15) = 3 of the 10 allowed
+    # iterations; gd_loop = 2 only sizes rew_mean / rew_std ([1, 20], planners.py:647-648)
+    tl = {}
+    N, nb, traj = 40, 3, 10
+    s, dens, attr = syn.make_pile(N, n_batch=nb, seed=33)
+    act_seq = np.stack([syn.nominal_pushes(1, seed=300 + i)[0] for i in range(traj)])[None]  # [1,traj,4]
+    np.random.seed(0)
+    res = planner.trajectory_optimization_ptcl_multi_traj(
+        s, dens, attr, obs_goal, model, act_seq, np.zeros(1), n_sample=traj, n_look_ahead=1,
+        n_update_iter=10, action_lower_lim=lo, action_upper_lim=hi, use_gpu=False, gd_loop=2, time_lim=50.0)
+    tl['s_cur'], tl['dens'], tl['attr'], tl['act_seq'] = s, dens, attr, act_seq
+    tl['n_update_iter'], tl['gd_loop'], tl['time_lim'] = np.array(10), np.array(2), np.array(50.0)
+    for k in ('action_sequence', 'action_full', 'reward_full', 'observation_sequence',
+              'reward', 'next_r', 'rew_mean', 'rew_std'):
+        tl['out/' + k] = np.asarray(res[k])
+    tl['out/iter_num'] = np.array(res['iter_num'])
+    tl['iter_time_model'] = np.array([[n, ref_planners.particle_num_to_iter_time(n)] for n in (2, 20, 40, 50, 100, 300)])
+    np.savez_compressed(os.path.join(HERE, 'gd_planner_tl.npz'), **tl)
+
+    # ---- stress cases for the split arithmetic (other weights, scales, attributes, densities) ------
+    # Everything above uses seed-0 default init, attr = 0, activations O(1).  Here: a second seed; weights
+    # scaled so the hidden activations of both encoders reach 1e2..1e3 (the fp16 pieces of the split relation
+    # encoder end at 65 504); weights scaled DOWN (activations ~1e-2: fp16 subnormal residuals); per-particle
+    # attributes in {0, 1}; densities at both ends of the training range [15, 6500]
+    # (dataset/dataset_gnn_dyn.py:79-84).  One predict_one_step and one 3-step rollout per case.
+    st = {}
+
+    def scaled_model(seed, enc_scale):
+        """enc_scale > 1: the first layer of both encoders scaled up (everything downstream follows);
+        enc_scale < 1: EVERY encoder layer scaled down (weights and biases), so the hidden activations shrink
+        layer by layer.  The predictor's last layer is rescaled to keep the displacement the size of a push's."""
+        m = make_model(torch, PropNetDiffDenModel, config, seed=seed)
+        with torch.no_grad():
+            if enc_scale >= 1.0:
+                layers = [m.model.relation_encoder.model[0], m.model.particle_encoder.model[0]]
+                out_scale = enc_scale
+            else:
+                layers = [m.model.relation_encoder.model[i] for i in (0, 2, 4)] + \
+                         [m.model.particle_encoder.model[i] for i in (0, 2)]
+                out_scale = 1.0          # the propagators' own biases dominate the effects then
+            for lin in layers:
+                lin.weight.mul_(enc_scale)
+                lin.bias.mul_(enc_scale)
+            m.model.particle_predictor.linear_1.weight.div_(out_scale)
+            m.model.particle_predictor.linear_1.bias.div_(out_scale)
+        return m
+
+    stress = [('seed1', 1, 1.0, 'zero', 'mid'), ('big', 0, 300.0, 'zero', 'mid'), ('huge', 2, 3000.0, 'zero', 'mid'),
+              ('small', 0, 0.2, 'zero', 'mid'), ('attr', 1, 1.0, 'random', 'mid'), ('attr_big', 0, 300.0, 'random', 'mid'),
+              ('dens_lo', 1, 1.0, 'zero', 'lo'), ('dens_hi', 1, 1.0, 'zero', 'hi'), ('dens_hi_big', 2, 300.0, 'random', 'hi')]
+    for name, wseed, enc_scale, attr_kind, dens_kind in stress:
+        m = scaled_model(wseed, enc_scale)
+        cap_s = Capture(m)
+        for k, v in state_dict_arrays(m).items():
+            st[name + '/' + k] = v
+        N, B = 96, 3
+        s, dens, attr = syn.make_pile(N, n_batch=B, seed=51)
+        rng = np.random.default_rng(17)
+        if attr_kind == 'random':
+            attr = (rng.random(attr.shape) < 0.5).astype(np.float32)
+            attr[2] = 1.0                        # one sample with uniform non-zero attributes
+        if dens_kind == 'lo':
+            dens = np.array([15.0, 40.0, 100.0], np.float32)
+        elif dens_kind == 'hi':
+            dens = np.array([6500.0, 5000.0, 3000.0], np.float32)
+        planner.particle_num = N
+        acts = np.array([[-3.5, 0.3, 2.5, -0.2], [0.2, -3.8, -0.1, 3.0], [-3.0, -3.0, 3.0, 3.0]], np.float32)
+        s_t = torch.from_numpy(s)
+        with torch.no_grad():
+            s_delta = planner.gen_s_delta(s_t, torch.from_numpy(acts))
+            s_pred = m.predict_one_step(torch.from_numpy(attr), s_t, s_delta, torch.from_numpy(dens))
+        st[name + '/s_cur'], st[name + '/s_delta'], st[name + '/attr'], st[name + '/dens'] = s, s_delta.numpy(), attr, dens
+        st[name + '/s_pred'] = s_pred.numpy()
+        st[name + '/max_relation_hidden'] = np.array(max(float(t.abs().max()) for t in cap_s.rec['relation_encoder']))
+        st[name + '/max_particle_effect'] = np.array(max(float(t.abs().max()) for t in cap_s.rec['particle_propagator']))
+        st[name + '/max_relation_effect'] = np.array(max(float(t.abs().max()) for t in cap_s.rec['relation_propagator']))
+        # 3-step rollout, 2 samples per column
+        acts_ro = np.stack([np.roll(acts, i, axis=0) for i in range(3)], 1)          # [3 rows, H=3, 4]
+        acts_ro = np.concatenate([acts_ro, acts_ro[::-1] * 0.9], 0).astype(np.float32)   # [6, 3, 4], row = sample*3 + column
+        with torch.no_grad():
+            out = planner.ptcl_model_rollout(s_t, torch.from_numpy(dens), torch.from_numpy(attr), m, torch.from_numpy(acts_ro))
+        st[name + '/act_seqs'] = acts_ro
+        st[name + '/state_pred'] = out['model_rollout']['state_pred'].numpy()
+        cap_s.close()
+    np.savez_compressed(os.path.join(HERE, 'stress.npz'), **st)
+
     cap.close()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):

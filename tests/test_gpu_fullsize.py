@@ -24,20 +24,28 @@ def ctx():
     eng.close()
 
 
-def oracle_steps(ctx, s0, dens, attr, acts, dev_states, rows, max_bad=0):
-    """Teacher-forced check of chosen samples: every step starts from the DEVICE's previous
-    state, so one flipped edge cannot cascade; returns the worst displacement-relative error."""
+def oracle_steps(ctx, s0, dens, attr, acts, dev_states, rows, steps=None):
+    """Teacher-forced check of the chosen samples (batched through the oracle): every step starts from
+    the DEVICE's previous state, so one flipped edge cannot cascade; returns the worst
+    displacement-relative error over samples and steps."""
+    rows = np.asarray(rows)
+    nr = len(rows)
+    prev = np.repeat(s0[:1], nr, 0)
+    at, de = np.repeat(attr[:1], nr, 0), np.repeat(dens[:1], nr)
     worst = 0.0
-    for b in rows:
-        prev = s0[0]
-        for t in range(acts.shape[1]):
-            sd = osp.gen_s_delta(prev[None], acts[b:b + 1, t], ctx.M34, 24.0)
-            ref = osp.predict_one_step(ctx.W, attr[:1], prev[None], sd, dens[:1])[0]
-            out = dev_states[b, t]
-            err = np.abs(out - ref).max() / max(np.abs(ref - prev).max(), 1e-12)
-            worst = max(worst, err)
-            prev = out
+    for t in range(acts.shape[1] if steps is None else steps):
+        sd = osp.gen_s_delta(prev, acts[rows, t], ctx.M34, 24.0)
+        ref = osp.predict_one_step(ctx.W, at, prev, sd, de)
+        out = dev_states[rows, t]
+        err = np.abs(out - ref).reshape(nr, -1).max(1) / np.maximum(np.abs(ref - prev).reshape(nr, -1).max(1), 1e-12)
+        worst = max(worst, float(err.max()))
+        prev = out
     return worst
+
+
+def spread(ns, k=32):
+    """k sample rows spread over the batch, first and last included."""
+    return np.unique(np.linspace(0, ns - 1, k).astype(int))
 
 
 def test_config2_engines_agree_and_samples_are_independent(ctx):
@@ -63,7 +71,7 @@ def test_config2_engines_agree_and_samples_are_independent(ctx):
     again, _ = ctx.rollout(s0, attr, dens, acts)
     np.testing.assert_array_equal(again, out['fused'])
     # oracle spot check, teacher-forced
-    assert oracle_steps(ctx, s0, dens, attr, acts, out['fused'], rows=[0, 511, 1023]) < 1e-4
+    assert oracle_steps(ctx, s0, dens, attr, acts, out['fused'], rows=spread(ns)) < 1e-4
 
 
 @pytest.mark.parametrize('N', [50, 150, 300, 600])
@@ -76,7 +84,7 @@ def test_dynamic_resolution_sweep(ctx, N):
     acts = syn.sample_pushes(ns, H, seed=N)
     st, _ = ctx.rollout(s0, attr, dens, acts)
     assert st.shape == (ns, H, N, 3) and np.isfinite(st).all()
-    assert oracle_steps(ctx, s0, dens, attr, acts, st, rows=[1, 777]) < 1e-4
+    assert oracle_steps(ctx, s0, dens, attr, acts, st, rows=spread(ns)) < 1e-4
     idx = ctx.debug_fetch('nbr_idx', (ns, N, 10), np.int16)
     cnt = ctx.debug_fetch('nbr_cnt', (ns, N), np.uint8)
     assert cnt.min() >= 1 and cnt.max() <= 10          # every particle keeps its self loop
@@ -101,7 +109,7 @@ def test_config5_dense_pile(ctx):
     ctx.set_goal(G, gc)
     st, rew = ctx.rollout(s0, attr, dens, acts, want_states=True, want_reward=True)
     assert np.isfinite(st).all() and np.isfinite(rew).all()
-    assert oracle_steps(ctx, s0, dens, attr, acts[:, :3], st, rows=[7]) < 1e-4
+    assert oracle_steps(ctx, s0, dens, attr, acts, st, rows=spread(ns), steps=4) < 1e-4
     ref_r = osp.reward(st[[0, 300], -1], G, syn.demo_cam_params(), gc)
     np.testing.assert_allclose(rew[[0, 300], -1], ref_r, rtol=2e-5)
     sub, _ = ctx.rollout(s0, attr, dens, acts[:8])
@@ -162,28 +170,48 @@ def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch):
     assert not np.array_equal(res[False, 'uniform'], res[False, 'mixed'])
 
 
-def test_sixteen_item_tiles_agree(monkeypatch):
-    """DRP_TILE16=1: the experimental propagation kernel on 16-receiver tiles (three waves per SIMD,
-    km_prop3_t16) against the default 32-receiver tiles -- the same arithmetic per item in another summation
-    order: agreement to a few ulp of the positions on the first step."""
-    from dyn_res_pile_manip_amd.engine import Engine
-    blob = weights.blob_from_state_dict(weights.random_state_dict(seed=0))
-    M34 = world2cam_affine(syn.demo_cam_extrinsics())
-    for N, ns, H in ((300, 512, 2), (70, 700, 2)):
-        s0, dens, attr = syn.make_pile(N, 1, seed=1)
-        acts = syn.sample_pushes(ns, H, seed=1)
-        res = {}
-        for t16 in (False, True):
-            if t16:
-                monkeypatch.setenv('DRP_TILE16', '1')
-            else:
-                monkeypatch.delenv('DRP_TILE16', raising=False)
-            eng = Engine(0)
-            eng.load_weights(blob, 0.08)
-            eng.set_camera(M34, 24.0, syn.demo_cam_params())
-            res[t16], _ = eng.rollout(s0, attr, dens, acts)
-            eng.close()
-        disp = np.abs(res[False][:, 0] - s0).max()
-        assert np.isfinite(res[True]).all()
-        assert np.abs(res[False][:, 0] - res[True][:, 0]).max() < 1e-4 * disp
-        assert np.median(np.abs(res[False] - res[True]).reshape(ns, -1).max(1)) < 5e-7
+def test_config3_eight_logical_shards_equal_one_batch(ctx):
+    """BASELINE configs[2] at full size on one GPU: 8192 samples x 300 particles x 10 steps as 8 logical ranks of
+    1024 samples (sample_offset = 1024 r, the Philox stream keyed by the GLOBAL sample index) against ONE
+    8192-sample batch.  Sampled pushes and rewards of every shard are the corresponding rows of the big batch
+    bit for bit; the 8 records, combined by the update kernel (softmax form) and by the elite kernel, give the
+    big batch's nominal sequence (float64 sums in another order: 1e-12)."""
+    from dyn_res_pile_manip_amd import sharding
+    N, ns, H, R = 300, 1024, 10, 8
+    ctx.set_engine(_lib.ENGINE_FUSED)
+    s0, dens, attr = syn.make_pile(N, 1, seed=0)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    ctx.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+    lo, hi = syn.action_limits()
+    nominal = syn.nominal_pushes(H, seed=0)
+    kw = dict(sigma=0.6, beta_filter=0.7, reward_weight=0.1, act_lo=lo, act_hi=hi, seed=2024)
+    k = 64
+    ctx.mpc_begin(s0, attr, dens, nominal, n_sample=ns * R, **kw)
+    ctx.mpc_sample(1)
+    ctx.mpc_rollout(False)
+    big = ctx.mpc_get(actions=True, rewards=True)
+    big_rec = ctx.mpc_partials()
+    want = ctx.mpc_update(big_rec)
+    want_elite = ctx.mpc_update_elite(ctx.mpc_elite(k), k)
+    assert np.isfinite(big['rewards']).all()
+    recs, erecs = [], []
+    for r in range(R):
+        ctx.mpc_begin(s0, attr, dens, nominal, n_sample=ns, sample_offset=ns * r, **kw)
+        ctx.mpc_sample(1)
+        ctx.mpc_rollout(False)
+        got = ctx.mpc_get(actions=True, rewards=True)
+        np.testing.assert_array_equal(got['actions'], big['actions'][ns * r:ns * (r + 1)])
+        np.testing.assert_array_equal(got['rewards'], big['rewards'][ns * r:ns * (r + 1)])
+        recs.append(ctx.mpc_partials())
+        erecs.append(ctx.mpc_elite(k))
+        host = sharding.make_record(0.1, got['rewards'], got['actions'], ns * r)
+        np.testing.assert_allclose(recs[-1], host, rtol=1e-9, atol=1e-9)
+    recs, erecs = np.stack(recs), np.stack(erecs)
+    np.testing.assert_allclose(ctx.mpc_update(recs), want, rtol=1e-12, atol=1e-12)
+    stats = ctx.mpc_stats()
+    assert stats['argmax'] == int(np.argmax(big['rewards']))
+    np.testing.assert_allclose(stats['mean'], big['rewards'].astype(np.float64).mean(), rtol=1e-10)
+    host_nominal, _ = sharding.combine_records(recs, ns * R)
+    np.testing.assert_allclose(host_nominal, want, rtol=1e-12, atol=1e-12)
+    # elite form: the k best of 8 x k records are the k best of the whole batch, summed in the same (rank) order
+    np.testing.assert_array_equal(ctx.mpc_update_elite(erecs, k), want_elite)

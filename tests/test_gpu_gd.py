@@ -73,6 +73,49 @@ def test_adam_iterations_and_planner_dict_match_the_reference(golden):
     assert res['iter_num'] == int(g['out/iter_num'])
 
 
+def test_binding_time_limit_gives_the_reference_iteration_count(golden):
+    """Rows a14 / a15: with time_lim = 50 ms and N = 40 (15 ms per iteration in the reference's model,
+    planners.py:25-28) the reference runs int(50 / 15) = 3 of the 10 allowed iterations (planners.py:679-682);
+    gd_loop = 2 only sizes rew_mean / rew_std.  Same iteration count, same Adam trajectory, same dict."""
+    config = syn.default_config()
+    config['mpc']['mpc_type'] = 'GD'
+    env = syn.SyntheticEnv(config)
+    model = PropNetDiffDenModel(config, True)
+    model.load_state_dict({k[2:]: torch.from_numpy(golden.weights_seed0[k]) for k in golden.weights_seed0.files
+                           if k.startswith('w/')}, strict=False)
+    planner = PlannerGD(config, env)
+    g = golden.gd_planner_tl
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    res = planner.trajectory_optimization_ptcl_multi_traj(
+        g['s_cur'], g['dens'], g['attr'], obs_goal, model, g['act_seq'], np.zeros(1), n_sample=10, n_look_ahead=1,
+        n_update_iter=int(g['n_update_iter']), action_lower_lim=lo, action_upper_lim=hi, use_gpu=True,
+        gd_loop=int(g['gd_loop']), time_lim=float(g['time_lim']))
+    assert res['iter_num'] == int(g['out/iter_num']) == 2
+    assert res['rew_mean'].shape == g['out/rew_mean'].shape == (1, 20)
+    np.testing.assert_allclose(res['rew_mean'], g['out/rew_mean'], rtol=1e-4)
+    np.testing.assert_allclose(res['rew_std'], g['out/rew_std'], rtol=2e-3)
+    np.testing.assert_allclose(res['action_full'], g['out/action_full'], atol=2e-3)
+    np.testing.assert_allclose(res['reward_full'], g['out/reward_full'], rtol=1e-4)
+    np.testing.assert_allclose(res['action_sequence'], g['out/action_sequence'], atol=2e-3)
+    np.testing.assert_allclose(res['observation_sequence'], g['out/observation_sequence'], atol=5e-6)
+    np.testing.assert_allclose(res['reward'], g['out/reward'], rtol=1e-4)
+    np.testing.assert_allclose(res['next_r'], g['out/next_r'], rtol=1e-4)
+    # the wall clock plays no part: a second call gives the same bits
+    res2 = planner.trajectory_optimization_ptcl_multi_traj(
+        g['s_cur'], g['dens'], g['attr'], obs_goal, model, g['act_seq'], np.zeros(1), n_sample=10, n_look_ahead=1,
+        n_update_iter=int(g['n_update_iter']), action_lower_lim=lo, action_upper_lim=hi, use_gpu=True,
+        gd_loop=int(g['gd_loop']), time_lim=float(g['time_lim']))
+    np.testing.assert_array_equal(res['action_full'], res2['action_full'])
+    assert res2['iter_num'] == 2
+    # a budget below one iteration: the reference fails at its return statement; here a clear error
+    with pytest.raises(ValueError):
+        planner.trajectory_optimization_ptcl_multi_traj(
+            g['s_cur'], g['dens'], g['attr'], obs_goal, model, g['act_seq'], np.zeros(1), n_sample=10, n_look_ahead=1,
+            n_update_iter=10, action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=10.0)
+    model.engine.close()
+
+
 def test_gradients_are_reproducible_and_both_list_paths_agree(ctx, golden, monkeypatch):
     """No atomics in the backward pass: two evaluations give bit-identical gradients, and the
     reversed neighbour lists built in LDS or in global memory (samples beyond 3072 particles,

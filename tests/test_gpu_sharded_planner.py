@@ -1,0 +1,66 @@
+"""GPU: the planner's comm= argument (sample axis sharded over ranks).
+
+One MI355X is what a test box has, so: (1) a one-rank RCCL communicator through the device transport
+(RcclComm, ncclAllGather forced even for one rank) must reproduce the un-sharded call bit for bit; (2) two
+PROCESSES sharing GPU 0, exchanging over gloo (TorchComm: records fetched, all-gathered on the host, uploaded
+to the combine kernel), must both return the un-sharded result: same pushes, same predicted observation --
+the Philox stream is keyed by the GLOBAL sample index, so the shards draw exactly the un-sharded samples."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+@pytest.mark.parametrize('mpc_type', ['MPPI', 'CEM', 'GD'])
+def test_one_rank_rccl_communicator_equals_no_communicator(mpc_type, monkeypatch):
+    import _shard_worker as w
+    from dyn_res_pile_manip_amd.engine import Engine
+    from dyn_res_pile_manip_amd.sharding import RcclComm
+    ref = w.run_planner(mpc_type, None)
+    monkeypatch.setenv('DRP_COMM_ALWAYS', '1')         # one rank still goes through ncclAllGather
+    probe = Engine(0)
+    uid = probe.comm_unique_id()
+    probe.close()
+    got = w.run_planner(mpc_type, RcclComm(uid, 0, 1))
+    got_t = w.run_planner(mpc_type, (0, 1, uid))        # the documented tuple form
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+        np.testing.assert_array_equal(got_t[k], ref[k], err_msg=k)
+
+
+@pytest.mark.parametrize('mpc_type', ['MPPI', 'CEM', 'GD'])
+def test_two_processes_sharing_the_gpu_equal_one(mpc_type, tmp_path):
+    import _shard_worker as w
+    ref = w.run_planner(mpc_type, None)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + os.getpid() % 2000), WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, '_shard_worker.py'), str(tmp_path), mpc_type],
+                              env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+    res = [np.load(os.path.join(str(tmp_path), '%s_rank%d.npz' % (mpc_type, r))) for r in range(2)]
+    for r in res:
+        assert int(r['iter_num']) == int(ref['iter_num'])
+        if mpc_type == 'GD':
+            # independent Adam problems: a shard's trajectories are bit-identical to the same rows of the full run
+            np.testing.assert_array_equal(r['action_sequence'], ref['action_sequence'])
+            np.testing.assert_array_equal(r['observation_sequence'], ref['observation_sequence'])
+        else:
+            # the softmax / elite mean is combined from two partial sums instead of one: last-ulp differences in the
+            # nominal sequence, hence in later samples
+            np.testing.assert_allclose(r['action_sequence'], ref['action_sequence'], atol=1e-5)
+            np.testing.assert_allclose(r['observation_sequence'], ref['observation_sequence'], atol=1e-6)
+        np.testing.assert_allclose(r['reward'], ref['reward'], rtol=1e-5)
+        np.testing.assert_allclose(r['rew_mean'], ref['rew_mean'], rtol=1e-5)
+        np.testing.assert_allclose(r['rew_std'], ref['rew_std'], rtol=1e-4)
+    # both ranks return the same plan; their action_full / reward_full are the two halves of the sample axis
+    np.testing.assert_array_equal(res[0]['action_sequence'], res[1]['action_sequence'])
+    full = np.concatenate([res[0]['reward_full'], res[1]['reward_full']])
+    assert full.shape == ref['reward_full'].shape
+    np.testing.assert_allclose(full, ref['reward_full'], rtol=1e-5)

@@ -129,3 +129,35 @@ def test_tiny_and_unpadded_batches(golden):
             scale = max(np.abs(ref_grads[k]).max(), 1e-8)
             assert np.abs(np.asarray(got[k]).reshape(ref_grads[k].shape) - ref_grads[k]).max() < 5e-4 * scale + 1e-9, (nums, k)
     model.engine.close()
+
+
+def test_checkpoint_round_trip_is_a_torch_state_dict(golden, tmp_path):
+    """train/train_gnn_dyn.py:214-215,226: `torch.save(model.state_dict(), path)` must write what torch's
+    `load_state_dict` accepts -- tensors under the reference's keys and shapes -- and what this package's own
+    loader reads back bit for bit."""
+    import torch
+    model = _model(golden)
+    sd = model.state_dict()
+    blob = model.engine.get_weights()
+    model.engine.close()
+    assert list(sd.keys()) == [k for k, _ in weights.STATE_DICT_KEYS]
+    for k, shape in weights.STATE_DICT_KEYS:
+        assert isinstance(sd[k], torch.Tensor) and sd[k].dtype == torch.float32 and tuple(sd[k].shape) == shape
+    # a torch module with the reference's parameter names (model/gnn_dyn.py:127-145) takes it with strict=True
+    class _Named(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            for k, shape in weights.STATE_DICT_KEYS:
+                self.register_parameter(k.replace('.', '__'), torch.nn.Parameter(torch.zeros(shape)))
+
+        def state_dict(self, *a, **kw):
+            return {k.replace('__', '.'): v for k, v in super().state_dict(*a, **kw).items()}
+
+        def load_state_dict(self, sd_, strict=True):
+            return super().load_state_dict({k.replace('.', '__'): v for k, v in sd_.items()}, strict=strict)
+    path = str(tmp_path / 'net_best.pth')
+    torch.save(sd, path)
+    m = _Named()
+    m.load_state_dict(torch.load(path, map_location='cpu'), strict=True)
+    np.testing.assert_array_equal(weights.blob_from_state_dict(m.state_dict()), blob)
+    np.testing.assert_array_equal(weights.load_checkpoint(path), blob)

@@ -167,3 +167,59 @@ def test_training_loss_gradients_and_adam(golden, case):
         gr = g[case + '/grad/' + k]
         firm = np.abs(gr) > 1e-3 * np.abs(gr).max()
         assert np.abs(v - g[case + '/after3/' + k])[firm].max() < 1e-5, k
+
+
+# ---- stress cases (tests/golden/stress.npz): other seeds, weight scales, attributes, densities ----
+STRESS = ['seed1', 'big', 'huge', 'small', 'attr', 'attr_big', 'dens_lo', 'dens_hi', 'dens_hi_big']
+
+
+def stress_weights(g, case):
+    class _W(object):
+        files = [k[len(case) + 1:] for k in g.files if k.startswith(case + '/w/')]
+
+        def __getitem__(self, k):
+            return g[case + '/' + k]
+    return _W()
+
+
+@pytest.mark.parametrize('case', STRESS)
+def test_oracle_on_stress_cases(golden, case):
+    """The oracle stays pinned when the weights are another seed's, scaled so the hidden activations reach
+    1e2..1e3 (or shrink to 1e-2), with per-particle attributes and at both ends of the density range."""
+    g = golden.stress
+    w = stress_weights(g, case)
+    Wd, Ws = od.load_weights(w), osp.weights_np(w)
+    out = od.predict_one_step(Wd, g[case + '/attr'], g[case + '/s_cur'], g[case + '/s_delta'], g[case + '/dens']).numpy()
+    assert disp_rel(out, g[case + '/s_pred'], g[case + '/s_cur']) < 1e-5
+    out2 = osp.predict_one_step(Ws, g[case + '/attr'], g[case + '/s_cur'], g[case + '/s_delta'], g[case + '/dens'])
+    assert disp_rel(out2, g[case + '/s_pred'], g[case + '/s_cur']) < 1e-4
+    ext = syn.demo_cam_extrinsics()
+    ref = g[case + '/state_pred']
+    ro = osp.rollout(Ws, g[case + '/s_cur'], g[case + '/dens'], g[case + '/attr'], g[case + '/act_seqs'],
+                     osp.world2cam_affine(ext, 24), 24)
+    prev = np.tile(g[case + '/s_cur'], (ref.shape[0] // g[case + '/s_cur'].shape[0], 1, 1))
+    for t in range(ref.shape[1]):
+        assert disp_rel(ro[:, t], ref[:, t], prev) < 1e-3, t
+        prev = ref[:, t]
+    if case in ('big', 'huge', 'attr_big', 'dens_hi_big'):
+        assert float(g[case + '/max_particle_effect']) > 100.0
+
+
+# ---- the GD planner's iteration bound (rows a14 / a15) ------------------------------------------
+def test_iteration_time_model_and_count(golden):
+    """planners.py:25-28 and :590,679-682 against values captured from the reference."""
+    from dyn_res_pile_manip_amd import planners as P
+    g = golden.gd_planner_tl
+    for n, ms in g['iter_time_model']:
+        assert P.particle_num_to_iter_time(int(n)) == int(ms)
+    assert P.particle_num_to_iter_time(100) == 72 and P.particle_num_to_iter_time(20) == 11
+    # the fixture's run: N = 40 -> 15 ms per iteration, 50 ms budget, 10 allowed -> 3 iterations (iter_num = 2)
+    n_iter = P.gd_iteration_count(int(g['n_update_iter']), float(g['time_lim']), g['s_cur'].shape[1])
+    assert n_iter == 3 == int(g['out/iter_num']) + 1
+    assert g['out/rew_mean'].shape == (1, int(g['n_update_iter']) * int(g['gd_loop']))
+    assert (g['out/rew_mean'][0, n_iter:] == 0).all() and (g['out/rew_mean'][0, :n_iter] != 0).all()
+    # the shipped demo (config/mpc/config.yaml:40-43): 2000 ms, 200 iterations allowed, N = 100 -> 27
+    assert P.gd_iteration_count(200, 2000.0, 100) == 27
+    assert P.gd_iteration_count(200, float('inf'), 100) == 200      # the signature's default: no bound
+    assert P.gd_iteration_count(5, 1e9, 40) == 5
+    assert P.gd_iteration_count(10, 10.0, 40) == 0

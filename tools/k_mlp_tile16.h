@@ -1,3 +1,6 @@
+// ARCHIVED EXPERIMENT -- not part of the product library ("16-item tiles").  It was built as
+// csrc/k_mlp_tile16.h behind DRP_TILE16=1 in round 1: correct to 6e-8, 9.35 vs 7.5 ms for the 32-item tile.
+// Kept for the record of the measurement; to run it again include it from drp_capi.hip after k_mlp_split.h.
 // The propagation kernel on 16-item tiles: v_mfma_f32_16x16x32_{f16,bf16}, 16 accumulator registers per
 // 64-feature fragment instead of 32, so the slot loop fits 168 VGPRs and THREE waves share a SIMD (12 per
 // workgroup) where the 32-item tile of k_mlp_split.h has two.  Same arithmetic per item (3-term fp16 split on
