@@ -61,6 +61,10 @@ struct drp_ctx {
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
     float adj_thresh = 0.08f, thr = 0.0064f;
+    SplitRange re_range{};          // range shift 2^k of the split relation encoder and the bound it rests on
+    float re_scale = 1.0f, re_inv = 1.0f;
+    bool re_ok = true;
+    int re_shift_env = 0x7fffffff;  // DRP_SPLIT_SHIFT=k: fixed shift instead of the one derived from the weights
     DevBuf w_raw, w_valu, w_mfma, w_mfma_bwd, w_split, w_split6;
     DrpCam cam{};
     DevBuf goal_field, goal_coor, cself;
@@ -73,6 +77,7 @@ struct drp_ctx {
 
     // MPC state
     bool mpc_on = false;
+    float sess_attr_max = 0.0f, sess_dens_max = 0.0f;   // of the running MPC session (range check of later uploads)
     drp_mpc_params mpc{};
     DevBuf nominal, noise, partials, gathered, stats, elite, elite_all, xchg;
     int n_ranks = 1, rank = 0;
@@ -317,7 +322,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             hipLaunchKernelGGL(km_edge_encode_split, dim3(mfma_grid(c, edge_tiles)), blk, KM_EDGE_SPLIT_LDS, st,
                                ptr<uint16_t>(c->w_split), mw, a.s_prev, a.prev_mod, a.prev_stride, a.attr,
                                a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx),
-                               ptr<uint8_t>(c->nbr_cnt), N, B, ptr<float>(c->c_edge));
+                               ptr<uint8_t>(c->nbr_cnt), N, B, ptr<float>(c->c_edge), c->re_scale, c->re_inv);
         else
             hipLaunchKernelGGL(km_edge_encode, dim3(mfma_grid(c, edge_tiles)), blk, KM_EDGE_LDS, st, mw,
                                a.s_prev, a.prev_mod, a.prev_stride, a.attr, a.attr_mod, a.dens, a.dens_mod,
@@ -338,7 +343,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
 #define PROP3_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
                    a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, pb, \
                    ptr<float>(c->c_node), eff_base, N, B, spw, phase_e ? (const float*)ptr<float>(c->s_delta) : (const float*)nullptr, \
-                   a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist
+                   a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist, c->re_scale, c->re_inv
             if (!tape) hipLaunchKernelGGL((km_prop3<false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
             else hipLaunchKernelGGL((km_prop3<true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
 #undef PROP3_ARGS
@@ -354,7 +359,8 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             float* agg_out = (tape && a.agg_hist) ? a.agg_hist + (size_t)p * bn64 : nullptr;
 #define PROP_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
                   a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, \
-                  ptr<float>(c->c_node), eff_in, eff_out, N, B, pb, a.s_out, a.out_stride, a.cself, a.cself_ok, mask_out, agg_out
+                  ptr<float>(c->c_node), eff_in, eff_out, N, B, pb, a.s_out, a.out_stride, a.cself, a.cself_ok, mask_out, agg_out, \
+                  c->re_scale, c->re_inv
             if (!tape) {
                 if (!last) hipLaunchKernelGGL((km_prop<false, false>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS);
                 else hipLaunchKernelGGL((km_prop<true, false>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS);
@@ -555,6 +561,45 @@ void launch_wgrad(drp_ctx* c, const float* g, int ldg, const float* x, int ldx, 
 // DRP_ESTATE instead of results computed from overwritten inputs.
 void end_sessions(drp_ctx* c) { c->mpc_on = false; c->gd_on = false; }
 
+// The split relation encoder's range shift was proven for an envelope of inputs (drp_load_weights); a call
+// whose attributes, densities or impulses leave it is refused instead of risking a saturated fp16 piece.
+float max_abs(const float* p, size_t n) {
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const float v = fabsf(p[i]);
+        if (v > m || v != v) m = (v != v) ? INFINITY : v;
+    }
+    return m;
+}
+// largest |s_delta| a push can cause (planners.py:238-254: the impulse is at most the push's own length in the
+// camera frame): actions [n][4] = (sx, sy, ex, ey) in world units
+float push_len_bound(const drp_ctx* c, const float* actions, size_t n) {
+    float fro = 0.0f;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) fro += c->cam.m[i * 4 + j] * c->cam.m[i * 4 + j];
+    fro = sqrtf(fro);
+    float l2 = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const float dx = actions[i * 4 + 2] - actions[i * 4 + 0], dy = actions[i * 4 + 3] - actions[i * 4 + 1];
+        const float v = dx * dx + dy * dy;
+        if (v > l2 || v != v) l2 = (v != v) ? INFINITY : v;
+    }
+    return fro * sqrtf(l2) / c->cam.gs;
+}
+int range_check(drp_ctx* c, float max_attr, float max_dens, float max_sdelta) {
+    if (c->engine != DRP_ENGINE_FUSED && c->engine != DRP_ENGINE_SPLIT) return DRP_OK;
+    const double A = max_attr, dm = max_dens / DRP_DENS_SCALE, D = (double)c->adj_thresh + 2.0 * max_sdelta;
+    const SplitRange& r = c->re_range;
+    if (!c->re_ok)
+        return fail(c, DRP_ERANGE, "weights outside the range of the split-fp16 relation encoder (largest |w| %g, activation "
+                    "bound %g, shift %d): use DRP_ENGINE_MFMA", (double)r.wmax, split_range_bound(r, r.env_attr, r.env_delta, r.env_dens), r.shift);
+    if (A <= r.env_attr && dm <= r.env_dens && D <= r.env_delta) return DRP_OK;
+    const double bound = split_range_bound(r, A, D, dm);
+    if (ldexp(bound, r.shift) <= 65504.0) return DRP_OK;       // outside the envelope, still provably inside fp16
+    return fail(c, DRP_ERANGE, "inputs beyond the range the split-fp16 relation encoder is scaled for (max |attr| %g, "
+                "density %g, |s_delta| %g; activation bound %g x 2^%d): use DRP_ENGINE_MFMA for this call",
+                A, (double)max_dens, (double)max_sdelta, bound, r.shift);
+}
+
 int check_bn(drp_ctx* c, int B, int N) {
     if (B <= 0 || N <= 0 || N > 4096) return fail(c, DRP_EINVAL, "bad shape B=%d N=%d (N <= 4096)", B, N);
     return DRP_OK;
@@ -590,6 +635,7 @@ int drp_create(int device, drp_ctx** out) {
     c->graph_strips = getenv("DRP_NO_GRAPH_STRIPS") == nullptr;
     c->prop3e = getenv("DRP_NO_PROP3E") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
+    if (const char* e = getenv("DRP_SPLIT_SHIFT")) c->re_shift_env = atoi(e);
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -696,8 +742,19 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
         pack_mfma_bwd(blob, mbv);
         CHK(h2d(c, c->w_mfma_bwd, mbv.data(), mbv.size() * sizeof(float)));
         HIPCHK(c, hipStreamSynchronize(c->stream));     // mbv is about to go out of scope... kept alive until here
+        // range shift of the split relation encoder: proven for |attr| <= 2 (the reference's are 0), |s_r - s_s| <= 1.5
+        // per coordinate (radius 0.08 + two impulses of at most the workspace diagonal, 0.59 camera-frame units),
+        // density <= 10 000 (training range: 15 .. 6 500); calls beyond are re-checked one by one (range_check)
+        split_range_init(blob, c->re_range, 2.0, 1.5, 2.0);
+        if (c->re_shift_env != 0x7fffffff) c->re_range.shift = c->re_shift_env;
+        // weights no shift can carry (a matrix entry beyond fp16, NaN): the split engines refuse every call
+        // (range_check); the fp32 engines are unaffected
+        c->re_ok = c->re_range.wmax < 6.0e4f &&
+                   ldexp(split_range_bound(c->re_range, 2.0, 1.5, 2.0), c->re_range.shift) <= 65504.0;
+        c->re_scale = ldexpf(1.0f, c->re_range.shift);
+        c->re_inv = ldexpf(1.0f, -c->re_range.shift);
         std::vector<uint16_t> sp;
-        pack_split(blob, sp);
+        pack_split(blob, sp, c->re_range.shift);
         CHK(h2d(c, c->w_split, sp.data(), sp.size() * sizeof(uint16_t)));
         std::vector<uint16_t> sp6;
         pack_split6(blob, sp6);
@@ -780,6 +837,7 @@ static int step_common(drp_ctx* c, const float* a_cur, const float* s_cur, const
     if (!a_cur || !s_cur || !s_delta || !dens || !s_pred_out) return fail(c, DRP_EINVAL, "null buffer");
     HIPCHK(c, hipSetDevice(c->device));
     end_sessions(c);
+    CHK(range_check(c, max_abs(a_cur, (size_t)B * N), max_abs(dens, (size_t)B), max_abs(s_delta, (size_t)B * N * 3)));
     CHK(ensure_step_ws(c, B, N));
     const size_t bn = (size_t)B * N;
     CHK(h2d(c, c->s_in, s_cur, bn * 3 * sizeof(float)));
@@ -825,6 +883,7 @@ int drp_rollout(drp_ctx* c, const float* s0, const float* attr, const float* den
         return fail(c, DRP_EINVAL, "bad rollout shape nb=%d B=%d H=%d (B must be a multiple of nb)", nb, B, H);
     HIPCHK(c, hipSetDevice(c->device));
     end_sessions(c);
+    CHK(range_check(c, max_abs(attr, (size_t)nb * N), max_abs(dens, (size_t)nb), push_len_bound(c, actions, (size_t)B * H)));
     CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
     CHK(h2d(c, c->attr, attr, (size_t)nb * N * sizeof(float)));
     CHK(h2d(c, c->dens, dens, (size_t)nb * sizeof(float)));
@@ -859,6 +918,14 @@ int drp_mpc_begin(drp_ctx* c, const drp_mpc_params* p, const float* s0, const fl
     const int nb = p->n_batch, N = p->n_particles, H = p->n_look_ahead, B = p->n_sample * nb;
     CHK(check_bn(c, B, N));
     HIPCHK(c, hipSetDevice(c->device));
+    {
+        // sampled pushes stay inside the clip box: its two longest diagonals bound every impulse
+        const float box[8] = {p->act_lo[0], p->act_lo[1], p->act_hi[2], p->act_hi[3],
+                              p->act_hi[0], p->act_hi[1], p->act_lo[2], p->act_lo[3]};
+        c->sess_attr_max = max_abs(attr, (size_t)nb * N);
+        c->sess_dens_max = max_abs(dens, (size_t)nb);
+        CHK(range_check(c, c->sess_attr_max, c->sess_dens_max, push_len_bound(c, box, 2)));
+    }
     c->mpc = *p;
     CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
     CHK(h2d(c, c->attr, attr, (size_t)nb * N * sizeof(float)));
@@ -902,6 +969,8 @@ int drp_mpc_set_actions(drp_ctx* c, const float* actions) {
     HIPCHK(c, hipSetDevice(c->device));
     if (!actions) return fail(c, DRP_EINVAL, "null actions");
     const drp_mpc_params& p = c->mpc;
+    CHK(range_check(c, c->sess_attr_max, c->sess_dens_max,
+                    push_len_bound(c, actions, (size_t)p.n_sample * p.n_batch * p.n_look_ahead)));
     CHK(h2d(c, c->actions, actions, (size_t)p.n_sample * p.n_batch * p.n_look_ahead * 4 * sizeof(float)));
     return DRP_OK;
 }
@@ -1586,6 +1655,12 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     if (H < 1 || H > 64) return fail(c, DRP_EINVAL, "bad horizon H=%d", H);
     if (nb <= 0 || B % nb != 0) return fail(c, DRP_EINVAL, "B must be a multiple of n_batch");
     HIPCHK(c, hipSetDevice(c->device));
+    {
+        // Adam moves the pushes, the clip keeps them in the box: bound by the box's diagonals and by the initial pushes
+        const float box[8] = {act_lo[0], act_lo[1], act_hi[2], act_hi[3], act_hi[0], act_hi[1], act_lo[2], act_lo[3]};
+        CHK(range_check(c, max_abs(attr, (size_t)nb * N), max_abs(dens, (size_t)nb),
+                        fmaxf(push_len_bound(c, box, 2), push_len_bound(c, actions, (size_t)B * H))));
+    }
     const size_t bn = (size_t)B * N;
     CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
     CHK(h2d(c, c->attr, attr, (size_t)nb * N * sizeof(float)));
@@ -1911,6 +1986,11 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
             return fail(c, DRP_EINVAL, "particle_nums[%d]=%d outside 1..%d", b, particle_nums[b], N);
     HIPCHK(c, hipSetDevice(c->device));
     end_sessions(c);
+    {
+        float amax = 0.0f;                                    // a_cur = attrs[:, 0]
+        for (int b = 0; b < B; ++b) amax = fmaxf(amax, max_abs(attrs + (size_t)b * (c->tr_nroll + 1) * N, (size_t)N));
+        CHK(range_check(c, amax, max_abs(particle_dens, (size_t)B), max_abs(states_delta, (size_t)B * c->tr_nroll * N * 3)));
+    }
     const int H = c->tr_nroll;
     const size_t bn = (size_t)B * N, bn64 = bn * 64, bnk = bn * DRP_K;
     const bool backward = mode != DRP_TRAIN_EVAL;

@@ -10,9 +10,19 @@
 // two values per instruction), the residual x - x_hi is exact in fp32 and is itself rounded to
 // fp16, so |x - x_hi - x_lo| < 2^-20 |x|; the dropped W_lo x_lo term is < 2^-21 relative.  The
 // residuals are fp16 SUBNORMALS for |x| < 0.06: the matrix cores honour them (checked operand by
-// operand, tools/f16_denorm_test.hip).  fp16 tops out at 65 504: activations of this network are
-// O(1); beyond that x_hi saturates (round toward zero never produces inf) and the result is wrong
-// but finite.  3 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles: 5.3x less matrix-pipe time.
+// operand, tools/f16_denorm_test.hip).  3 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles: 5.3x less
+// matrix-pipe time.
+//
+// RANGE.  fp16 tops out at 65 504 (x_hi would saturate: round toward zero never produces inf -- a wrong but
+// finite result) and loses the residual's bits below 6e-5.  The hidden activations are therefore carried
+// through the chain multiplied by an exact power of two, 2^k, chosen on the host from the weights
+// (split_range_shift below: the largest k that keeps a proven bound of every hidden activation under 2^15):
+//     W1' = 2^k W1, b1' = 2^k b1, b2' = 2^k b2, b3' = 2^k b3   (host, exact)      h_l' = 2^k h_l
+//     c   = 2^-k (2^k (b + d w_d + P_r) + W_e h3')                                  (one fma where an add was)
+// ReLU is positively homogeneous and scaling by 2^k commutes with every fp32 rounding, so the result is the
+// unscaled chain's bit for bit wherever that one neither saturates nor touches subnormals, and correct
+// beyond: weights 1e7 times larger than a trained network's still give the fp32 engines' answer.  A call
+// whose inputs exceed the envelope the bound was proven for is refused with DRP_ERANGE (drp_capi.hip).
 // (The first version split into bf16 pairs: same MFMA count, but v_cvt_pk_bf16_f32 issues at about a
 // third of the rate of v_cvt_pkrtz_f16_f32 -- tools/mfma_bench.hip -- and carries 3 bits less.)
 // The node layers (6-term split further down) stay on three bf16 pieces.
@@ -38,8 +48,53 @@ enum {
     S_RE2 = S_RE0 + 256,
     S_RE4 = S_RE2 + 1024,
     S_RPE = S_RE4 + 1024,
-    S_TOTAL = S_RPE + 1024     // x 16 bytes
+    S_TOTAL = S_RPE + 1024,    // x 16 bytes
+    S_ROWS = S_TOTAL,          // then 256 floats: 2^k b2, 2^k b4, b_rp, wd_rp (the chain's bias rows, scaled)
+    S_ALLOC = S_ROWS + 64      // units in the device buffer
 };
+
+// ---- range of the split relation encoder (host) ------------------------------------------------
+// Bound of the hidden activations for inputs |attr| <= A, |s_r - s_s| <= D per coordinate, d <= dm:
+//   h1 <= max_o (|w_o0| + |w_o1|) A + (|w_o2| + |w_o3| + |w_o4|) D + |w_o5| dm + |b_o|,
+//   h_{l+1} <= max_o sum_k |W_l[o,k]| h_l + |b_l[o]|.
+struct SplitRange {
+    float a1[64], d1[64], m1[64], b1[64];     // first layer: row coefficients of A, D, dm, |bias|
+    float rs2[64], b2[64], rs4[64], b4[64];   // row abs sums and |bias| of the two hidden layers
+    float wmax;                               // largest |weight| of the unscaled matrices packed as fp16
+    int shift;                                // k
+    float env_attr, env_delta, env_dens;      // the envelope k was chosen for
+};
+inline double split_range_bound(const SplitRange& r, double A, double D, double dm) {
+    double h1 = 0, h2 = 0, h3 = 0;
+    for (int o = 0; o < 64; ++o) h1 = fmax(h1, r.a1[o] * A + r.d1[o] * D + r.m1[o] * dm + r.b1[o]);
+    for (int o = 0; o < 64; ++o) h2 = fmax(h2, r.rs2[o] * h1 + r.b2[o]);
+    for (int o = 0; o < 64; ++o) h3 = fmax(h3, r.rs4[o] * h2 + r.b4[o]);
+    return fmax(fmax(h1, h2), fmax(h3, 1.0));      // 1.0: the constant input column of the first layer
+}
+inline void split_range_init(const float* w, SplitRange& r, double A, double D, double dm) {
+    r.wmax = 0.0f;
+    for (int o = 0; o < 64; ++o) {
+        const float* w1 = w + W_RE0_W + o * 6;
+        r.a1[o] = fabsf(w1[0]) + fabsf(w1[1]);
+        r.d1[o] = fabsf(w1[2]) + fabsf(w1[3]) + fabsf(w1[4]);
+        r.m1[o] = fabsf(w1[5]);
+        r.b1[o] = fabsf(w[W_RE0_B + o]);
+        float s2 = 0, s4 = 0;
+        for (int k = 0; k < 64; ++k) {
+            s2 += fabsf(w[W_RE2_W + o * 64 + k]);
+            s4 += fabsf(w[W_RE4_W + o * 64 + k]);
+            r.wmax = fmaxf(r.wmax, fmaxf(fabsf(w[W_RE2_W + o * 64 + k]), fmaxf(fabsf(w[W_RE4_W + o * 64 + k]), fabsf(w[W_RP_W + o * 193 + k]))));
+        }
+        r.rs2[o] = s2; r.b2[o] = fabsf(w[W_RE2_B + o]);
+        r.rs4[o] = s4; r.b4[o] = fabsf(w[W_RE4_B + o]);
+    }
+    r.env_attr = (float)A; r.env_delta = (float)D; r.env_dens = (float)dm;
+    const double bound = split_range_bound(r, A, D, dm);
+    int k = (int)floor(log2(32768.0 / bound));       // 2^k bound <= 2^15: a factor two under fp16's end
+    if (k > 14) k = 14;
+    if (k < -60) k = -60;
+    r.shift = k;
+}
 
 inline uint16_t host_bf16_rne(float f) {
     uint32_t u;
@@ -74,9 +129,17 @@ inline int split_feature(int s, int h, int jj) {
     return 32 * (s >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
 }
 
-// host: state_dict blob -> split-fp16 fragments (uint16 storage, 8 per f16x8)
-inline void pack_split(const float* w, std::vector<uint16_t>& out) {
-    out.assign((size_t)S_TOTAL * 8, 0);
+// host: state_dict blob -> split-fp16 fragments (uint16 storage, 8 per f16x8); `shift` = k of the RANGE note:
+// first layer and the hidden biases carry 2^k
+inline void pack_split(const float* w, std::vector<uint16_t>& out, int shift) {
+    out.assign((size_t)S_ALLOC * 8, 0);
+    float* srows = reinterpret_cast<float*>(out.data() + (size_t)S_ROWS * 8);
+    for (int o = 0; o < 64; ++o) {
+        srows[o] = ldexpf(w[W_RE2_B + o], shift);
+        srows[64 + o] = ldexpf(w[W_RE4_B + o], shift);
+        srows[128 + o] = w[W_RP_B + o];
+        srows[192 + o] = w[W_RP_W + o * 193 + 192];
+    }
     auto put = [&](int unit, int jj, int part, float v) {
         // unit = index of the hi f16x8; the lo copy sits `part_stride` units later (given by caller)
         (void)part;
@@ -102,6 +165,7 @@ inline void pack_split(const float* w, std::vector<uint16_t>& out) {
                 float v = 0.0f;
                 if (h == 0 && jj < 6) v = w[W_RE0_W + o * 6 + jj];
                 else if (h == 0 && jj == 6) v = w[W_RE0_B + o];
+                v = ldexpf(v, shift);
                 const float hi = host_f16_to_f32(host_f16_rne(v));
                 put(S_RE0 + (0 * 2 + ob) * 64 + lane, jj, 0, hi);
                 put(S_RE0 + (1 * 2 + ob) * 64 + lane, jj, 1, v - hi);
@@ -210,8 +274,9 @@ __device__ __forceinline__ void mfma_layer8_split(const f16x8* __restrict__ wp, 
 
 // the relation-encoder chain of one tile: inputs -> c_edge fragment
 __device__ __forceinline__ void edge_chain_split(const f16x8* __restrict__ wsp /*LDS, S_* offsets*/,
-                                                 const float* __restrict__ rows /*b2,b4,b_rp,wd_rp*/,
-                                                 const float (&x)[8], float d, int h, int lane, Frag& out) {
+                                                 const float* __restrict__ rows /*2^k b2, 2^k b4, b_rp, wd_rp*/,
+                                                 const float (&x)[8], float d, int h, int lane, float sc, float inv,
+                                                 Frag& out) {
     Frag a, c;
     FragB fb;
     frag_zero(a);
@@ -224,7 +289,11 @@ __device__ __forceinline__ void edge_chain_split(const f16x8* __restrict__ wsp /
     mfma_layer64_split(wsp + S_RE4, fb, a, lane);
     split_frag<true>(a, fb);
     frag_bias_dens(rows + 128, rows + 192, d, h, out);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { out.v[0][r] *= sc; out.v[1][r] *= sc; }
     mfma_layer64_split(wsp + S_RPE, fb, out, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { out.v[0][r] *= inv; out.v[1][r] *= inv; }
 }
 
 // same contract as km_edge_encode (k_mlp_mfma.h)
@@ -233,13 +302,12 @@ km_edge_encode_split(const uint16_t* __restrict__ sw, const float* __restrict__ 
                      const float* __restrict__ s_cur, int s_mod, size_t s_stride,
                      const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
                      const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt, int N, int B,
-                     float* __restrict__ c_edge) {
+                     float* __restrict__ c_edge, float re_scale, float re_inv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wsp_f = lds;                          // S_TOTAL * 4 floats
-    float* rows = wsp_f + S_TOTAL * 4;           // b2, b4, b_rp, wd_rp
+    float* rows = wsp_f + S_TOTAL * 4;           // 2^k b2, 2^k b4, b_rp, wd_rp
     float* tiles = rows + 256;
-    lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
-    lds_fill(rows, mw + R_RE2_B, 256);
+    lds_fill(wsp_f, reinterpret_cast<const float*>(sw), (S_TOTAL + 64) * 4);      // the rows follow the fragments
     __syncthreads();
     const f16x8* wsp = reinterpret_cast<const f16x8*>(wsp_f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -267,7 +335,7 @@ km_edge_encode_split(const uint16_t* __restrict__ sw, const float* __restrict__ 
         x[6] = 1.0f;
         x[7] = 0.0f;
         Frag c;
-        edge_chain_split(wsp, rows, x, d, h, lane, c);
+        edge_chain_split(wsp, rows, x, d, h, lane, re_scale, re_inv, c);
         const int rows_valid = min(32, nslots - t * 32);
         frag_store_tile(c, c_edge + ((size_t)b * nslots + (size_t)t * 32) * 64, 64, rows_valid, tile, lane);
     }
@@ -471,6 +539,7 @@ struct PropArgs {
     float* proj_next; float* s_out; size_t out_stride;
     const float* cself; const uint8_t* cself_ok;
     unsigned* mask_out; float* agg_out;
+    float re_scale, re_inv;      // 2^k and 2^-k of the relation encoder's range shift
 };
 struct PropLds {
     const f16x8* wsp;         // edge chain, S_* offsets
@@ -600,6 +669,13 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         } else {
             frag_zero(acc);
         }
+        {
+            // the chain below runs on activations scaled by 2^k: so does its initial accumulator
+            const float sc = A.re_scale;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { bpr.v[0][r] *= sc; bpr.v[1][r] *= sc; }
+        }
+        const float inv = A.re_inv;
         const float pix = hd.pix, piy = hd.piy, piz = hd.piz, pia = hd.pia;
         // two-deep software pipeline on the dependent loads (index -> sender position): the
         // position of slot k+1 and the index of slot k+2 are requested while slot k computes
@@ -647,14 +723,14 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             if (!TAPE) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    acc.v[0][r] += relu1(c.v[0][r] + sv.v[0][r]);
-                    acc.v[1][r] += relu1(c.v[1][r] + sv.v[1][r]);
+                    acc.v[0][r] += relu1(fmaf(c.v[0][r], inv, sv.v[0][r]));
+                    acc.v[1][r] += relu1(fmaf(c.v[1][r], inv, sv.v[1][r]));
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    c.v[0][r] = relu1(c.v[0][r] + sv.v[0][r]);
-                    c.v[1][r] = relu1(c.v[1][r] + sv.v[1][r]);
+                    c.v[0][r] = relu1(fmaf(c.v[0][r], inv, sv.v[0][r]));
+                    c.v[1][r] = relu1(fmaf(c.v[1][r], inv, sv.v[1][r]));
                     acc.v[0][r] += c.v[0][r];
                     acc.v[1][r] += c.v[1][r];
                 }
@@ -755,7 +831,8 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         float* __restrict__ eff, int N, int B, float* __restrict__ proj_next, float* __restrict__ s_out,
         size_t out_stride, const float* __restrict__ cself /* nullable [B,64] */,
         const uint8_t* __restrict__ cself_ok,
-        unsigned* __restrict__ mask_out /* TAPE: [B*N*10][2] */, float* __restrict__ agg_out /* TAPE, nullable: [B*N,64] */) {
+        unsigned* __restrict__ mask_out /* TAPE: [B*N*10][2] */, float* __restrict__ agg_out /* TAPE, nullable: [B*N,64] */,
+        float re_scale, float re_inv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef PROP_STAMPS
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
@@ -771,7 +848,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     } else {
         lds_fill(w6_f + 1536 * 4, reinterpret_cast<const float*>(sw6) + S6_RPR * 4, 2 * 1536 * 4);
     }
-    lds_fill(rows, mw + R_RE2_B, 256);
+    lds_fill(rows, reinterpret_cast<const float*>(sw) + S_ROWS * 4, 256);
     int* tile_ctr = reinterpret_cast<int*>(rows + 516);
     if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
     __syncthreads();
@@ -802,7 +879,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
 #endif
     const PropArgs A = {mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj, c_node, eff_in, eff,
-                        N, B, proj_next, s_out, out_stride, cself, cself_ok, mask_out, agg_out};
+                        N, B, proj_next, s_out, out_stride, cself, cself_ok, mask_out, agg_out, re_scale, re_inv};
     const PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
                        reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
     prop_tiles<LAST, TAPE>(A, L, decode, lane, wave PROP_STAMPS_ARG);
@@ -836,7 +913,8 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
          float* __restrict__ eff /* !TAPE: in place; TAPE: effect history [4][B*N,64] */, int N, int B, int spw,
          const float* __restrict__ s_delta /* not null: the particle encoder runs here first (phase E) */,
          float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself, const uint8_t* __restrict__ cself_ok,
-         unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */) {
+         unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */,
+         float re_scale, float re_inv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef PROP_STAMPS
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
@@ -856,7 +934,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
         lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
     }
     lds_fill(w6_f, reinterpret_cast<const float*>(sw6) + S6_AGG * 4, 4 * 1536 * 4);   // S6_AGG, RPR, RPS, PR0 are consecutive
-    lds_fill(rows, mw + R_RE2_B, 256);
+    lds_fill(rows, reinterpret_cast<const float*>(sw) + S_ROWS * 4, 256);
     lds_fill(rows + 256, mw + R_PR0_B, 260);
     int* tile_ctr = reinterpret_cast<int*>(rows + 516);
     if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
@@ -923,7 +1001,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
 #endif
     const size_t bn64 = (size_t)B * N * 64;
     PropArgs A = {mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, c_node, eff, eff,
-                  N, B, proj_b, s_out, out_stride, cself, cself_ok, nullptr, nullptr};
+                  N, B, proj_b, s_out, out_stride, cself, cself_ok, nullptr, nullptr, re_scale, re_inv};
     PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
                  reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
 #pragma unroll 1

@@ -39,7 +39,11 @@ enum {
     DRP_ESTATE = -2,    /* call order: weights / camera / goal / state not set */
     DRP_EHIP = -3,      /* HIP runtime error */
     DRP_ENOMEM = -4,
-    DRP_ECOMM = -5      /* RCCL error */
+    DRP_ECOMM = -5,     /* RCCL error */
+    DRP_ERANGE = -6     /* weights or inputs outside the range the split-fp16 relation encoder of
+                           DRP_ENGINE_FUSED / _SPLIT is scaled for (its hidden activations travel as two fp16
+                           pieces times an exact power of two chosen from the weights): nothing was computed;
+                           DRP_ENGINE_MFMA / _VALU have no such limit */
 };
 
 /* which kernels compute the MLPs */

@@ -40,30 +40,68 @@ def test_stress_case_matches_the_reference(eng, golden, case, engine):
     check_rollout(eng, None, s, a, d, g[case + '/act_seqs'], g[case + '/state_pred'], states)
 
 
-def test_fp16_range_is_reported(eng, golden):
-    """Weights far beyond any trained network's (first encoder layers x 1e7): the hidden activations leave
-    fp16's range, where the split relation encoder would saturate.  The engine must not return wrong-but-finite
-    positions: the call either fails with DRP_ERANGE or gives the fp32 engines' answer."""
-    g = golden.stress
-    sd_ = {k: np.array(stress_weights(g, 'seed1')[k]) for k in stress_weights(g, 'seed1').files}
+def _scaled_blob(g, factor):
+    w = stress_weights(g, 'seed1')
+    sd_ = {k: np.array(w[k]) for k in w.files}
     for k in ('w/model.relation_encoder.model.0.weight', 'w/model.relation_encoder.model.0.bias'):
-        sd_[k] = sd_[k] * np.float32(1e7)
+        sd_[k] = sd_[k] * np.float32(factor)
 
     class _W(object):
         files = list(sd_.keys())
 
         def __getitem__(self, k):
             return sd_[k]
-    blob = weights.blob_from_state_dict(_W())
+    return weights.blob_from_state_dict(_W())
+
+
+@pytest.mark.parametrize('factor', [1e7, 1e-6])
+def test_weights_far_outside_fp16_still_give_the_fp32_answer(eng, golden, factor):
+    """First relation-encoder layer x 1e7 (hidden activations ~1e7: an un-shifted fp16 piece would saturate at
+    65 504 and return wrong-but-finite positions) and x 1e-6 (residuals below fp16's subnormals): the range
+    shift 2^k chosen from the weights keeps the split engines on the fp32 engines' answer."""
+    g = golden.stress
     case = 'seed1'
     s, sdl, a, d = g[case + '/s_cur'], g[case + '/s_delta'], g[case + '/attr'], g[case + '/dens']
-    eng.load_weights(blob, 0.08)
+    eng.load_weights(_scaled_blob(g, factor), 0.08)
     eng.set_engine(_lib.ENGINE_MFMA)
     ref = eng.step(a, s, sdl, d)
-    eng.set_engine(_lib.ENGINE_FUSED)
-    try:
+    assert np.isfinite(ref).all()
+    for engine in ('split', 'fused'):
+        eng.set_engine(_lib.ENGINES[engine])
         out = eng.step(a, s, sdl, d)
-    except _lib.DrpError as e:
-        assert 'range' in str(e).lower()
-        return
-    assert disp_rel(out, ref, s) < 1e-4
+        assert disp_rel(out, ref, s) < 1e-4, engine
+
+
+def test_inputs_beyond_the_proven_range_are_refused(eng, golden):
+    """DRP_ERANGE instead of wrong-but-finite: attributes a million times the envelope the range shift was proven
+    for, and weights with a matrix entry beyond fp16, are refused by the split engines (nothing is computed) and
+    served by the fp32 engines."""
+    g = golden.stress
+    case = 'seed1'
+    s, sdl, a, d = g[case + '/s_cur'], g[case + '/s_delta'], g[case + '/attr'], g[case + '/dens']
+    eng.load_weights(weights.blob_from_state_dict(stress_weights(g, case)), 0.08)
+    eng.set_engine(_lib.ENGINE_FUSED)
+    with pytest.raises(_lib.DrpError, match='range'):
+        eng.step(a + np.float32(1e6), s, sdl, d)
+    with pytest.raises(_lib.DrpError, match='range'):
+        eng.rollout(s, a, d * np.float32(1e9), g[case + '/act_seqs'])
+    out = eng.step(a, s, sdl, d)                               # the context stays usable
+    assert disp_rel(out, g[case + '/s_pred'], s) < 1e-4
+    eng.set_engine(_lib.ENGINE_MFMA)
+    assert np.isfinite(eng.step(a + np.float32(1e6), s, sdl, d)).all()
+    # a hidden-layer weight of 1e5 cannot be written as two fp16 pieces
+    w = stress_weights(g, case)
+    sd_ = {k: np.array(w[k]) for k in w.files}
+    sd_['w/model.relation_encoder.model.2.weight'][3, 5] = 1e5
+
+    class _W(object):
+        files = list(sd_.keys())
+
+        def __getitem__(self, k):
+            return sd_[k]
+    eng.load_weights(weights.blob_from_state_dict(_W()), 0.08)
+    ref = eng.step(a, s, sdl, d)                               # fp32 MFMA engine: fine
+    assert np.isfinite(ref).all()
+    eng.set_engine(_lib.ENGINE_FUSED)
+    with pytest.raises(_lib.DrpError, match='range'):
+        eng.step(a, s, sdl, d)
