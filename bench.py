@@ -228,11 +228,27 @@ def main():
     dominant = max(per_class, key=lambda k: per_class[k][0])
     cnt_last = eng.debug_fetch('nbr_cnt', (ns, N), np.uint8)
     kbar = float(cnt_last.mean())
-    # slot iterations km_prop runs per 32-receiver tile: the largest in-degree of the tile, minus the
-    # self loop when its encoder chain is replaced by the per-sample constant (attributes are zeros here)
-    pad = (-N) % 32
-    tile_max = np.pad(cnt_last, ((0, 0), (0, pad))).reshape(ns, -1, 32).max(-1).astype(np.float64)
+    # slot iterations the propagation kernel runs per 32-receiver tile: the largest in-degree of the tile, minus the
+    # self loop when its encoder chain is replaced by the per-sample constant (attributes are zeros here).
+    # km_prop3 (chip-filling batches) cuts the rows of a workgroup's samples, ordered by in-degree, into tiles;
+    # km_prop cuts every sample on its own.
     self_const = engine == 'fused' and os.environ.get('DRP_NO_SELF_CONST') is None
+    n_cu = eng.device_info()['n_cu']
+    spw = -(-ns // n_cu)
+    prop3 = (engine == 'fused' and os.environ.get('DRP_NO_PROP3') is None and ns >= n_cu and spw * ((N + 31) // 32) >= 8)
+    tile_max = []
+    if prop3:
+        ordered = os.environ.get('DRP_NO_PROP3_ORDER') is None and spw * N <= 4900
+        for w in range(0, ns, spw):
+            rows = cnt_last[w:w + spw].ravel()
+            if ordered:
+                rows = np.sort(rows)[::-1]
+            rows = np.pad(rows, (0, (-rows.size) % 32))
+            tile_max.append(rows.reshape(-1, 32).max(-1))
+        tile_max = np.concatenate(tile_max).astype(np.float64)
+    else:
+        tile_max = np.pad(cnt_last, ((0, 0), (0, (-N) % 32))).reshape(ns, -1, 32).max(-1).astype(np.float64).ravel()
+    n_tiles = int(tile_max.size)
     slots_per_tile = float((tile_max - (1.0 if self_const else 0.0)).clip(min=0).mean())
     eng.probe_begin(dominant)
     fence()
@@ -301,7 +317,7 @@ def main():
         total = args.samples_total_job * N * H * args.steps
         avg_s = dom_ms / max(dom_n, 1) * 1e-3
         B = ns
-        tiles = B * ((N + 31) // 32)
+        tiles = n_tiles
         if dominant == 'prop':
             # km_prop: per 32-receiver tile, one 78-MFMA chain (the 3-term split
             # relation encoder) per slot iteration + the 6-term split node layers (144 MFMAs, 96 in
@@ -321,6 +337,7 @@ def main():
             roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                     'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
                     'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile,
+                    'tiles_per_step': tiles, 'mean_in_degree_minus_self': kbar - (1.0 if self_const else 0.0),
                     'propagation_steps_per_launch': psteps, 'particle_encoder_in_launch': bool(encoder_inside)}
         elif dominant == 'aggregate':
             work = B * N * (2 * kbar + 2) * 256.0

@@ -56,6 +56,7 @@ struct drp_ctx {
     bool prop3 = true;              // DRP_NO_PROP3=1: one launch per propagation step even for chip-filling batches
     bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
+    bool prop3_order = true;        // DRP_NO_PROP3_ORDER=1: km_prop3's tiles in the natural row order instead of by in-degree
     bool prop3e = true;             // DRP_NO_PROP3E=1: the particle encoder stays its own launch in front of km_prop3
 
     // model constants
@@ -343,7 +344,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
 #define PROP3_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
                    a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, pb, \
                    ptr<float>(c->c_node), eff_base, N, B, spw, phase_e ? (const float*)ptr<float>(c->s_delta) : (const float*)nullptr, \
-                   a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist, c->re_scale, c->re_inv
+                   a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist, c->re_scale, c->re_inv, c->prop3_order ? 1 : 0
             if (!tape) hipLaunchKernelGGL((km_prop3<false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
             else hipLaunchKernelGGL((km_prop3<true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
 #undef PROP3_ARGS
@@ -634,6 +635,7 @@ int drp_create(int device, drp_ctx** out) {
     c->prop3 = getenv("DRP_NO_PROP3") == nullptr;
     c->graph_strips = getenv("DRP_NO_GRAPH_STRIPS") == nullptr;
     c->prop3e = getenv("DRP_NO_PROP3E") == nullptr;
+    c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
     if (const char* e = getenv("DRP_SPLIT_SHIFT")) c->re_shift_env = atoi(e);
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;

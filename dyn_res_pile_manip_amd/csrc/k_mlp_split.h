@@ -545,17 +545,32 @@ struct PropLds {
     const f16x8* wsp;         // edge chain, S_* offsets
     const bf16x8* w_agg;      // W_agg
     const bf16x8* w_x;        // !LAST: W_r | W_s;  LAST: predictor layer 0
-    const float* rows;        // b2, b4, b_rp, wd_rp
+    const float* rows;        // 2^k b2, 2^k b4, b_rp, wd_rp
     const float* rows_pr;     // LAST: b_pr0, w_pr1[3], b_pr1
     int* tile_ctr;            // next tile of this workgroup's share
 };
 struct TileId {
     bool valid;
-    int b, t;
+    int b, t;                 // km_prop: sample and tile of the sample; km_prop3: t = tile of the workgroup's rows
+};
+// Which receiver a lane of a tile works on.  km_prop's tiles are 32 consecutive receivers of ONE sample (b uniform);
+// km_prop3's are 32 entries of its workgroup's row order, which runs over all of the workgroup's samples, so the
+// sample, and with it the position / attribute / projection bases and the density, are per-lane quantities.
+struct LaneRow {
+    int b, i;                 // sample, receiver within the sample
+    bool live;                // false: a clamped duplicate past the end (computed, never stored)
 };
 
-template <bool LAST, bool TAPE, class Decode>
-__device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, Decode decode, int lane, int wave
+// quotient and remainder of small non-negative integers through the fp32 reciprocal, corrected to be exact
+__device__ __forceinline__ void divmod_small(int x, int n, float inv_n, int& q, int& r) {
+    q = (int)((float)x * inv_n);
+    r = x - q * n;
+    if (r < 0) { r += n; --q; }
+    else if (r >= n) { r -= n; ++q; }
+}
+
+template <bool LAST, bool TAPE, class Decode, class RowOf>
+__device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, Decode decode, RowOf row_of, int lane, int wave
 #ifdef PROP_STAMPS
                                            , unsigned long long (&st_sum)[8]
 #endif
@@ -573,6 +588,24 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
     const f16x8* wsp = L.wsp;
     const float* rows = L.rows;
     const int j = lane & 31, h = lane >> 5;
+    // attr_mod == dens_mod (n_batch or B) for every caller; s_mod is one of the two as well
+    const float inv_mod = 1.0f / (float)attr_mod;
+    const bool s_by_sample = s_mod != attr_mod;            // states of a running rollout: one block per sample
+    // per-lane bases of a receiver's sample
+    struct Bases {
+        const float* s;       // positions of the sample (s_cur + (b % s_mod) * s_stride)
+        const float* at;      // attributes of the sample
+        float d;              // density feature
+    };
+    auto bases_of = [&](int b) {
+        int q, bm;
+        divmod_small(b, attr_mod, inv_mod, q, bm);
+        Bases B_;
+        B_.s = s_cur + (size_t)(s_by_sample ? b : bm) * s_stride;   // s_mod is B or attr_mod (every caller)
+        B_.at = attr + (size_t)bm * N;
+        B_.d = dens[bm] / DRP_DENS_SCALE;
+        return B_;
+    };
     // What a tile needs before its first slot can start hangs on a chain of dependent global loads
     // (in-degree and first neighbours -> self-loop test -> sender positions: three round trips of 2-3 us
     // each under load, measured 8 us per tile with tools/prop_stamps.py).  The chain is software-pipelined
@@ -580,41 +613,40 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
     // requested when this tile's node part starts, the positions of its first two senders when that part
     // ends, so a tile begins with everything but its P_r / P_s rows on hand.
     struct TileHead {
+        LaneRow lr;
+        Bases bs;
         int cnt, ok;
         unsigned nbw0, nbw1;          // neighbours 0..3 (int16 pairs)
         float pix, piy, piz, pia;
     };
     auto tile_head = [&](const TileId& id) {
-        const int b = id.b;
-        const int i = min(id.t * 32 + j, N - 1);
-        const size_t row = (size_t)b * N + i;
-        const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
         TileHead hd;
+        hd.lr = row_of(id, j);
+        const int b = hd.lr.b, i = hd.lr.i;
+        const size_t row = (size_t)b * N + i;
+        hd.bs = bases_of(b);
         hd.cnt = nbr_cnt[row];
         hd.ok = (cself != nullptr) ? (int)cself_ok[b] : 0;
         const unsigned* nbw = reinterpret_cast<const unsigned*>(nbr_idx + row * DRP_K);   // rows are 20 B: dword aligned
         hd.nbw0 = nbw[0];
         hd.nbw1 = nbw[1];
-        hd.pix = s[i * 3 + 0]; hd.piy = s[i * 3 + 1]; hd.piz = s[i * 3 + 2];
-        hd.pia = attr[(size_t)(b % attr_mod) * N + i];
+        hd.pix = hd.bs.s[i * 3 + 0]; hd.piy = hd.bs.s[i * 3 + 1]; hd.piz = hd.bs.s[i * 3 + 2];
+        hd.pia = hd.bs.at[i];
         return hd;
     };
     struct TileFirst {
         int ks, j0, j1;
         float p0x, p0y, p0z, p0a;
     };
-    auto tile_first = [&](const TileId& id, const TileHead& hd) {
-        const int b = id.b;
-        const int i = min(id.t * 32 + j, N - 1);
-        const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
-        const float* at = attr + (size_t)(b % attr_mod) * N;
+    auto tile_first = [&](const TileHead& hd) {
+        const int i = hd.lr.i;
         const int nb0 = (int)(hd.nbw0 & 0xffffu), nb1 = (int)(hd.nbw0 >> 16), nb2 = (int)(hd.nbw1 & 0xffffu);
         TileFirst f;
         // self slot first (k_graph self_first) and a per-sample self-edge constant: the self loop is skipped
-        f.ks = (hd.ok && __all(hd.cnt > 0 && nb0 == i)) ? 1 : 0;
+        f.ks = __all(hd.ok && hd.cnt > 0 && nb0 == i) ? 1 : 0;
         f.j0 = (f.ks < hd.cnt) ? (f.ks ? nb1 : nb0) : i;
         f.j1 = (f.ks + 1 < hd.cnt) ? (f.ks ? nb2 : nb1) : i;
-        f.p0x = s[f.j0 * 3 + 0]; f.p0y = s[f.j0 * 3 + 1]; f.p0z = s[f.j0 * 3 + 2]; f.p0a = at[f.j0];
+        f.p0x = hd.bs.s[f.j0 * 3 + 0]; f.p0y = hd.bs.s[f.j0 * 3 + 1]; f.p0z = hd.bs.s[f.j0 * 3 + 2]; f.p0a = hd.bs.at[f.j0];
         return f;
     };
     // A workgroup's share of the tiles is handed out to its waves on demand through a counter in LDS: the two
@@ -626,19 +658,18 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
     TileFirst tf_next = {};
     if (cur.valid) {
         hd_next = tile_head(cur);
-        tf_next = tile_first(cur, hd_next);
+        tf_next = tile_first(hd_next);
     }
     for (; cur.valid; cur = nxt) {
-        const int b = cur.b, t = cur.t;
-        const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
-        const float* at = attr + (size_t)(b % attr_mod) * N;
-        const float* pj = proj + (size_t)b * N * 128;
-        const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
-        const int i = min(t * 32 + j, N - 1);
-        const bool live = (t * 32 + j) < N;
-        const size_t row = (size_t)b * N + i;
         const TileHead hd = hd_next;
         const TileFirst tf = tf_next;
+        const int b = hd.lr.b, i = hd.lr.i;
+        const bool live = hd.lr.live;
+        const float* s = hd.bs.s;
+        const float* at = hd.bs.at;
+        const float d = hd.bs.d;
+        const size_t row = (size_t)b * N + i;
+        const float* pj = proj + ((size_t)b * N) * 128;
         const int cnt = hd.cnt;
         const int16_t* nb = nbr_idx + row * DRP_K;
         Frag acc, bpr;
@@ -687,7 +718,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
 #endif
 #pragma unroll 1
         for (int k = ks; k < DRP_K; ++k) {
-            if (__all(k >= cnt)) break;              // sparse piles: no receiver of this tile has a slot k
+            if (__all(k >= cnt)) break;              // no receiver of this tile has a slot k
 #ifdef PROP_STAMPS
             ++st_slots;
 #endif
@@ -768,7 +799,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         if (live) frag_to_row(eff + row * 64, h, e);
         split_frag6(e, f6);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) tf_next = tile_first(nxt, hd_next);     // the head has landed by now
+        if (more) tf_next = tile_first(hd_next);          // the head has landed by now
         __builtin_amdgcn_sched_barrier(0);
         if (!LAST) {
             Frag p;
@@ -779,10 +810,10 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             mfma_layer64_split6(L.w_x + 1536, f6, p, lane);
             if (live) frag_to_row(proj_next + row * 128 + 64, h, p);
         } else {
-            Frag hd;
-            frag_from_row(L.rows_pr, h, hd);
-            mfma_layer64_split6(L.w_x, f6, hd, lane);
-            frag_relu(hd);
+            Frag hp;
+            frag_from_row(L.rows_pr, h, hp);
+            mfma_layer64_split6(L.w_x, f6, hp, lane);
+            frag_relu(hp);
             float out[3];
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
@@ -790,9 +821,9 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
                 frag_from_row(L.rows_pr + 64 + 64 * o, h, w);
                 float p = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p = fmaf(hd.v[0][r], w.v[0][r], p);
+                for (int r = 0; r < 16; ++r) p = fmaf(hp.v[0][r], w.v[0][r], p);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p = fmaf(hd.v[1][r], w.v[1][r], p);
+                for (int r = 0; r < 16; ++r) p = fmaf(hp.v[1][r], w.v[1][r], p);
                 out[o] = p + __shfl_xor(p, 32, 64);
             }
             if (h == 0 && live) {
@@ -882,7 +913,15 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
                         N, B, proj_next, s_out, out_stride, cself, cself_ok, mask_out, agg_out, re_scale, re_inv};
     const PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
                        reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
-    prop_tiles<LAST, TAPE>(A, L, decode, lane, wave PROP_STAMPS_ARG);
+    // a tile = 32 consecutive receivers of one sample
+    auto row_of = [&](const TileId& id, int j) {
+        LaneRow r;
+        r.b = id.b;
+        r.live = (id.t * 32 + j) < N;
+        r.i = min(id.t * 32 + j, N - 1);
+        return r;
+    };
+    prop_tiles<LAST, TAPE>(A, L, decode, row_of, lane, wave PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS
     st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
     st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // all tiles of this wave
@@ -903,6 +942,17 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
 // All four node matrices stay in LDS (153.6 KB).  grid = ceil(B / spw) workgroups, spw = samples per
 // workgroup; the host uses it when every CU gets at least one sample and a workgroup at least PROP_WAVES
 // tiles per step, and the one-step kernels otherwise (small batches spread by tiles, not by samples).
+//
+// Tiles.  The workgroup's receivers -- nb x N rows, contiguous in every per-row buffer -- are ONE list cut into
+// tiles of 32, so only the list's last tile has idle lanes (4 x 300 rows: 38 tiles instead of 4 x 10; 4 x 50:
+// 7 instead of 8).  A tile runs as many slot iterations as its largest in-degree, so the list is ordered by
+// in-degree, largest first (a stable counting sort over 0..10 by the whole workgroup, once per launch: the lists
+// do not change between the propagation steps; `perm` in LDS, 2 B per row): a tile's slot count is then its
+// receivers' own, and the longest tiles are drawn first.  Per-row results do not depend on which tile a row
+// is in (lanes are independent columns of every MFMA), so the order changes no bit -- except that the self-edge
+// shortcut needs every lane of a tile to qualify, which the order does not disturb for uniform batches.
+// Lists too long for the LDS left over (PROP3_PERM_MAX rows) keep the natural order.
+#define PROP3_PERM_MAX 4900
 template <bool TAPE>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
@@ -914,16 +964,16 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
          const float* __restrict__ s_delta /* not null: the particle encoder runs here first (phase E) */,
          float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself, const uint8_t* __restrict__ cself_ok,
          unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */,
-         float re_scale, float re_inv) {
+         float re_scale, float re_inv, int order_rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef PROP_STAMPS
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
 #endif
     float* wsp_f = lds;
     float* w6_f = wsp_f + S_TOTAL * 4;               // AGG | RPR | RPS | PR0
-    float* rows = w6_f + 4 * 1536 * 4;               // b2,b4,b_rp,wd_rp | b_pr0, w_pr1[3], b_pr1
-    float* pe0_f = rows + 520;                       // phase E: first layer of the particle encoder, then b_pe2, b_pp, wd_pp
-    float* rows_e = pe0_f + 384 * 4;
+    float* rows = w6_f + 4 * 1536 * 4;               // 2^k b2, 2^k b4, b_rp, wd_rp | b_pr0, w_pr1[3], b_pr1
+    float* pe0_f = rows + 520;                       // phase E: first layer of the particle encoder, then b_pe2, b_pp, wd_pp;
+    float* rows_e = pe0_f + 384 * 4;                 // afterwards: the row order (perm, hist)
     const bool phase_e = s_delta != nullptr;
     if (phase_e) {
         // the particle encoder's two 64x64 layers borrow the edge chain's region; W_r and W_s are resident anyway
@@ -940,24 +990,29 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tps = (N + 31) >> 5;
     const int b0 = blockIdx.x * spw, nb = min(spw, B - b0);
-    const int wg_tiles = (nb > 0 ? nb : 0) * tps;
+    const int wg_rows = (nb > 0 ? nb : 0) * N;       // this workgroup's receivers: rows b0*N .. b0*N + wg_rows
+    const int wg_tiles = (wg_rows + 31) >> 5;
+    const float inv_N = 1.0f / (float)N;
     if (phase_e) {
-        // ---- phase E: km_node_encode_split's tile over this workgroup's samples (same arithmetic, same order)
+        // ---- phase E: the particle encoder over this workgroup's rows (km_node_encode_split's arithmetic per row)
         const bf16x8* wpe2 = reinterpret_cast<const bf16x8*>(wsp_f);
         const bf16x8* wrs = reinterpret_cast<const bf16x8*>(w6_f) + 1536;
         const bf16x8* wpe0 = reinterpret_cast<const bf16x8*>(pe0_f);
         const int j = lane & 31, h = lane >> 5;
+        const float inv_mod = 1.0f / (float)attr_mod;
         for (int li = wave; li < wg_tiles;) {
             asm volatile("" ::: "memory");
-            const int m = li / tps, t = li - m * tps, b = b0 + m;
-            const int i = min(t * 32 + j, N - 1);
-            const bool live = (t * 32 + j) < N;
-            const size_t row = (size_t)b * N + i;
-            const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+            const bool live = (li * 32 + j) < wg_rows;
+            const int r = min(li * 32 + j, wg_rows - 1);
+            int m, i, q, bm;
+            divmod_small(r, N, inv_N, m, i);
+            const int b = b0 + m;
+            divmod_small(b, attr_mod, inv_mod, q, bm);
+            const size_t row = (size_t)b0 * N + r;
+            const float d = dens[bm] / DRP_DENS_SCALE;
             const float* sd = s_delta + row * 3;
-            float x[8] = {sd[0], sd[1], sd[2], attr[(size_t)(b % attr_mod) * N + i], d, 1.0f, 0.0f, 0.0f};
+            float x[8] = {sd[0], sd[1], sd[2], attr[(size_t)bm * N + i], d, 1.0f, 0.0f, 0.0f};
             Frag a, pe, c;
             FragB6 f6;
             frag_zero(a);
@@ -978,22 +1033,84 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
             frag_zero(c);
             mfma_layer64_split6(wrs + 1536, f6, c, lane);
             if (live) frag_to_row(proj_a + row * 128 + 64, h, c);
-            int q = 0;
-            if (lane == 0) q = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            li = __builtin_amdgcn_readfirstlane(q);
+            int qn = 0;
+            if (lane == 0) qn = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            li = __builtin_amdgcn_readfirstlane(qn);
         }
         __syncthreads();                                 // the encoder's rows of this workgroup's samples are written
         lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
         if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
-        __syncthreads();
     }
+    // ---- row order: in-degree descending, row ascending within a degree (deterministic; the encoder's LDS is free now)
+    uint16_t* perm = reinterpret_cast<uint16_t*>(pe0_f);
+    const bool ordered = order_rows != 0 && wg_rows <= PROP3_PERM_MAX && wg_rows > 0;
+    if (ordered) {
+        int* hist = reinterpret_cast<int*>(perm + ((PROP3_PERM_MAX + 1) & ~1));      // [PROP_WAVES][11]
+        const uint8_t* cnt_rows = nbr_cnt + (size_t)b0 * N;
+        const int groups = (wg_rows + 63) >> 6;
+        const int g_lo = (groups * wave) / PROP_WAVES, g_hi = (groups * (wave + 1)) / PROP_WAVES;   // this wave's 64-row groups
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        int mine[DRP_K + 1];
+#pragma unroll
+        for (int v = 0; v <= DRP_K; ++v) mine[v] = 0;
+        for (int g = g_lo; g < g_hi; ++g) {
+            const int r = g * 64 + lane;
+            const int c = (r < wg_rows) ? min((int)cnt_rows[r], DRP_K) : -1;
+#pragma unroll
+            for (int v = 0; v <= DRP_K; ++v) mine[v] += __popcll(__ballot(c == v));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v <= DRP_K; ++v) hist[wave * (DRP_K + 1) + v] = mine[v];
+        }
+        __syncthreads();
+        // first position of (degree v, this wave): every higher degree of every wave, then degree v of the waves before
+        int base[DRP_K + 1];
+        {
+            int above = 0;
+#pragma unroll
+            for (int v = DRP_K; v >= 0; --v) {
+                int before = 0, total = 0;
+                for (int w = 0; w < PROP_WAVES; ++w) {
+                    const int t = hist[w * (DRP_K + 1) + v];
+                    before += (w < wave) ? t : 0;
+                    total += t;
+                }
+                base[v] = above + before;
+                above += total;
+            }
+        }
+        for (int g = g_lo; g < g_hi; ++g) {
+            const int r = g * 64 + lane;
+            const int c = (r < wg_rows) ? min((int)cnt_rows[r], DRP_K) : -1;
+            int pos = 0;
+#pragma unroll
+            for (int v = 0; v <= DRP_K; ++v) {
+                const unsigned long long m = __ballot(c == v);
+                if (c == v) pos = base[v] + __popcll(m & lt_mask);
+                base[v] += __popcll(m);
+            }
+            if (c >= 0) perm[pos] = (uint16_t)r;
+        }
+    }
+    __syncthreads();
     auto decode = [&](int li) {
         TileId id;
         id.valid = li < wg_tiles;
-        const int m = li / tps;
-        id.t = li - m * tps;
-        id.b = b0 + m;
+        id.b = b0;
+        id.t = li;
         return id;
+    };
+    auto row_of = [&](const TileId& id, int j) {
+        LaneRow lr;
+        const int g = id.t * 32 + j;
+        lr.live = g < wg_rows;
+        const int gc = min(g, wg_rows - 1);
+        const int r = ordered ? (int)perm[gc] : gc;
+        int m;
+        divmod_small(r, N, inv_N, m, lr.i);
+        lr.b = b0 + m;
+        return lr;
     };
 #ifdef PROP_STAMPS
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1020,10 +1137,10 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
             A.agg_out = agg_hist ? agg_hist + (size_t)p * bn64 : nullptr;
         }
         if (p + 1 < DRP_PSTEP) {
-            prop_tiles<false, TAPE>(A, L, decode, lane, wave PROP_STAMPS_ARG);
+            prop_tiles<false, TAPE>(A, L, decode, row_of, lane, wave PROP_STAMPS_ARG);
         } else {
             L.w_x = reinterpret_cast<const bf16x8*>(w6_f) + 3 * 1536;
-            prop_tiles<true, TAPE>(A, L, decode, lane, wave PROP_STAMPS_ARG);
+            prop_tiles<true, TAPE>(A, L, decode, row_of, lane, wave PROP_STAMPS_ARG);
         }
     }
 #ifdef PROP_STAMPS
@@ -1036,7 +1153,8 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     }
 #endif
 }
-#define KM_PROP3_LDS ((size_t)(S_TOTAL * 4 + 4 * 1536 * 4 + 256 + 260 + 4 + 384 * 4 + 192) * sizeof(float))
+// the encoder's first layer + rows (6 912 B) are followed by slack up to the row order's 9 800 + 352 B
+#define KM_PROP3_LDS ((size_t)(S_TOTAL * 4 + 4 * 1536 * 4 + 256 + 260 + 4) * sizeof(float) + (size_t)(((PROP3_PERM_MAX + 1) & ~1) * 2 + PROP_WAVES * (DRP_K + 1) * 4))
 
 
 // ---- particle encoder, node constant and first projections on the 6-term split --------------

@@ -25,10 +25,10 @@ def test_one_rank_rccl_communicator_equals_no_communicator(mpc_type, monkeypatch
     ref = w.run_planner(mpc_type, None)
     monkeypatch.setenv('DRP_COMM_ALWAYS', '1')         # one rank still goes through ncclAllGather
     probe = Engine(0)
-    uid = probe.comm_unique_id()
+    uid, uid2 = probe.comm_unique_id(), probe.comm_unique_id()     # an ncclUniqueId serves one communicator
     probe.close()
     got = w.run_planner(mpc_type, RcclComm(uid, 0, 1))
-    got_t = w.run_planner(mpc_type, (0, 1, uid))        # the documented tuple form
+    got_t = w.run_planner(mpc_type, (0, 1, uid2))       # the documented tuple form
     for k in ref:
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
         np.testing.assert_array_equal(got_t[k], ref[k], err_msg=k)
