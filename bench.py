@@ -40,7 +40,14 @@ CONFIGS = {
     'c4-300': (300, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 300 particles x 1024 samples x 10 steps'),
     'c4-600': (600, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 600 particles x 1024 samples x 10 steps'),
     'c5': (1200, 4096, 20, 'strong', 'BASELINE configs[4]: 1200-particle dense pile, 4096 samples in total, 20-step horizon'),
+    # the reference's LIVE planner (mpc_type 'GD', config/mpc/config.yaml:38-43): 50 trajectories x 30 particle
+    # re-samplings = 1500 independent Adam problems, horizon 1; a "step" = one iteration of planners.py:682-764
+    # (rollout, final-step reward, reverse mode, Adam, clip box).  samples = trajectories x 30 here.
+    'gd-demo': (100, 1500, 1, 'weak', "the reference's live GD planner at its demo shape: 50 trajectories x 30 re-samplings x 100 particles, horizon 1 "
+                                      '(config/mpc/config.yaml:38-43), one Adam iteration per step'),
 }
+GD_CLASSES = ['graph', 'node_encode', 'prop', 'reward', 'tape_copy', 'bwd_reward', 'bwd_lists', 'bwd_node', 'bwd_edge',
+              'bwd_push', 'opt']
 KERNEL_CLASSES = ['graph', 'node_encode', 'edge_encode', 'project', 'aggregate', 'update',
                   'predict', 'reward', 'mppi', 'prop']
 # algorithmic work of one LAUNCH of each class, per particle (node) or per edge
@@ -148,8 +155,141 @@ def cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam):
                       'Rr/Rs PyTorch fp32, %d of %d host threads of %s), %.1f s' % (ns, N, H, cores, avail, host_cpu_model(), dt)}
 
 
+def run_gd(args):
+    """--config gd-demo: the gradient-descent planner's iteration (drp_gd_step) at the demo shape."""
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    import torch
+    import torch.distributed as dist
+    from dyn_res_pile_manip_amd import synthetic as syn, weights, _lib
+    from dyn_res_pile_manip_amd.engine import Engine
+    from dyn_res_pile_manip_amd.planners import world2cam_affine
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    N, H, nb = args.particles, args.horizon, 30
+    rows = args.samples_total_job // world if args.scaling == 'strong' else args.samples_total_job // args.gpus
+    traj = max(1, rows // nb)
+    B = traj * nb
+    eng = Engine(local_rank)
+    sd = weights.random_state_dict(seed=0)
+    eng.load_weights(weights.blob_from_state_dict(sd), 0.08)
+    cam = syn.demo_cam_params()
+    eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, cam)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    G, goal_coor = eng.set_goal_image(obs_goal, 5 * N, fps_init=0, mode='cv5', want=True)
+    s0, dens, attr = syn.make_pile(N, nb, seed=N)
+    acts = np.repeat(np.stack([syn.nominal_pushes(H, seed=rank * 1000 + i) for i in range(traj)]), nb, axis=0).astype(np.float32)
+    lo, hi = syn.action_limits()
+    eng.gd_begin(s0, attr, dens, acts, 0.05, lo, hi)
+
+    def step():
+        eng._ck(eng.lib.drp_gd_step(eng.h, None))
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    per_class = {}
+    for kc in GD_CLASSES:
+        eng.probe_begin(kc)
+        step()
+        per_class[kc] = eng.probe_read()
+    dominant = max(per_class, key=lambda k: per_class[k][0])
+    cnt = eng.debug_fetch('nbr_cnt', (B, N), np.uint8)
+    kbar = float(cnt.mean())
+    eng.probe_begin(dominant)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    dom_ms, dom_n = eng.probe_read()
+    eng.probe_begin(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    per_iter = []
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        step()
+        eng.sync()
+        per_iter.append(time.perf_counter() - t1)
+    med = float(np.median(per_iter))
+    if rank == 0:
+        avg_s = dom_ms / max(dom_n, 1) * 1e-3
+        if dominant == 'prop':
+            # the forward kernel of the tape-writing instantiation: the same MFMAs as bench's MPPI model
+            n_cu = eng.device_info()['n_cu']
+            spw = -(-B // n_cu)
+            tile_max = []
+            for w in range(0, B, spw):
+                r = cnt[w:w + spw].ravel()
+                if spw * N <= 4900 and (r == r.max()).sum() * 16 < r.size * 15:
+                    r = np.sort(r)[::-1]
+                r = np.pad(r, (0, (-r.size) % 32))
+                tile_max.append(r.reshape(-1, 32).max(-1))
+            tile_max = np.concatenate(tile_max).astype(np.float64)
+            mfmas = 3 * tile_max.size * ((tile_max - 1).clip(min=0).mean() * 78 + (2 * 144 + 96) / 3.0) + tile_max.size * 204
+            roof = {'bound': 'mfma', 'achieved': mfmas * 32768.0 / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                    'slot_iterations_per_tile': float((tile_max - 1).clip(min=0).mean()), 'tiles_per_step': int(tile_max.size)}
+        elif dominant == 'bwd_edge':
+            # kb_edge_terms per node and propagation step: own g_agg row + own masks read, both g_proj halves written,
+            # then one (mask, g_agg row, list entry) per edge the node feeds
+            work = B * N * (256 + 8 * kbar + 512 + 8 + kbar * (8 + 256 + 4))
+            roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+        else:
+            roof = {'bound': 'hbm', 'achieved': 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+        roof.update({'frac': roof['achieved'] / roof['peak'], 'kernel': dominant, 'avg_launch_ms': avg_s * 1e3,
+                     'launches': dom_n, 'traffic': None, 'traffic_source': None})
+        total = world * B * N * H * args.steps
+        out = {'metric': 'MPC rollout-steps/sec (samples x particles x steps/sec)', 'value': total / dt,
+               'unit': 'particle-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'ms_per_step_median': med * 1e3, 'value_median': world * B * N * H / med,
+               'dtype': 'f32 (forward MLP products as split fp16 / bf16 MFMA terms, backward node stages on fp32 MFMA, fp32 accumulate)',
+               'data': 'synthetic',
+               'config': {'workload': args.workload, 'name': args.config_name, 'n_particles': N, 'n_trajectories_per_gpu': traj,
+                          'n_batch': nb, 'rows_per_gpu': B, 'n_look_ahead': H, 'engine': 'fused', 'mean_in_degree': kbar,
+                          'reference_time_model_ms': None},
+               'roofline': roof, 'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items()},
+               'cpu_baseline': None}
+        from dyn_res_pile_manip_amd.planners import particle_num_to_iter_time
+        out['config']['reference_time_model_ms'] = particle_num_to_iter_time(N)     # planners.py:25-28, batch 300 on its GPU
+        if world == 1 and not args.no_cpu_baseline:
+            import torch as _t
+            from oracle import propnet_dense as od
+            W = od.load_weights(sd)
+            cpu_traj = 4
+            a_cpu = acts[:cpu_traj * nb]
+            _t.set_num_threads(min(32, os.cpu_count() or 1))
+            od.gd_loss_and_grads(W, s0, dens, attr, a_cpu[:nb], G, cam, goal_coor, syn.demo_cam_extrinsics(), 24)   # warm-up
+            t0 = time.perf_counter()
+            od.gd_loss_and_grads(W, s0, dens, attr, a_cpu, G, cam, goal_coor, syn.demo_cam_extrinsics(), 24)
+            dtc = time.perf_counter() - t0
+            out['cpu_baseline'] = {'value': cpu_traj * nb * N * H / dtc, 'unit': 'particle-steps/s', 'cores': _t.get_num_threads(),
+                                   'kind': 'port', 'cpu_model': host_cpu_model(),
+                                   'sample': '%d trajectories x %d columns x %d particles, forward + autograd backward of '
+                                             'oracle/propnet_dense.py, %.1f s' % (cpu_traj, nb, N, dtc)}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.config_name == 'gd-demo':
+        return run_gd(args)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -241,7 +381,7 @@ def main():
         ordered = os.environ.get('DRP_NO_PROP3_ORDER') is None and spw * N <= 4900
         for w in range(0, ns, spw):
             rows = cnt_last[w:w + spw].ravel()
-            if ordered:
+            if ordered and (rows == rows.max()).sum() * 16 < rows.size * 15:     # saturated piles keep the natural order
                 rows = np.sort(rows)[::-1]
             rows = np.pad(rows, (0, (-rows.size) % 32))
             tile_max.append(rows.reshape(-1, 32).max(-1))

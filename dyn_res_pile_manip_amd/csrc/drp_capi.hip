@@ -33,9 +33,11 @@ namespace {
 std::string g_create_error;
 
 enum KClass { KC_GRAPH = 0, KC_NODE_ENCODE, KC_EDGE_ENCODE, KC_PROJECT, KC_AGGREGATE, KC_UPDATE,
-              KC_PREDICT, KC_REWARD, KC_MPPI, KC_PROP, KC_COUNT };
+              KC_PREDICT, KC_REWARD, KC_MPPI, KC_PROP, KC_TAPE_COPY, KC_BWD_REWARD, KC_BWD_LISTS, KC_BWD_NODE, KC_BWD_EDGE,
+              KC_BWD_PUSH, KC_OPT, KC_COUNT };
 const char* const kclass_names[KC_COUNT] = {"graph", "node_encode", "edge_encode", "project",
-                                            "aggregate", "update", "predict", "reward", "mppi", "prop"};
+                                            "aggregate", "update", "predict", "reward", "mppi", "prop",
+                                            "tape_copy", "bwd_reward", "bwd_lists", "bwd_node", "bwd_edge", "bwd_push", "opt"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -1555,6 +1557,7 @@ int gd_forward_backward(drp_ctx* c) {
         a.cself = cself; a.cself_ok = cself_ok;
         rc = run_step(c, a);
         if (rc != DRP_OK) break;
+        ProbeScope ps(c, KC_TAPE_COPY);
         rc = d2d(ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, c->s_delta.p, bn * 3 * sizeof(float));
         if (rc == DRP_OK) rc = d2d(ptr<int16_t>(c->tape_idx) + (size_t)t * bn * DRP_K, c->nbr_idx.p, bn * DRP_K * sizeof(int16_t));
         if (rc == DRP_OK) rc = d2d(ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn, c->nbr_cnt.p, bn);
@@ -1567,9 +1570,12 @@ int gd_forward_backward(drp_ctx* c) {
     const float* vw = ptr<float>(c->w_valu);
     const float* wraw = ptr<float>(c->w_raw);
     float* g_state = ptr<float>(c->g_state);                 // [H][B,N,3]
-    hipLaunchKernelGGL(kb_reward, dim3(B), dim3(256), KB_REWARD_LDS(N), st, states + (size_t)(H - 1) * N * 3, hstride,
-                       N, ptr<float>(c->goal_field), c->goal_h, c->goal_w, ptr<float>(c->goal_coor), c->goal_m, c->cam,
-                       1, g_state + (size_t)(H - 1) * bn * 3, (size_t)N * 3);
+    {
+        ProbeScope ps(c, KC_BWD_REWARD);
+        hipLaunchKernelGGL(kb_reward, dim3(B), dim3(256), KB_REWARD_LDS(N), st, states + (size_t)(H - 1) * N * 3, hstride,
+                           N, ptr<float>(c->goal_field), c->goal_h, c->goal_w, ptr<float>(c->goal_coor), c->goal_m, c->cam,
+                           1, g_state + (size_t)(H - 1) * bn * 3, (size_t)N * 3);
+    }
     for (int t = H - 1; t >= 0; --t) {
         const float* s_prev = (t == 0) ? ptr<float>(c->s_in) : states + (size_t)(t - 1) * N * 3;
         const int prev_mod = (t == 0) ? nb : B;
@@ -1580,69 +1586,100 @@ int gd_forward_backward(drp_ctx* c) {
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
         float* gah = ptr<float>(c->g_agg_hist);
-        hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
-                           cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
+        {
+            ProbeScope ps(c, KC_BWD_LISTS);
+            hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
+                               cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
+        }
         if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES) {      // node stages on the matrix cores
             const float* mw = ptr<float>(c->w_mfma);
             const float* mb = ptr<float>(c->w_mfma_bwd);
             const long node_tiles = (long)B * ((N + 31) / 32);
             const dim3 ngrid(mfma_grid(c, node_tiles)), nblk(64 * MFMA_WAVES);
+            { ProbeScope ps(c, KC_BWD_NODE);
             hipLaunchKernelGGL(kmb_predict, ngrid, nblk, KMB_PREDICT_LDS, st, mw, mb, eht + 3 * bn * 64, g_out, (size_t)N * 3, N, B,
                                ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr);
+            }
             // update of the last propagation step, then per step: edge terms, and in one launch the
             // projection of this step with the update of the one before
+            { ProbeScope ps(c, KC_BWD_NODE);
             hipLaunchKernelGGL((kmb_node_step<false, true>), ngrid, nblk, KMB_STEP_LDS(false, true), st, mb, ptr<float>(c->g_eff),
                                (const float*)nullptr, eht + (size_t)DRP_PSTEP * bn * 64, ptr<float>(c->g_cnode), 1,
                                gah + (size_t)(DRP_PSTEP - 1) * bn * 64, N, B);
+            }
             for (int p = DRP_PSTEP - 1; p >= 0; --p) {
                 float* g_agg_p = gah + (size_t)p * bn * 64;
                 const unsigned* mask_p = mht + (size_t)p * bn * DRP_K * 2;
+                { ProbeScope ps(c, KC_BWD_EDGE);
                 hipLaunchKernelGGL(kb_edge_terms, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, cnt, ptr<int>(c->rev_off),
                                    ptr<int>(c->rev), N, ptr<float>(c->g_proj), 1);
+                }
                 if (p > 0)
+                    { ProbeScope ps(c, KC_BWD_NODE);
                     hipLaunchKernelGGL((kmb_node_step<true, true>), ngrid, nblk, KMB_STEP_LDS(true, true), st, mb,
                                        ptr<float>(c->g_eff), ptr<float>(c->g_proj), eht + (size_t)p * bn * 64,
                                        ptr<float>(c->g_cnode), 0, gah + (size_t)(p - 1) * bn * 64, N, B);
+                    }
                 else
+                    { ProbeScope ps(c, KC_BWD_NODE);
                     hipLaunchKernelGGL((kmb_node_step<true, false>), ngrid, nblk, KMB_STEP_LDS(true, false), st, mb,
                                        ptr<float>(c->g_eff), ptr<float>(c->g_proj), (const float*)nullptr, (float*)nullptr, 0,
                                        (float*)nullptr, N, B);
+                    }
             }
+            { ProbeScope ps(c, KC_BWD_NODE);
             hipLaunchKernelGGL(kmb_node_encode, ngrid, nblk, KMB_NODE_ENCODE_LDS, st, mw, mb,
                                ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb,
                                eht, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, B, ptr<float>(c->g_sdelta), (float*)nullptr,
                                (float*)nullptr, (float*)nullptr, (float*)nullptr);
+            }
         } else {
+            { ProbeScope ps(c, KC_BWD_NODE);
             hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn * 64, g_out, (size_t)N * 3, N,
                                ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr, 1);
+            }
             for (int p = DRP_PSTEP - 1; p >= 0; --p) {
                 float* g_agg_p = gah + (size_t)p * bn * 64;
                 const unsigned* mask_p = mht + (size_t)p * bn * DRP_K * 2;
+                { ProbeScope ps(c, KC_BWD_NODE);
                 hipLaunchKernelGGL(kb_update, dim3(B), dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn * 64,
                                    ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, 1);
+                }
+                { ProbeScope ps(c, KC_BWD_EDGE);
                 hipLaunchKernelGGL(kb_edge_terms, dim3(B), dim3(256), 0, st, g_agg_p, mask_p, cnt, ptr<int>(c->rev_off),
                                    ptr<int>(c->rev), N, ptr<float>(c->g_proj), 1);
+                }
+                { ProbeScope ps(c, KC_BWD_NODE);
                 hipLaunchKernelGGL(kb_project, dim3(B), dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), 1);
+                }
             }
+            { ProbeScope ps(c, KC_BWD_NODE);
             hipLaunchKernelGGL(kb_node_encode, dim3(B), dim3(256), 0, st, vw, wraw,
                                ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb, ptr<float>(c->dens),
                                nb, eht, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta),
                                (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1);
+            }
         }
         float* g_prev = nullptr;
         if (t > 0) {
             // d loss / d state[t-1] = residual share + relation encoder + gen_s_delta's position dependence
             g_prev = g_state + (size_t)(t - 1) * bn * 3;
             CHK(d2d(g_prev, g_out, bn * 3 * sizeof(float)));
+            { ProbeScope ps(c, KC_BWD_EDGE);
             hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw,
                                s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx, cnt,
                                gah, mht, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), KbEdgeDump{}, 1);
+            }
+            { ProbeScope ps(c, KC_BWD_EDGE);
             hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
                                ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3);
+            }
         }
+        { ProbeScope ps(c, KC_BWD_PUSH);
         hipLaunchKernelGGL(kb_sdelta, dim3(B), dim3(256), 0, st, s_prev, prev_mod, prev_stride,
                            ptr<float>(c->actions) + (size_t)t * 4, (size_t)H * 4, ptr<float>(c->g_sdelta), N, c->cam,
                            ptr<float>(c->g_act) + (size_t)t * 4, (size_t)H * 4, g_prev, (size_t)N * 3);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
@@ -1728,10 +1765,12 @@ int drp_gd_step(drp_ctx* c, float* rewards_out) {
     // torch.optim.Adam: step_size = lr / (1 - beta1^t), denom = sqrt(v) / sqrt(1 - beta2^t) + eps
     const double bc1 = 1.0 - pow(0.9, (double)c->gd_iter), bc2 = 1.0 - pow(0.999, (double)c->gd_iter);
     const int n = c->gd_B * c->gd_H * 4;
+    { ProbeScope ps(c, KC_OPT);
     hipLaunchKernelGGL(k_adam, dim3((n + 255) / 256), dim3(256), 0, c->stream, ptr<float>(c->actions),
                        ptr<float>(c->g_act), ptr<float>(c->adam_m), ptr<float>(c->adam_v), n, (float)(c->gd_lr / bc1),
                        (float)sqrt(bc2), make_float4(c->gd_lo[0], c->gd_lo[1], c->gd_lo[2], c->gd_lo[3]),
                        make_float4(c->gd_hi[0], c->gd_hi[1], c->gd_hi[2], c->gd_hi[3]));
+    }
     HIPCHK(c, hipGetLastError());
     if (rewards_out) {
         CHK(d2h(c, rewards_out, c->rewards.p, (size_t)c->gd_B * sizeof(float)));

@@ -1043,7 +1043,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     }
     // ---- row order: in-degree descending, row ascending within a degree (deterministic; the encoder's LDS is free now)
     uint16_t* perm = reinterpret_cast<uint16_t*>(pe0_f);
-    const bool ordered = order_rows != 0 && wg_rows <= PROP3_PERM_MAX && wg_rows > 0;
+    bool ordered = order_rows != 0 && wg_rows <= PROP3_PERM_MAX && wg_rows > 0;
     if (ordered) {
         int* hist = reinterpret_cast<int*>(perm + ((PROP3_PERM_MAX + 1) & ~1));      // [PROP_WAVES][11]
         const uint8_t* cnt_rows = nbr_cnt + (size_t)b0 * N;
@@ -1066,6 +1066,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
         __syncthreads();
         // first position of (degree v, this wave): every higher degree of every wave, then degree v of the waves before
         int base[DRP_K + 1];
+        int top = 0;                                   // rows of the largest in-degree present
         {
             int above = 0;
 #pragma unroll
@@ -1077,10 +1078,14 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
                     total += t;
                 }
                 base[v] = above + before;
+                if (above == 0) top = total;
                 above += total;
             }
         }
-        for (int g = g_lo; g < g_hi; ++g) {
+        // a saturated pile (15 of 16 receivers at the largest in-degree: every tile runs that many slots whatever the
+        // order) keeps the natural order, whose rows are consecutive in memory
+        ordered = top * 16 < wg_rows * 15;
+        for (int g = g_lo; g < g_hi && ordered; ++g) {
             const int r = g * 64 + lane;
             const int c = (r < wg_rows) ? min((int)cnt_rows[r], DRP_K) : -1;
             int pos = 0;
