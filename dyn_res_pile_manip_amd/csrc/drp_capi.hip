@@ -58,6 +58,7 @@ struct drp_ctx {
     bool prop3 = true;              // DRP_NO_PROP3=1: one launch per propagation step even for chip-filling batches
     bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
+    bool bwd_fused = true;          // DRP_NO_BWD_FUSED=1: the GD planner's backward pass as one launch per stage
     bool prop3_order = true;        // DRP_NO_PROP3_ORDER=1: km_prop3's tiles in the natural row order instead of by in-degree
     bool prop3e = true;             // DRP_NO_PROP3E=1: the particle encoder stays its own launch in front of km_prop3
 
@@ -638,6 +639,7 @@ int drp_create(int device, drp_ctx** out) {
     c->graph_strips = getenv("DRP_NO_GRAPH_STRIPS") == nullptr;
     c->prop3e = getenv("DRP_NO_PROP3E") == nullptr;
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
+    c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
     if (const char* e = getenv("DRP_SPLIT_SHIFT")) c->re_shift_env = atoi(e);
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
@@ -666,6 +668,7 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_prop<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kmb_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
@@ -1591,7 +1594,17 @@ int gd_forward_backward(drp_ctx* c) {
             hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
                                cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
         }
-        if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES) {      // node stages on the matrix cores
+        const int spw_b = (B + c->n_cu - 1) / c->n_cu;
+        if (c->bwd_fused && B >= c->n_cu && (long)spw_b * N >= 32 * KMB_FUSED_WAVES) {
+            // chip-filling batches: everything between the reward's gradient and the impulses' in one launch,
+            // a workgroup owning whole samples (kmb_step_bwd)
+            ProbeScope ps(c, KC_BWD_NODE);
+            hipLaunchKernelGGL(kmb_step_bwd, dim3((unsigned)((B + spw_b - 1) / spw_b)), dim3(64 * KMB_FUSED_WAVES), KMB_FUSED_LDS, st,
+                               ptr<float>(c->w_mfma), ptr<float>(c->w_mfma_bwd), eht, mht, cnt, ptr<int>(c->rev_off), ptr<int>(c->rev),
+                               g_out, (size_t)N * 3, ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb,
+                               ptr<float>(c->dens), nb, N, B, spw_b, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), gah,
+                               ptr<float>(c->g_sdelta));
+        } else if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES) {      // node stages on the matrix cores
             const float* mw = ptr<float>(c->w_mfma);
             const float* mb = ptr<float>(c->w_mfma_bwd);
             const long node_tiles = (long)B * ((N + 31) / 32);

@@ -244,3 +244,245 @@ kmb_node_encode(const float* __restrict__ mw, const float* __restrict__ mb, cons
 // LDS fill of the packed weights is not amortised)
 #define KMB_MIN_TILES 1024
 #define KMB_NODE_ENCODE_LDS ((size_t)(512 + 2 * 4096 + 192) * sizeof(float))
+
+// ---- the whole node / edge part of one rollout step's backward pass in ONE launch (the GD planner) ------------
+// The sequence above -- kmb_predict, then per propagation step kb_edge_terms between two kmb_node_step halves,
+// then kmb_node_encode -- is nine launches whose intermediates (g_proj [B,N,128] written and read three times,
+// g_eff, g_cnode) cross HBM each time: 0.75 ms of a 1.31 ms planner iteration at the demo shape, none of it
+// arithmetic.  Here a workgroup owns whole samples, as km_prop3 does forward: the only cross-row dependency of the
+// backward pass is the gather of g_agg rows over the REVERSED neighbour lists, and those are rows of the same
+// sample, so __syncthreads() between phases is all the ordering it needs.
+//   phase P : predictor backward and the update of propagation step 2          (row-local)   -> g_eff, g_cnode, g_agg[2]
+//   phase p = 2, 1, 0 : receiver term (own masks) and sender term (reversed lists, masks, gathered g_agg[p] rows)
+//             stay in registers and go straight into W_r^T / W_s^T; then the update of step p-1 (-> g_agg[p-1]),
+//             or, for p = 0, the particle encoder's backward (-> g_s_delta)       -> g_proj never exists
+// Tiles are 32 consecutive rows of the workgroup's row list (only its last tile has idle lanes), drawn on demand.
+// Every sum runs in a fixed order (slot order, reversed-list order): gradients are bit-reproducible.
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout, as the launch-per-stage kernels.
+#define KMB_FUSED_WAVES 8
+#define KMB_FUSED_LDS ((size_t)(7 * 4096 + 512 + 256 + 192 + 4) * sizeof(float))
+__global__ void __launch_bounds__(64 * KMB_FUSED_WAVES)
+kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
+             const float* __restrict__ eff_hist /* [4][B*N,64] */, const unsigned* __restrict__ mask_hist /* [3][B*N*10][2] */,
+             const uint8_t* __restrict__ nbr_cnt, const int* __restrict__ rev_off, const int* __restrict__ rev,
+             const float* __restrict__ g_out, size_t g_stride, const float* __restrict__ s_delta,
+             const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+             int N, int B, int spw, float* __restrict__ g_eff, float* __restrict__ g_cnode,
+             float* __restrict__ g_agg_hist /* [3][B*N,64] */, float* __restrict__ g_sdelta) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w0 = lds;                 // predictor layer 0, forward pack
+    float* w0t = w0 + 4096;          // transposed
+    float* wagg = w0t + 4096;        // W_agg^T
+    float* wr = wagg + 4096;         // W_r^T
+    float* ws = wr + 4096;           // W_s^T
+    float* wpet = ws + 4096;         // W_pe^T
+    float* w2t = wpet + 4096;        // particle encoder layer 2, transposed
+    float* w1 = w2t + 4096;          // particle encoder layer 0, forward pack (K = 8)
+    float* rows_pr = w1 + 512;       // b_pr0 [64], w_pr1 [3][64]
+    float* rows_pe = rows_pr + 256;  // encoder layer-0 columns 0..2
+    int* ctr = reinterpret_cast<int*>(rows_pe + 192);
+    lds_fill(w0, mw + M_PR0, 4096);
+    lds_fill(w0t, mb + MB_PR0, 4096);
+    lds_fill(wagg, mb + MB_AGG, 3 * 4096);          // MB_AGG, MB_RPR, MB_RPS are consecutive
+    lds_fill(wpet, mb + MB_PPE, 2 * 4096);          // MB_PPE, MB_PE2
+    lds_fill(w1, mw + M_PE0, 512);
+    lds_fill(rows_pr, mw + R_PR0_B, 256);
+    lds_fill(rows_pe, mb + RB_PE0, 192);
+    if (threadIdx.x == 0) *ctr = KMB_FUSED_WAVES;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b0 = blockIdx.x * spw, nbw = min(spw, B - b0);
+    const int wg_rows = (nbw > 0 ? nbw : 0) * N;
+    const int wg_tiles = (wg_rows + 31) >> 5;
+    const float inv_N = 1.0f / (float)N;
+    const size_t bn64 = (size_t)B * N * 64;
+    const size_t bnk2 = (size_t)B * N * DRP_K * 2;
+    auto next_tile = [&]() {
+        int q = 0;
+        if (lane == 0) q = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(q);
+    };
+    auto phase_end = [&]() {
+        __syncthreads();                                   // this phase's rows of the workgroup's samples are written
+        if (threadIdx.x == 0) *ctr = KMB_FUSED_WAVES;
+        __syncthreads();
+    };
+    // ---- phase P: predictor backward (kmb_predict) + update of the last propagation step
+    {
+        const float* eff3 = eff_hist + 3 * bn64;
+        float* g_agg2 = g_agg_hist + 2 * bn64;
+        for (int li = wave; li < wg_tiles; li = next_tile()) {
+            const bool live = (li * 32 + j) < wg_rows;
+            const int r = min(li * 32 + j, wg_rows - 1);
+            int m, i;
+            divmod_small(r, N, inv_N, m, i);
+            const int b = b0 + m;
+            const size_t row = (size_t)b0 * N + r;
+            Frag x, hh, gh, ge;
+            frag_from_row(eff3 + row * 64, h, x);
+            frag_from_row(rows_pr, h, hh);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(w0), x, hh, lane);
+            const float* go = g_out + (size_t)b * g_stride + (size_t)i * 3;
+            const float g0 = go[0], g1 = go[1], g2 = go[2];
+            {
+                Frag wx, wy, wz;
+                frag_from_row(rows_pr + 64, h, wx);
+                frag_from_row(rows_pr + 128, h, wy);
+                frag_from_row(rows_pr + 192, h, wz);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float g = wx.v[ob][q] * g0 + wy.v[ob][q] * g1 + wz.v[ob][q] * g2;
+                        gh.v[ob][q] = hh.v[ob][q] > 0.0f ? g : 0.0f;
+                    }
+            }
+            frag_zero(ge);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(w0t), gh, ge, lane);
+            // update of step 2: g_z = g_eff . [eff3 > 0]; g_cnode = g_z; g_agg[2] = W_agg^T g_z
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                ge.v[0][q] = x.v[0][q] > 0.0f ? ge.v[0][q] : 0.0f;
+                ge.v[1][q] = x.v[1][q] > 0.0f ? ge.v[1][q] : 0.0f;
+            }
+            if (live) {
+                frag_to_row(g_eff + row * 64, h, ge);
+                frag_to_row(g_cnode + row * 64, h, ge);
+            }
+            Frag ga;
+            frag_zero(ga);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(wagg), ge, ga, lane);
+            if (live) frag_to_row(g_agg2 + row * 64, h, ga);
+        }
+    }
+    // ---- phases p = 2, 1, 0
+#pragma unroll 1
+    for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+        phase_end();
+        const float* g_agg_p = g_agg_hist + (size_t)p * bn64;
+        const unsigned* mask_p = mask_hist + (size_t)p * bnk2;
+        for (int li = wave; li < wg_tiles; li = next_tile()) {
+            const bool live = (li * 32 + j) < wg_rows;
+            const int r = min(li * 32 + j, wg_rows - 1);
+            int m, i;
+            divmod_small(r, N, inv_N, m, i);
+            const int b = b0 + m;
+            const size_t row = (size_t)b0 * N + r;
+            const size_t srow0 = (size_t)b * N;                       // first row of the lane's sample
+            // receiver term: g_agg[p][row] under the masks of the row's own slots, one addition per slot
+            Frag gi, pr, ps;
+            frag_from_row(g_agg_p + row * 64, h, gi);
+            frag_zero(pr);
+            frag_zero(ps);
+            const int cnt = nbr_cnt[row];
+            const int* ro = rev_off + (size_t)b * (N + 1);
+            const int p0 = ro[i], p1 = ro[i + 1];
+            const int* rv = rev + srow0 * DRP_K;
+            const unsigned* mk = mask_p + srow0 * DRP_K * 2;          // the sample's slots, word h of a slot at [slot * 2 + h]
+            int cmax = cnt, lmax = p1 - p0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                cmax = max(cmax, __shfl_xor(cmax, o, 64));
+                lmax = max(lmax, __shfl_xor(lmax, o, 64));
+            }
+            for (int k = 0; k < cmax; ++k) {
+                const unsigned w = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + h] : 0u;
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        pr.v[ob][q] += ((w >> (31 - (16 * ob + q))) & 1u) ? gi.v[ob][q] : 0.0f;
+            }
+            // sender term over the reversed list (ascending receiver, then slot): the entry after next is
+            // requested while this one's mask word and row are in flight
+            int e0 = (0 < p1 - p0) ? rv[p0] : 0;
+            int e1 = (1 < p1 - p0) ? rv[p0 + 1] : 0;
+            for (int q0 = 0; q0 < lmax; ++q0) {
+                const bool on = q0 < p1 - p0;
+                const int e = e0;
+                e0 = e1;
+                e1 = (q0 + 2 < p1 - p0) ? rv[p0 + q0 + 2] : 0;
+                const unsigned w = on ? mk[(size_t)e * 2 + h] : 0u;
+                int er, ek;
+                divmod_small(e, DRP_K, 0.1f, er, ek);
+                Frag v;
+                frag_from_row(g_agg_p + (srow0 + (on ? er : i)) * 64, h, v);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        ps.v[ob][q] += ((w >> (31 - (16 * ob + q))) & 1u) ? v.v[ob][q] : 0.0f;
+            }
+            // projection backward: g_eff += W_r^T (receiver term) + W_s^T (sender term)
+            Frag ge;
+            frag_from_row(g_eff + row * 64, h, ge);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(wr), pr, ge, lane);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(ws), ps, ge, lane);
+            if (p > 0) {
+                // update of step p - 1: g_z = g_eff . [eff_p > 0]; g_eff <- g_z; g_cnode += g_z; g_agg[p-1] = W_agg^T g_z
+                Frag en, ga;
+                frag_from_row(eff_hist + (size_t)p * bn64 + row * 64, h, en);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    ge.v[0][q] = en.v[0][q] > 0.0f ? ge.v[0][q] : 0.0f;
+                    ge.v[1][q] = en.v[1][q] > 0.0f ? ge.v[1][q] : 0.0f;
+                }
+                if (live) frag_to_row(g_eff + row * 64, h, ge);
+                frag_from_row(g_cnode + row * 64, h, en);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { en.v[0][q] += ge.v[0][q]; en.v[1][q] += ge.v[1][q]; }
+                if (live) frag_to_row(g_cnode + row * 64, h, en);
+                frag_zero(ga);
+                mfma_layer64<false>(reinterpret_cast<const float4*>(wagg), ge, ga, lane);
+                if (live) frag_to_row(g_agg_hist + (size_t)(p - 1) * bn64 + row * 64, h, ga);
+            } else {
+                // particle encoder backward (kmb_node_encode): g_pe = g_eff0 + W_pe^T g_cnode, through
+                // relu(W2 relu(W1 x + b1) + b2) to the three impulse inputs
+                int q_, bm;
+                divmod_small(b, attr_mod, 1.0f / (float)attr_mod, q_, bm);
+                const float d = dens[bm] / DRP_DENS_SCALE;
+                const float* sd = s_delta + row * 3;
+                const float at = attr[(size_t)bm * N + i];
+                float x[4];
+                if (h == 0) { x[0] = sd[0]; x[1] = sd[2]; x[2] = d; x[3] = 0.0f; }
+                else { x[0] = sd[1]; x[1] = at; x[2] = 1.0f; x[3] = 0.0f; }
+                Frag h1, g, gh;
+                frag_zero(h1);
+                mfma_layer8(reinterpret_cast<const float4*>(w1), x, h1, lane);
+                frag_from_row(g_cnode + row * 64, h, g);
+                mfma_layer64<false>(reinterpret_cast<const float4*>(wpet), g, ge, lane);
+                frag_from_row(eff_hist + row * 64, h, g);                 // pe = effect after the encoder
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    ge.v[0][q] = g.v[0][q] > 0.0f ? ge.v[0][q] : 0.0f;
+                    ge.v[1][q] = g.v[1][q] > 0.0f ? ge.v[1][q] : 0.0f;
+                }
+                frag_zero(gh);
+                mfma_layer64<false>(reinterpret_cast<const float4*>(w2t), ge, gh, lane);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    gh.v[0][q] = h1.v[0][q] > 0.0f ? gh.v[0][q] : 0.0f;
+                    gh.v[1][q] = h1.v[1][q] > 0.0f ? gh.v[1][q] : 0.0f;
+                }
+                float out[3];
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    Frag w;
+                    frag_from_row(rows_pe + 64 * o, h, w);
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc = fmaf(gh.v[0][q], w.v[0][q], acc);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc = fmaf(gh.v[1][q], w.v[1][q], acc);
+                    out[o] = acc + __shfl_xor(acc, 32, 64);
+                }
+                if (live && h == 0) {
+                    g_sdelta[row * 3 + 0] = out[0];
+                    g_sdelta[row * 3 + 1] = out[1];
+                    g_sdelta[row * 3 + 2] = out[2];
+                }
+            }
+        }
+    }
+}

@@ -253,6 +253,14 @@ __device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ s
     if (i < n) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
 }
 
+// quotient and remainder of small non-negative integers through the fp32 reciprocal, corrected to be exact
+__device__ __forceinline__ void divmod_small(int x, int n, float inv_n, int& q, int& r) {
+    q = (int)((float)x * inv_n);
+    r = x - q * n;
+    if (r < 0) { r += n; --q; }
+    else if (r >= n) { r -= n; ++q; }
+}
+
 // bias row + d * w_d row, as this lane's fragment
 __device__ __forceinline__ void frag_bias_dens(const float* b_row, const float* wd_row, float d, int h, Frag& f) {
     Frag w;

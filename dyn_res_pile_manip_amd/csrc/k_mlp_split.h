@@ -561,14 +561,6 @@ struct LaneRow {
     bool live;                // false: a clamped duplicate past the end (computed, never stored)
 };
 
-// quotient and remainder of small non-negative integers through the fp32 reciprocal, corrected to be exact
-__device__ __forceinline__ void divmod_small(int x, int n, float inv_n, int& q, int& r) {
-    q = (int)((float)x * inv_n);
-    r = x - q * n;
-    if (r < 0) { r += n; --q; }
-    else if (r >= n) { r -= n; ++q; }
-}
-
 template <bool LAST, bool TAPE, class Decode, class RowOf>
 __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, Decode decode, RowOf row_of, int lane, int wave
 #ifdef PROP_STAMPS
