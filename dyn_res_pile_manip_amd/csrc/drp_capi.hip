@@ -650,7 +650,8 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)k_graph_strips<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REWARD_LDS(4096)) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_EDGE_ENCODE_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)kb_reverse_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kb_reverse_lists<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kb_reverse_lists<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_aggregate_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                             K_AGG_LDS_MAX_N * 256) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
@@ -1558,12 +1559,15 @@ int gd_forward_backward(drp_ctx* c) {
         a.eff_hist = eh + (size_t)t * 4 * bn * 64;
         a.mask_hist = mh + (size_t)t * DRP_PSTEP * bn * DRP_K * 2;
         a.cself = cself; a.cself_ok = cself_ok;
+        // the step's impulses and neighbour lists are part of the tape: the step writes them there (its
+        // workspace pointers are lent the tape's slices for the call) instead of being copied afterwards
+        void* const save_sd = c->s_delta.p; void* const save_idx = c->nbr_idx.p; void* const save_cnt = c->nbr_cnt.p;
+        c->s_delta.p = ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3;
+        c->nbr_idx.p = ptr<int16_t>(c->tape_idx) + (size_t)t * bn * DRP_K;
+        c->nbr_cnt.p = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         rc = run_step(c, a);
+        c->s_delta.p = save_sd; c->nbr_idx.p = save_idx; c->nbr_cnt.p = save_cnt;
         if (rc != DRP_OK) break;
-        ProbeScope ps(c, KC_TAPE_COPY);
-        rc = d2d(ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, c->s_delta.p, bn * 3 * sizeof(float));
-        if (rc == DRP_OK) rc = d2d(ptr<int16_t>(c->tape_idx) + (size_t)t * bn * DRP_K, c->nbr_idx.p, bn * DRP_K * sizeof(int16_t));
-        if (rc == DRP_OK) rc = d2d(ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn, c->nbr_cnt.p, bn);
     }
     c->engine = saved_engine;
     CHK(rc);
@@ -1591,8 +1595,12 @@ int gd_forward_backward(drp_ctx* c) {
         float* gah = ptr<float>(c->g_agg_hist);
         {
             ProbeScope ps(c, KC_BWD_LISTS);
-            hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
-                               cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
+            if (N <= 512)
+                hipLaunchKernelGGL(kb_reverse_lists<256>, dim3(B), dim3(256), KB_REV_LDS(N, rev_lds), st, idx,
+                                   cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
+            else
+                hipLaunchKernelGGL(kb_reverse_lists<1024>, dim3(B), dim3(1024), KB_REV_LDS(N, rev_lds), st, idx,
+                                   cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
         }
         const int spw_b = (B + c->n_cu - 1) / c->n_cu;
         if (c->bwd_fused && B >= c->n_cu && (long)spw_b * N >= 32 * KMB_FUSED_WAVES) {
@@ -1891,8 +1899,12 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
         float* gah = ptr<float>(c->g_agg_hist);
-        hipLaunchKernelGGL(kb_reverse_lists, dim3(B), dim3(KB_REV_THREADS), KB_REV_LDS(N, rev_lds), st, idx,
-                           cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums));
+        if (N <= 512)
+            hipLaunchKernelGGL(kb_reverse_lists<256>, dim3(B), dim3(256), KB_REV_LDS(N, rev_lds), st, idx,
+                               cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums));
+        else
+            hipLaunchKernelGGL(kb_reverse_lists<1024>, dim3(B), dim3(1024), KB_REV_LDS(N, rev_lds), st, idx,
+                               cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums));
         // node-level stages: on the matrix cores when the batch has enough 32-row tiles to fill the chip,
         // otherwise the row kernels chunked over (sample, rows)
         if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES) {
@@ -2246,6 +2258,14 @@ long drp_debug_fetch(drp_ctx* c, const char* name, void* out, size_t out_bytes) 
     else if (!strcmp(name, "agg")) { b = &c->agg; bytes = bn * 64 * 4; }
     else if (!strcmp(name, "stats")) { b = &c->stats; bytes = 8 * sizeof(double); }
     else return fail(c, DRP_EINVAL, "unknown buffer '%s'", name);
+    // a GD session keeps every step's impulses and lists in its tape, not in the step workspace: the last step's
+    DevBuf tape{};
+    if (c->gd_on && c->gd_H > 0 && bn == (size_t)c->gd_B * c->gd_N) {
+        const size_t t = (size_t)c->gd_H - 1;
+        if (b == &c->s_delta) { tape.p = ptr<float>(c->tape_sdelta) + t * bn * 3; tape.cap = bytes; b = &tape; }
+        else if (b == &c->nbr_idx) { tape.p = ptr<int16_t>(c->tape_idx) + t * bn * DRP_K; tape.cap = bytes; b = &tape; }
+        else if (b == &c->nbr_cnt) { tape.p = ptr<uint8_t>(c->tape_cnt) + t * bn; tape.cap = bytes; b = &tape; }
+    }
     if (!b->p || bytes == 0 || bytes > b->cap) return fail(c, DRP_ESTATE, "buffer '%s' not populated", name);
     if (out_bytes < bytes) return fail(c, DRP_EINVAL, "buffer '%s' needs %zu bytes", name, bytes);
     if (hipMemcpyAsync(out, b->p, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

@@ -201,13 +201,16 @@ kb_update(const float* __restrict__ wraw, const float* __restrict__ eff_next, fl
 #define KB_REV_THREADS 1024
 #define KB_REV_LDS(N, in_lds) ((size_t)((in_lds) ? 12 : 2) * (N) * sizeof(int))
 #define KB_REV_LDS_MAX_N 3072
-__global__ void __launch_bounds__(KB_REV_THREADS)
+// T threads per sample: 1024, or 256 for samples of up to 512 particles (four times as many samples in flight per CU:
+// the kernel is a chain of short LDS phases, 45 -> 15 us at 1500 x 100)
+template <int T>
+__global__ void __launch_bounds__(T)
 kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt, int N,
                  int* __restrict__ rev_off /* [B][N+1] */, int* __restrict__ rev /* [B][N*10] */, int in_lds,
                  const int* __restrict__ n_real /* nullable [B]: receivers >= n_real[b] are padding whose
                                                    gradient is identically zero (training batches) */) {
     extern __shared__ int s_rev[];
-    __shared__ int s_w[KB_REV_THREADS / 64];
+    __shared__ int s_w[T / 64];
     int* deg = s_rev;
     int* off = s_rev + N;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -217,15 +220,15 @@ kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict_
     int* rv = rev + (size_t)b * N * DRP_K;
     int* fill = in_lds ? s_rev + 2 * N : rv;
     const int n_recv = n_real ? n_real[b] : N;
-    for (int i = tid; i < N; i += KB_REV_THREADS) deg[i] = 0;
+    for (int i = tid; i < N; i += T) deg[i] = 0;
     __syncthreads();
-    for (int e = tid; e < N * DRP_K; e += KB_REV_THREADS) {
+    for (int e = tid; e < N * DRP_K; e += T) {
         const int i = e / DRP_K, k = e - i * DRP_K;
         if (k < nc[i] && i < n_recv) atomicAdd(&deg[nb[e]], 1);
     }
     __syncthreads();
     // exclusive scan of deg: every thread owns a contiguous segment
-    const int seg = (N + KB_REV_THREADS - 1) / KB_REV_THREADS;
+    const int seg = (N + T - 1) / T;
     const int lo = min(tid * seg, N), hi = min(lo + seg, N);
     int sum = 0;
     for (int i = lo; i < hi; ++i) sum += deg[i];
@@ -239,16 +242,16 @@ kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict_
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
     int base = inc - sum, total = 0;
-    for (int w = 0; w < KB_REV_THREADS / 64; ++w) {
+    for (int w = 0; w < T / 64; ++w) {
         if (w < wave) base += s_w[w];
         total += s_w[w];
     }
     for (int i = lo; i < hi; ++i) { off[i] = base; base += deg[i]; }
     __syncthreads();
-    for (int i = tid; i < N; i += KB_REV_THREADS) { ro[i] = off[i]; deg[i] = 0; }
+    for (int i = tid; i < N; i += T) { ro[i] = off[i]; deg[i] = 0; }
     if (tid == 0) ro[N] = total;
     __syncthreads();
-    for (int e = tid; e < N * DRP_K; e += KB_REV_THREADS) {
+    for (int e = tid; e < N * DRP_K; e += T) {
         const int i = e / DRP_K, k = e - i * DRP_K;
         if (k < nc[i] && i < n_recv) {
             const int j = nb[e];
@@ -256,7 +259,7 @@ kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict_
         }
     }
     __syncthreads();
-    for (int j = tid; j < N; j += KB_REV_THREADS) {  // fixed order inside every sender's list
+    for (int j = tid; j < N; j += T) {  // fixed order inside every sender's list
         int* seg_j = fill + off[j];
         const int n = deg[j];
         for (int a = 1; a < n; ++a) {
@@ -268,7 +271,7 @@ kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict_
     }
     if (in_lds) {
         __syncthreads();
-        for (int p = tid; p < total; p += KB_REV_THREADS) rv[p] = fill[p];
+        for (int p = tid; p < total; p += T) rv[p] = fill[p];
     }
 }
 
