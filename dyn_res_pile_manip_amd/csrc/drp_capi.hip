@@ -1571,9 +1571,7 @@ int gd_forward_backward(drp_ctx* c) {
     }
     c->engine = saved_engine;
     CHK(rc);
-    // reward of the final step only (planners.py:436-438)
-    CHK(run_reward(c, states + (size_t)(H - 1) * N * 3, hstride, B, N, 1, ptr<float>(c->rewards)));
-    // ---- backward through time
+    // reward of the final step only (planners.py:436-438) and its gradient, in one launch
     const float* vw = ptr<float>(c->w_valu);
     const float* wraw = ptr<float>(c->w_raw);
     float* g_state = ptr<float>(c->g_state);                 // [H][B,N,3]
@@ -1581,7 +1579,7 @@ int gd_forward_backward(drp_ctx* c) {
         ProbeScope ps(c, KC_BWD_REWARD);
         hipLaunchKernelGGL(kb_reward, dim3(B), dim3(256), KB_REWARD_LDS(N), st, states + (size_t)(H - 1) * N * 3, hstride,
                            N, ptr<float>(c->goal_field), c->goal_h, c->goal_w, ptr<float>(c->goal_coor), c->goal_m, c->cam,
-                           1, g_state + (size_t)(H - 1) * bn * 3, (size_t)N * 3);
+                           1, g_state + (size_t)(H - 1) * bn * 3, (size_t)N * 3, ptr<float>(c->rewards));
     }
     for (int t = H - 1; t >= 0; --t) {
         const float* s_prev = (t == 0) ? ptr<float>(c->s_in) : states + (size_t)(t - 1) * N * 3;

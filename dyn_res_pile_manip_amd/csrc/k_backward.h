@@ -15,6 +15,7 @@
 // (kb_reverse_lists, kb_edge_terms, kb_gather_pos): no atomics, reproducible sums.
 #pragma once
 #include "drp_common.h"
+#include "k_reward.h"
 #include "k_graph.h"
 #include "k_mlp_valu.h"
 
@@ -53,14 +54,18 @@ __device__ __forceinline__ KbRange kb_range(int N, int chunks) {
 //   r2 = sum_m min_n |g_m - pix_n|     -> -(g_m - pix_n*) / dist to the arg-min particle n*
 //   pix = (x fx / z + cx, y fy / z + cy)
 // one workgroup per state row; gradient accumulated in LDS, then written.  dynamic LDS = KB_REWARD_LDS(N).
-#define KB_REWARD_LDS(N) ((size_t)(2 * (N)) * sizeof(float) + (size_t)(2 * (N)) * sizeof(long long))
+// reward_out (nullable): the reward itself too, in k_reward's arithmetic and reduction order (the same bits) --
+// the planner's iteration then needs one launch for the reward and its gradient instead of two.
+#define KB_REWARD_LDS(N) ((size_t)(2 * (N) + 8) * sizeof(float) + (size_t)(2 * (N)) * sizeof(long long))
 __global__ void __launch_bounds__(256)
 kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float* __restrict__ G, int Hh, int Ww,
           const float* __restrict__ goal_coor, int M, DrpCam cam, int normalize, float* __restrict__ g_state,
-          size_t g_stride) {
+          size_t g_stride, float* __restrict__ reward_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* px = lds;
     float* py = lds + N;
+    float* red = lds + 2 * N + 4 * N;                 // behind the two long long arrays
+    float r1 = 0.0f, r2 = 0.0f;
     // d loss / d pixel, accumulated as 2^-40 fixed point: integer adds commute, so the many goal
     // points whose nearest particle is the same one can add in any order and the sum is the same
     // bits every run (fp32 LDS atomics were the last source of run-to-run differences)
@@ -93,6 +98,19 @@ kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float
         const float dgy = (g10 - g00) * (1.0f - tx) + (g11 - g01) * tx;
         gx[n] = __float2ll_rn(scale * dgx * mx * FIX);
         gy[n] = __float2ll_rn(scale * dgy * my * FIX);
+        if (reward_out != nullptr) {
+            // k_reward's forward value: border clamp of the coordinates and of the upper taps
+            const float fx_ = fminf(fmaxf(((nx + 1.0f) * (float)Ww - 1.0f) / 2.0f, 0.0f), (float)(Ww - 1));
+            const float fy_ = fminf(fmaxf(((ny + 1.0f) * (float)Hh - 1.0f) / 2.0f, 0.0f), (float)(Hh - 1));
+            const float fx0 = floorf(fx_), fy0 = floorf(fy_);
+            const float ftx = fx_ - fx0, fty = fy_ - fy0;
+            const int ax0 = (int)fx0, ay0 = (int)fy0;
+            const int ax1 = min(ax0 + 1, Ww - 1), ay1 = min(ay0 + 1, Hh - 1);
+            const float f00 = G[(size_t)ay0 * Ww + ax0], f01 = G[(size_t)ay0 * Ww + ax1];
+            const float f10 = G[(size_t)ay1 * Ww + ax0], f11 = G[(size_t)ay1 * Ww + ax1];
+            r1 += f00 * ((1.0f - ftx) * (1.0f - fty)) + f01 * (ftx * (1.0f - fty)) +
+                  f10 * ((1.0f - ftx) * fty) + f11 * (ftx * fty);
+        }
     }
     __syncthreads();
     for (int m = threadIdx.x; m < M; m += blockDim.x) {
@@ -104,7 +122,8 @@ kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float
             const float d2 = dx * dx + dy * dy;
             if (d2 < best) { best = d2; arg = n; }       // first minimum, as torch.min
         }
-        const float dist = sqrtf(best);
+        const float dist = __fsqrt_rn(best);
+        r2 += dist;
         // d |q - p| / d p = -(q - p) / dist
         atomicAdd(reinterpret_cast<unsigned long long*>(&gx[arg]), (unsigned long long)__float2ll_rn(-scale * (qx - px[arg]) / dist * FIX));
         atomicAdd(reinterpret_cast<unsigned long long*>(&gy[arg]), (unsigned long long)__float2ll_rn(-scale * (qy - py[arg]) / dist * FIX));
@@ -117,6 +136,15 @@ kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float
         g[n * 3 + 0] = gxn * cam.fx / z;
         g[n * 3 + 1] = gyn * cam.fy / z;
         g[n * 3 + 2] = -(gxn * x * cam.fx + gyn * y * cam.fy) / (z * z);
+    }
+    if (reward_out != nullptr) {
+        const float t1 = block_sum_256(r1, red);
+        const float t2 = block_sum_256(r2, red);
+        if (threadIdx.x == 0) {
+            float r = t1 + t2;
+            if (normalize) r = __fdiv_rn(r, (float)N);
+            reward_out[blockIdx.x] = -r;
+        }
     }
 }
 
