@@ -17,7 +17,7 @@ import os
 import sys
 
 CLASS = {'k_graph': 'graph', 'k_graph_strips': 'graph', 'k_graph_sort': 'graph_sort', 'k_node_encode': 'node_encode', 'k_edge_encode': 'edge_encode',
-         'k_project': 'project', 'k_aggregate': 'aggregate', 'k_update': 'update',
+         'k_project': 'project', 'k_aggregate': 'aggregate', 'k_aggregate_lds': 'aggregate', 'k_update': 'update',
          'k_predict': 'predict', 'km_node_encode': 'node_encode', 'km_node_encode_split': 'node_encode', 'km_edge_encode': 'edge_encode',
          'km_update<false>': 'update', 'km_update<true>': 'predict', 'k_reward': 'reward',
          'km_prop<false>': 'prop', 'km_prop<true>': 'prop_last', 'km_prop3': 'prop3'}
