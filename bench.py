@@ -242,6 +242,17 @@ def run_gd(args):
             mfmas = 3 * tile_max.size * ((tile_max - 1).clip(min=0).mean() * 78 + (2 * 144 + 96) / 3.0) + tile_max.size * 204
             roof = {'bound': 'mfma', 'achieved': mfmas * 32768.0 / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                     'slot_iterations_per_tile': float((tile_max - 1).clip(min=0).mean()), 'tiles_per_step': int(tile_max.size)}
+        elif dominant == 'bwd_node' and per_class['bwd_edge'][1] == 0:
+            # kmb_step_bwd (the whole node / edge backward of a rollout step in one launch): algorithmic
+            # bytes per node -- phase P: effect row + reward gradient in, g_eff / g_cnode / g_agg rows out; per
+            # propagation step: own g_agg and g_eff rows, own masks, one (list entry, mask, g_agg row) per edge the
+            # node feeds; steps 2 and 1 also the effect row in, g_eff / g_agg rows out and g_cnode in and out; step 0
+            # g_cnode, encoder effect and impulse in, impulse gradient out
+            per_node = (256 + 12 + 3 * 256) + 3 * (2 * 256 + 8 * kbar + kbar * (4 + 8 + 256)) + 2 * (256 + 2 * 256 + 2 * 256) + (2 * 256 + 24)
+            work = B * N * per_node
+            roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'algorithmic_bytes_per_launch': work,
+                    'note': 'kmb_step_bwd: fp32 MFMA for the seven 64x64 products per node, bound by the rows it moves; the gathered g_agg rows mostly hit L2'}
         elif dominant == 'bwd_edge':
             # kb_edge_terms per node and propagation step: own g_agg row + own masks read, both g_proj halves written,
             # then one (mask, g_agg row, list entry) per edge the node feeds
@@ -269,7 +280,7 @@ def run_gd(args):
             import torch as _t
             from oracle import propnet_dense as od
             W = od.load_weights(sd)
-            cpu_traj = 4
+            cpu_traj = traj            # the whole demo batch: about 5 s of host work
             a_cpu = acts[:cpu_traj * nb]
             _t.set_num_threads(min(32, os.cpu_count() or 1))
             od.gd_loss_and_grads(W, s0, dens, attr, a_cpu[:nb], G, cam, goal_coor, syn.demo_cam_extrinsics(), 24)   # warm-up
