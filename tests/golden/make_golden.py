@@ -362,6 +362,28 @@ def main():
         gr[name + '/grad_act'] = a_t.grad.numpy()
     np.savez_compressed(os.path.join(HERE, 'grad.npz'), **gr)
 
+    # ---- the sampler's other noise types (planners.py:123-135,169-175): statistics of the reference's draws --------
+    mn = {}
+    nom = syn.nominal_pushes(5, seed=0)
+    for nt in ('uniform', 'total_rand'):
+        np.random.seed(4321)
+        samp = planner.sample_action_sequences(nom[:, None, :], np.zeros(5), 4096, lo, hi, noise_type=nt)[:, :, 0, :]
+        mn[nt + '/mean'], mn[nt + '/std'] = samp.mean(0), samp.std(0)
+        mn[nt + '/min'], mn[nt + '/max'] = samp.min(0), samp.max(0)
+        resid = samp - nom[None]
+        mn[nt + '/resid_lag1_corr'] = np.array([np.corrcoef(resid[:, t, 0], resid[:, t + 1, 0])[0, 1] for t in range(4)])
+    mn['nominal'] = nom
+    # the 2-D form clips a step to the convex region its label selects (planners.py:151-159): two regions, labels 0/1
+    env2 = syn.SyntheticEnv(config)
+    env2.cvx_region = np.array([[-5.0, 5.0, -5.0, 5.0], [-2.0, 1.0, -1.0, 3.0]])
+    planner2 = ref_planners.PlannerGD(config, env2)
+    np.random.seed(99)
+    lab = np.array([0, 1, 1, 0, 1])
+    s2 = planner2.sample_action_sequences(nom, lab, 512, lo, hi)
+    mn['label/labels'], mn['label/cvx_region'] = lab, env2.cvx_region
+    mn['label/min'], mn['label/max'] = s2.min(0), s2.max(0)
+    np.savez_compressed(os.path.join(HERE, 'mppi_noise.npz'), **mn)
+
     # ---- the GD planner with a BINDING time budget (a14, a15; planners.py:590,679-682) -------------
     # N = 40 -> particle_num_to_iter_time = 15 ms; time_lim = 50 ms -> int(50 / 15) = 3 of the 10 allowed
     # iterations; gd_loop = 2 only sizes rew_mean / rew_std ([1, 20], planners.py:647-648)

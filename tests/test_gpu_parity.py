@@ -219,6 +219,42 @@ def test_mppi_sampler(ctx, golden):
     assert np.abs(b - a).max() > 0.1                        # a new iteration draws new noise
 
 
+@pytest.mark.parametrize('noise_type', ['uniform', 'total_rand'])
+def test_device_sampler_noise_types(ctx, golden, noise_type):
+    """drp_mpc_params.noise_type (planners.py:123-135,169-175): host-fed draws reproduce the host mirror's
+    arithmetic exactly; Philox draws match the statistics of the reference's own sampler (mppi_noise.npz)."""
+    g = golden.mppi_noise
+    N = 16
+    s0, dens, attr = syn.make_pile(N, 1, seed=0)
+    lo, hi = syn.action_limits()
+    ns, H = 4096, 5
+    nom = g['nominal']
+    sigma = 2.0 * 24 / 12.0 if noise_type == 'uniform' else 0.6
+    ctx.mpc_begin(s0, attr, dens, nom, n_sample=ns, sigma=sigma, beta_filter=0.7, reward_weight=0.1, act_lo=lo,
+                  act_hi=hi, seed=11, noise_type=noise_type)
+    rng = np.random.default_rng(6)
+    u = (rng.random((ns, H, 4)) * (2.0 if noise_type == 'uniform' else 1.0) - (1.0 if noise_type == 'uniform' else 0.0)).astype(np.float32)
+    ctx.mpc_sample(0, noise=u)
+    a = ctx.mpc_get(actions=True)['actions'].astype(np.float64)
+    if noise_type == 'uniform':
+        resid = np.zeros((ns, 4))
+        expect = np.empty((ns, H, 4))
+        for t in range(H):
+            resid = 0.7 * (sigma * u[:, t].astype(np.float64)) + resid * (1.0 - 0.7)
+            expect[:, t] = np.clip(nom[t] + resid, lo, hi)
+    else:
+        expect = lo + u.astype(np.float64) * (np.asarray(hi) - np.asarray(lo))
+    np.testing.assert_allclose(a, expect, rtol=0, atol=2e-6)
+    ctx.mpc_sample(1)
+    a = ctx.mpc_get(actions=True)['actions'].astype(np.float64)
+    np.testing.assert_allclose(a.mean(0), g[noise_type + '/mean'], atol=0.15)
+    np.testing.assert_allclose(a.std(0), g[noise_type + '/std'], rtol=0.08, atol=0.02)
+    assert (a.min(0) >= np.asarray(lo) - 1e-6).all() and (a.max(0) <= np.asarray(hi) + 1e-6).all()
+    resid = a - nom[None]
+    corr = [np.corrcoef(resid[:, t, 0], resid[:, t + 1, 0])[0, 1] for t in range(H - 1)]
+    np.testing.assert_allclose(corr, g[noise_type + '/resid_lag1_corr'], atol=0.08)
+
+
 def test_mppi_two_shards_combine_on_device(ctx, golden):
     """Two ranks' records (sample_offset 0 and 32) combined by the device kernel == one rank
     with all 64 samples == the host mirror in sharding.py."""
