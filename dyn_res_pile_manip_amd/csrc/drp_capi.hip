@@ -56,6 +56,10 @@ struct drp_ctx {
     bool rev_global_only = false;   // DRP_REV_GLOBAL=1: reversed neighbour lists built in global memory (the N > 3072 path)
     bool self_const = true;         // DRP_NO_SELF_CONST=1: always run the encoder chain on the self slot too
     bool prop3 = true;              // DRP_NO_PROP3=1: one launch per propagation step even for chip-filling batches
+    bool graph_cells = true;        // DRP_NO_GRAPH_CELLS=1: x strips only (k_graph_strips) for large samples
+    int graph_cells_min_n = 400;    // DRP_GRAPH_CELLS_MIN_N: two-dimensional cells from this many particles up (measured: slower at 300, 8 % faster at 450)
+    float graph_cells_halo = 0.0f;  // DRP_GRAPH_CELLS_HALO: first-sweep halo in camera-frame units (default: from the particle count)
+    float graph_cells_hb = 0.0f;    // DRP_GRAPH_CELLS_HB: band height in camera-frame units (default: from the particle count)
     bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
     bool bwd_fused = true;          // DRP_NO_BWD_FUSED=1: the GD planner's backward pass as one launch per stage
@@ -205,7 +209,7 @@ int ensure_step_ws(drp_ctx* c, int B, int N) {
     CHK(ensure(c, c->proj2, bn * 128 * sizeof(float)));
     // edge constants [B,N,10,64] for the engines that materialise them; the fused engine only parks the graph build's
     // sorted positions and strip starts there (launch_graph)
-    const size_t graph_scratch = (size_t)B * (((size_t)N + 3) & ~(size_t)3) * 16 + (size_t)B * (GRAPH_STRIPS + 1) * sizeof(int);
+    const size_t graph_scratch = (size_t)B * (((size_t)N + 3) & ~(size_t)3) * 16 + (size_t)B * (GC_MAX_BANDS * GC_XS + 1) * sizeof(int);
     CHK(ensure(c, c->c_edge, c->engine == DRP_ENGINE_FUSED ? graph_scratch : bn * DRP_K * 64 * sizeof(float)));
     c->lastB = B;
     c->lastN = N;
@@ -240,7 +244,31 @@ size_t graph_lds(int N) { return (size_t)4 * N * sizeof(float); }
 void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod, size_t prev_stride, const float* actions,
                   size_t act_stride, float* s_delta, int B, int N, int16_t* nbr_idx, uint8_t* nbr_cnt, int self_first,
                   bool padded) {
-    if (c->graph_strips && !padded && N > GRAPH_THREADS) {
+    if (c->graph_cells && c->graph_strips && !padded && N >= c->graph_cells_min_n) {
+        // two-dimensional cells: y bands of height hb ~ sqrt(16 / density) (a 16-receiver block of a band is then about
+        // as wide as the band is high; the density of a pile spread over the 0.4 x 0.4 workspace -- any positive hb
+        // gives the same lists), 1-cm x strips inside a band
+        const size_t Np = ((size_t)N + 3) & ~(size_t)3;
+        float4* sorted = reinterpret_cast<float4*>(c->c_edge.p);
+        int* starts = reinterpret_cast<int*>(sorted + (size_t)B * Np);
+        float hb = sqrtf(16.0f * 0.16f / (float)N);
+        if (c->graph_cells_hb > 0.0f) hb = c->graph_cells_hb;
+        int gy = (int)ceilf(0.64f / hb);
+        if (gy > GC_MAX_BANDS) gy = GC_MAX_BANDS;
+        if (gy < 1) gy = 1;
+        const float inv_hb = (float)gy / 0.64f;
+        const int ncell = gy * GC_XS;
+        hipLaunchKernelGGL(k_graph_sort2, dim3(B), dim3(GRAPH_SORT_THREADS), 0, st, s_prev, prev_mod, prev_stride, actions,
+                           act_stride, s_delta, N, c->cam, gy, inv_hb, sorted, starts);
+        // receivers are dealt to quarter waves band by band: at most N / 16 + gy quarters, 16 per workgroup
+        const int chunks = ((N + 15) / 16 + gy + GRAPH_CELLS_THREADS / 16 - 1) / (GRAPH_CELLS_THREADS / 16);
+        hipLaunchKernelGGL(k_graph_cells<GRAPH_CELLS_THREADS>, dim3(B * chunks), dim3(GRAPH_CELLS_THREADS),
+                           GRAPH_CELLS_LDS(N, ncell, GRAPH_CELLS_THREADS), st, (const float4*)sorted, (const int*)starts, N, gy,
+                           inv_hb, nbr_idx, nbr_cnt, c->thr, chunks, self_first,
+                           // expected distance of the 10th neighbour in a pile of this density, with a third to spare
+                           c->graph_cells_halo > 0.0f ? c->graph_cells_halo : 1.3f * sqrtf(10.0f * 0.16f / (3.14159265f * (float)N)));
+    }
+    else if (c->graph_strips && !padded && N > GRAPH_THREADS) {
         // sorted positions and strip starts live in the edge-constant buffer: whatever uses it runs after the lists exist
         const size_t Np = ((size_t)N + 3) & ~(size_t)3;
         float4* sorted = reinterpret_cast<float4*>(c->c_edge.p);
@@ -637,6 +665,10 @@ int drp_create(int device, drp_ctx** out) {
     c->self_const = getenv("DRP_NO_SELF_CONST") == nullptr;
     c->prop3 = getenv("DRP_NO_PROP3") == nullptr;
     c->graph_strips = getenv("DRP_NO_GRAPH_STRIPS") == nullptr;
+    c->graph_cells = getenv("DRP_NO_GRAPH_CELLS") == nullptr;
+    if (const char* e = getenv("DRP_GRAPH_CELLS_MIN_N")) c->graph_cells_min_n = atoi(e);
+    if (const char* e = getenv("DRP_GRAPH_CELLS_HB")) c->graph_cells_hb = (float)atof(e);
+    if (const char* e = getenv("DRP_GRAPH_CELLS_HALO")) c->graph_cells_halo = (float)atof(e);
     c->prop3e = getenv("DRP_NO_PROP3E") == nullptr;
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
@@ -648,6 +680,7 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)k_elite_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips<GRAPH_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_graph_cells<GRAPH_CELLS_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REWARD_LDS(4096)) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reverse_lists<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||

@@ -437,3 +437,311 @@ k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts
     nbr_cnt[(size_t)b * N + i] = (uint8_t)w;
     for (int q = w; q < DRP_K; ++q) out[q] = -1;
 }
+
+// ---- the same lists with the senders bucketed into two-dimensional cells ------------------------------------
+// What the sweep costs is receivers x candidates x (8 distance + 10 insertion) vector instructions, and the
+// candidates of a lane are the senders of the region its WAVE sweeps (wave-uniform regions keep the LDS reads
+// broadcasts).  With x strips that region is (strips of the wave's 64 receivers + halo) x the WHOLE y extent.
+// Here the positions are sorted into cells -- y bands of height hb (the host picks hb ~ sqrt(16 / density), so that
+// 16 consecutive particles of a band span about hb in x too), each band ordered by the 1-cm x strip -- and a QUARTER
+// wave (16 lanes, 16 consecutive receivers of the order: a compact block) sweeps its own region: for every band
+// within the halo of its receivers' bands, the run of strips within the halo of their strips -- a contiguous run of
+// the order per band.  The four quarters of a wave read four different LDS addresses per instruction (still
+// conflict-free), and run in lockstep under per-candidate masks.  A 16-receiver block + halo is a quarter of the
+// area a 64-receiver strip range + halo x full height covers at 1 200 particles.
+// Same two-stage first sweep (half-radius halo -> provisional 10th distance -> the ring that is still missing, swept
+// as band runs minus the runs already done) and the same narrowed second sweep as k_graph_strips; runs are swept
+// exactly (no alignment padding: a sender met twice would take two places of the ten), candidates past a run's
+// end are masked to +inf.  A quarter never straddles two bands (the end of one band and the start of the next are
+// the two ENDS of the workspace in x: such a block would sweep the whole width, and its wave with it): every band's
+// receivers are dealt to quarters of their own, the last one of a band partly idle.  Lists identical to k_graph's.
+#define GC_XS 64
+#define GC_MAX_BANDS 32
+#define GRAPH_CELLS_THREADS 256
+
+__device__ __forceinline__ int graph_band(float y, float inv_hb, int gy) {
+    const float t = __fmul_rn(__fsub_rn(y, GRAPH_STRIP_X0), inv_hb);
+    return (int)fminf(fmaxf(t, 0.0f), (float)(gy - 1));
+}
+
+// sorted[b][Np] = (x, y, z, index) in cell order (band-major, strip-minor), starts[b][gy * 64 + 1]
+__global__ void __launch_bounds__(GRAPH_SORT_THREADS)
+k_graph_sort2(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
+              const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
+              DrpCam cam, int gy, float inv_hb, float4* __restrict__ sorted, int* __restrict__ starts) {
+    __shared__ int cursor[GC_MAX_BANDS * GC_XS];
+    __shared__ int s_w[GRAPH_SORT_THREADS / 64];
+    const int b = blockIdx.x, Np = (N + 3) & ~3, ncell = gy * GC_XS;
+    const float* s = s_prev + (size_t)(b % prev_mod) * prev_stride;
+    float* sd = s_delta + (size_t)b * N * 3;
+    float4* q4 = sorted + (size_t)b * Np;
+    int* sstart = starts + (size_t)b * (ncell + 1);
+    PushFrame f = {};
+    if (actions != nullptr) f = push_frame(cam, actions + (size_t)b * act_stride);
+    auto displaced = [&](int i, float& x, float& y, float& z, bool write_delta) {
+        const float sx = s[i * 3 + 0], sy = s[i * 3 + 1], sz = s[i * 3 + 2];
+        float ox, oy, oz;
+        if (actions != nullptr) {
+            push_delta(f, sx, sy, sz, ox, oy, oz);
+            if (write_delta) {
+                sd[i * 3 + 0] = ox;
+                sd[i * 3 + 1] = oy;
+                sd[i * 3 + 2] = oz;
+            }
+        } else {
+            ox = sd[i * 3 + 0]; oy = sd[i * 3 + 1]; oz = sd[i * 3 + 2];
+        }
+        x = __fadd_rn(sx, ox);                                    // gnn_dyn.py:224
+        y = __fadd_rn(sy, oy);
+        z = __fadd_rn(sz, oz);
+    };
+    for (int c = threadIdx.x; c < ncell; c += GRAPH_SORT_THREADS) cursor[c] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += GRAPH_SORT_THREADS) {
+        float x, y, z;
+        displaced(i, x, y, z, false);
+        atomicAdd(&cursor[graph_band(y, inv_hb, gy) * GC_XS + graph_strip(x)], 1);
+    }
+    __syncthreads();
+    {   // exclusive scan of the cell counts: every thread owns a contiguous segment of cells
+        const int per = (ncell + GRAPH_SORT_THREADS - 1) / GRAPH_SORT_THREADS;
+        const int lo = min((int)threadIdx.x * per, ncell), hi = min(lo + per, ncell);
+        int sum = 0;
+        for (int c = lo; c < hi; ++c) sum += cursor[c];
+        int inc = sum;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int base = inc - sum;
+        for (int w = 0; w < wave; ++w) base += s_w[w];
+        if (threadIdx.x == 0) sstart[0] = 0;
+        for (int c = lo; c < hi; ++c) {
+            const int n = cursor[c];
+            cursor[c] = base;
+            base += n;
+            sstart[c + 1] = base;
+        }
+    }
+    if ((int)threadIdx.x < Np - N) q4[N + threadIdx.x] = make_float4(1e18f, 0.0f, 0.0f, __int_as_float(-1));
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += GRAPH_SORT_THREADS) {
+        float x, y, z;
+        displaced(i, x, y, z, true);
+        const int slot = atomicAdd(&cursor[graph_band(y, inv_hb, gy) * GC_XS + graph_strip(x)], 1);
+        q4[slot] = make_float4(x, y, z, __int_as_float(i));
+    }
+}
+
+#define GRAPH_CELLS_LDS(N, ncell, T) ((size_t)((((N) + 3) & ~3) + 4) * 16 + ((size_t)(ncell) + 4) * 4 + (size_t)(T) * DRP_K * 2)
+
+template <int T>
+__global__ void __launch_bounds__(T)
+k_graph_cells(const float4* __restrict__ sorted, const int* __restrict__ starts, int N, int gy, float inv_hb,
+              int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, float thr, int chunks, int self_first,
+              float halo_first /* first guess of the 10th-nearest distance (any positive value gives the same lists) */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Np = (N + 3) & ~3, ncell = gy * GC_XS;
+    float4* q4 = reinterpret_cast<float4*>(lds);                 // the staged bands, at their positions in the order
+    int* cs = reinterpret_cast<int*>(q4 + Np + 4);               // [ncell + 1] first slot of every cell
+    int16_t* lst = reinterpret_cast<int16_t*>(cs + ((ncell + 4) & ~3));     // [T][DRP_K] chosen indices, unsorted
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const float4* g4 = sorted + (size_t)b * Np;
+    const int* gs = starts + (size_t)b * (ncell + 1);
+    for (int c = threadIdx.x; c <= ncell; c += T) cs[c] = gs[c];
+    __shared__ int qstart[GC_MAX_BANDS + 1];                     // first quarter of every band: sum of ceil(n_band / 16)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int q = 0;
+        for (int bb = 0; bb < gy; ++bb) {
+            qstart[bb] = q;
+            q += (cs[(bb + 1) * GC_XS] - cs[bb * GC_XS] + 15) >> 4;
+        }
+        qstart[gy] = q;
+    }
+    __syncthreads();
+    const int nq = qstart[gy];
+    const int q_first = chunk * (T / 16);
+    if (q_first >= nq) return;                                   // the grid is sized for the worst case N / 16 + gy quarters
+    const int q_last = min(q_first + T / 16, nq) - 1;
+    auto band_of_quarter = [&](int q) {
+        int bb = 0;
+        while (bb + 1 < gy && qstart[bb + 1] <= q) ++bb;
+        return bb;
+    };
+    const float radius = __fsqrt_rn(fmaxf(thr, 0.0f)) * 1.000001f;
+    // cells a halo h reaches beyond a receiver's own: a sender within h in one coordinate sits at most ceil(h / cell) cells
+    // away; the 1e-3 of a cell covers the rounding of the cell index at a boundary (about 1e-5 of a cell)
+    auto reach_x = [&](float hh) { return (int)fminf(ceilf(hh * GRAPH_STRIP_INV_W + 1e-3f), (float)GC_XS); };
+    auto reach_y = [&](float hh) { return (int)fminf(ceilf(hh * inv_hb + 1e-3f), (float)gy); };
+    // stage whole bands: those of the workgroup's quarters widened by the radius
+    const int wg_b0 = band_of_quarter(q_first), wg_b1 = band_of_quarter(q_last);
+    {
+        const int rbw = reach_y(radius);
+        const int wlo = cs[max(wg_b0 - rbw, 0) * GC_XS] & ~3;
+        const int whi = min((cs[(min(wg_b1 + rbw, gy - 1) + 1) * GC_XS] + 3) & ~3, Np);
+        for (int j = wlo + (int)threadIdx.x; j < whi; j += T) q4[j] = g4[j];
+        if (threadIdx.x < 4) q4[Np + threadIdx.x] = make_float4(1e18f, 0.0f, 0.0f, __int_as_float(-1));
+    }
+    __syncthreads();
+
+    // this lane's receiver: slot (lane & 15) of its quarter's 16 consecutive receivers inside the quarter's band
+    const int qid = q_first + ((int)threadIdx.x >> 4);
+    const int qb = band_of_quarter(min(qid, nq - 1));
+    const int band_lo = cs[qb * GC_XS], band_hi = cs[(qb + 1) * GC_XS];
+    const int si = band_lo + ((min(qid, nq - 1) - qstart[qb]) << 4) + ((int)threadIdx.x & 15);
+    const bool valid = qid < nq && si < band_hi;
+    if (__ballot(valid) == 0) return;
+    const float4 pi = q4[valid ? si : max(band_hi - 1, band_lo)];     // an idle lane mirrors its band's last receiver
+    const int i = __float_as_int(pi.w);
+    // the quarter's block: strips and bands of its 16 receivers
+    int xs_min = graph_strip(pi.x), xs_max = xs_min, yb_min = graph_band(pi.y, inv_hb, gy), yb_max = yb_min;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        xs_min = min(xs_min, __shfl_xor(xs_min, o, 64));
+        xs_max = max(xs_max, __shfl_xor(xs_max, o, 64));
+        yb_min = min(yb_min, __shfl_xor(yb_min, o, 64));
+        yb_max = max(yb_max, __shfl_xor(yb_max, o, 64));
+    }
+    auto quarter_max = [&](float v) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        return v;
+    };
+    auto wave_max_i = [&](int v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+        return v;
+    };
+    // every quarter walks its own region -- bands [yb_min - rb, yb_max + rb], in each the strips [xs_min - rx, xs_max + rx],
+    // minus (excl) the region of the halo (rbE, rxE) swept before -- as runs [ja, jb) of the order; the wave goes through
+    // the runs of its four quarters in lockstep and `body(j, jb)` masks what lies past a quarter's own run end
+    auto for_region = [&](int rb, int rx, bool excl, int rbE, int rxE, auto body) {
+        const int b_lo = max(yb_min - rb, 0), b_hi = min(yb_max + rb, gy - 1);
+        const int x0 = max(xs_min - rx, 0), x1 = min(xs_max + rx, GC_XS - 1);
+        const int eb_lo = max(yb_min - rbE, 0), eb_hi = min(yb_max + rbE, gy - 1);
+        const int e0 = max(xs_min - rxE, 0), e1 = min(xs_max + rxE, GC_XS - 1);
+        const int nb_max = wave_max_i(b_hi - b_lo + 1);
+        for (int bi = 0; bi < nb_max; ++bi) {
+            const int bb = min(b_lo + bi, gy - 1);
+            const bool on = (b_lo + bi) <= b_hi;
+            const int* cb = cs + bb * GC_XS;
+            int ra = 0, rbnd = 0, ta = 0, tb = 0;
+            if (on) {
+                if (excl && bb >= eb_lo && bb <= eb_hi) {
+                    ra = cb[x0]; rbnd = cb[e0];                     // strips x0 .. e0 - 1
+                    ta = cb[e1 + 1]; tb = cb[x1 + 1];               // strips e1 + 1 .. x1
+                } else {
+                    ra = cb[x0]; rbnd = cb[x1 + 1];
+                }
+            }
+            // whole groups of four in every quarter: no masks; the ends of the runs: masked
+            int j = ra;
+            for (; __all(j + 4 <= rbnd); j += 4) body(j, rbnd, false);
+            for (; __any(j < rbnd); j += 4) body(min(j, Np), rbnd, true);
+            if (__any(ta < tb))
+                for (j = ta; __any(j < tb); j += 4) body(min(j, Np), tb, true);
+        }
+    };
+
+    float best[DRP_K];
+#pragma unroll
+    for (int q = 0; q < DRP_K; ++q) best[q] = thr;
+    auto insert4 = [&](int j, int jb, bool masked) {
+        const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
+        float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
+                       pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float d = (!masked || j + u < jb) ? d4[u] : __builtin_inff();
+#pragma unroll
+            for (int q = DRP_K - 1; q > 0; --q) best[q] = __builtin_amdgcn_fmed3f(d, best[q - 1], best[q]);
+            best[0] = min_nonneg(d, best[0]);
+        }
+    };
+    // first sweep, stage A: a halo of the expected 10th-nearest distance (from the pile's density, host); stage B: what
+    // the provisional 10th distance found there still allows
+    const float halo_a = fminf(fmaxf(halo_first, 0.0f), radius);
+    const int rba = reach_y(halo_a), rxa = reach_x(halo_a);
+    for_region(rba, rxa, false, 0, 0, insert4);
+    {
+        const float kprov = quarter_max(valid ? best[DRP_K - 1] : 0.0f);
+        const float halo_b = fminf(radius, __fsqrt_rn(fmaxf(kprov, 0.0f)) * 1.000001f);
+        const bool more = halo_b > halo_a;
+        if (__any(more)) {
+            const int rbb = more ? max(reach_y(halo_b), rba) : rba, rxb = more ? max(reach_x(halo_b), rxa) : rxa;
+            for_region(rbb, rxb, true, rba, rxa, insert4);
+        }
+    }
+    const float kth = best[DRP_K - 1];
+    // second sweep: senders strictly nearer than kth are in; the ones AT kth fill what is left, lowest index first.
+    // Nothing farther than sqrt(kth) is emitted: the region narrows to the quarter's largest 10th-nearest distance
+    const float halo_2 = fminf(radius, __fsqrt_rn(fmaxf(quarter_max(valid ? kth : 0.0f), 0.0f)) * 1.000001f);
+    const int rb2 = reach_y(halo_2), rx2 = reach_x(halo_2);
+    const int skip = (self_first && thr > 0.0f) ? i : -1;
+    int16_t* mine = lst + threadIdx.x * DRP_K;
+    int cnt = 0, ties = 0, min_tie = 0x7fff;
+    for_region(rb2, rx2, false, 0, 0, [&](int j, int jb, bool masked) {
+        const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
+        const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
+                             pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
+        const int o4[4] = {__float_as_int(q0.w), __float_as_int(q1.w), __float_as_int(q2.w), __float_as_int(q3.w)};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool inr = (!masked || j + u < jb) && __fsub_rn(d4[u], thr) < 0.0f;
+            if (inr && d4[u] < kth && o4[u] != skip && cnt < DRP_K) mine[cnt++] = (int16_t)o4[u];
+            if (inr && d4[u] == kth && o4[u] != skip) {
+                ++ties;
+                min_tie = min(min_tie, o4[u]);
+            }
+        }
+    });
+    const int room = DRP_K - cnt - (skip >= 0 ? 1 : 0);
+    if (ties == 1 && room > 0) {
+        mine[cnt++] = (int16_t)min_tie;
+    } else if (ties > 1 && room > 0) {
+        // several senders at exactly kth: take the lowest indices among them, one walk over the lane's own region each
+        const int b_lo = max(yb_min - rb2, 0), b_hi = min(yb_max + rb2, gy - 1);
+        const int x0 = max(xs_min - rx2, 0), x1 = min(xs_max + rx2, GC_XS - 1);
+        int last = -1;
+        for (int r = 0; r < room && r < ties; ++r) {
+            int nxt = 0x7fff;
+            for (int bb = b_lo; bb <= b_hi; ++bb)
+                for (int j = cs[bb * GC_XS + x0]; j < cs[bb * GC_XS + x1 + 1]; ++j) {
+                    const float4 q = q4[j];
+                    const float d = pair_dis(pi.x, pi.y, pi.z, q.x, q.y, q.z);
+                    const int o = __float_as_int(q.w);
+                    if (__fsub_rn(d, thr) < 0.0f && d == kth && o != skip && o > last) nxt = min(nxt, o);
+                }
+            mine[cnt++] = (int16_t)nxt;
+            last = nxt;
+        }
+    }
+    if (!valid) return;
+    // ascending index through a 10-input sorting network (29 compare-exchanges); empty slots sort last
+    int v[DRP_K];
+#pragma unroll
+    for (int q = 0; q < DRP_K; ++q) v[q] = (q < cnt) ? (int)mine[q] : 0x7fff;
+#define CE(a, b) sort2(v[a], v[b])
+    CE(0, 5); CE(1, 6); CE(2, 7); CE(3, 8); CE(4, 9);
+    CE(0, 3); CE(1, 4); CE(5, 8); CE(6, 9);
+    CE(0, 2); CE(3, 6); CE(7, 9);
+    CE(0, 1); CE(2, 4); CE(5, 7); CE(8, 9);
+    CE(1, 2); CE(3, 5); CE(4, 6); CE(7, 8);
+    CE(1, 3); CE(2, 5); CE(4, 7); CE(6, 8);
+    CE(2, 3); CE(4, 5); CE(6, 7);
+    CE(3, 4); CE(5, 6);
+#undef CE
+    int16_t* out = nbr_idx + ((size_t)b * N + i) * DRP_K;
+    int w = 0;
+    if (skip >= 0) out[w++] = (int16_t)i;
+#pragma unroll
+    for (int q = 0; q < DRP_K; ++q)
+        if (q < cnt && w < DRP_K) out[w++] = (int16_t)v[q];
+    nbr_cnt[(size_t)b * N + i] = (uint8_t)w;
+    for (int q = w; q < DRP_K; ++q) out[q] = -1;
+}

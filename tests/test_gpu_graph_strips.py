@@ -1,4 +1,6 @@
-"""GPU: the x-strip neighbour build (k_graph_sort + k_graph_strips, samples of more than 128 particles) against
+"""GPU: the x-strip neighbour build (k_graph_sort + k_graph_strips, samples of more than 128 particles) and the
+two-dimensional cell build (k_graph_sort2 + k_graph_cells, forced here for every size and with band heights from a
+quarter of the radius to more than the workspace) against
 the plain two-sweep kernel (DRP_NO_GRAPH_STRIPS=1) -- the same lists bit for bit, in both emission orders
 (ascending index through drp_build_graph; self loop first inside the fused engine's rollouts) -- and against
 the reference's own lists through the golden one-step cases elsewhere (tests/test_gpu_parity.py)."""
@@ -16,16 +18,24 @@ def _engines(monkeypatch):
     blob = weights.blob_from_state_dict(weights.random_state_dict(seed=0))
     M34 = world2cam_affine(syn.demo_cam_extrinsics())
     out = {}
-    for plain in (False, True):
-        if plain:
-            monkeypatch.setenv('DRP_NO_GRAPH_STRIPS', '1')
-        else:
-            monkeypatch.delenv('DRP_NO_GRAPH_STRIPS', raising=False)
+    # False: x strips; True: the plain sweep; 'cells', 'cells_lo', 'cells_hi': two-dimensional cells for every size
+    # with the default, a 2-cm and a 70-cm band height
+    for key, env in ((False, {'DRP_NO_GRAPH_CELLS': '1'}), (True, {'DRP_NO_GRAPH_STRIPS': '1'}),
+                     ('cells', {'DRP_GRAPH_CELLS_MIN_N': '1'}),
+                     ('cells_lo', {'DRP_GRAPH_CELLS_MIN_N': '1', 'DRP_GRAPH_CELLS_HB': '0.02'}),
+                     ('cells_hi', {'DRP_GRAPH_CELLS_MIN_N': '1', 'DRP_GRAPH_CELLS_HB': '0.7'})):
+        for k in ('DRP_NO_GRAPH_STRIPS', 'DRP_NO_GRAPH_CELLS', 'DRP_GRAPH_CELLS_MIN_N', 'DRP_GRAPH_CELLS_HB'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         eng = Engine(0)
         eng.load_weights(blob, 0.08)
         eng.set_camera(M34, 24.0, syn.demo_cam_params())
-        out[plain] = eng
+        out[key] = eng
     return out
+
+
+CELLS = ('cells', 'cells_lo', 'cells_hi')
 
 
 @pytest.mark.parametrize('N,B,kind,scale', [(129, 5, 'uniform', 1.0), (300, 6, 'uniform', 1.0), (300, 4, 'blob', 1.0),
@@ -42,10 +52,14 @@ def test_lists_equal_plain_sweep(monkeypatch, N, B, kind, scale):
     sd = (0.004 * rng.standard_normal(s.shape)).astype(np.float32)
     i0, c0 = engs[False].build_graph(s, sd)
     i1, c1 = engs[True].build_graph(s, sd)
+    cells = {k: engs[k].build_graph(s, sd) for k in CELLS}
     for e in engs.values():
         e.close()
     assert np.array_equal(c0, c1)
     assert np.array_equal(i0, i1)
+    for k in CELLS:
+        assert np.array_equal(cells[k][1], c1), k
+        assert np.array_equal(cells[k][0], i1), k
     assert c0.max() == 10 or scale > 1.0
 
 
@@ -62,10 +76,14 @@ def test_coincident_particles_tie_at_the_cut(monkeypatch):
     sd = np.zeros_like(s)
     i0, c0 = engs[False].build_graph(s, sd)
     i1, c1 = engs[True].build_graph(s, sd)
+    cells = {k: engs[k].build_graph(s, sd) for k in CELLS}
     for e in engs.values():
         e.close()
     assert np.array_equal(c0, c1)
     assert np.array_equal(i0, i1)
+    for k in CELLS:
+        assert np.array_equal(cells[k][1], c1), k
+        assert np.array_equal(cells[k][0], i1), k
     assert (i0[0, 40:100, :10] < 100).all() and (i0[0, 40:100, 0] == 40).all()
 
 
@@ -77,7 +95,24 @@ def test_rollouts_equal_with_self_loop_first(monkeypatch):
     acts = syn.sample_pushes(ns, H, seed=2)
     r0, _ = engs[False].rollout(s0, attr, dens, acts)
     r1, _ = engs[True].rollout(s0, attr, dens, acts)
+    rc, _ = engs['cells'].rollout(s0, attr, dens, acts)
     for e in engs.values():
         e.close()
     assert np.isfinite(r0).all()
     assert np.array_equal(r0, r1)
+    assert np.array_equal(rc, r1)
+
+
+def test_cells_on_the_reference_cases(monkeypatch, golden):
+    """The two-dimensional build against the REFERENCE's own lists (tests/golden/one_step.npz), forced for every size."""
+    engs = _engines(monkeypatch)
+    g = golden.one_step
+    try:
+        for case in ('n64', 'n50', 'n150', 'n300', 'n600', 'n8', 'blob150'):
+            for k in CELLS:
+                idx, cnt = engs[k].build_graph(g[case + '/s_cur'], g[case + '/s_delta'])
+                np.testing.assert_array_equal(cnt, g[case + '/nbr_cnt'], err_msg='%s %s' % (case, k))
+                np.testing.assert_array_equal(idx, g[case + '/nbr_idx'], err_msg='%s %s' % (case, k))
+    finally:
+        for e in engs.values():
+            e.close()
