@@ -23,17 +23,22 @@ for case in range(n_cases):
     nb = int(rng.choice([1, 1, 2, 3]))
     ns = int(rng.choice([1, 2, 5, 16, 16, 300, 517]))   # >= 256 rows: the fused engine runs km_prop3 (three steps per launch)
     if ns >= 256 and N > 300:
-        N = 300
+        N = int(rng.choice([300, 300, 450]))             # 450: the two-dimensional cell graph under km_prop3
     H = int(rng.choice([1, 2, 4]))
     kind = str(rng.choice(['uniform', 'blob']))
     s0, dens, attr = syn.make_pile(N, nb, seed=case, kind=kind)
     scale = float(rng.choice([1.0, 0.3, 3.0]))          # clumped (everything within the radius) or sparse (isolated particles)
     s0[..., :2] *= scale
-    mode = int(rng.integers(0, 3))
+    mode = int(rng.integers(0, 4))
     if mode == 1:
         attr = np.full_like(attr, 0.25)
     elif mode == 2:
         attr = rng.uniform(-1, 1, attr.shape).astype(np.float32)
+    elif mode == 3 and nb > 1:
+        # some columns with uniform attributes, some without: km_prop3's tiles span samples, so a tile can hold
+        # receivers with and without the self-edge shortcut
+        attr = attr.copy()
+        attr[1::2] = rng.uniform(-1, 1, attr[1::2].shape).astype(np.float32)
     dens = (dens * rng.uniform(0.3, 2.0, dens.shape)).astype(np.float32)
     acts = syn.sample_pushes(ns * nb, H, seed=case)
     outs = {}
