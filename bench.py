@@ -69,6 +69,12 @@ def parse():
     ap.add_argument('--force-comm', action='store_true',
                     help='one process: still attach an RCCL communicator (ncclCommInitRank with one rank, the id broadcast '
                          'through torch.distributed) and run the update through ncclAllGather')
+    ap.add_argument('--comm', choices=['rccl', 'gloo'], default='rccl',
+                    help="transport of the one exchange: 'rccl' = ncclAllGather on the stream (the product path); 'gloo' = the "
+                         "rank's record fetched, all-gathered through torch.distributed on the host and uploaded to the combine "
+                         "kernel (sharding.TorchComm's path) -- with --share-gpu it lets N processes exercise the sharded "
+                         "bench on ONE GPU")
+    ap.add_argument('--share-gpu', action='store_true', help='every rank uses GPU 0 (with --comm gloo: a dry run of the N-rank bench on one GPU)')
     ap.add_argument('--engine', default=os.environ.get('DRP_ENGINE', 'auto'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=None, help='samples of the CPU baseline (default: about 10 s of host work)')
@@ -312,13 +318,19 @@ def main():
     from dyn_res_pile_manip_amd.engine import Engine
     from dyn_res_pile_manip_amd.planners import world2cam_affine
 
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_comm = world > 1 or args.force_comm
+    gloo = args.comm == 'gloo'
+    red_dev = 'cpu' if gloo else 'cuda'          # where the max-over-ranks timings are reduced
     if use_comm:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if gloo:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     from dyn_res_pile_manip_amd.sharding import shard_range
     N, H = args.particles, args.horizon
@@ -343,17 +355,25 @@ def main():
     nominal = syn.nominal_pushes(H, seed=0)
     eng.mpc_begin(s0, attr, dens, nominal, n_sample=ns, sigma=0.3 * 24 / 12.0, beta_filter=0.7,
                   reward_weight=0.1, act_lo=lo, act_hi=hi, seed=1234, sample_offset=s_lo)
-    if use_comm:
+    if use_comm and not gloo:
         uid = [eng.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(uid[0], rank, world)
+    if gloo:
+        from dyn_res_pile_manip_amd.sharding import allgather_records
 
     it = [0]
 
     def step():
         eng.mpc_sample(it[0])
         eng.mpc_rollout(False)
-        if args.update == 'elite':
+        if gloo and world > 1:
+            # host transport: this rank's record -> all-gather over gloo -> combine kernel
+            if args.update == 'elite':
+                eng.mpc_update_elite(allgather_records(eng.mpc_elite(args.elite).ravel()).reshape(world, args.elite, -1), args.elite)
+            else:
+                eng.mpc_update(allgather_records(eng.mpc_partials()))
+        elif args.update == 'elite':
             eng.mpc_update_elite_device(args.elite)
         else:
             eng.mpc_update_device()
@@ -411,7 +431,7 @@ def main():
     dom_ms, dom_n = eng.probe_read()
     eng.probe_begin(None)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -426,7 +446,7 @@ def main():
     fence()
     med = float(np.median(per_iter))
     if world > 1:
-        t = torch.tensor([med], dtype=torch.float64, device='cuda')
+        t = torch.tensor([med], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         med = float(t.item())
 
@@ -458,7 +478,7 @@ def main():
                        'algorithmic_bytes_per_launch': agg_bytes, 'mean_in_degree': kbar_alt,
                        'traffic': None, 'traffic_source': None}
         if world > 1:
-            t = torch.tensor([dta], dtype=torch.float64, device='cuda')
+            t = torch.tensor([dta], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dta = float(t.item())
         alt = {'engine': 'mfma', 'dtype': 'f32', 'value': args.samples_total_job * N * H * args.steps / dta,
@@ -533,7 +553,8 @@ def main():
             'config': {'workload': args.workload, 'name': args.config_name,
                        'n_particles': N, 'n_sample_per_gpu': ns, 'n_sample_total': args.samples_total_job,
                        'n_look_ahead': H, 'engine': engine,
-                       'communicator': ('rccl, %d rank%s' % (world, '' if world == 1 else 's')) if use_comm else None,
+                       'communicator': ('%s, %d rank%s%s' % (args.comm, world, '' if world == 1 else 's',
+                                                             ', all on GPU 0' if args.share_gpu else '')) if use_comm else None,
                        'mean_in_degree': kbar, 'parallelism': 'samples sharded x%d' % world,
                        'update': 'softmax mean (optimize_action)' if args.update == 'mppi' else 'mean of the %d best (elite)' % args.elite},
             'roofline': roof,
