@@ -471,6 +471,36 @@ def main():
         cap_s.close()
     np.savez_compressed(os.path.join(HERE, 'stress.npz'), **st)
 
+    # ---- gradients of the GD planner's loss under other weights (f1): second seed with per-particle attributes, and
+    # ---- first encoder layers x 300 (hidden activations ~1e2: the tape's masks come from the split-fp16 forward) ----
+    gs = {}
+    for name, wseed, enc_scale, attr_kind, N, nb, traj, H, seed in [('seed1_attr_h1', 1, 1.0, 'random', 48, 2, 5, 1, 61),
+                                                                     ('big_h1', 0, 300.0, 'zero', 40, 3, 4, 1, 62),
+                                                                     ('big_attr_h2', 2, 300.0, 'random', 36, 2, 3, 2, 63)]:
+        m = scaled_model(wseed, enc_scale)
+        for k, v in state_dict_arrays(m).items():
+            gs[name + '/' + k] = v
+        s, dens, attr = syn.make_pile(N, n_batch=nb, seed=seed)
+        if attr_kind == 'random':
+            attr = (np.random.default_rng(seed).random(attr.shape) < 0.5).astype(np.float32)
+        planner.particle_num = N
+        goal_coor = syn.goal_coor_strided(obs_goal, 5 * N)
+        acts0 = np.stack([syn.nominal_pushes(H, seed=400 + seed + i) for i in range(traj)])
+        acts0[:, 0] = [-3.5, 0.3, 2.5, -0.2]                      # through the pile: every row has a gradient
+        acts0[:, 0, 1] += 0.15 * np.arange(traj)
+        acts0 = np.repeat(acts0, nb, axis=0).astype(np.float32)
+        a_t = torch.tensor(acts0, requires_grad=True)
+        out = planner.ptcl_model_rollout(torch.from_numpy(s), torch.from_numpy(dens), torch.from_numpy(attr), m, a_t)
+        sp = out['model_rollout']['state_pred']
+        obs_seqs = sp.reshape(traj * nb, 1, H, N, 3).permute(0, 2, 1, 3, 4)
+        rs, _ = planner.ptcl_evaluate_traj(obs_seqs, torch.from_numpy(obs_goal), torch.from_numpy(goal_coor))
+        torch.sum(-rs).backward()
+        gs[name + '/s_cur'], gs[name + '/dens'], gs[name + '/attr'] = s, dens, attr
+        gs[name + '/act_seqs'], gs[name + '/goal_coor'] = acts0, goal_coor
+        gs[name + '/reward'] = rs.detach().numpy()
+        gs[name + '/grad_act'] = a_t.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'grad_stress.npz'), **gs)
+
     cap.close()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):

@@ -44,6 +44,34 @@ def test_gradients_match_the_reference(ctx, golden, case):
     np.testing.assert_array_equal(np.abs(ga).sum((1, 2)) == 0, np.abs(ref_ga).sum((1, 2)) == 0)
 
 
+@pytest.mark.parametrize('case', ['seed1_attr_h1', 'big_h1', 'big_attr_h2'])
+def test_gradients_under_other_weights_match_the_reference(golden, case):
+    """Beyond the seed-0 weights (tests/golden/grad_stress.npz): a second seed with per-particle attributes in two
+    batch columns, and first encoder layers x 300 (hidden activations ~1e2; the tape's ReLU masks come from the
+    split-fp16 forward pass under its range shift), horizons 1 and 2 -- small batches (the launch-per-stage
+    kernels) and the same cases replicated to a chip-filling batch (kmb_step_bwd)."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    from test_oracle_golden import stress_weights
+    g = golden.grad_stress
+    eng = Engine(0)
+    eng.load_weights(weights.blob_from_state_dict(stress_weights(g, case)), 0.08)
+    eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    eng.set_goal(syn.goal_field(obs_goal), g[case + '/goal_coor'])
+    lo, hi = syn.action_limits()
+    ref_ga = g[case + '/grad_act']
+    N = g[case + '/s_cur'].shape[1]
+    for reps in (1, -(-1100 // (ref_ga.shape[0] * ((N + 31) // 32)))):
+        acts = np.tile(g[case + '/act_seqs'], (reps, 1, 1))
+        eng.gd_begin(g[case + '/s_cur'], g[case + '/attr'], g[case + '/dens'], acts, 0.05, lo, hi)
+        r, ga, _ = eng.gd_grad()
+        want = np.tile(ref_ga, (reps, 1, 1))
+        np.testing.assert_allclose(r, np.tile(g[case + '/reward'][:, 0], reps), rtol=2e-5)
+        assert np.abs(ga - want).max() < 2e-3 * np.abs(ref_ga).max(), reps
+        assert np.abs(ga).sum((1, 2)).min() > 0
+    eng.close()
+
+
 def test_adam_iterations_and_planner_dict_match_the_reference(golden):
     """The reference's own GD planner run (3 Adam iterations, 10 trajectories x 3 columns, N = 40),
     called exactly as env/flex_env.py:1048-1065 calls it."""

@@ -259,3 +259,16 @@ def test_host_sampler_noise_types_and_label_regions(golden):
                 assert s2[:, t, c].min() == blo[c]
             if abs(g['label/max'][t, c] - bhi[c]) < 1e-12:
                 assert s2[:, t, c].max() == bhi[c]
+
+
+@pytest.mark.parametrize('case', ['seed1_attr_h1', 'big_h1', 'big_attr_h2'])
+def test_gd_gradients_under_other_weights(golden, case):
+    """Row f1 beyond the seed-0 weights: the oracle's autograd against the reference's (grad_stress.npz)."""
+    g = golden.grad_stress
+    w = stress_weights(g, case)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    r, ga, _ = od.gd_loss_and_grads(od.load_weights(w), g[case + '/s_cur'], g[case + '/dens'], g[case + '/attr'],
+                                    g[case + '/act_seqs'], syn.goal_field(obs_goal), syn.demo_cam_params(),
+                                    g[case + '/goal_coor'], syn.demo_cam_extrinsics(), 24)
+    np.testing.assert_allclose(r, g[case + '/reward'][:, 0], rtol=2e-6)
+    np.testing.assert_allclose(ga, g[case + '/grad_act'], rtol=0, atol=1e-3 * np.abs(g[case + '/grad_act']).max())
