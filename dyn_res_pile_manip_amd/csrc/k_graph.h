@@ -98,39 +98,9 @@ __device__ __forceinline__ float pair_dis(float xi, float yi, float zi, float xj
 #define GRAPH_THREADS 128
 #endif
 
-__global__ void __launch_bounds__(GRAPH_THREADS)
-k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
-        const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
-        int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks,
-        int self_first) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float4* p4 = reinterpret_cast<float4*>(lds);                       // [N] displaced positions
-    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
-    const float* s = s_prev + (size_t)(b % prev_mod) * prev_stride;
-    float* sd = s_delta + (size_t)b * N * 3;
-
-    if (actions != nullptr) {
-        const PushFrame f = push_frame(cam, actions + (size_t)b * act_stride);
-        for (int i = threadIdx.x; i < N; i += GRAPH_THREADS) {
-            float x = s[i * 3 + 0], y = s[i * 3 + 1], z = s[i * 3 + 2];
-            float ox, oy, oz;
-            push_delta(f, x, y, z, ox, oy, oz);
-            if (chunk == 0) {
-                sd[i * 3 + 0] = ox;
-                sd[i * 3 + 1] = oy;
-                sd[i * 3 + 2] = oz;
-            }
-            p4[i] = make_float4(__fadd_rn(x, ox), __fadd_rn(y, oy), __fadd_rn(z, oz), 0.0f);  // gnn_dyn.py:224
-        }
-    } else {
-        for (int i = threadIdx.x; i < N; i += GRAPH_THREADS)
-            p4[i] = make_float4(__fadd_rn(s[i * 3 + 0], sd[i * 3 + 0]), __fadd_rn(s[i * 3 + 1], sd[i * 3 + 1]),
-                                __fadd_rn(s[i * 3 + 2], sd[i * 3 + 2]), 0.0f);
-    }
-    __syncthreads();
-
-    const int i = chunk * GRAPH_THREADS + threadIdx.x;
-    if (i >= N) return;
+// one receiver: both sweeps over the N displaced positions of its sample in `p4` (LDS), list to out[10] / cnt_out
+__device__ __forceinline__ void graph_receiver(const float4* __restrict__ p4, int N, int i, float thr, int self_first,
+                                               int16_t* __restrict__ out, uint8_t* __restrict__ cnt_out) {
     const float4 pi = p4[i];
     float best[DRP_K];
 #pragma unroll
@@ -155,7 +125,6 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
         best[0] = min_nonneg(d, best[0]);
     }
     const float kth = best[DRP_K - 1];
-    int16_t* out = nbr_idx + ((size_t)b * N + i) * DRP_K;
     int cnt = 0;
     // self_first (fused engine with a per-sample self-edge constant, km_prop): the self loop --
     // distance 0, inside any positive radius and never beyond the 10th smallest -- takes slot 0
@@ -190,8 +159,44 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
             else if (ties_left > 0) { out[cnt++] = (int16_t)j; --ties_left; }
         }
     }
-    nbr_cnt[(size_t)b * N + i] = (uint8_t)cnt;
+    *cnt_out = (uint8_t)cnt;
     for (int q = cnt; q < DRP_K; ++q) out[q] = -1;
+}
+
+__global__ void __launch_bounds__(GRAPH_THREADS)
+k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
+        const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
+        int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks,
+        int self_first) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* p4 = reinterpret_cast<float4*>(lds);                       // [N] displaced positions
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const float* s = s_prev + (size_t)(b % prev_mod) * prev_stride;
+    float* sd = s_delta + (size_t)b * N * 3;
+
+    if (actions != nullptr) {
+        const PushFrame f = push_frame(cam, actions + (size_t)b * act_stride);
+        for (int i = threadIdx.x; i < N; i += GRAPH_THREADS) {
+            float x = s[i * 3 + 0], y = s[i * 3 + 1], z = s[i * 3 + 2];
+            float ox, oy, oz;
+            push_delta(f, x, y, z, ox, oy, oz);
+            if (chunk == 0) {
+                sd[i * 3 + 0] = ox;
+                sd[i * 3 + 1] = oy;
+                sd[i * 3 + 2] = oz;
+            }
+            p4[i] = make_float4(__fadd_rn(x, ox), __fadd_rn(y, oy), __fadd_rn(z, oz), 0.0f);  // gnn_dyn.py:224
+        }
+    } else {
+        for (int i = threadIdx.x; i < N; i += GRAPH_THREADS)
+            p4[i] = make_float4(__fadd_rn(s[i * 3 + 0], sd[i * 3 + 0]), __fadd_rn(s[i * 3 + 1], sd[i * 3 + 1]),
+                                __fadd_rn(s[i * 3 + 2], sd[i * 3 + 2]), 0.0f);
+    }
+    __syncthreads();
+
+    const int i = chunk * GRAPH_THREADS + threadIdx.x;
+    if (i >= N) return;
+    graph_receiver(p4, N, i, thr, self_first, nbr_idx + ((size_t)b * N + i) * DRP_K, nbr_cnt + (size_t)b * N + i);
 }
 
 // ---- the same lists with the senders bucketed into x strips --------------------------------------------
