@@ -111,6 +111,7 @@ struct drp_ctx {
     int tr_nroll = 0, tr_iter = 0;
     double tr_lr = 1e-3, tr_beta1 = 0.9;
     std::vector<float> w_host;
+    std::vector<WgradJob> wg_jobs;  // weight-gradient jobs waiting for the next flush_wgrad
     DevBuf tr_part, tr_states, tr_sdelta, tr_nums, tr_grad, tr_m, tr_v, tr_loss, agg_hist, tr_hact, tr_gh, tr_gpe, tr_a1n,
         tr_gh1, tr_xn, ed_re, ed_a2, ed_a1, ed_x0, ed_gce, ed_g3, ed_g2, ed_g1;
 
@@ -575,17 +576,36 @@ int need(drp_ctx* c, bool weights, bool cam, bool goal) {
     return DRP_OK;
 }
 
+// Weight-gradient jobs are queued and go out together (flush_wgrad): one pair of launches for all the jobs whose
+// inputs exist at that point of the stream.  flush_wgrad must run before a kernel overwrites a queued job's g or x.
+void flush_wgrad(drp_ctx* c) {
+    const int n = (int)c->wg_jobs.size();
+    if (n == 0) return;
+    WgradJobs J{};
+    int max_blocks = 1;
+    for (int q = 0; q < n; ++q) {
+        J.j[q] = c->wg_jobs[q];
+        J.j[q].part = static_cast<float*>(c->tr_part.p) + (size_t)q * KT_WGRAD_MAX_BLOCKS * 66 * 64;
+        if (J.j[q].blocks > max_blocks) max_blocks = J.j[q].blocks;
+    }
+    hipLaunchKernelGGL(kt_wgrad_multi, dim3((unsigned)max_blocks, (unsigned)n), dim3(256), KT_WGRAD_MULTI_LDS, c->stream, J);
+    hipLaunchKernelGGL(kt_wgrad_reduce_multi, dim3(66, (unsigned)n), dim3(256), 0, c->stream, J);
+    c->wg_jobs.clear();
+}
+
 template <int IN>
 void launch_wgrad(drp_ctx* c, const float* g, int ldg, const float* x, int ldx, long M, float* dW, int lane_stride,
                   int k_stride, float* db, float* dwd, const float* dens, int dens_mod, long rows_per_sample) {
     long blocks = (M + 63) / 64;
     if (blocks > KT_WGRAD_MAX_BLOCKS) blocks = KT_WGRAD_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
-    float* part = static_cast<float*>(c->tr_part.p);       // sized for KT_WGRAD_MAX_BLOCKS x 66 x 64 by drp_train_begin
-    hipLaunchKernelGGL(kt_wgrad<IN>, dim3((unsigned)blocks), dim3(256), KT_WGRAD_LDS(IN), c->stream, g, ldg, x, ldx, M, part,
-                       dwd ? dens : nullptr, dens_mod, rows_per_sample);
-    hipLaunchKernelGGL(kt_wgrad_reduce<IN>, dim3(IN + 2), dim3(256), 0, c->stream, part, (int)blocks, dW, lane_stride, k_stride,
-                       db, dwd);
+    if ((int)c->wg_jobs.size() == KT_WGRAD_MAX_JOBS) flush_wgrad(c);
+    WgradJob q{};
+    q.g = g; q.x = x; q.dW = dW; q.db = db; q.dwd = dwd; q.dens = dens; q.part = nullptr;
+    q.M = M; q.rows_per_sample = rows_per_sample;
+    q.ldg = ldg; q.ldx = ldx; q.lane_stride = lane_stride; q.k_stride = k_stride; q.dens_mod = dens_mod; q.in = IN;
+    q.blocks = (int)blocks;
+    c->wg_jobs.push_back(q);
 }
 
 // The one-shot entry points stage their inputs in the buffers the planner sessions keep their state in
@@ -703,6 +723,7 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_prop3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kt_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
@@ -1968,6 +1989,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                                  nullptr, nullptr, nullptr, 1, 1);
                 launch_wgrad<64>(c, ptr<float>(c->g_proj) + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
                                  1, nullptr, nullptr, nullptr, 1, 1);
+                flush_wgrad(c);                          // before the next kernel overwrites g_eff (and, next step, g_proj)
                 if (p > 0)
                     hipLaunchKernelGGL((kmb_node_step<true, true>), ngrid, nblk, KMB_STEP_LDS(true, true), st, mb,
                                        ptr<float>(c->g_eff), ptr<float>(c->g_proj), eht + (size_t)p * bn64,
@@ -1988,6 +2010,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                              nullptr, nullptr, 1, 1);
             launch_wgrad<5>(c, ptr<float>(c->tr_gh1), 64, ptr<float>(c->tr_xn), 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
                             nullptr, nullptr, 1, 1);
+            flush_wgrad(c);
         } else {
             // predictor
             hipLaunchKernelGGL(kb_predict, rgrid, dim3(256), 0, st, vw, wraw, eht + 3 * bn64, g_out, (size_t)N * 3, N,
@@ -2011,6 +2034,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                                  nullptr, nullptr, nullptr, 1, 1);
                 launch_wgrad<64>(c, ptr<float>(c->g_proj) + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
                                  1, nullptr, nullptr, nullptr, 1, 1);
+                flush_wgrad(c);                          // before kb_project overwrites g_eff
                 hipLaunchKernelGGL(kb_project, rgrid, dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), chunks);
             }
             // particle propagator, encoder columns + density column + bias; particle encoder
@@ -2024,6 +2048,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                              nullptr, nullptr, 1, 1);
             launch_wgrad<5>(c, ptr<float>(c->tr_gh1), 64, ptr<float>(c->tr_xn), 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
                             nullptr, nullptr, 1, 1);
+            flush_wgrad(c);
         }
         // the previous step's output feeds this step as s_cur: residual + relation encoder
         float* g_prev = nullptr;
@@ -2041,7 +2066,9 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         launch_wgrad<64>(c, ed.g3, 64, ed.a2, 64, (long)bnk, G + W_RE4_W, 64, 1, G + W_RE4_B, nullptr, nullptr, 1, 1);
         launch_wgrad<64>(c, ed.g2, 64, ed.a1, 64, (long)bnk, G + W_RE2_W, 64, 1, G + W_RE2_B, nullptr, nullptr, 1, 1);
         launch_wgrad<6>(c, ed.g1, 64, ed.x0, 8, (long)bnk, G + W_RE0_W, 6, 1, G + W_RE0_B, nullptr, nullptr, 1, 1);
+        flush_wgrad(c);                                  // the next rollout step rewrites the dumps these jobs read
     }
+    flush_wgrad(c);
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
@@ -2060,7 +2087,7 @@ int drp_train_begin(drp_ctx* c, int n_rollout, double lr, double beta1) {
     CHK(ensure(c, c->tr_grad, (size_t)W_TOTAL * sizeof(float)));
     CHK(ensure(c, c->tr_m, (size_t)W_TOTAL * sizeof(float)));
     CHK(ensure(c, c->tr_v, (size_t)W_TOTAL * sizeof(float)));
-    CHK(ensure(c, c->tr_part, (size_t)KT_WGRAD_MAX_BLOCKS * 66 * 64 * sizeof(float)));
+    CHK(ensure(c, c->tr_part, (size_t)KT_WGRAD_MAX_JOBS * KT_WGRAD_MAX_BLOCKS * 66 * 64 * sizeof(float)));
     HIPCHK(c, hipMemsetAsync(c->tr_m.p, 0, (size_t)W_TOTAL * sizeof(float), c->stream));
     HIPCHK(c, hipMemsetAsync(c->tr_v.p, 0, (size_t)W_TOTAL * sizeof(float), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -121,6 +121,97 @@ kt_wgrad_reduce(const float* __restrict__ part, int nblocks, float* __restrict__
     else if (dwd != nullptr) dwd[(size_t)lane * lane_stride] += t;
 }
 
+// ---- several outer-product sums per launch ------------------------------------------------------------------
+// A training iteration needs 17 weight gradients per rollout step, each a 20-us kernel over ~1 000 - 12 000 rows
+// plus its reduction: 34 launches per step, a fifth of the iteration in launch overheads and tails.  The jobs
+// whose inputs exist at the same point of the stream (the three of a propagation step, the encoder's, the relation
+// encoder's four ...) go through ONE pair of launches: blockIdx.y selects the job, the arithmetic, the row -> (block,
+// wave) assignment and the order of every sum are kt_wgrad<IN>'s / kt_wgrad_reduce<IN>'s, so the gradients keep
+// their bits.  IN is a run-time number here (rows of x shorter than 64 are read as zero beyond IN).
+#define KT_WGRAD_MAX_JOBS 6
+struct WgradJob {
+    const float* g; const float* x; float* dW; float* db; float* dwd; const float* dens; float* part;
+    long M, rows_per_sample;
+    int ldg, ldx, lane_stride, k_stride, dens_mod, in, blocks;
+};
+struct WgradJobs {
+    WgradJob j[KT_WGRAD_MAX_JOBS];
+};
+
+__global__ void __launch_bounds__(256)
+kt_wgrad_multi(WgradJobs J) {
+    extern __shared__ float s_part[];                  // [3][66][64]
+    const WgradJob& q = J.j[blockIdx.y];
+    if ((int)blockIdx.x >= q.blocks) return;
+    const int IN = q.in;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* __restrict__ g = q.g;
+    const float* __restrict__ x = q.x;
+    const float* __restrict__ dens = q.dwd ? q.dens : nullptr;
+    float acc[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) acc[k] = 0.0f;
+    float accb = 0.0f, accd = 0.0f;
+    for (long row = (long)blockIdx.x * 4 + wave; row < q.M; row += (long)q.blocks * 4) {
+        const float gv = g[row * q.ldg + lane];
+        const float xv = (lane < IN) ? x[row * q.ldx + lane] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) acc[k] = fmaf(gv, bcast_lane(xv, k), acc[k]);
+        accb += gv;
+        if (dens != nullptr) accd = fmaf(gv, dens[(row / q.rows_per_sample) % q.dens_mod] / DRP_DENS_SCALE, accd);
+    }
+    if (wave > 0) {
+        float* dst = s_part + (size_t)(wave - 1) * 66 * 64;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) dst[k * 64 + lane] = acc[k];
+        dst[64 * 64 + lane] = accb;
+        dst[65 * 64 + lane] = accd;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float* src = s_part + (size_t)w * 66 * 64;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) acc[k] += src[k * 64 + lane];
+            accb += src[64 * 64 + lane];
+            accd += src[65 * 64 + lane];
+        }
+        float* out = q.part + (size_t)blockIdx.x * 66 * 64;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) out[k * 64 + lane] = acc[k];
+        out[64 * 64 + lane] = accb;
+        out[65 * 64 + lane] = accd;
+    }
+}
+#define KT_WGRAD_MULTI_LDS ((size_t)3 * 66 * 64 * sizeof(float))
+
+__global__ void __launch_bounds__(256)
+kt_wgrad_reduce_multi(WgradJobs J) {
+    __shared__ float s_w[4][64];
+    const WgradJob& q = J.j[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = blockIdx.x;      // k: 0..63 columns, 64 bias, 65 density column
+    if (k < 64 && k >= q.in) return;
+    const float* __restrict__ part = q.part;
+    const int nblocks = q.blocks;
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+    int b = wave;
+    for (; b + 12 < nblocks; b += 16) {
+        t0 += part[((size_t)b * 66 + k) * 64 + lane];
+        t1 += part[((size_t)(b + 4) * 66 + k) * 64 + lane];
+        t2 += part[((size_t)(b + 8) * 66 + k) * 64 + lane];
+        t3 += part[((size_t)(b + 12) * 66 + k) * 64 + lane];
+    }
+    for (; b < nblocks; b += 4) t0 += part[((size_t)b * 66 + k) * 64 + lane];
+    s_w[wave][lane] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (wave != 0) return;
+    const float t = (s_w[0][lane] + s_w[1][lane]) + (s_w[2][lane] + s_w[3][lane]);
+    if (k < 64) q.dW[(size_t)lane * q.lane_stride + (size_t)k * q.k_stride] += t;
+    else if (k == 64) { if (q.db != nullptr) q.db[lane] += t; }
+    else if (q.dwd != nullptr) q.dwd[(size_t)lane * q.lane_stride] += t;
+}
+
 // column sums of a [M,3] gradient (bias of the predictor's last layer)
 __global__ void __launch_bounds__(256) kt_colsum3(const float* __restrict__ g, long M, float* __restrict__ out) {
     float a[3] = {0.f, 0.f, 0.f};
