@@ -335,6 +335,8 @@ class PlannerGD(Planner):
                 raise ValueError('time_lim %.3g ms admits no iteration at %d particles (%d ms each, planners.py:25-28)'
                                  % (time_lim, N, particle_num_to_iter_time(N)))
             t_lo, t_hi = sharding.shard_range(traj_num, rank, n_ranks)
+            if t_hi == t_lo:
+                raise ValueError('%d trajectories cannot be sharded over %d ranks' % (traj_num, n_ranks))
             cand = np.repeat(act_seq[:, t_lo:t_hi].transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)
             eng.gd_begin(state_cur_np, attr_cur_np, state_param, cand, cfg['gd']['lr'], lo, hi)   # [traj*nb,H,4]
             reward_seqs = np.zeros((cand.shape[0],), np.float32)
@@ -369,6 +371,8 @@ class PlannerGD(Planner):
             nominal = act_seq[:, int(np.argmax(r0.mean(1))), :].astype(np.float64)
             s_lo, s_hi = sharding.shard_range(n_sample, rank, n_ranks)
             ns_loc = s_hi - s_lo
+            if ns_loc == 0:
+                raise ValueError('%d samples cannot be sharded over %d ranks' % (n_sample, n_ranks))
             if n_iter > 1:
                 eng.mpc_begin(state_cur_np, attr_cur_np, state_param, nominal, n_sample=ns_loc, sample_offset=s_lo, **mp)
             k_elite = int(cfg.get('cem', {}).get('n_elite', max(1, n_sample // 10)))
