@@ -85,6 +85,9 @@ struct drp_ctx {
 
     // MPC state
     bool mpc_on = false;
+    unsigned mpc_cself_tag = 0;     // the session's self-edge constants are in c->cself while this equals cself_tag
+    const float* mpc_cself = nullptr;
+    const uint8_t* mpc_cself_ok = nullptr;
     float sess_attr_max = 0.0f, sess_dens_max = 0.0f;   // of the running MPC session (range check of later uploads)
     drp_mpc_params mpc{};
     DevBuf nominal, noise, partials, gathered, stats, elite, elite_all, xchg;
@@ -502,7 +505,7 @@ int prepare_cself(drp_ctx* c, int attr_mod, int N, int B, const float** cself, c
     return DRP_OK;
 }
 
-int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool reward_last) {
+int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool reward_last, bool session = false) {
     CHK(ensure_step_ws(c, B, N));
     CHK(ensure(c, c->states, (size_t)B * H * N * 3 * sizeof(float)));
     CHK(ensure(c, c->rewards, (size_t)B * H * sizeof(float)));
@@ -511,7 +514,15 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
     const size_t hstride = (size_t)H * N * 3;
     const float* cself = nullptr;
     const uint8_t* cself_ok = nullptr;
-    CHK(prepare_cself(c, nb, N, B, &cself, &cself_ok));
+    // the self-edge constants depend on attributes and densities only: an MPC session computes them once (its first
+    // rollout) and keeps them while nobody else has refilled the buffer
+    if (session && c->mpc_cself_tag != 0 && c->mpc_cself_tag == c->cself_tag) {
+        cself = c->mpc_cself;
+        cself_ok = c->mpc_cself_ok;
+    } else {
+        CHK(prepare_cself(c, nb, N, B, &cself, &cself_ok));
+        if (session) { c->mpc_cself_tag = c->cself_tag; c->mpc_cself = cself; c->mpc_cself_ok = cself_ok; }
+    }
     for (int t = 0; t < H; ++t) {
         StepArgs a{};
         a.cself = cself; a.cself_ok = cself_ok;
@@ -1004,6 +1015,7 @@ int drp_mpc_begin(drp_ctx* c, const drp_mpc_params* p, const float* s0, const fl
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->mpc_on = true;
     c->gd_on = false;
+    c->mpc_cself_tag = 0;           // new attributes / densities / batch size
     return DRP_OK;
 }
 
@@ -1017,7 +1029,7 @@ int drp_mpc_sample(drp_ctx* c, const float* noise, uint64_t iteration) {
         dnoise = ptr<float>(c->noise);
     }
     ProbeScope ps(c, KC_MPPI);
-    hipLaunchKernelGGL(k_mppi_sample, dim3((p.n_sample + 127) / 128), dim3(128), 0, c->stream,
+    hipLaunchKernelGGL(k_mppi_sample, dim3((4 * p.n_sample + 255) / 256), dim3(256), 0, c->stream,
                        ptr<double>(c->nominal), dnoise, p.n_sample, p.n_batch, p.n_look_ahead, p.sigma,
                        p.beta_filter, make_float4(p.act_lo[0], p.act_lo[1], p.act_lo[2], p.act_lo[3]),
                        make_float4(p.act_hi[0], p.act_hi[1], p.act_hi[2], p.act_hi[3]), p.seed,
@@ -1042,7 +1054,7 @@ int drp_mpc_rollout(drp_ctx* c, int reward_all_steps) {
     HIPCHK(c, hipSetDevice(c->device));
     const drp_mpc_params& p = c->mpc;
     return run_rollout(c, p.n_batch, p.n_particles, p.n_sample * p.n_batch, p.n_look_ahead,
-                       reward_all_steps != 0, reward_all_steps == 0);
+                       reward_all_steps != 0, reward_all_steps == 0, true);
 }
 
 static int launch_partials(drp_ctx* c, double* out) {

@@ -49,40 +49,38 @@ __global__ void k_mppi_sample(const double* __restrict__ nominal, const float* _
                               int n_sample, int n_batch, int H, double sigma, double beta, float4 lo,
                               float4 hi, uint64_t seed, uint64_t sample_offset, uint64_t iteration,
                               int noise_type, float* __restrict__ actions) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    // four threads per sample, one per push component: the temporal filter runs along t only (the four lanes of a
+    // sample evaluate the same Philox block -- one block yields the draws of all four components)
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = tid >> 2, c = tid & 3;
     if (s >= n_sample) return;
     const float lo_[4] = {lo.x, lo.y, lo.z, lo.w}, hi_[4] = {hi.x, hi.y, hi.z, hi.w};
-    double resid[4] = {0.0, 0.0, 0.0, 0.0};
+    const double lc = (double)lo_[c], hc = (double)hi_[c];
+    double resid = 0.0;
     for (int t = 0; t < H; ++t) {
-        float n[4];
+        float n;
         if (noise != nullptr) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) n[c] = noise[((size_t)s * H + t) * 4 + c];
+            n = noise[((size_t)s * H + t) * 4 + c];
         } else {
             const uint64_t gs = sample_offset + (uint64_t)s;
             uint32_t ctr[4] = {(uint32_t)gs, (uint32_t)(gs >> 32), (uint32_t)t, (uint32_t)iteration};
             philox4x32(ctr, seed);
             if (noise_type == 0) {
-                box_muller(ctr[0], ctr[1], n[0], n[1]);
-                box_muller(ctr[2], ctr[3], n[2], n[3]);
+                float n0, n1;
+                box_muller(ctr[c & 2], ctr[(c & 2) + 1], n0, n1);
+                n = (c & 1) ? n1 : n0;
             } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float u = (float)(ctr[c] >> 8) * 5.9604644775390625e-08f;      // [0,1), 24 bits
-                    n[c] = (noise_type == 1) ? 2.0f * u - 1.0f : u;
-                }
+                const float u = (float)(ctr[c] >> 8) * 5.9604644775390625e-08f;      // [0,1), 24 bits
+                n = (noise_type == 1) ? 2.0f * u - 1.0f : u;
             }
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const double z = (noise_type == 2) ? 0.0 : sigma * (double)n[c];
-            resid[c] = beta * z + resid[c] * (1.0 - beta);
-            double a = nominal[t * 4 + c] + resid[c];
-            a = fmin(fmax(a, (double)lo_[c]), (double)hi_[c]);
-            if (noise_type == 2) a = (double)lo_[c] + (double)n[c] * ((double)hi_[c] - (double)lo_[c]);
-            for (int j = 0; j < n_batch; ++j)
-                actions[(((size_t)s * n_batch + j) * H + t) * 4 + c] = (float)a;
-        }
+        const double z = (noise_type == 2) ? 0.0 : sigma * (double)n;
+        resid = beta * z + resid * (1.0 - beta);
+        double a = nominal[t * 4 + c] + resid;
+        a = fmin(fmax(a, lc), hc);
+        if (noise_type == 2) a = lc + (double)n * (hc - lc);
+        for (int j = 0; j < n_batch; ++j)
+            actions[(((size_t)s * n_batch + j) * H + t) * 4 + c] = (float)a;
     }
 }
 
