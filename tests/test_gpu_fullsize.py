@@ -215,3 +215,21 @@ def test_config3_eight_logical_shards_equal_one_batch(ctx):
     np.testing.assert_allclose(host_nominal, want, rtol=1e-12, atol=1e-12)
     # elite form: the k best of 8 x k records are the k best of the whole batch, summed in the same (rank) order
     np.testing.assert_array_equal(ctx.mpc_update_elite(erecs, k), want_elite)
+
+
+@pytest.mark.parametrize('N,ns', [(1300, 300), (1300, 1100), (37, 2000)])
+def test_row_lists_longer_than_the_order_buffer_and_odd_shapes(ctx, N, ns):
+    """km_prop3's row order lives in LDS up to 4 900 rows per workgroup: 2 x 1 300 rows are ordered, 5 x 1 300 keep
+    the natural order, 8 x 37 rows leave a ragged last tile -- all against the fp32 MFMA engine, one step."""
+    s0, dens, attr = syn.make_pile(N, 1, seed=N + ns)
+    s0[..., :2] *= (3.0 if N > 1000 else 1.6)            # spread out: mixed in-degrees
+    acts = syn.sample_pushes(ns, 1, seed=N)
+    out = {}
+    for name in ('mfma', 'fused'):
+        ctx.set_engine(_lib.ENGINES[name])
+        out[name], _ = ctx.rollout(s0, attr, dens, acts)
+    cnt = ctx.debug_fetch('nbr_cnt', (ns, N), np.uint8)
+    assert cnt.min() >= 1 and cnt.max() <= 10
+    disp = np.abs(out['mfma'][:, 0] - s0).max()
+    assert np.abs(out['fused'] - out['mfma']).max() < 1e-4 * disp
+    ctx.set_engine(_lib.ENGINE_FUSED)

@@ -39,7 +39,8 @@ CELLS = ('cells', 'cells_lo', 'cells_hi')
 
 
 @pytest.mark.parametrize('N,B,kind,scale', [(129, 5, 'uniform', 1.0), (300, 6, 'uniform', 1.0), (300, 4, 'blob', 1.0),
-                                            (515, 3, 'uniform', 3.0), (700, 2, 'blob', 0.3), (1200, 2, 'uniform', 1.0)])
+                                            (515, 3, 'uniform', 3.0), (700, 2, 'blob', 0.3), (1200, 2, 'uniform', 1.0),
+                                            (2500, 2, 'blob', 1.0), (4096, 1, 'uniform', 1.0)])
 def test_lists_equal_plain_sweep(monkeypatch, N, B, kind, scale):
     """Jittered piles: uniform over the workspace, clumped (everything within a radius or two: the strips prune
     nothing), spread out (most strips empty, particles beyond the clamped end strips)."""
