@@ -308,16 +308,15 @@ class PlannerGD(Planner):
                 acts = acts.reshape(n_batch, H, self.action_dim)
             else:
                 r = rewards.reshape(ns, n_batch)
-                cur_max, idx = r.max(0), r.argmax(0)
-                acts = [actions[idx[j] * n_batch + j] for j in range(n_batch)]
+                cur_max, idx = r.max(0), r.argmax(0)                     # first maximum, as torch.max
+                acts = actions.reshape(ns, n_batch, H, self.action_dim)[idx, np.arange(n_batch)]
                 idx = idx + index_offset
                 mean = r[:, 0].mean()
                 std = r[:, 0].std(ddof=1) if ns > 1 else 0.0
-            for j in range(n_batch):
-                if cur_max[j] > max_reward[j]:
-                    max_reward[j] = cur_max[j]
-                    max_reward_traj_idx[j] = idx[j]
-                    best_actions_of_samples[j] = acts[j]
+            better = np.asarray(cur_max) > max_reward                     # strictly, per column (planners.py:724)
+            max_reward[better] = np.asarray(cur_max)[better]
+            max_reward_traj_idx[better] = np.asarray(idx)[better]
+            best_actions_of_samples[better] = np.asarray(acts)[better]
             if it < rew_mean.shape[1]:
                 rew_mean[0, it], rew_std[0, it] = mean, std
 

@@ -34,4 +34,12 @@ for mpc_type, N, n_batch, traj, H, iters in (('GD', 20, 30, 50, 1, 200), ('GD', 
           'optimiser %.0f ms); reward %.3f -> %.3f' % (mpc_type, N, n_batch, traj, H, res['iter_num'], ms, ms / max(res['iter_num'], 1),
                                                       res['times']['rollout_time'], res['times']['optim_time'],
                                                       res['rew_mean'][0, 0], res['reward'][0]), flush=True)
+    if mpc_type == 'GD':
+        # the shipped budget (config/mpc/config.yaml:40-43: time_lim 2000 ms, n_update_iter 200): the reference's
+        # iteration count min(200, int(2000 / particle_num_to_iter_time(N)))
+        kw2 = dict(kw, time_lim=2000.0)
+        t0 = time.perf_counter()
+        res = planner.trajectory_optimization_ptcl_multi_traj(s, dens, attr, obs_goal, model, act_seq, np.zeros(H), **kw2)
+        ms = (time.perf_counter() - t0) * 1e3
+        print('     with the shipped time_lim = 2000 ms: %d iterations (the reference\'s count), whole planner call %.1f ms' % (res['iter_num'] + 1, ms), flush=True)
     model.engine.close()
