@@ -3,14 +3,14 @@
 # this is for a maintainer with an 8-GPU box).  One process per GPU, RCCL over xGMI, rendezvous on 127.0.0.1.
 #   c3: weak scaling, 1024 samples per GPU (8192 at 8 GPUs = BASELINE configs[2])
 #   c5: strong scaling, 4096 samples in total (512 per GPU at 8 GPUs = BASELINE configs[4])
-# usage: tools/scale.sh [steps] [warmup]     -> one JSON line per run in scale_<config>.jsonl
+# usage: [GPU_COUNTS="1 2 4 8"] tools/scale.sh [steps] [warmup]     -> one JSON line per run in scale_<config>.jsonl
 set -e
 cd "$(dirname "$0")/.."
 STEPS=${1:-20}; WARM=${2:-3}; PORT=${MASTER_PORT:-29621}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 for CFG in c3 c5; do
   : > scale_$CFG.jsonl
-  for N in 1 2 4 8; do
+  for N in ${GPU_COUNTS:-1 2 4 8}; do
     if [ "$N" = 1 ]; then
       python bench.py --gpus 1 --config $CFG --steps $STEPS --warmup $WARM --no-alt | tail -1 >> scale_$CFG.jsonl
     else
