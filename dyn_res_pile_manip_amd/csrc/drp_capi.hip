@@ -264,13 +264,14 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
         const int ncell = gy * GC_XS;
         hipLaunchKernelGGL(k_graph_sort2, dim3(B), dim3(GRAPH_SORT_THREADS), 0, st, s_prev, prev_mod, prev_stride, actions,
                            act_stride, s_delta, N, c->cam, gy, inv_hb, sorted, starts);
-        // receivers are dealt to quarter waves band by band: at most N / 16 + gy quarters, 16 per workgroup
-        const int chunks = ((N + 15) / 16 + gy + GRAPH_CELLS_THREADS / 16 - 1) / (GRAPH_CELLS_THREADS / 16);
-        hipLaunchKernelGGL(k_graph_cells<GRAPH_CELLS_THREADS>, dim3(B * chunks), dim3(GRAPH_CELLS_THREADS),
-                           GRAPH_CELLS_LDS(N, ncell, GRAPH_CELLS_THREADS), st, (const float4*)sorted, (const int*)starts, N, gy,
-                           inv_hb, nbr_idx, nbr_cnt, c->thr, chunks, self_first,
+        const float halo = c->graph_cells_halo > 0.0f ? c->graph_cells_halo
                            // expected distance of the 10th neighbour in a pile of this density, with a third to spare
-                           c->graph_cells_halo > 0.0f ? c->graph_cells_halo : 1.3f * sqrtf(10.0f * 0.16f / (3.14159265f * (float)N)));
+                           : 1.3f * sqrtf(10.0f * 0.16f / (3.14159265f * (float)N));
+        // receivers are dealt to quarter waves band by band: at most N / 16 + gy quarters, 16 per workgroup
+        const int chunks = ((N + 15) / 16 + gy + GC_THREADS / 16 - 1) / (GC_THREADS / 16);
+        hipLaunchKernelGGL(k_graph_cells, dim3(SPREAD_GRID(B * chunks)), dim3(GC_THREADS), GRAPH_CELLS_LDS(ncell), st,
+                           (const float4*)sorted, (const int*)starts, N, gy, inv_hb, nbr_idx, nbr_cnt, c->thr, chunks,
+                           B * chunks, self_first, halo);
     }
     else if (c->graph_strips && !padded && N > GRAPH_THREADS) {
         // sorted positions and strip starts live in the edge-constant buffer: whatever uses it runs after the lists exist
@@ -281,17 +282,17 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
                            act_stride, s_delta, N, c->cam, sorted, starts);
         if (N >= 800) {
             const int chunks = (N + 255) / 256;
-            hipLaunchKernelGGL(k_graph_strips<256>, dim3(B * chunks), dim3(256), GRAPH_STRIPS_LDS(N, 256), st,
-                               (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, chunks, self_first);
+            hipLaunchKernelGGL(k_graph_strips<256>, dim3(SPREAD_GRID(B * chunks)), dim3(256), GRAPH_STRIPS_LDS(N, 256), st,
+                               (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, chunks, B * chunks, self_first);
         } else {
-            hipLaunchKernelGGL(k_graph_strips<GRAPH_THREADS>, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N, GRAPH_THREADS), st,
-                               (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), self_first);
+            hipLaunchKernelGGL(k_graph_strips<GRAPH_THREADS>, dim3(SPREAD_GRID(B * graph_chunks(N))), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N, GRAPH_THREADS), st,
+                               (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), B * graph_chunks(N), self_first);
         }
     }
     else
-        hipLaunchKernelGGL(k_graph, dim3(B * graph_chunks(N)), dim3(GRAPH_THREADS), graph_lds(N), st, s_prev,
+        hipLaunchKernelGGL(k_graph, dim3(SPREAD_GRID(B * graph_chunks(N))), dim3(GRAPH_THREADS), graph_lds(N), st, s_prev,
                            prev_mod, prev_stride, actions, act_stride, s_delta, N, nbr_idx, nbr_cnt, c->cam, c->thr,
-                           graph_chunks(N), self_first);
+                           graph_chunks(N), B * graph_chunks(N), self_first);
 }
 
 void launch_aggregate(drp_ctx* c, int B, int N) {
@@ -711,7 +712,6 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)k_elite_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips<GRAPH_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_graph_cells<GRAPH_CELLS_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REWARD_LDS(4096)) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reverse_lists<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||
@@ -2345,3 +2345,14 @@ long drp_debug_fetch(drp_ctx* c, const char* name, void* out, size_t out_bytes) 
 }
 
 }  // extern "C"
+
+#ifdef GC_STATS
+extern "C" int drp_gc_stats(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gc_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gc_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -12,6 +12,7 @@
 // Distances are evaluated exactly as torch does: ((dx*dx + dy*dy) + dz*dz) in fp32 with
 // no FMA contraction, and the radius test is (dis - thr) < 0 (model/gnn_dyn.py:229-236).
 #pragma once
+#include <type_traits>
 #include "drp_common.h"
 
 struct PushFrame {           // per-sample push geometry in the camera frame
@@ -73,6 +74,16 @@ __global__ void k_sdelta(const float* __restrict__ s_cur, const float* __restric
         o[i * 3 + 1] = y;
         o[i * 3 + 2] = z;
     }
+}
+
+// Work items of unequal weight (the chunks of a sample: the last one is partly empty).  The hardware hands workgroups
+// out statically -- id mod 8 picks the XCD, (id / 8) mod 4 one of its four shader-engine queues -- so with 2, 4 or 8
+// chunks per sample all the light ones land on the same queues and the heavy ones share the rest: measured 37 - 45 %
+// on k_graph_cells at 4 chunks per sample against 3 or 5, and on k_graph_strips at 400 particles (4 chunks) against
+// 350 (3).  Queue q takes the q-th thirty-second of the item list instead: grids are rounded up to a multiple of 32.
+#define SPREAD_GRID(n_items) (((n_items) + 31) & ~31)
+__device__ __forceinline__ int spread_item() {
+    return ((int)blockIdx.x & 31) * ((int)gridDim.x >> 5) + ((int)blockIdx.x >> 5);
 }
 
 __device__ __forceinline__ float pair_dis(float xi, float yi, float zi, float xj, float yj, float zj) {
@@ -167,10 +178,12 @@ __global__ void __launch_bounds__(GRAPH_THREADS)
 k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
         const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
         int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks,
-        int self_first) {
+        int n_items /* B * chunks; grid = SPREAD_GRID(n_items) */, int self_first) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* p4 = reinterpret_cast<float4*>(lds);                       // [N] displaced positions
-    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const int item = spread_item();
+    if (item >= n_items) return;
+    const int b = item / chunks, chunk = item - b * chunks;
     const float* s = s_prev + (size_t)(b % prev_mod) * prev_stride;
     float* sd = s_delta + (size_t)b * N * 3;
 
@@ -303,13 +316,16 @@ k_graph_sort(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
 template <int T>
 __global__ void __launch_bounds__(T)
 k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts, int N,
-               int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, float thr, int chunks, int self_first) {
+               int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, float thr, int chunks,
+               int n_items /* B * chunks; grid = SPREAD_GRID(n_items) */, int self_first) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Np = (N + 3) & ~3;
     float4* q4 = reinterpret_cast<float4*>(lds);                 // the staged range of the sorted senders
     int* sstart = reinterpret_cast<int*>(q4 + Np);               // [GRAPH_STRIPS + 1]
     int16_t* lst = reinterpret_cast<int16_t*>(sstart + GRAPH_STRIPS + 1);   // [T][DRP_K] chosen indices, unsorted
-    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const int item = spread_item();
+    if (item >= n_items) return;
+    const int b = item / chunks, chunk = item - b * chunks;
     const float4* g4 = sorted + (size_t)b * Np;
     if (threadIdx.x <= GRAPH_STRIPS) sstart[threadIdx.x] = starts[(size_t)b * (GRAPH_STRIPS + 1) + threadIdx.x];
     const int s_first = chunk * T;
@@ -445,24 +461,21 @@ k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts
 
 // ---- the same lists with the senders bucketed into two-dimensional cells ------------------------------------
 // What the sweep costs is receivers x candidates x (8 distance + 10 insertion) vector instructions, and the
-// candidates of a lane are the senders of the region its WAVE sweeps (wave-uniform regions keep the LDS reads
-// broadcasts).  With x strips that region is (strips of the wave's 64 receivers + halo) x the WHOLE y extent.
-// Here the positions are sorted into cells -- y bands of height hb (the host picks hb ~ sqrt(16 / density), so that
-// 16 consecutive particles of a band span about hb in x too), each band ordered by the 1-cm x strip -- and a QUARTER
-// wave (16 lanes, 16 consecutive receivers of the order: a compact block) sweeps its own region: for every band
-// within the halo of its receivers' bands, the run of strips within the halo of their strips -- a contiguous run of
-// the order per band.  The four quarters of a wave read four different LDS addresses per instruction (still
-// conflict-free), and run in lockstep under per-candidate masks.  A 16-receiver block + halo is a quarter of the
-// area a 64-receiver strip range + halo x full height covers at 1 200 particles.
-// Same two-stage first sweep (half-radius halo -> provisional 10th distance -> the ring that is still missing, swept
-// as band runs minus the runs already done) and the same narrowed second sweep as k_graph_strips; runs are swept
-// exactly (no alignment padding: a sender met twice would take two places of the ten), candidates past a run's
-// end are masked to +inf.  A quarter never straddles two bands (the end of one band and the start of the next are
-// the two ENDS of the workspace in x: such a block would sweep the whole width, and its wave with it): every band's
-// receivers are dealt to quarters of their own, the last one of a band partly idle.  Lists identical to k_graph's.
+// candidates of a lane are the senders of the region its GROUP sweeps.  With x strips that region is (strips of the
+// wave's 64 receivers + halo) x the WHOLE y extent.  Here the positions are sorted into cells -- y bands of height hb
+// (the host picks hb ~ sqrt(16 / density), so that 16 consecutive particles of a band span about hb in x too), each
+// band ordered by the 1-cm x strip (k_graph_sort2) -- and a QUARTER wave (16 lanes, 16 consecutive receivers of the
+// order: a compact block) sweeps its own region: for every band within the halo of its receivers' bands, the run of
+// strips within the halo of their strips -- a contiguous run of the order per band.  A 16-receiver block + halo is a
+// quarter of the area a 64-receiver strip range + halo x full height covers at 1 200 particles.
+// Same two-stage first sweep (a halo of the expected 10th-nearest distance -> provisional 10th distance -> the ring
+// that is still missing, swept as band runs minus the runs already done) and the same narrowed second sweep as
+// k_graph_strips; runs are swept exactly (a sender met twice would take two places of the ten).  A quarter never
+// straddles two bands (the end of one band and the start of the next are the two ENDS of the workspace in x: such a
+// block would sweep the whole width): every band's receivers are dealt to quarters of their own, the last one of a
+// band partly idle.  Lists identical to k_graph's.
 #define GC_XS 64
 #define GC_MAX_BANDS 32
-#define GRAPH_CELLS_THREADS 256
 
 __device__ __forceinline__ int graph_band(float y, float inv_hb, int gy) {
     const float t = __fmul_rn(__fsub_rn(y, GRAPH_STRIP_X0), inv_hb);
@@ -542,23 +555,78 @@ k_graph_sort2(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride
     }
 }
 
-#define GRAPH_CELLS_LDS(N, ncell, T) ((size_t)((((N) + 3) & ~3) + 4) * 16 + ((size_t)(ncell) + 4) * 4 + (size_t)(T) * DRP_K * 2)
+// ---- k_graph_cells: a quarter is a DPP row --------------------------------------------------------------------
+// Lane l of the quarter loads candidate 16 c + l of the quarter's region (one coalesced global load per lane and
+// sixteen candidates, the next chunk requested before this one is used), and the sixteen lanes see all sixteen
+// through `row_ror:r`, r = 0 ... 15, folded into the subtraction that starts the distance (v_sub_f32_dpp: no
+// instruction more).  Every lane meets the same sixteen candidates in a rotated order; the ten smallest distances
+// and the emitted set do not depend on the order.  A quarter's region is ONE sequence -- its runs listed with their
+// prefix sums in a small LDS table, position -> slot by a scan of that table -- so the wave's trip count is the
+// longest of its four quarters' TOTALS, and a run's end costs no masked tail: positions past the total read as
+// x = 1e18.  No positions in LDS: 18 KB per workgroup whatever N, eight waves per SIMD.
+// (The first version broadcast every candidate from LDS to the 16 lanes -- one ds_read_b128 per candidate and lane,
+// the sample's positions staged by every workgroup, 19 KB at 1 200 particles, the four quarters in lockstep band by
+// band -- 3.9 ms per iteration at 1 200 x 512 x 20 against 3.0 now)
+#define GC_THREADS 256
+#define GC_RUNS (2 * GC_MAX_BANDS)
+#define GC_LIST 11                                                // ten entries + the slot a full list keeps overwriting
+#define GRAPH_CELLS_LDS(ncell) \
+    ((((size_t)(ncell) + 4) & ~(size_t)3) * 4 + (size_t)(GC_THREADS / 16) * GC_RUNS * 8 + (size_t)GC_THREADS * GC_LIST * 2 + 16)
 
-template <int T>
-__global__ void __launch_bounds__(T)
+template <int R>
+__device__ __forceinline__ int row_ror_i(int v) {
+    if constexpr (R == 0) return v;
+    else return __builtin_amdgcn_update_dpp(0, v, 0x120 + R, 0xf, 0xf, true);
+}
+template <int R>
+__device__ __forceinline__ float row_ror(float v) { return __int_as_float(row_ror_i<R>(__float_as_int(v))); }
+template <int R, class F>
+__device__ __forceinline__ void for_rot16(F&& f) {
+    f(std::integral_constant<int, R>{});
+    if constexpr (R + 1 < 16) for_rot16<R + 1>(f);
+}
+// all-reduce over the 16 lanes of a row: four rotations, each folded into its min / max
+__device__ __forceinline__ int row_min_i(int v) {
+    v = min(v, row_ror_i<8>(v)); v = min(v, row_ror_i<4>(v)); v = min(v, row_ror_i<2>(v)); return min(v, row_ror_i<1>(v));
+}
+__device__ __forceinline__ int row_max_i(int v) {
+    v = max(v, row_ror_i<8>(v)); v = max(v, row_ror_i<4>(v)); v = max(v, row_ror_i<2>(v)); return max(v, row_ror_i<1>(v));
+}
+__device__ __forceinline__ float row_max_f(float v) {
+    v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); return fmaxf(v, row_ror<1>(v));
+}
+// largest of a value that is uniform within every row: a scalar
+__device__ __forceinline__ int rows_max_i(int v) {
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+#ifdef GC_STATS
+__device__ unsigned long long gc_stats[16];
+#define GC_STAT(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&gc_stats[k], (unsigned long long)(v)); } while (0)
+#define GC_STATQ(k, v) do { if ((threadIdx.x & 15) == 0) atomicAdd(&gc_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define GC_STAT(k, v)
+#define GC_STATQ(k, v)
+#endif
+__global__ void __launch_bounds__(GC_THREADS)
 k_graph_cells(const float4* __restrict__ sorted, const int* __restrict__ starts, int N, int gy, float inv_hb,
-              int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, float thr, int chunks, int self_first,
-              float halo_first /* first guess of the 10th-nearest distance (any positive value gives the same lists) */) {
+               int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, float thr, int chunks, int n_items /* B * chunks */,
+               int self_first, float halo_first) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int T = GC_THREADS;
     const int Np = (N + 3) & ~3, ncell = gy * GC_XS;
-    float4* q4 = reinterpret_cast<float4*>(lds);                 // the staged bands, at their positions in the order
-    int* cs = reinterpret_cast<int*>(q4 + Np + 4);               // [ncell + 1] first slot of every cell
-    int16_t* lst = reinterpret_cast<int16_t*>(cs + ((ncell + 4) & ~3));     // [T][DRP_K] chosen indices, unsorted
-    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    int* cs = reinterpret_cast<int*>(lds);                                   // [ncell + 1] first slot of every cell
+    int2* tabs = reinterpret_cast<int2*>(cs + ((ncell + 4) & ~3));           // [T / 16][GC_RUNS] (first slot - prefix, prefix)
+    int16_t* lst = reinterpret_cast<int16_t*>(tabs + (T / 16) * GC_RUNS);   // [T][GC_LIST] chosen indices, unsorted
+    const int item = spread_item();
+    if (item >= n_items) return;
+    const int b = item / chunks, chunk = item - b * chunks;
     const float4* g4 = sorted + (size_t)b * Np;
     const int* gs = starts + (size_t)b * (ncell + 1);
     for (int c = threadIdx.x; c <= ncell; c += T) cs[c] = gs[c];
-    __shared__ int qstart[GC_MAX_BANDS + 1];                     // first quarter of every band: sum of ceil(n_band / 16)
+    for (int c = threadIdx.x; c < (T / 16) * GC_RUNS; c += T) tabs[c] = make_int2(0, 0x7fffffff);   // no run starts here
+    __shared__ int qstart[GC_MAX_BANDS + 1];
     __syncthreads();
     if (threadIdx.x == 0) {
         int q = 0;
@@ -570,164 +638,179 @@ k_graph_cells(const float4* __restrict__ sorted, const int* __restrict__ starts,
     }
     __syncthreads();
     const int nq = qstart[gy];
-    const int q_first = chunk * (T / 16);
-    if (q_first >= nq) return;                                   // the grid is sized for the worst case N / 16 + gy quarters
-    const int q_last = min(q_first + T / 16, nq) - 1;
-    auto band_of_quarter = [&](int q) {
-        int bb = 0;
-        while (bb + 1 < gy && qstart[bb + 1] <= q) ++bb;
-        return bb;
-    };
+    const int qid = chunk * (T / 16) + ((int)threadIdx.x >> 4);
+    const bool q_on = qid < nq;
+    if (__ballot(q_on) == 0) return;                             // no barrier below: a wave is on its own from here
+    int qb = 0;
+    {
+        const int qq = min(qid, nq - 1);
+        while (qb + 1 < gy && qstart[qb + 1] <= qq) ++qb;
+    }
     const float radius = __fsqrt_rn(fmaxf(thr, 0.0f)) * 1.000001f;
-    // cells a halo h reaches beyond a receiver's own: a sender within h in one coordinate sits at most ceil(h / cell) cells
-    // away; the 1e-3 of a cell covers the rounding of the cell index at a boundary (about 1e-5 of a cell)
     auto reach_x = [&](float hh) { return (int)fminf(ceilf(hh * GRAPH_STRIP_INV_W + 1e-3f), (float)GC_XS); };
     auto reach_y = [&](float hh) { return (int)fminf(ceilf(hh * inv_hb + 1e-3f), (float)gy); };
-    // stage whole bands: those of the workgroup's quarters widened by the radius
-    const int wg_b0 = band_of_quarter(q_first), wg_b1 = band_of_quarter(q_last);
-    {
-        const int rbw = reach_y(radius);
-        const int wlo = cs[max(wg_b0 - rbw, 0) * GC_XS] & ~3;
-        const int whi = min((cs[(min(wg_b1 + rbw, gy - 1) + 1) * GC_XS] + 3) & ~3, Np);
-        for (int j = wlo + (int)threadIdx.x; j < whi; j += T) q4[j] = g4[j];
-        if (threadIdx.x < 4) q4[Np + threadIdx.x] = make_float4(1e18f, 0.0f, 0.0f, __int_as_float(-1));
-    }
-    __syncthreads();
-
-    // this lane's receiver: slot (lane & 15) of its quarter's 16 consecutive receivers inside the quarter's band
-    const int qid = q_first + ((int)threadIdx.x >> 4);
-    const int qb = band_of_quarter(min(qid, nq - 1));
     const int band_lo = cs[qb * GC_XS], band_hi = cs[(qb + 1) * GC_XS];
-    const int si = band_lo + ((min(qid, nq - 1) - qstart[qb]) << 4) + ((int)threadIdx.x & 15);
-    const bool valid = qid < nq && si < band_hi;
-    if (__ballot(valid) == 0) return;
-    const float4 pi = q4[valid ? si : max(band_hi - 1, band_lo)];     // an idle lane mirrors its band's last receiver
+    const int l16 = (int)threadIdx.x & 15;
+    const int si = band_lo + ((min(qid, nq - 1) - qstart[qb]) << 4) + l16;
+    const bool valid = q_on && si < band_hi;
+    const int si_safe = valid ? si : max(band_hi - 1, band_lo);  // an idle lane mirrors its band's last receiver
+    const float4 pi = g4[si_safe];
     const int i = __float_as_int(pi.w);
-    // the quarter's block: strips and bands of its 16 receivers
-    int xs_min = graph_strip(pi.x), xs_max = xs_min, yb_min = graph_band(pi.y, inv_hb, gy), yb_max = yb_min;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        xs_min = min(xs_min, __shfl_xor(xs_min, o, 64));
-        xs_max = max(xs_max, __shfl_xor(xs_max, o, 64));
-        yb_min = min(yb_min, __shfl_xor(yb_min, o, 64));
-        yb_max = max(yb_max, __shfl_xor(yb_max, o, 64));
-    }
-    auto quarter_max = [&](float v) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-        return v;
-    };
-    auto wave_max_i = [&](int v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-        return v;
-    };
-    // every quarter walks its own region -- bands [yb_min - rb, yb_max + rb], in each the strips [xs_min - rx, xs_max + rx],
-    // minus (excl) the region of the halo (rbE, rxE) swept before -- as runs [ja, jb) of the order; the wave goes through
-    // the runs of its four quarters in lockstep and `body(j, jb)` masks what lies past a quarter's own run end
-    auto for_region = [&](int rb, int rx, bool excl, int rbE, int rxE, auto body) {
+    const int xs = graph_strip(pi.x), yb = graph_band(pi.y, inv_hb, gy);
+    const int xs_min = row_min_i(xs), xs_max = row_max_i(xs), yb_min = row_min_i(yb), yb_max = row_max_i(yb);
+    // the quarter's region -- bands [yb_min - rb, yb_max + rb], in each the strips [xs_min - rx, xs_max + rx], minus
+    // (excl) the region of the halo (rbE, rxE) swept before -- as a table of runs: position p of the region, with
+    // prefix <= p < next prefix, is slot p + (first slot - prefix); entries past the last run keep prefix = INT_MAX
+    int2* tab = tabs + ((int)threadIdx.x >> 4) * GC_RUNS;
+    int nr = 0, nr_hi = 0, total = 0;
+    auto build = [&](int rb, int rx, bool excl, int rbE, int rxE) {
         const int b_lo = max(yb_min - rb, 0), b_hi = min(yb_max + rb, gy - 1);
         const int x0 = max(xs_min - rx, 0), x1 = min(xs_max + rx, GC_XS - 1);
         const int eb_lo = max(yb_min - rbE, 0), eb_hi = min(yb_max + rbE, gy - 1);
         const int e0 = max(xs_min - rxE, 0), e1 = min(xs_max + rxE, GC_XS - 1);
-        const int nb_max = wave_max_i(b_hi - b_lo + 1);
-        for (int bi = 0; bi < nb_max; ++bi) {
-            const int bb = min(b_lo + bi, gy - 1);
-            const bool on = (b_lo + bi) <= b_hi;
+        nr = 0;
+        total = 0;
+        for (int bb = b_lo; bb <= b_hi; ++bb) {
             const int* cb = cs + bb * GC_XS;
-            int ra = 0, rbnd = 0, ta = 0, tb = 0;
-            if (on) {
-                if (excl && bb >= eb_lo && bb <= eb_hi) {
-                    ra = cb[x0]; rbnd = cb[e0];                     // strips x0 .. e0 - 1
-                    ta = cb[e1 + 1]; tb = cb[x1 + 1];               // strips e1 + 1 .. x1
-                } else {
-                    ra = cb[x0]; rbnd = cb[x1 + 1];
-                }
+            int ra, re, ta = 0, tb = 0;
+            if (excl && bb >= eb_lo && bb <= eb_hi) {
+                ra = cb[x0]; re = cb[e0];                          // strips x0 .. e0 - 1
+                ta = cb[e1 + 1]; tb = cb[x1 + 1];                  // strips e1 + 1 .. x1
+            } else {
+                ra = cb[x0]; re = cb[x1 + 1];
             }
-            // whole groups of four in every quarter: no masks; the ends of the runs: masked
-            int j = ra;
-            for (; __all(j + 4 <= rbnd); j += 4) body(j, rbnd, false);
-            for (; __any(j < rbnd); j += 4) body(min(j, Np), rbnd, true);
-            if (__any(ta < tb))
-                for (j = ta; __any(j < tb); j += 4) body(min(j, Np), tb, true);
+            if (re > ra) { tab[nr] = make_int2(ra - total, total); ++nr; total += re - ra; }
+            if (tb > ta) { tab[nr] = make_int2(ta - total, total); ++nr; total += tb - ta; }
+        }
+        for (int r = nr; r < nr_hi; ++r) tab[r] = make_int2(0, 0x7fffffff);
+        nr_hi = max(nr_hi, nr);
+    };
+    int stat_slot = 0;
+    auto sweep = [&](auto body16) {
+        const int nch = rows_max_i((total + 15) >> 4);
+        const int nrm = rows_max_i(nr);
+        GC_STAT(stat_slot, nch);                                  // chunks the wave runs
+        GC_STATQ(stat_slot + 1, q_on ? total : 0);                // candidates of the quarter's region
+        GC_STATQ(stat_slot + 2, q_on ? nr : 0);
+        auto fetch = [&](int pos) {
+            int dlt = 0;
+            for (int r = 0; r < nrm; ++r) {
+                const int2 t = tab[r];
+                dlt = (pos >= t.y) ? t.x : dlt;
+            }
+            const bool in = pos < total;
+            float4 q = g4[in ? pos + dlt : si_safe];
+            q.x = in ? q.x : 1e18f;
+            return q;
+        };
+        if (nch == 0) return;
+        float4 cur = fetch(l16);
+        for (int c = 0; c < nch; ++c) {
+            float4 nxt = cur;
+            if (c + 1 < nch) nxt = fetch(((c + 1) << 4) + l16);
+            body16(cur);
+            cur = nxt;
         }
     };
 
     float best[DRP_K];
 #pragma unroll
     for (int q = 0; q < DRP_K; ++q) best[q] = thr;
-    auto insert4 = [&](int j, int jb, bool masked) {
-        const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
-        float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
-                       pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
+    auto insert16 = [&](const float4& q) {
+        for_rot16<0>([&](auto rr) {
+            constexpr int R = decltype(rr)::value;
+            const float d = pair_dis(pi.x, pi.y, pi.z, row_ror<R>(q.x), row_ror<R>(q.y), row_ror<R>(q.z));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float d = (!masked || j + u < jb) ? d4[u] : __builtin_inff();
-#pragma unroll
-            for (int q = DRP_K - 1; q > 0; --q) best[q] = __builtin_amdgcn_fmed3f(d, best[q - 1], best[q]);
+            for (int k = DRP_K - 1; k > 0; --k) best[k] = __builtin_amdgcn_fmed3f(d, best[k - 1], best[k]);
             best[0] = min_nonneg(d, best[0]);
-        }
+        });
     };
-    // first sweep, stage A: a halo of the expected 10th-nearest distance (from the pile's density, host); stage B: what
-    // the provisional 10th distance found there still allows
-    const float halo_a = fminf(fmaxf(halo_first, 0.0f), radius);
-    const int rba = reach_y(halo_a), rxa = reach_x(halo_a);
-    for_region(rba, rxa, false, 0, 0, insert4);
+    // first sweep, stage A: a halo of the expected 10th-nearest distance; stage B: what the provisional 10th distance
+    // found there still allows
+    const float halo_req = fminf(fmaxf(halo_first, 0.0f), radius);
+    const int rba = reach_y(halo_req), rxa = reach_x(halo_req);
+    // the cells of that reach hold every sender within halo_a of a receiver of the block: whole cells are swept
+    // anyway, so the first stage vouches for all they cover (and the second one runs that much less often)
+    const float halo_a = fminf(radius, fminf(rxa >= GC_XS ? radius : ((float)rxa - 2e-3f) * (1.0f / GRAPH_STRIP_INV_W),
+                                             rba >= gy ? radius : ((float)rba - 2e-3f) / inv_hb));
+    build(rba, rxa, false, 0, 0);
+    GC_STAT(12, 1);
+    GC_STATQ(13, q_on ? 1 : 0);
+    sweep(insert16);
     {
-        const float kprov = quarter_max(valid ? best[DRP_K - 1] : 0.0f);
+        const float kprov = row_max_f(valid ? best[DRP_K - 1] : 0.0f);
         const float halo_b = fminf(radius, __fsqrt_rn(fmaxf(kprov, 0.0f)) * 1.000001f);
         const bool more = halo_b > halo_a;
         if (__any(more)) {
             const int rbb = more ? max(reach_y(halo_b), rba) : rba, rxb = more ? max(reach_x(halo_b), rxa) : rxa;
-            for_region(rbb, rxb, true, rba, rxa, insert4);
+            build(rbb, rxb, true, rba, rxa);
+            stat_slot = 3;
+            GC_STAT(14, 1);
+            GC_STATQ(15, (q_on && more) ? 1 : 0);
+            sweep(insert16);
         }
     }
     const float kth = best[DRP_K - 1];
-    // second sweep: senders strictly nearer than kth are in; the ones AT kth fill what is left, lowest index first.
-    // Nothing farther than sqrt(kth) is emitted: the region narrows to the quarter's largest 10th-nearest distance
-    const float halo_2 = fminf(radius, __fsqrt_rn(fmaxf(quarter_max(valid ? kth : 0.0f), 0.0f)) * 1.000001f);
-    const int rb2 = reach_y(halo_2), rx2 = reach_x(halo_2);
+    // second sweep over what the quarter's largest 10th-nearest distance still reaches.  Edges are the senders with
+    // d - thr < 0 that are nearer than kth, plus the ones AT kth while slots are left, lowest index first.  kth is the
+    // tenth smallest in-radius distance (or thr when there are fewer): at most nine are nearer, and when no more than
+    // ten are at or below it every one of them is an edge -- the common case, one compare per candidate: d <= kle with
+    // kle = kth below the radius, else the largest float under thr (d <= kle <=> d < thr).  More than ten (several
+    // senders at exactly kth): the list is rebuilt by the exact rule.
+    const float halo_2 = fminf(radius, __fsqrt_rn(fmaxf(row_max_f(valid ? kth : 0.0f), 0.0f)) * 1.000001f);
+    build(reach_y(halo_2), reach_x(halo_2), false, 0, 0);
     const int skip = (self_first && thr > 0.0f) ? i : -1;
-    int16_t* mine = lst + threadIdx.x * DRP_K;
-    int cnt = 0, ties = 0, min_tie = 0x7fff;
-    for_region(rb2, rx2, false, 0, 0, [&](int j, int jb, bool masked) {
-        const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
-        const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
-                             pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
-        const int o4[4] = {__float_as_int(q0.w), __float_as_int(q1.w), __float_as_int(q2.w), __float_as_int(q3.w)};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool inr = (!masked || j + u < jb) && __fsub_rn(d4[u], thr) < 0.0f;
-            if (inr && d4[u] < kth && o4[u] != skip && cnt < DRP_K) mine[cnt++] = (int16_t)o4[u];
-            if (inr && d4[u] == kth && o4[u] != skip) {
-                ++ties;
-                min_tie = min(min_tie, o4[u]);
-            }
-        }
+    const float kle = (kth < thr) ? kth : (thr > 0.0f ? __int_as_float(__float_as_int(thr) - 1) : -1.0f);
+    int16_t* mine = lst + threadIdx.x * GC_LIST;
+    int cnt = 0;
+    stat_slot = 6;
+    sweep([&](const float4& q) {
+        for_rot16<0>([&](auto rr) {
+            constexpr int R = decltype(rr)::value;
+            const float d = pair_dis(pi.x, pi.y, pi.z, row_ror<R>(q.x), row_ror<R>(q.y), row_ror<R>(q.z));
+            mine[min(cnt, DRP_K)] = (int16_t)row_ror_i<R>(__float_as_int(q.w));     // kept only if the count moves on
+            cnt += (d <= kle) ? 1 : 0;
+        });
     });
-    const int room = DRP_K - cnt - (skip >= 0 ? 1 : 0);
-    if (ties == 1 && room > 0) {
-        mine[cnt++] = (int16_t)min_tie;
-    } else if (ties > 1 && room > 0) {
-        // several senders at exactly kth: take the lowest indices among them, one walk over the lane's own region each
-        const int b_lo = max(yb_min - rb2, 0), b_hi = min(yb_max + rb2, gy - 1);
-        const int x0 = max(xs_min - rx2, 0), x1 = min(xs_max + rx2, GC_XS - 1);
-        int last = -1;
-        for (int r = 0; r < room && r < ties; ++r) {
-            int nxt = 0x7fff;
-            for (int bb = b_lo; bb <= b_hi; ++bb)
-                for (int j = cs[bb * GC_XS + x0]; j < cs[bb * GC_XS + x1 + 1]; ++j) {
-                    const float4 q = q4[j];
-                    const float d = pair_dis(pi.x, pi.y, pi.z, q.x, q.y, q.z);
-                    const int o = __float_as_int(q.w);
-                    if (__fsub_rn(d, thr) < 0.0f && d == kth && o != skip && o > last) nxt = min(nxt, o);
+    if (cnt > DRP_K) {
+        // the exact rule, one walk over the lane's own region per pass
+        auto walk = [&](auto f) {
+            for (int u = 0; u < nr; ++u) {
+                const int2 t = tab[u];
+                const int len = ((u + 1 < nr) ? tab[u + 1].y : total) - t.y;
+                for (int j = t.x + t.y; j < t.x + t.y + len; ++j) {
+                    const float4 q = g4[j];
+                    f(pair_dis(pi.x, pi.y, pi.z, q.x, q.y, q.z), __float_as_int(q.w));
                 }
+            }
+        };
+        cnt = 0;
+        walk([&](float d, int o) {
+            if (__fsub_rn(d, thr) < 0.0f && d < kth && o != skip && cnt < DRP_K) mine[cnt++] = (int16_t)o;
+        });
+        const int room = DRP_K - cnt - (skip >= 0 ? 1 : 0);
+        int last = -1;
+        for (int r = 0; r < room; ++r) {
+            int nxt = 0x7fff;
+            walk([&](float d, int o) {
+                if (__fsub_rn(d, thr) < 0.0f && d == kth && o != skip && o > last) nxt = min(nxt, o);
+            });
+            if (nxt == 0x7fff) break;
             mine[cnt++] = (int16_t)nxt;
             last = nxt;
         }
     }
+    if (skip >= 0) {                                               // the receiver itself is slot 0 of the output, not an entry
+        int at = -1;
+#pragma unroll
+        for (int q = 0; q < DRP_K; ++q)
+            if (q < cnt && (int)mine[q] == skip) at = q;
+        if (at >= 0) {
+            mine[at] = mine[cnt - 1];
+            --cnt;
+        }
+    }
     if (!valid) return;
-    // ascending index through a 10-input sorting network (29 compare-exchanges); empty slots sort last
     int v[DRP_K];
 #pragma unroll
     for (int q = 0; q < DRP_K; ++q) v[q] = (q < cnt) ? (int)mine[q] : 0x7fff;
