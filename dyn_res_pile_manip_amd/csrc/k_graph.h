@@ -311,7 +311,8 @@ k_graph_sort(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
 
 // T receivers per workgroup: 128, or 256 for large samples (fewer workgroups stage overlapping ranges: graph build
 // 6.0 -> 5.1 ms per iteration at 1200 particles, but 2 % slower at 300)
-#define GRAPH_STRIPS_LDS(N, T) ((size_t)(((N) + 3) & ~3) * 16 + (GRAPH_STRIPS + 1) * 4 + (T) * DRP_K * 2)
+#define GS_LIST 11                                                 // ten entries + the slot a full list keeps overwriting
+#define GRAPH_STRIPS_LDS(N, T) ((size_t)(((N) + 3) & ~3) * 16 + (GRAPH_STRIPS + 1) * 4 + (T) * GS_LIST * 2 + 16)
 
 template <int T>
 __global__ void __launch_bounds__(T)
@@ -322,7 +323,7 @@ k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts
     const int Np = (N + 3) & ~3;
     float4* q4 = reinterpret_cast<float4*>(lds);                 // the staged range of the sorted senders
     int* sstart = reinterpret_cast<int*>(q4 + Np);               // [GRAPH_STRIPS + 1]
-    int16_t* lst = reinterpret_cast<int16_t*>(sstart + GRAPH_STRIPS + 1);   // [T][DRP_K] chosen indices, unsorted
+    int16_t* lst = reinterpret_cast<int16_t*>(sstart + GRAPH_STRIPS + 1);   // [T][GS_LIST] chosen indices, unsorted
     const int item = spread_item();
     if (item >= n_items) return;
     const int b = item / chunks, chunk = item - b * chunks;
@@ -399,8 +400,14 @@ k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts
     const int jlo2 = max(sstart[max(smin - reach2, 0)] & ~3, jlo);
     const int jhi2 = min((sstart[min(smax + reach2, GRAPH_STRIPS - 1) + 1] + 3) & ~3, jhi);
     const int skip = (self_first && thr > 0.0f) ? i : -1;
-    int16_t* mine = lst + threadIdx.x * DRP_K;
-    int cnt = 0, ties = 0, min_tie = 0x7fff;
+    // kth is the tenth smallest in-radius distance (or thr when there are fewer): at most nine senders are nearer, and
+    // when no more than ten are at or below it every one of them is an edge -- the common case, one compare per
+    // candidate: d <= kle with kle = kth below the radius, else the largest float under thr (d <= kle <=> d < thr).
+    // The entry is written unconditionally and kept only if the count moves on.  More than ten (several senders at
+    // exactly kth): the list is rebuilt by the exact rule.
+    const float kle = (kth < thr) ? kth : (thr > 0.0f ? __int_as_float(__float_as_int(thr) - 1) : -1.0f);
+    int16_t* mine = lst + threadIdx.x * GS_LIST;
+    int cnt = 0;
     for (int j = jlo2; j < jhi2; j += 4) {
         const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
         const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
@@ -408,21 +415,21 @@ k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts
         const int o4[4] = {__float_as_int(q0.w), __float_as_int(q1.w), __float_as_int(q2.w), __float_as_int(q3.w)};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool inr = __fsub_rn(d4[u], thr) < 0.0f;
-            if (inr && d4[u] < kth && o4[u] != skip && cnt < DRP_K) mine[cnt++] = (int16_t)o4[u];
-            if (inr && d4[u] == kth && o4[u] != skip) {
-                ++ties;
-                min_tie = min(min_tie, o4[u]);
-            }
+            mine[min(cnt, DRP_K)] = (int16_t)o4[u];
+            cnt += (d4[u] <= kle) ? 1 : 0;
         }
     }
-    const int room = DRP_K - cnt - (skip >= 0 ? 1 : 0);
-    if (ties == 1 && room > 0) {
-        mine[cnt++] = (int16_t)min_tie;
-    } else if (ties > 1 && room > 0) {
-        // several senders at exactly kth: take the lowest indices among them, one sweep each
+    if (cnt > DRP_K) {
+        cnt = 0;
+        for (int j = jlo2; j < jhi2; ++j) {
+            const float4 q = q4[j];
+            const float d = pair_dis(pi.x, pi.y, pi.z, q.x, q.y, q.z);
+            const int o = __float_as_int(q.w);
+            if (__fsub_rn(d, thr) < 0.0f && d < kth && o != skip && cnt < DRP_K) mine[cnt++] = (int16_t)o;
+        }
+        const int room = DRP_K - cnt - (skip >= 0 ? 1 : 0);
         int last = -1;
-        for (int r = 0; r < room && r < ties; ++r) {
+        for (int r = 0; r < room; ++r) {                         // the lowest indices among the senders at kth, one sweep each
             int nxt = 0x7fff;
             for (int j = jlo2; j < jhi2; ++j) {
                 const float4 q = q4[j];
@@ -430,8 +437,19 @@ k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts
                 const int o = __float_as_int(q.w);
                 if (__fsub_rn(d, thr) < 0.0f && d == kth && o != skip && o > last) nxt = min(nxt, o);
             }
+            if (nxt == 0x7fff) break;
             mine[cnt++] = (int16_t)nxt;
             last = nxt;
+        }
+    }
+    if (skip >= 0) {                                               // the receiver itself is slot 0 of the output, not an entry
+        int at = -1;
+#pragma unroll
+        for (int q = 0; q < DRP_K; ++q)
+            if (q < cnt && (int)mine[q] == skip) at = q;
+        if (at >= 0) {
+            mine[at] = mine[cnt - 1];
+            --cnt;
         }
     }
     if (!valid) return;
