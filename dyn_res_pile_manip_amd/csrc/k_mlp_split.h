@@ -1091,11 +1091,21 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
         }
     }
     __syncthreads();
+    // Waves w and w + 4 of a workgroup share a SIMD (tools/hwid.hip).  With no more tiles than waves every wave runs one
+    // tile per step, and in the in-degree order tile t is heavier than tile t + 1: waves 4 ... 7 take the tiles from the
+    // light end, so that a SIMD gets a heavy and a light one (4 x 50 particles, 7 tiles: 0 + 6, 1 + 5, 2 + 4, 3 instead
+    // of 0 + 4, 1 + 5, 2 + 6, 3).  With more tiles than waves the queue hands them out heaviest first as before.
+    const bool snake = ordered && wg_tiles <= PROP_WAVES;
     auto decode = [&](int li) {
         TileId id;
-        id.valid = li < wg_tiles;
         id.b = b0;
-        id.t = li;
+        if (snake && li >= PROP_WAVES / 2) {
+            id.t = wg_tiles - 1 - (li - PROP_WAVES / 2);
+            id.valid = li < PROP_WAVES && id.t >= PROP_WAVES / 2;
+        } else {
+            id.t = li;
+            id.valid = li < wg_tiles;
+        }
         return id;
     };
     auto row_of = [&](const TileId& id, int j) {
