@@ -56,6 +56,9 @@ struct drp_ctx {
     bool rev_global_only = false;   // DRP_REV_GLOBAL=1: reversed neighbour lists built in global memory (the N > 3072 path)
     bool self_const = true;         // DRP_NO_SELF_CONST=1: always run the encoder chain on the self slot too
     bool prop3 = true;              // DRP_NO_PROP3=1: one launch per propagation step even for chip-filling batches
+    int prop3_min_b = 0;                // DRP_PROP3_MIN_B: km_prop3 / kmb_step_bwd from this many samples (default: whole_samples())
+    int prop3_min_tiles = 1;   // DRP_PROP3_MIN_TILES: km_prop3 from this many tiles per workgroup and step
+    int bwd_fused_min_tiles = 1;   // DRP_BWD_FUSED_MIN_TILES: the same for kmb_step_bwd
     bool graph_cells = true;        // DRP_NO_GRAPH_CELLS=1: x strips only (k_graph_strips) for large samples
     int graph_cells_min_n = 400;    // DRP_GRAPH_CELLS_MIN_N: two-dimensional cells from this many particles up (measured: slower at 300, 8 % faster at 450)
     float graph_cells_halo = 0.0f;  // DRP_GRAPH_CELLS_HALO: first-sweep halo in camera-frame units (default: from the particle count)
@@ -237,6 +240,16 @@ struct StepArgs {
     bool padded = false;            // training batches: zero-padded (coincident) particles -> plain k_graph
 };
 
+// km_prop3 / kmb_step_bwd (a workgroup owns whole samples and runs all propagation steps in one launch) or the
+// per-step kernels (the tiles of all samples dealt over the chip)?  Whole samples whenever (nearly) every CU gets one --
+// and for ANY batch of samples of up to 256 particles (one round of tiles per step for the workgroup's eight waves):
+// a small batch is latency, and one launch per rollout step instead of five is what counts (B = 32 ... 255 at 50 / 100
+// particles: 1.7 - 2.0 -> 1.0 - 1.2 ms per MPPI iteration; 300 particles: 2 - 7 % slower below 200 samples, 27 % faster
+// at 255).  DRP_PROP3_MIN_B overrides the batch bound.
+bool whole_samples(const drp_ctx* c, long B, int N) {
+    if (c->prop3_min_b > 0) return B >= c->prop3_min_b;
+    return B >= c->n_cu - c->n_cu / 5 || N <= 256;
+}
 int graph_chunks(int N) { return (N + GRAPH_THREADS - 1) / GRAPH_THREADS; }
 // neighbour lists: x-strip variant for samples of at least two workgroups (below that a wave's range is the whole
 // sample anyway), plain sweep otherwise and for zero-padded batches (coincident particles tie at the cut)
@@ -336,7 +349,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     // particle encoder is its first phase unless switched off
     const int tps3 = (N + 31) / 32;
     const int spw = (int)((B + c->n_cu - 1) / c->n_cu);
-    const bool prop3 = c->engine == DRP_ENGINE_FUSED && c->prop3 && B >= c->n_cu && (long)spw * tps3 >= PROP_WAVES;
+    const bool prop3 = c->engine == DRP_ENGINE_FUSED && c->prop3 && whole_samples(c, B, N) && ((long)spw * N + 31) / 32 >= c->prop3_min_tiles;
     const bool phase_e = prop3 && c->prop3e;
     if (!phase_e) {
         ProbeScope ps(c, KC_NODE_ENCODE);
@@ -698,6 +711,9 @@ int drp_create(int device, drp_ctx** out) {
     c->prop3 = getenv("DRP_NO_PROP3") == nullptr;
     c->graph_strips = getenv("DRP_NO_GRAPH_STRIPS") == nullptr;
     c->graph_cells = getenv("DRP_NO_GRAPH_CELLS") == nullptr;
+    if (const char* e = getenv("DRP_PROP3_MIN_B")) c->prop3_min_b = atoi(e);
+    if (const char* e = getenv("DRP_PROP3_MIN_TILES")) c->prop3_min_tiles = atoi(e);
+    if (const char* e = getenv("DRP_BWD_FUSED_MIN_TILES")) c->bwd_fused_min_tiles = atoi(e);
     if (const char* e = getenv("DRP_GRAPH_CELLS_MIN_N")) c->graph_cells_min_n = atoi(e);
     if (const char* e = getenv("DRP_GRAPH_CELLS_HB")) c->graph_cells_hb = (float)atof(e);
     if (const char* e = getenv("DRP_GRAPH_CELLS_HALO")) c->graph_cells_halo = (float)atof(e);
@@ -1667,7 +1683,7 @@ int gd_forward_backward(drp_ctx* c) {
                                    cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
         }
         const int spw_b = (B + c->n_cu - 1) / c->n_cu;
-        if (c->bwd_fused && B >= c->n_cu && (long)spw_b * N >= 32 * KMB_FUSED_WAVES) {
+        if (c->bwd_fused && whole_samples(c, B, N) && ((long)spw_b * N + 31) / 32 >= c->bwd_fused_min_tiles) {
             // chip-filling batches: everything between the reward's gradient and the impulses' in one launch,
             // a workgroup owning whole samples (kmb_step_bwd)
             ProbeScope ps(c, KC_BWD_NODE);

@@ -11,7 +11,7 @@ eng.load_weights(weights.blob_from_state_dict(weights.random_state_dict(0)), 0.0
 eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
 obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
 lo, hi = syn.action_limits()
-for N in (20, 50, 100, 300):
+for N in ([int(a) for a in sys.argv[1:]] or (20, 50, 100, 300)):
     eng.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
     s0, dens, attr = syn.make_pile(N, 30, seed=N)
     acts = np.repeat(np.stack([syn.nominal_pushes(1, seed=i) for i in range(50)]), 30, axis=0).astype(np.float32)
