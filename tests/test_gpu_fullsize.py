@@ -140,14 +140,18 @@ def test_mpc_iteration_is_reproducible_and_improves(ctx):
     assert (runs[0][1] >= lo_ - 1e-9).all() and (runs[0][1] <= hi_ + 1e-9).all()
 
 
-def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch):
+@pytest.mark.parametrize('N,ns', [(70, 700),      # not a multiple of the samples per workgroup, a ragged last tile
+                                  (50, 1024),     # 7 tiles for 8 waves: waves 4 ... 7 take theirs from the light end
+                                  (12, 1500),     # 3 tiles per workgroup: most waves idle (the planner's small piles)
+                                  (100, 40),      # a batch far smaller than the chip: one sample per workgroup
+                                  (5, 300)])      # less than one tile per sample
+def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch, N, ns):
     """km_prop3 (a workgroup owns whole samples, the three propagation steps in one launch; chosen for
-    chip-filling batches) against one km_prop launch per step (DRP_NO_PROP3=1): same tiles, same
-    arithmetic in the same order -> the same bits.  700 samples are not a multiple of the samples per
-    workgroup, 70 particles leave a ragged last tile, the second case has per-particle attributes (the
-    self loop then runs the encoder chain like any other edge)."""
+    chip-filling batches and for every batch of small samples) against one km_prop launch per step
+    (DRP_NO_PROP3=1): same tiles, same arithmetic in the same order -> the same bits.  The second pass has
+    per-particle attributes (the self loop then runs the encoder chain like any other edge)."""
     from dyn_res_pile_manip_amd.engine import Engine
-    N, ns, H = 70, 700, 3
+    H = 3
     s0, dens, attr = syn.make_pile(N, 1, seed=3)
     acts = syn.sample_pushes(ns, H, seed=3)
     blob = weights.blob_from_state_dict(weights.random_state_dict(seed=0))

@@ -198,3 +198,35 @@ def test_large_batches_take_the_matrix_core_node_kernels(ctx, golden, case):
     assert np.abs(ga - ref_ga).max() < 1e-4
     # replicas are independent samples: identical bits
     np.testing.assert_array_equal(ga[:B0], ga[-B0:])
+
+
+@pytest.mark.parametrize('N,B', [(12, 1500), (40, 300), (100, 64), (5, 260)])
+def test_fused_backward_equals_the_stage_kernels_for_small_piles_and_batches(monkeypatch, N, B):
+    """kmb_step_bwd (a workgroup owns whole samples; everything between the reward's gradient and the impulses in one
+    launch) runs for every tile count and for small batches of small samples since late round 2; the stage kernels
+    (DRP_NO_BWD_FUSED=1) are the cross-check: the same gradients to rounding (the two sum a row's edges in different
+    groupings), rewards bit for bit."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    from dyn_res_pile_manip_amd import weights
+    from dyn_res_pile_manip_amd.planners import world2cam_affine
+    s0, dens, attr = syn.make_pile(N, 1, seed=N)
+    acts = syn.sample_pushes(B, 1, seed=B)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    res = {}
+    for stage in (False, True):
+        if stage:
+            monkeypatch.setenv('DRP_NO_BWD_FUSED', '1')
+        else:
+            monkeypatch.delenv('DRP_NO_BWD_FUSED', raising=False)
+        eng = Engine(0)
+        eng.load_weights(weights.blob_from_state_dict(weights.random_state_dict(seed=0)), 0.08)
+        eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+        eng.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+        eng.gd_begin(s0, attr, dens, acts, 0.05, lo, hi)
+        res[stage] = eng.gd_grad()
+        eng.close()
+    np.testing.assert_array_equal(res[False][0], res[True][0])
+    scale = np.abs(res[True][1]).max()
+    assert scale > 0 and np.isfinite(res[False][1]).all()
+    assert np.abs(res[False][1] - res[True][1]).max() < 2e-5 * scale
