@@ -11,7 +11,7 @@ from dyn_res_pile_manip_amd import synthetic as syn, weights, _lib
 from dyn_res_pile_manip_amd.engine import Engine
 from dyn_res_pile_manip_amd.planners import world2cam_affine
 
-N, ns, H = 300, 1024, 10
+N, ns, H = (int(sys.argv[1]) if len(sys.argv) > 1 else 300), (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 10
 if os.environ.get('DRP_NO_PROP3') == '':
     del os.environ['DRP_NO_PROP3']
 eng = Engine(0)
