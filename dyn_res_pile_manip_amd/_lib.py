@@ -111,6 +111,8 @@ SIGNATURES = {
     'drp_gd_grad': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p]),
     'drp_gd_step': (ctypes.c_int, [ctypes.c_void_p, c_float_p]),
     'drp_gd_get': (ctypes.c_int, [ctypes.c_void_p, c_float_p]),
+    'drp_gd_step_async': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'drp_gd_wait': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, c_float_p]),
     'drp_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'drp_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'drp_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),

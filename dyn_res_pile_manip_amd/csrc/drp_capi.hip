@@ -100,6 +100,10 @@ struct drp_ctx {
     // gradient-descent planner state
     bool gd_on = false;
     int gd_nb = 0, gd_N = 0, gd_B = 0, gd_H = 0, gd_iter = 0;
+    float* gd_pin[2] = {nullptr, nullptr};   // drp_gd_step_async: pinned host copies [B rewards | B*H*4 pushes] of two iterations in flight
+    size_t gd_pin_floats = 0;
+    hipEvent_t gd_ev[2] = {nullptr, nullptr};
+    bool gd_pending[2] = {false, false};
     unsigned gd_cself_tag = 0;      // the self-edge constants of this GD problem are in c->cself while the tags match
     const float* gd_cself = nullptr;
     const uint8_t* gd_cself_ok = nullptr;
@@ -636,7 +640,7 @@ void launch_wgrad(drp_ctx* c, const float* g, int ldg, const float* x, int ldx, 
 // The one-shot entry points stage their inputs in the buffers the planner sessions keep their state in
 // (s_in, attr, dens, actions, states): a session interrupted by one of them is over -- its next call returns
 // DRP_ESTATE instead of results computed from overwritten inputs.
-void end_sessions(drp_ctx* c) { c->mpc_on = false; c->gd_on = false; }
+void end_sessions(drp_ctx* c) { c->mpc_on = false; c->gd_on = false; c->gd_pending[0] = c->gd_pending[1] = false; }
 
 // The split relation encoder's range shift was proven for an envelope of inputs (drp_load_weights); a call
 // whose attributes, densities or impulses leave it is refused instead of risking a saturated fp16 piece.
@@ -782,6 +786,10 @@ void drp_destroy(drp_ctx* c) {
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : c->probe_ev) (void)hipEventDestroy(ev);
+    for (int q = 0; q < 2; ++q) {
+        if (c->gd_pin[q]) (void)hipHostFree(c->gd_pin[q]);
+        if (c->gd_ev[q]) (void)hipEventDestroy(c->gd_ev[q]);
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1831,6 +1839,7 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     HIPCHK(c, hipMemsetAsync(c->adam_v.p, 0, (size_t)B * H * 4 * sizeof(float), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->gd_nb = nb; c->gd_N = N; c->gd_B = B; c->gd_H = H; c->gd_iter = 0; c->gd_lr = lr;
+    c->gd_pending[0] = c->gd_pending[1] = false;           // a new problem drops what the last one left in flight
     c->gd_cself_tag = 0;
     memcpy(c->gd_lo, act_lo, 4 * sizeof(float));
     memcpy(c->gd_hi, act_hi, 4 * sizeof(float));
@@ -1858,9 +1867,9 @@ int drp_gd_grad(drp_ctx* c, float* rewards_out, float* grad_act_out, float* grad
     return drp_sync(c);
 }
 
-int drp_gd_step(drp_ctx* c, float* rewards_out) {
-    if (!c || !c->gd_on) return fail(c, DRP_ESTATE, "drp_gd_begin not called");
-    HIPCHK(c, hipSetDevice(c->device));
+namespace {
+// one iteration on the stream: forward, backward, Adam, clip
+int gd_iteration(drp_ctx* c) {
     CHK(gd_forward_backward(c));
     c->gd_iter += 1;
     // torch.optim.Adam: step_size = lr / (1 - beta1^t), denom = sqrt(v) / sqrt(1 - beta2^t) + eps
@@ -1873,10 +1882,57 @@ int drp_gd_step(drp_ctx* c, float* rewards_out) {
                        make_float4(c->gd_hi[0], c->gd_hi[1], c->gd_hi[2], c->gd_hi[3]));
     }
     HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+}  // namespace
+
+int drp_gd_step(drp_ctx* c, float* rewards_out) {
+    if (!c || !c->gd_on) return fail(c, DRP_ESTATE, "drp_gd_begin not called");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(gd_iteration(c));
     if (rewards_out) {
         CHK(d2h(c, rewards_out, c->rewards.p, (size_t)c->gd_B * sizeof(float)));
         return drp_sync(c);
     }
+    return DRP_OK;
+}
+
+// The planner's loop needs every iteration's rewards and updated pushes on the host (per-column bookkeeping,
+// planners.py:721-727), but no iteration waits for the host: slot s of two takes the iteration's results into pinned
+// memory behind the kernels, the caller enqueues the NEXT iteration before it waits for this one.
+int drp_gd_step_async(drp_ctx* c, int slot) {
+    if (!c || !c->gd_on) return fail(c, DRP_ESTATE, "drp_gd_begin not called");
+    if (slot < 0 || slot > 1) return fail(c, DRP_EINVAL, "slot must be 0 or 1");
+    if (c->gd_pending[slot]) return fail(c, DRP_ESTATE, "slot %d holds an iteration nobody has waited for", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nr = (size_t)c->gd_B, na = (size_t)c->gd_B * c->gd_H * 4;
+    if (c->gd_pin_floats < nr + na) {
+        for (int q = 0; q < 2; ++q) {
+            if (c->gd_pending[q]) return fail(c, DRP_ESTATE, "the batch grew while an iteration was in flight");
+            if (c->gd_pin[q]) HIPCHK(c, hipHostFree(c->gd_pin[q]));
+            c->gd_pin[q] = nullptr;
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->gd_pin[q]), (nr + na) * sizeof(float), hipHostMallocDefault));
+            if (!c->gd_ev[q]) HIPCHK(c, hipEventCreateWithFlags(&c->gd_ev[q], hipEventDisableTiming));
+        }
+        c->gd_pin_floats = nr + na;
+    }
+    CHK(gd_iteration(c));
+    HIPCHK(c, hipMemcpyAsync(c->gd_pin[slot], c->rewards.p, nr * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->gd_pin[slot] + nr, c->actions.p, na * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->gd_ev[slot], c->stream));
+    c->gd_pending[slot] = true;
+    return DRP_OK;
+}
+
+int drp_gd_wait(drp_ctx* c, int slot, float* rewards_out, float* actions_out) {
+    if (!c) return DRP_EINVAL;
+    if (slot < 0 || slot > 1 || !c->gd_pending[slot]) return fail(c, DRP_ESTATE, "no iteration in flight in slot %d", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->gd_ev[slot]));
+    c->gd_pending[slot] = false;
+    const size_t nr = (size_t)c->gd_B, na = (size_t)c->gd_B * c->gd_H * 4;
+    if (rewards_out) memcpy(rewards_out, c->gd_pin[slot], nr * sizeof(float));
+    if (actions_out) memcpy(actions_out, c->gd_pin[slot] + nr, na * sizeof(float));
     return DRP_OK;
 }
 

@@ -396,6 +396,18 @@ class Engine(object):
         self._ck(self.lib.drp_gd_step(self.h, _fp(r)))
         return r
 
+    def gd_step_async(self, slot):
+        """Enqueue one iteration; its rewards and updated pushes go to pinned memory behind it (gd_wait)."""
+        self._ck(self.lib.drp_gd_step_async(self.h, int(slot)))
+
+    def gd_wait(self, slot):
+        """(rewards [B] of the iterate before the update, pushes [B,H,4] after it) of the iteration in `slot`."""
+        B, H, N = self._gd
+        r = np.empty((B,), np.float32)
+        a = np.empty((B, H, 4), np.float32)
+        self._ck(self.lib.drp_gd_wait(self.h, int(slot), _fp(r), _fp(a)))
+        return r, a
+
     def gd_actions(self):
         B, H, N = self._gd
         a = np.empty((B, H, 4), np.float32)

@@ -340,16 +340,27 @@ class PlannerGD(Planner):
             eng.gd_begin(state_cur_np, attr_cur_np, state_param, cand, cfg['gd']['lr'], lo, hi)   # [traj*nb,H,4]
             reward_seqs = np.zeros((cand.shape[0],), np.float32)
             act_seqs_last = cand
+            # Iteration i + 1 is enqueued before the host waits for iteration i (its rewards and updated pushes arrive in
+            # pinned memory behind its kernels): the bookkeeping below runs beside the device.  With the opt-in wall-clock
+            # break the loop may stop after any iteration, so nothing is enqueued ahead there.
+            ahead = not wallclock_limit
+            t0 = time.perf_counter()
+            if ahead:
+                eng.gd_step_async(0)
             for i in range(n_iter):
                 before = act_seqs_last
-                t0 = time.perf_counter()
-                reward_seqs = eng.gd_step()
-                act_seqs_last = eng.gd_actions()
-                optim_time += (time.perf_counter() - t0) * 1e3
+                if ahead:
+                    if i + 1 < n_iter:
+                        eng.gd_step_async((i + 1) & 1)
+                    reward_seqs, act_seqs_last = eng.gd_wait(i & 1)
+                else:
+                    reward_seqs = eng.gd_step()
+                    act_seqs_last = eng.gd_actions()
                 # the rewards belong to the pushes before the update
                 aggregate(i, reward_seqs, before, t_hi - t_lo, index_offset=t_lo, exchange=sharded)
                 if wallclock_limit and (time.time() - start) > time_lim_s:
                     break
+            optim_time += (time.perf_counter() - t0) * 1e3
             nominal = None
         else:
             n_iter = int(n_update_iter)

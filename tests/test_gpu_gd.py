@@ -230,3 +230,32 @@ def test_fused_backward_equals_the_stage_kernels_for_small_piles_and_batches(mon
     scale = np.abs(res[True][1]).max()
     assert scale > 0 and np.isfinite(res[False][1]).all()
     assert np.abs(res[False][1] - res[True][1]).max() < 2e-5 * scale
+
+
+def test_pipelined_iterations_equal_the_blocking_ones(ctx, golden):
+    """drp_gd_step_async / drp_gd_wait (iteration i + 1 enqueued before the host waits for iteration i) against
+    drp_gd_step + drp_gd_get: the same rewards and pushes, bit for bit, in every iteration; a slot that has not been
+    waited for is refused."""
+    from dyn_res_pile_manip_amd import _lib
+    g = golden.grad
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    ctx.set_goal(syn.goal_field(obs_goal), g['h1/goal_coor'])
+    lo, hi = syn.action_limits()
+    args = (g['h1/s_cur'], g['h1/attr'], g['h1/dens'], g['h1/act_seqs'], 0.05, lo, hi)
+    ctx.gd_begin(*args)
+    want = []
+    for _ in range(5):
+        r = ctx.gd_step()
+        want.append((r, ctx.gd_actions()))
+    ctx.gd_begin(*args)
+    ctx.gd_step_async(0)
+    with pytest.raises(_lib.DrpError):
+        ctx.gd_step_async(0)
+    for i in range(5):
+        if i + 1 < 5:
+            ctx.gd_step_async((i + 1) & 1)
+        r, a = ctx.gd_wait(i & 1)
+        np.testing.assert_array_equal(r, want[i][0])
+        np.testing.assert_array_equal(a, want[i][1])
+    with pytest.raises(_lib.DrpError):
+        ctx.gd_wait(0)
