@@ -299,30 +299,37 @@ class PlannerGD(Planner):
         optim_time = 0.0
         time_lim_s = time_lim / 1000.0
 
-        def aggregate(it, rewards, actions, ns, index_offset=0, exchange=False):
+        # Sharded over ranks, every rank keeps this bookkeeping for its own rows and the call ends with ONE exchange
+        # (sharding.make_run_record / combine_run_records): no host collective per iteration.
+        sharded = comm is not None and n_ranks > 1
+        n_it_cap = rew_mean.shape[1]
+        it_sums = np.zeros((n_it_cap, 3), dtype=np.float64)
+        it_repl = np.zeros(n_it_cap, dtype=bool)
+        best_iter = np.zeros(n_batch, dtype=np.int64)
+
+        def aggregate(it, rewards, actions, ns, index_offset=0, replicated=False):
             """planners.py:721-727,736-738: per-column running max / argmax / best pushes, and the
-            iteration's reward mean / std over column 0.  exchange: the rows are this rank's shard."""
-            if exchange:
-                rec = sharding.make_column_record(rewards, actions, n_batch, index_offset)
-                mean, std, cur_max, idx, acts = sharding.combine_column_records(comm.allgather(rec), n_batch)
-                acts = acts.reshape(n_batch, H, self.action_dim)
-            else:
-                r = rewards.reshape(ns, n_batch)
-                cur_max, idx = r.max(0), r.argmax(0)                     # first maximum, as torch.max
-                acts = actions.reshape(ns, n_batch, H, self.action_dim)[idx, np.arange(n_batch)]
-                idx = idx + index_offset
-                mean = r[:, 0].mean()
-                std = r[:, 0].std(ddof=1) if ns > 1 else 0.0
+            iteration's reward mean / std over column 0.  replicated: every rank runs these same rows."""
+            r = rewards.reshape(ns, n_batch)
+            cur_max, idx = r.max(0), r.argmax(0)                         # first maximum, as torch.max
+            acts = actions.reshape(ns, n_batch, H, self.action_dim)[idx, np.arange(n_batch)]
+            idx = idx + index_offset
             better = np.asarray(cur_max) > max_reward                     # strictly, per column (planners.py:724)
             max_reward[better] = np.asarray(cur_max)[better]
             max_reward_traj_idx[better] = np.asarray(idx)[better]
             best_actions_of_samples[better] = np.asarray(acts)[better]
-            if it < rew_mean.shape[1]:
-                rew_mean[0, it], rew_std[0, it] = mean, std
+            best_iter[better] = it
+            if it < n_it_cap:
+                if sharded:
+                    c0 = r[:, 0].astype(np.float64)
+                    it_sums[it] = (ns, c0.sum(), (c0 * c0).sum())
+                    it_repl[it] = replicated
+                else:
+                    rew_mean[0, it] = r[:, 0].mean()
+                    rew_std[0, it] = r[:, 0].std(ddof=1) if ns > 1 else 0.0
 
         mpc_type = cfg.get('mpc_type', 'MPPI')
         i = 0
-        sharded = comm is not None and n_ranks > 1
         if mpc_type == 'GD':
             # the reference's live loop (planners.py:661-764): every trajectory x batch column is an
             # independent Adam problem on its own push; rollout, reward, backward, Adam and the clip all
@@ -357,7 +364,7 @@ class PlannerGD(Planner):
                     reward_seqs = eng.gd_step()
                     act_seqs_last = eng.gd_actions()
                 # the rewards belong to the pushes before the update
-                aggregate(i, reward_seqs, before, t_hi - t_lo, index_offset=t_lo, exchange=sharded)
+                aggregate(i, reward_seqs, before, t_hi - t_lo, index_offset=t_lo)
                 if wallclock_limit and (time.time() - start) > time_lim_s:
                     break
             optim_time += (time.perf_counter() - t0) * 1e3
@@ -374,7 +381,7 @@ class PlannerGD(Planner):
             eng.mpc_rollout(False)
             got = eng.mpc_get(rewards=True)
             rollout_time += (time.perf_counter() - t0) * 1e3
-            aggregate(0, got['rewards'], cand, traj_num)
+            aggregate(0, got['rewards'], cand, traj_num, replicated=True)
             reward_seqs = got['rewards'].copy()
             act_seqs_last = cand
             r0 = reward_seqs.reshape(traj_num, n_batch)
@@ -405,12 +412,21 @@ class PlannerGD(Planner):
                 t2 = time.perf_counter()
                 rollout_time += (t1 - t0) * 1e3
                 optim_time += (t2 - t1) * 1e3
-                aggregate(i, got['rewards'], got['actions'], ns_loc, index_offset=s_lo, exchange=sharded)
+                aggregate(i, got['rewards'], got['actions'], ns_loc, index_offset=s_lo)
                 reward_seqs, act_seqs_last = got['rewards'], got['actions']
                 if wallclock_limit and (time.time() - start) > time_lim_s:
                     break
             if n_iter > 1:
                 nominal = eng.mpc_get(nominal=True)['nominal']
+
+        if sharded:
+            rec = sharding.make_run_record(it_sums, it_repl, max_reward, max_reward_traj_idx, best_iter,
+                                           best_actions_of_samples)
+            mean, std, ran, mr, mi, acts = sharding.combine_run_records(comm.allgather(rec), n_it_cap, n_batch)
+            rew_mean[0, ran], rew_std[0, ran] = mean[ran], std[ran]
+            max_reward[:] = mr
+            max_reward_traj_idx[:] = mi
+            best_actions_of_samples[:] = acts.reshape(n_batch, H, self.action_dim)
 
         # planners.py:773-781: vote = most frequent best-trajectory index over the columns,
         # ties -> the column with the highest reward

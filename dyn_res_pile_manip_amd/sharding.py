@@ -189,3 +189,44 @@ def combine_column_records(records, n_batch):
     g = body[:, :, 0].argmax(0)                       # first rank attaining the column maximum
     cols = np.arange(n_batch)
     return mean, std, body[g, cols, 0], body[g, cols, 1].astype(np.int64), body[g, cols, 2:]
+
+
+# ---- the planner's bookkeeping over a whole call: ONE exchange at its end --------------------------------------
+# planners.py:721-738 keeps, per batch column, the best reward seen so far (strictly better replaces), its trajectory
+# index and pushes, and per iteration the mean / std of column 0.  Every rank can keep that for its own rows; the
+# global answer is the lexicographic best of the ranks' bests -- highest reward, then the EARLIEST iteration, then the
+# lowest index: what the sequential "strictly better" rule over all rows would have kept -- and per-iteration sums.
+# An iteration every rank ran on the same rows (the MPPI planner's iteration 0) counts once.
+def make_run_record(it_sums, it_replicated, max_reward, max_idx, best_iter, best_actions):
+    """it_sums [n_it, 3] (n, sum, sum of squares of column 0), it_replicated [n_it] bool; per column: best reward,
+    global trajectory index, iteration it was found in, pushes [n_batch, H, 4] -> float64 record."""
+    it_sums = np.asarray(it_sums, dtype=np.float64)
+    nb = len(max_reward)
+    acts = np.asarray(best_actions, dtype=np.float64).reshape(nb, -1)
+    body = np.concatenate([np.asarray(max_reward, np.float64)[:, None], np.asarray(max_idx, np.float64)[:, None],
+                           np.asarray(best_iter, np.float64)[:, None], acts], axis=1)
+    return np.concatenate([it_sums.reshape(-1), np.asarray(it_replicated, np.float64), body.reshape(-1)])
+
+
+def combine_run_records(records, n_it, n_batch):
+    """[n_ranks, record] -> (mean [n_it], unbiased std [n_it], ran [n_it] bool; per column: best reward, index,
+    pushes [n_batch, 4H])."""
+    rec = np.asarray(records, dtype=np.float64)
+    R = rec.shape[0]
+    sums = rec[:, :3 * n_it].reshape(R, n_it, 3)
+    repl = rec[0, 3 * n_it:4 * n_it] > 0.5
+    w = np.ones((R, n_it, 1))
+    w[1:, repl, :] = 0.0                                   # a replicated iteration counts once: rank 0's rows
+    tot = (sums * w).sum(0)
+    n, s1, s2 = tot[:, 0], tot[:, 1], tot[:, 2]
+    ran = n > 0
+    mean = np.where(ran, s1 / np.maximum(n, 1.0), 0.0)
+    var = np.where(n > 1, (s2 - s1 * mean) / np.maximum(n - 1.0, 1.0), 0.0)
+    std = np.sqrt(np.maximum(var, 0.0))
+    body = rec[:, 4 * n_it:].reshape(R, n_batch, -1)
+    best = np.zeros(n_batch, dtype=np.int64)
+    for j in range(n_batch):
+        keys = [(-body[r, j, 0], body[r, j, 2], body[r, j, 1], r) for r in range(R)]
+        best[j] = min(keys)[3]
+    cols = np.arange(n_batch)
+    return mean, std, ran, body[best, cols, 0], body[best, cols, 1].astype(np.int64), body[best, cols, 3:]

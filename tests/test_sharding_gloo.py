@@ -111,3 +111,51 @@ def test_column_records_fold_like_the_unsharded_bookkeeping():
     assert cidx[1] == 11
     for j in range(nb):
         np.testing.assert_array_equal(cact[j].reshape(H, 4), a[r.argmax(0)[j] * nb + j])
+
+
+def test_run_records_fold_a_whole_call_like_the_sequential_bookkeeping():
+    """The planner's bookkeeping over a whole call with ONE exchange at its end (sharding.make_run_record /
+    combine_run_records): every rank keeps the running per-column best of its own rows (strictly better replaces) and
+    per-iteration sums; the merge -- highest reward, then the earliest iteration, then the lowest index -- equals the
+    sequential rule of planners.py:721-727 over all rows, ties across ranks and across iterations included; iteration
+    0 is run by every rank on the same rows and counts once."""
+    from dyn_res_pile_manip_amd import sharding
+    rng = np.random.default_rng(11)
+    ns, nb, H, n_it, R = 23, 3, 2, 5, 3
+    r = rng.normal(-30, 5, (n_it, ns, nb)).astype(np.float32)
+    a = rng.normal(0, 2, (n_it, ns, nb, H, 4)).astype(np.float32)
+    top = r.max() + 1.0
+    r[2, 20, 1] = r[1, 4, 1] = r[1, 17, 1] = top          # one tie inside an iteration, one across iterations
+    r[3, 2, 2] = r[3, 22, 2] = top                        # a tie across ranks in the same iteration
+    # the sequential rule over all rows (iteration 0: the replicated rows, global index = row)
+    want_max = np.full(nb, -np.inf, np.float32); want_idx = np.zeros(nb, np.int64); want_act = np.zeros((nb, H, 4), np.float32)
+    for it in range(n_it):
+        cur, idx = r[it].max(0), r[it].argmax(0)
+        better = cur > want_max
+        want_max[better] = cur[better]; want_idx[better] = idx[better]
+        want_act[better] = a[it][idx, np.arange(nb)][better]
+    recs = []
+    for rank in range(R):
+        lo, hi = sharding.shard_range(ns, rank, R)
+        mx = np.full(nb, -np.inf, np.float32); mi = np.zeros(nb, np.int64); bi = np.zeros(nb, np.int64)
+        ma = np.zeros((nb, H, 4), np.float32)
+        sums = np.zeros((n_it + 2, 3)); repl = np.zeros(n_it + 2, bool)      # two iterations more than were run
+        for it in range(n_it):
+            l, h = (0, ns) if it == 0 else (lo, hi)
+            rr = r[it, l:h]
+            cur, idx = rr.max(0), rr.argmax(0)
+            better = cur > mx
+            mx[better] = cur[better]; mi[better] = idx[better] + l; bi[better] = it
+            ma[better] = a[it, l:h][idx, np.arange(nb)][better]
+            c0 = rr[:, 0].astype(np.float64)
+            sums[it] = (h - l, c0.sum(), (c0 * c0).sum()); repl[it] = it == 0
+        recs.append(sharding.make_run_record(sums, repl, mx, mi, bi, ma))
+    mean, std, ran, cmax, cidx, cact = sharding.combine_run_records(np.stack(recs), n_it + 2, nb)
+    assert ran.tolist() == [True] * n_it + [False, False]
+    for it in range(n_it):
+        np.testing.assert_allclose(mean[it], r[it, :, 0].astype(np.float64).mean(), rtol=1e-12)
+        np.testing.assert_allclose(std[it], r[it, :, 0].astype(np.float64).std(ddof=1), rtol=1e-9)
+    np.testing.assert_array_equal(cmax, want_max)
+    np.testing.assert_array_equal(cidx, want_idx)
+    assert cidx[1] == 4 and cidx[2] == 2
+    np.testing.assert_array_equal(cact.reshape(nb, H, 4), want_act)
