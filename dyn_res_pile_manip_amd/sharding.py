@@ -159,38 +159,6 @@ def as_comm(comm):
     return RcclComm(uid, rank, n_ranks)
 
 
-# The planner's per-iteration bookkeeping (planners.py:721-727,736-738) over a sharded sample axis: every rank
-# reduces its own samples to one record
-#     [n, sum r, sum r^2 of column 0 | per batch column: max r, global index of the first sample attaining it,
-#      that sample's pushes (4H)]
-# and folds the gathered records in rank order -- ranks own ascending index ranges, so "first maximum"
-# (torch.max's rule) is the lowest rank attaining the column maximum.
-def make_column_record(rewards, actions, n_batch, index_offset):
-    """rewards [ns*n_batch] (row = sample * n_batch + column), actions [ns*n_batch, H, 4] -> float64 record."""
-    r = np.asarray(rewards, dtype=np.float64).reshape(-1, n_batch)
-    a = np.asarray(actions, dtype=np.float64).reshape(r.shape[0], n_batch, -1)
-    rec = np.empty(3 + n_batch * (2 + a.shape[2]), dtype=np.float64)
-    rec[0], rec[1], rec[2] = r.shape[0], r[:, 0].sum(), (r[:, 0] * r[:, 0]).sum()
-    body = rec[3:].reshape(n_batch, 2 + a.shape[2])
-    idx = r.argmax(0)
-    for j in range(n_batch):
-        body[j, 0], body[j, 1] = r[idx[j], j], float(idx[j] + index_offset)
-        body[j, 2:] = a[idx[j], j]
-    return rec
-
-
-def combine_column_records(records, n_batch):
-    """[n_ranks, record] -> (mean, unbiased std of column 0; per column: max, global argmax, pushes [n_batch, 4H])."""
-    rec = np.asarray(records, dtype=np.float64)
-    n, s1, s2 = rec[:, 0].sum(), rec[:, 1].sum(), rec[:, 2].sum()
-    mean = s1 / n
-    std = float(np.sqrt(max((s2 - s1 * mean) / (n - 1.0), 0.0))) if n > 1 else 0.0
-    body = rec[:, 3:].reshape(rec.shape[0], n_batch, -1)
-    g = body[:, :, 0].argmax(0)                       # first rank attaining the column maximum
-    cols = np.arange(n_batch)
-    return mean, std, body[g, cols, 0], body[g, cols, 1].astype(np.int64), body[g, cols, 2:]
-
-
 # ---- the planner's bookkeeping over a whole call: ONE exchange at its end --------------------------------------
 # planners.py:721-738 keeps, per batch column, the best reward seen so far (strictly better replaces), its trajectory
 # index and pushes, and per iteration the mean / std of column 0.  Every rank can keep that for its own rows; the

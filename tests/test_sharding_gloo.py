@@ -90,29 +90,6 @@ def test_shard_range_covers_everything():
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
-def test_column_records_fold_like_the_unsharded_bookkeeping():
-    """planners.py:721-727,736-738 over a sharded sample axis: per-shard records folded in rank order ==
-    max / first argmax / pushes / mean / unbiased std of the whole batch (ties included)."""
-    from dyn_res_pile_manip_amd import sharding
-    rng = np.random.default_rng(5)
-    ns, nb, H = 37, 3, 2
-    r = rng.normal(-30, 5, (ns, nb))
-    r[11, 1] = r[29, 1] = r[:, 1].max() + 1.0            # a tie across shards: the lower index wins
-    a = rng.normal(0, 2, (ns * nb, H, 4))
-    recs = []
-    for rank in range(4):
-        lo, hi = sharding.shard_range(ns, rank, 4)
-        recs.append(sharding.make_column_record(r[lo:hi].ravel(), a[lo * nb:hi * nb], nb, lo))
-    mean, std, cmax, cidx, cact = sharding.combine_column_records(np.stack(recs), nb)
-    np.testing.assert_allclose(mean, r[:, 0].mean(), rtol=1e-12)
-    np.testing.assert_allclose(std, r[:, 0].std(ddof=1), rtol=1e-10)
-    np.testing.assert_array_equal(cmax, r.max(0))
-    np.testing.assert_array_equal(cidx, r.argmax(0))
-    assert cidx[1] == 11
-    for j in range(nb):
-        np.testing.assert_array_equal(cact[j].reshape(H, 4), a[r.argmax(0)[j] * nb + j])
-
-
 def test_run_records_fold_a_whole_call_like_the_sequential_bookkeeping():
     """The planner's bookkeeping over a whole call with ONE exchange at its end (sharding.make_run_record /
     combine_run_records): every rank keeps the running per-column best of its own rows (strictly better replaces) and
