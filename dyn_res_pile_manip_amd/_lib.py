@@ -84,6 +84,8 @@ SIGNATURES = {
     'drp_mpc_update_elite_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'drp_mpc_get': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                    c_double_p]),
+    'drp_mpc_fetch_async': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'drp_mpc_wait': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, c_float_p]),
     'drp_fps': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                ctypes.POINTER(ctypes.c_int32), c_float_p]),
     'drp_train_begin': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double]),

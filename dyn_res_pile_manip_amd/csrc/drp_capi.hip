@@ -104,6 +104,10 @@ struct drp_ctx {
     size_t gd_pin_floats = 0;
     hipEvent_t gd_ev[2] = {nullptr, nullptr};
     bool gd_pending[2] = {false, false};
+    float* mpc_pin[2] = {nullptr, nullptr};  // drp_mpc_fetch_async: [B*H*4 pushes | B final rewards] of two iterations in flight
+    size_t mpc_pin_floats = 0;
+    hipEvent_t mpc_ev[2] = {nullptr, nullptr};
+    bool mpc_pending[2] = {false, false};
     unsigned gd_cself_tag = 0;      // the self-edge constants of this GD problem are in c->cself while the tags match
     const float* gd_cself = nullptr;
     const uint8_t* gd_cself_ok = nullptr;
@@ -640,7 +644,12 @@ void launch_wgrad(drp_ctx* c, const float* g, int ldg, const float* x, int ldx, 
 // The one-shot entry points stage their inputs in the buffers the planner sessions keep their state in
 // (s_in, attr, dens, actions, states): a session interrupted by one of them is over -- its next call returns
 // DRP_ESTATE instead of results computed from overwritten inputs.
-void end_sessions(drp_ctx* c) { c->mpc_on = false; c->gd_on = false; c->gd_pending[0] = c->gd_pending[1] = false; }
+void end_sessions(drp_ctx* c) {
+    c->mpc_on = false;
+    c->gd_on = false;
+    c->gd_pending[0] = c->gd_pending[1] = false;
+    c->mpc_pending[0] = c->mpc_pending[1] = false;
+}
 
 // The split relation encoder's range shift was proven for an envelope of inputs (drp_load_weights); a call
 // whose attributes, densities or impulses leave it is refused instead of risking a saturated fp16 piece.
@@ -789,6 +798,8 @@ void drp_destroy(drp_ctx* c) {
     for (int q = 0; q < 2; ++q) {
         if (c->gd_pin[q]) (void)hipHostFree(c->gd_pin[q]);
         if (c->gd_ev[q]) (void)hipEventDestroy(c->gd_ev[q]);
+        if (c->mpc_pin[q]) (void)hipHostFree(c->mpc_pin[q]);
+        if (c->mpc_ev[q]) (void)hipEventDestroy(c->mpc_ev[q]);
     }
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1037,6 +1048,7 @@ int drp_mpc_begin(drp_ctx* c, const drp_mpc_params* p, const float* s0, const fl
     CHK(ensure(c, c->rewards, (size_t)B * H * sizeof(float)));
     CHK(ensure(c, c->scratch, (size_t)B * sizeof(float)));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->mpc_pending[0] = c->mpc_pending[1] = false;         // a new problem drops what the last one left in flight
     c->mpc_on = true;
     c->gd_on = false;
     c->mpc_cself_tag = 0;           // new attributes / densities / batch size
@@ -1251,6 +1263,48 @@ int drp_mpc_get(drp_ctx* c, float* actions, float* rewards, float* rewards_all, 
     if (states) CHK(d2h(c, states, c->states.p, (size_t)B * H * N * 3 * sizeof(float)));
     if (nominal) CHK(d2h(c, nominal, c->nominal.p, (size_t)H * 4 * sizeof(double)));
     return drp_sync(c);
+}
+
+// The planner's loop reads every iteration's pushes and final rewards (planners.py:721-738) but no iteration waits for
+// the host: the copies go to pinned memory behind the iteration's kernels (and before the next sampling overwrites the
+// pushes), the caller enqueues the next iteration and then waits for this slot's event.
+int drp_mpc_fetch_async(drp_ctx* c, int slot) {
+    if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    if (slot < 0 || slot > 1) return fail(c, DRP_EINVAL, "slot must be 0 or 1");
+    if (c->mpc_pending[slot]) return fail(c, DRP_ESTATE, "slot %d holds an iteration nobody has waited for", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    const drp_mpc_params& p = c->mpc;
+    const int H = p.n_look_ahead, B = p.n_sample * p.n_batch;
+    const size_t na = (size_t)B * H * 4, nr = (size_t)B;
+    if (c->mpc_pin_floats < na + nr) {
+        for (int q = 0; q < 2; ++q) {
+            if (c->mpc_pending[q]) return fail(c, DRP_ESTATE, "the batch grew while an iteration was in flight");
+            if (c->mpc_pin[q]) HIPCHK(c, hipHostFree(c->mpc_pin[q]));
+            c->mpc_pin[q] = nullptr;
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->mpc_pin[q]), (na + nr) * sizeof(float), hipHostMallocDefault));
+            if (!c->mpc_ev[q]) HIPCHK(c, hipEventCreateWithFlags(&c->mpc_ev[q], hipEventDisableTiming));
+        }
+        c->mpc_pin_floats = na + nr;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->mpc_pin[slot], c->actions.p, na * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->mpc_pin[slot] + na, sizeof(float), ptr<float>(c->rewards) + (H - 1), H * sizeof(float),
+                               sizeof(float), B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->mpc_ev[slot], c->stream));
+    c->mpc_pending[slot] = true;
+    return DRP_OK;
+}
+
+int drp_mpc_wait(drp_ctx* c, int slot, float* actions, float* rewards) {
+    if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
+    if (slot < 0 || slot > 1 || !c->mpc_pending[slot]) return fail(c, DRP_ESTATE, "no iteration in flight in slot %d", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->mpc_ev[slot]));
+    c->mpc_pending[slot] = false;
+    const drp_mpc_params& p = c->mpc;
+    const size_t na = (size_t)p.n_sample * p.n_batch * p.n_look_ahead * 4, nr = (size_t)p.n_sample * p.n_batch;
+    if (actions) memcpy(actions, c->mpc_pin[slot], na * sizeof(float));
+    if (rewards) memcpy(rewards, c->mpc_pin[slot] + na, nr * sizeof(float));
+    return DRP_OK;
 }
 
 int drp_fps(drp_ctx* c, const float* pts, int n, int dim, int k, int init_idx, int32_t* idx_out, float* max_dist_out) {

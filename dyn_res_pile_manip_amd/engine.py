@@ -248,6 +248,17 @@ class Engine(object):
                                       _dp(n) if nominal else None))
         return {'actions': a, 'rewards': r, 'rewards_all': ra, 'states': s, 'nominal': n}
 
+    def mpc_fetch_async(self, slot):
+        """The enqueued iteration's pushes and final rewards go to pinned memory behind its kernels (mpc_wait)."""
+        self._ck(self.lib.drp_mpc_fetch_async(self.h, int(slot)))
+
+    def mpc_wait(self, slot):
+        B = self.ns * self.nb
+        a = np.empty((B, self.H, 4), np.float32)
+        r = np.empty((B,), np.float32)
+        self._ck(self.lib.drp_mpc_wait(self.h, int(slot), _fp(a), _fp(r)))
+        return {'actions': a, 'rewards': r}
+
     def mpc_stats(self):
         out = np.empty((8,), dtype=np.float64)
         self._ck(self.lib.drp_debug_fetch(self.h, b'stats', out.ctypes.data_as(ctypes.c_void_p), out.nbytes))

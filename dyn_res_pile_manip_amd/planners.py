@@ -393,11 +393,10 @@ class PlannerGD(Planner):
             if n_iter > 1:
                 eng.mpc_begin(state_cur_np, attr_cur_np, state_param, nominal, n_sample=ns_loc, sample_offset=s_lo, **mp)
             k_elite = int(cfg.get('cem', {}).get('n_elite', max(1, n_sample // 10)))
-            for i in range(1, n_iter):
-                t0 = time.perf_counter()
-                eng.mpc_sample(i)
+            def enqueue(it):
+                """One iteration on the stream: sample, rollout, update, and its results on their way to the host."""
+                eng.mpc_sample(it)
                 eng.mpc_rollout(False)
-                t1 = time.perf_counter()
                 if comm is None or comm.device_update:
                     # partials -> [one RCCL all-gather] -> combine, on the stream
                     if mpc_type == 'CEM':
@@ -408,14 +407,27 @@ class PlannerGD(Planner):
                     eng.mpc_update_elite(comm.allgather(eng.mpc_elite(k_elite)), k_elite)
                 else:
                     eng.mpc_update(comm.allgather(eng.mpc_partials()))
-                got = eng.mpc_get(rewards=True, actions=True)
-                t2 = time.perf_counter()
-                rollout_time += (t1 - t0) * 1e3
-                optim_time += (t2 - t1) * 1e3
+                eng.mpc_fetch_async(it & 1)
+
+            # iteration i + 1 is enqueued before the host waits for iteration i: the bookkeeping runs beside the device
+            # (not with the opt-in wall-clock break, after which nothing may have run, nor with a host-transport update,
+            # whose exchange blocks anyway)
+            ahead = not wallclock_limit and (comm is None or comm.device_update)
+            t0 = time.perf_counter()
+            if ahead and n_iter > 1:
+                enqueue(1)
+            for i in range(1, n_iter):
+                if ahead:
+                    if i + 1 < n_iter:
+                        enqueue(i + 1)
+                else:
+                    enqueue(i)
+                got = eng.mpc_wait(i & 1)
                 aggregate(i, got['rewards'], got['actions'], ns_loc, index_offset=s_lo)
                 reward_seqs, act_seqs_last = got['rewards'], got['actions']
                 if wallclock_limit and (time.time() - start) > time_lim_s:
                     break
+            optim_time += (time.perf_counter() - t0) * 1e3
             if n_iter > 1:
                 nominal = eng.mpc_get(nominal=True)['nominal']
 

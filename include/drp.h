@@ -190,6 +190,13 @@ int drp_mpc_update_elite(drp_ctx* ctx, const double* records, int n_ranks, int k
 int drp_mpc_update_elite_device(drp_ctx* ctx, int k);
 int drp_mpc_get(drp_ctx* ctx, float* actions /*[B,H,4]*/, float* rewards /*[B] final*/,
                 float* rewards_all /*[B,H]*/, float* states /*[B,H,N,3]*/, double* nominal);
+/* The pushes and final rewards of the iteration just enqueued, without a host wait: slot (0 or 1) takes them into pinned
+ * memory behind the iteration's kernels -- before the next drp_mpc_sample overwrites the pushes --; drp_mpc_wait(slot)
+ * blocks until they are there and copies them out (each pointer nullable).  The planner's loop enqueues iteration i + 1
+ * before it waits for iteration i.  A slot must be waited for before it is used again; drp_mpc_begin and the one-shot
+ * calls drop what is in flight. */
+int drp_mpc_fetch_async(drp_ctx* ctx, int slot);
+int drp_mpc_wait(drp_ctx* ctx, int slot, float* actions /*[B,H,4]*/, float* rewards /*[B] final*/);
 
 /* fps_np (utils.py:451-466): farthest-point subsample of pts [n,dim] (dim 2 or 3) to k points
  * starting from init_idx; idx_out [k] are indices into pts, max_dist_out the largest distance

@@ -197,3 +197,26 @@ def test_one_mpc_step_end_to_end(stack):
     assert (out['action_sequence'][0] >= lo - 1e-6).all() and (out['action_sequence'][0] <= hi + 1e-6).all()
     assert out['iter_num'] == 3 and np.isfinite(out['reward']).all()
     dev.set_engine(None)
+
+
+@pytest.mark.parametrize('mpc_type', ['MPPI', 'CEM', 'GD'])
+def test_pipelined_loop_returns_what_the_blocking_loop_returns(stack, golden, mpc_type):
+    """The planner enqueues iteration i + 1 before it waits for iteration i's pushes and rewards (drp_mpc_fetch_async /
+    drp_gd_step_async); with the opt-in wall-clock break (a limit that never binds here) it runs the blocking loop.
+    Same seed, same dict, bit for bit."""
+    import copy
+    _, env, model, _ = stack
+    g = golden.gd_planner
+    s, dens, attr, act_seq = g['s_cur'], g['dens'], g['attr'], g['act_seq']
+    config = copy.deepcopy(syn.default_config())
+    config['mpc']['mpc_type'] = mpc_type
+    planner = PlannerGD(config, env)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    kw = dict(n_sample=act_seq.shape[1] if mpc_type == 'GD' else 96, n_look_ahead=1, n_update_iter=5,
+              action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=1e9, seed=77)
+    res = [planner.trajectory_optimization_ptcl_multi_traj(s, dens, attr, obs_goal, model, act_seq, np.zeros(1),
+                                                           wallclock_limit=w, **kw) for w in (False, True)]
+    assert res[0]['iter_num'] == res[1]['iter_num']
+    for k in ('action_sequence', 'action_full', 'reward_full', 'observation_sequence', 'reward', 'next_r', 'rew_mean', 'rew_std'):
+        np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
