@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: one "step" = one sampling-MPC iteration on the device
   sample pushes (MPPI) -> H-step GNN rollout (graph rebuild + impulse + PropNet each step)
-  -> final-step reward -> softmax-weighted update [-> RCCL all-gather when sharded].
+  -> final-step reward -> softmax-weighted update [-> ONE RCCL all-gather when sharded].
 
 Metric (BASELINE.json): particle-steps/s = samples x particles x steps / wall time.
 Workload at N=1: BASELINE.json configs[1] -- 300-particle pile, 1024 MPPI samples,
 10-step horizon (inputs resident in HBM).  With --gpus N the sample axis is sharded,
 1024 samples per GPU (weak scaling, configs[2] at N=8).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4-50|c4-150|c4-300|c4-600|c5]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-      --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4-50|c4-150|c4-300|c4-600|c5|c5-share|gd-demo]
 
---config selects a BASELINE.json workload (default c2 at one GPU, c3 = the same per-GPU share under
---gpus N); c5 is the strong-scaling one (4096 samples in total).  --force-comm (under the launcher with
-one process) attaches a one-rank RCCL communicator and runs the update through ncclAllGather.
-tools/scale.sh runs the 1/2/4/8-GPU series of c3 and c5.
+`python bench.py --gpus N` with N > 1 and no launcher around it starts its own N rank processes (one per GPU) as
+CHILD processes -- before anything in this process has touched the GPU -- relays rank 0's JSON line and exits with
+the children's status; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (how the
+driver launches it) the ranks come from the environment.  WORLD_SIZE and --gpus must agree, and with the RCCL
+transport the communicator's own ncclCommCount must equal both, or the run exits non-zero.
+
+The ranks rendezvous over a gloo process group (the ncclUniqueId broadcast, the barrier and the max-over-ranks of the
+timings); torch's NCCL process group is never created, so ONE RCCL serves the process: the one libdrp.so binds at
+run time (config.rccl in the line names its version and file).
+
+The default one-GPU run also carries a `sweep` block: the other BASELINE workloads (configs[3] 50 / 150 / 600
+particles, the per-GPU share of configs[4], the reference's live GD planner shape), 5 iterations each after 2
+warm-ups.  --config selects one of them as the headline instead; c5 is the strong-scaling one (4096 samples in
+total).  --force-comm attaches a one-rank RCCL communicator and runs the update through ncclAllGather.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -40,12 +49,14 @@ CONFIGS = {
     'c4-300': (300, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 300 particles x 1024 samples x 10 steps'),
     'c4-600': (600, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 600 particles x 1024 samples x 10 steps'),
     'c5': (1200, 4096, 20, 'strong', 'BASELINE configs[4]: 1200-particle dense pile, 4096 samples in total, 20-step horizon'),
+    'c5-share': (1200, 512, 20, 'weak', "BASELINE configs[4], one GPU's share at 8 GPUs: 1200 particles x 512 samples x 20 steps"),
     # the reference's LIVE planner (mpc_type 'GD', config/mpc/config.yaml:38-43): 50 trajectories x 30 particle
     # re-samplings = 1500 independent Adam problems, horizon 1; a "step" = one iteration of planners.py:682-764
     # (rollout, final-step reward, reverse mode, Adam, clip box).  samples = trajectories x 30 here.
     'gd-demo': (100, 1500, 1, 'weak', "the reference's live GD planner at its demo shape: 50 trajectories x 30 re-samplings x 100 particles, horizon 1 "
                                       '(config/mpc/config.yaml:38-43), one Adam iteration per step'),
 }
+SWEEP = ['c4-50', 'c4-150', 'c4-600', 'c5-share', 'gd-demo']     # the default run's extra block (configs[1] is the headline)
 GD_CLASSES = ['graph', 'node_encode', 'prop', 'reward', 'tape_copy', 'bwd_reward', 'bwd_lists', 'bwd_node', 'bwd_edge',
               'bwd_push', 'opt']
 KERNEL_CLASSES = ['graph', 'node_encode', 'edge_encode', 'project', 'aggregate', 'update',
@@ -54,6 +65,8 @@ KERNEL_CLASSES = ['graph', 'node_encode', 'edge_encode', 'project', 'aggregate',
 FLOP_PER_EDGE_ENCODE = 2 * (6 * 64 + 3 * 64 * 64)
 FLOP_PER_NODE = {'node_encode': 2 * (5 * 64 + 2 * 64 * 64), 'project': 2 * 2 * 64 * 64,
                  'update': 2 * 64 * 64, 'predict': 2 * (64 * 64 + 3 * 64)}
+EXIT_WORLD_MISMATCH = 4      # WORLD_SIZE / --gpus / ncclCommCount disagree
+EXIT_TIMEOUT = 124           # the self-launched ranks did not finish in --timeout seconds
 
 
 def parse():
@@ -67,8 +80,8 @@ def parse():
     ap.add_argument('--samples-total', type=int, default=None, help='MPPI samples over all GPUs (strong scaling)')
     ap.add_argument('--horizon', type=int, default=None)
     ap.add_argument('--force-comm', action='store_true',
-                    help='one process: still attach an RCCL communicator (ncclCommInitRank with one rank, the id broadcast '
-                         'through torch.distributed) and run the update through ncclAllGather')
+                    help='one process: still attach an RCCL communicator (ncclCommInitRank with one rank) and run the '
+                         'update through ncclAllGather')
     ap.add_argument('--comm', choices=['rccl', 'gloo'], default='rccl',
                     help="transport of the one exchange: 'rccl' = ncclAllGather on the stream (the product path); 'gloo' = the "
                          "rank's record fetched, all-gathered through torch.distributed on the host and uploaded to the combine "
@@ -79,14 +92,16 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=None, help='samples of the CPU baseline (default: about 10 s of host work)')
     ap.add_argument('--no-alt', action='store_true', help='skip the fp32-MFMA engine comparison run')
+    ap.add_argument('--no-sweep', action='store_true', help='skip the sweep block of the default one-GPU run')
+    ap.add_argument('--sweep', action='store_true', help='add the sweep block to a run that would not carry it')
     ap.add_argument('--update', choices=['mppi', 'elite'], default='mppi',
                     help='the planner update that ends an iteration: softmax-weighted mean (the reference\'s optimize_action) '
                          'or the mean of the --elite best sequences; either is one small RCCL all-gather when sharded')
     ap.add_argument('--elite', type=int, default=64)
+    ap.add_argument('--timeout', type=float, default=1500.0,
+                    help='self-launched ranks (--gpus N without a launcher): seconds before the parent ends them and exits %d' % EXIT_TIMEOUT)
+    ap.add_argument('--fault-rank', type=int, default=None, help=argparse.SUPPRESS)   # tests: this rank exits(7) after the warm-up
     args = ap.parse_args()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1:
-        args.gpus = world
     cfg = args.config or ('c2' if args.gpus == 1 else 'c3')
     N, ns, H, scaling, label = CONFIGS[cfg]
     custom = any(v is not None for v in (args.particles, args.samples, args.samples_total, args.horizon))
@@ -106,7 +121,96 @@ def parse():
         # about 10 s of host work for the dense formulation: its cost per sample grows with N^2
         args.cpu_samples = int(min(1024, max(4, 128 * (300.0 / args.particles) ** 2 * 10.0 / args.horizon)))
     args.config_name = cfg if not custom else 'custom'
+    args.do_sweep = args.sweep or (args.config is None and not custom and args.gpus == 1 and not args.no_sweep
+                                   and args.engine in ('auto', 'fused') and not args.force_comm)
     return args
+
+
+# ---- N > 1 without a launcher: this process becomes the parent of N rank processes ---------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """Start one child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, as
+    torch.distributed.run would set them), relay rank 0's JSON line, return the exit status.  The parent imports
+    neither torch.cuda nor the engine and makes no HIP call: nothing here may initialise the GPU before the children
+    exist, and no process image is ever replaced.  A rank that fails, or --timeout, ends every child (each is its own
+    process group, killed by its pgid -- never by pattern)."""
+    import signal
+    import tempfile
+    n = args.gpus
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        out = tempfile.TemporaryFile() if r == 0 else subprocess.DEVNULL
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
+                                      stdout=out, start_new_session=True))
+
+    def end_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        t_end = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                p.wait()
+
+    deadline = time.time() + args.timeout
+    status = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                sys.stderr.write('bench.py: rank %d exited with status %d; ending the other ranks\n' % bad[0])
+                status = bad[0][1] if bad[0][1] > 0 else 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                sys.stderr.write('bench.py: %d ranks did not finish in %.0f s; ending them\n' % (n, args.timeout))
+                status = EXIT_TIMEOUT
+                break
+            time.sleep(0.05)
+    finally:
+        end_all()
+    outs[0].seek(0)
+    text = outs[0].read().decode(errors='replace')
+    lines = [l for l in text.splitlines() if l.startswith('{')]
+    if status == 0:
+        if len(lines) != 1:
+            sys.stderr.write('bench.py: expected ONE json line from rank 0, got %d\n' % len(lines))
+            status = 1
+        else:
+            try:
+                got = json.loads(lines[0]).get('n_gpus')
+            except ValueError:
+                got = None
+            if got != n:
+                sys.stderr.write('bench.py: rank 0 reports n_gpus=%r, --gpus %d\n' % (got, n))
+                status = EXIT_WORLD_MISMATCH
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    return status
 
 
 def host_cpu_model():
@@ -161,31 +265,199 @@ def cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam):
                       'Rr/Rs PyTorch fp32, %d of %d host threads of %s), %.1f s' % (ns, N, H, cores, avail, host_cpu_model(), dt)}
 
 
-def run_gd(args):
-    """--config gd-demo: the gradient-descent planner's iteration (drp_gd_step) at the demo shape."""
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    import torch
-    import torch.distributed as dist
-    from dyn_res_pile_manip_amd import synthetic as syn, weights, _lib
-    from dyn_res_pile_manip_amd.engine import Engine
-    from dyn_res_pile_manip_amd.planners import world2cam_affine
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    N, H, nb = args.particles, args.horizon, 30
-    rows = args.samples_total_job // world if args.scaling == 'strong' else args.samples_total_job // args.gpus
-    traj = max(1, rows // nb)
+def load_traffic():
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    except Exception:
+        return {}
+
+
+TRAFFIC_SOURCE = 'profiles/traffic.json (builder-side rocprofv3 --pmc passes of this command, not measured in this run)'
+
+
+def tile_slot_model(cnt, N, ns, n_cu, engine, self_const):
+    """Slot iterations the propagation kernel runs per 32-receiver tile: the largest in-degree of the tile, minus the
+    self loop when its encoder chain is replaced by the per-sample constant (attributes are zeros here).  km_prop3
+    (whole_samples() in drp_capi.hip: chip-filling batches, or any batch of samples of up to 256 particles) cuts the
+    rows of a workgroup's samples, ordered by in-degree unless the pile is saturated, into tiles; km_prop cuts every
+    sample on its own.  -> (tiles per propagation step, mean slot iterations per tile, whole-sample kernel?)"""
+    spw = -(-ns // n_cu)
+    prop3 = (engine == 'fused' and os.environ.get('DRP_NO_PROP3') is None and (ns >= n_cu - n_cu // 5 or N <= 256))
+    tile_max = []
+    if prop3:
+        ordered = os.environ.get('DRP_NO_PROP3_ORDER') is None and spw * N <= 4900
+        for w in range(0, ns, spw):
+            rows = cnt[w:w + spw].ravel()
+            if ordered and (rows == rows.max()).sum() * 16 < rows.size * 15:     # saturated piles keep the natural order
+                rows = np.sort(rows)[::-1]
+            rows = np.pad(rows, (0, (-rows.size) % 32))
+            tile_max.append(rows.reshape(-1, 32).max(-1))
+        tile_max = np.concatenate(tile_max).astype(np.float64)
+    else:
+        tile_max = np.pad(cnt, ((0, 0), (0, (-N) % 32))).reshape(ns, -1, 32).max(-1).astype(np.float64).ravel()
+    slots = float((tile_max - (1.0 if self_const else 0.0)).clip(min=0).mean())
+    return int(tile_max.size), slots, prop3
+
+
+def prop_roofline(tiles, slots_per_tile, kbar, self_const, B, N, avg_s, launches, prop_steps_total, encoder_launches):
+    """km_prop / km_prop3: per 32-receiver tile, one 78-MFMA chain (the 3-term split relation
+    encoder) per slot iteration + the 6-term split node layers (144 MFMAs, 96 in the last step); roofline on the
+    16-bit FLOPs actually EXECUTED, 2*32*32*16 per MFMA.  A launch covers one propagation step (km_prop) or all
+    three of a rollout step (km_prop3): told apart by the launches the probe counted."""
+    psteps = max(1, int(round(float(prop_steps_total) / max(launches, 1))))
+    mfmas = psteps * tiles * (slots_per_tile * 78 + (2 * 144 + 96) / 3.0)
+    alg = psteps * B * N * (kbar * FLOP_PER_EDGE_ENCODE + 2 * 64 * 64 * (1 + 2 * 2 / 3.0 + 1 / 3.0))
+    # the particle encoder runs as the first phase of km_prop3 when no launch of its own was counted:
+    # 12 + 4 x 48 bf16 MFMAs per tile (first layer + four 64x64 products on the 6-term split)
+    encoder_inside = psteps == 3 and encoder_launches == 0
+    if encoder_inside:
+        mfmas += tiles * 204
+        alg += B * N * FLOP_PER_NODE['node_encode'] + B * N * 2 * 2 * 64 * 64
+    work = mfmas * 32768.0
+    return {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+            'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
+            'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile,
+            'tiles_per_step': tiles, 'mean_in_degree_minus_self': kbar - (1.0 if self_const else 0.0),
+            'propagation_steps_per_launch': psteps, 'particle_encoder_in_launch': bool(encoder_inside)}, work
+
+
+class Rig(object):
+    """One rank's engine with the model constants installed; workloads are begun on it one after the other."""
+
+    def __init__(self, local_rank, engine):
+        from dyn_res_pile_manip_amd import synthetic as syn, weights, _lib
+        from dyn_res_pile_manip_amd.engine import Engine
+        from dyn_res_pile_manip_amd.planners import world2cam_affine
+        self.syn, self._lib = syn, _lib
+        self.eng = Engine(local_rank)
+        self.engine = 'fused' if engine == 'auto' else engine
+        self.eng.set_engine(_lib.ENGINES[self.engine])
+        self.sd = weights.random_state_dict(seed=0)
+        self.eng.load_weights(weights.blob_from_state_dict(self.sd), 0.08)
+        self.cam = syn.demo_cam_params()
+        self.eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, self.cam)
+        self.obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+        self.n_cu = self.eng.device_info()['n_cu']
+        self.goal_n = None
+
+    def goal(self, N):
+        # goal field (OpenCV's 5x5 chamfer, as the reference) and the farthest-point subsample of the goal pixels to
+        # 5N points, built and kept on the device (rows f3); the copies feed the CPU baseline
+        self.G, self.goal_coor = self.eng.set_goal_image(self.obs_goal, 5 * N, fps_init=0, mode='cv5', want=True)
+        self.goal_n = N
+
+
+def bench_mppi(rig, N, ns, H, s_lo, steps, warmup, step_extra, fence, classes, want_median, fault=False):
+    """W warm-ups, one calibration iteration per kernel class (HIP-event probe), then EXACTLY `steps` timed iterations
+    bracketed by fence().  step_extra(eng): the update that ends an iteration.  -> dict of raw measurements."""
+    eng, syn = rig.eng, rig.syn
+    rig.goal(N)
+    s0, dens, attr = syn.make_pile(N, 1, seed=0)
+    lo, hi = syn.action_limits()
+    nominal = syn.nominal_pushes(H, seed=0)
+    eng.mpc_begin(s0, attr, dens, nominal, n_sample=ns, sigma=0.3 * 24 / 12.0, beta_filter=0.7,
+                  reward_weight=0.1, act_lo=lo, act_hi=hi, seed=1234, sample_offset=s_lo)
+    it = [0]
+
+    def step():
+        eng.mpc_sample(it[0])
+        eng.mpc_rollout(False)
+        step_extra(eng)
+        it[0] += 1
+
+    for _ in range(warmup):
+        step()
+    if fault:
+        eng.sync()
+        os._exit(7)                     # a rank that is simply gone: no clean-up, no goodbye to the group
+    fence()
+    per_class = {}
+    for kc in classes:
+        eng.probe_begin(kc)
+        step()
+        per_class[kc] = eng.probe_read()
+    dominant = max(per_class, key=lambda k: per_class[k][0])
+    cnt_last = eng.debug_fetch('nbr_cnt', (ns, N), np.uint8)
+    eng.probe_begin(dominant)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    dom_ms, dom_n = eng.probe_read()
+    eng.probe_begin(None)
+    med = None
+    if want_median:
+        # per-iteration times (each iteration synchronised; SURVEY.md 8d asks for the median): a second pass, so the
+        # contract's K back-to-back iterations above stay un-synchronised
+        per_iter = []
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            step()
+            eng.sync()
+            per_iter.append(time.perf_counter() - t1)
+        fence()
+        med = float(np.median(per_iter))
+    return {'dt': dt, 'median': med, 'per_class': per_class, 'dominant': dominant, 'dom_ms': dom_ms, 'dom_n': dom_n,
+            'cnt': cnt_last, 'kbar': float(cnt_last.mean()), 'step': step, 's0': s0, 'dens': dens, 'attr': attr}
+
+
+def mppi_roofline(rig, m, N, ns, H, steps):
+    """Roofline of the dominant kernel of an MPPI workload measured by bench_mppi."""
+    engine, dominant = rig.engine, m['dominant']
+    avg_s = m['dom_ms'] / max(m['dom_n'], 1) * 1e-3
+    kbar = m['kbar']
+    self_const = engine == 'fused' and os.environ.get('DRP_NO_SELF_CONST') is None
+    work = None
+    if dominant == 'prop':
+        tiles, slots, _ = tile_slot_model(m['cnt'], N, ns, rig.n_cu, engine, self_const)
+        roof, work = prop_roofline(tiles, slots, kbar, self_const, ns, N, avg_s, m['dom_n'], 3.0 * H * steps,
+                                   m['per_class'].get('node_encode', (0, 0))[1])
+    elif dominant == 'aggregate':
+        work = ns * N * (2 * kbar + 2) * 256.0
+        roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+    elif dominant == 'edge_encode':
+        work = ns * N * kbar * FLOP_PER_EDGE_ENCODE
+        roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s'}
+    elif dominant in FLOP_PER_NODE:
+        work = ns * N * FLOP_PER_NODE[dominant]
+        roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s'}
+    else:
+        roof = {'bound': 'hbm', 'achieved': 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+    roof['frac'] = roof['achieved'] / roof['peak']
+    roof['kernel'] = dominant
+    roof['avg_launch_ms'] = avg_s * 1e3
+    roof['launches'] = m['dom_n']
+    roof['work_per_launch'] = work
+    return roof
+
+
+def scatter_roofline(ns, N, kbar, agg_ms, agg_n, traffic_bytes):
+    """The segmented sum of the un-fused pipeline (k_aggregate_lds / k_aggregate, engine mfma).  SURVEY.md 8d's
+    ALGORITHMIC bytes per receiver and propagation step -- own row + K sender rows + K edge-constant rows read, one
+    row written, 256 B each -- are reported as such (`algorithmic_*`); they are not all HBM bytes: the kernel stages a
+    sample's sender rows in LDS once, so (K - 1) / K of the sender-row reads never leave the CU.  `frac` is therefore
+    computed from HBM-side bytes only: the PMC traffic of profiles/ when this is the profiled shape, otherwise the
+    COMPULSORY bytes (every edge-constant row, every projection row and every output row once) -- never a fraction
+    above 1 of the HBM peak."""
+    agg_s = agg_ms / agg_n * 1e-3
+    alg = ns * N * (2 * kbar + 2) * 256.0
+    compulsory = ns * N * (kbar * 256.0 + 512.0 + 256.0)
+    hbm, basis = (traffic_bytes, 'pmc traffic') if traffic_bytes else (compulsory, 'compulsory bytes (each row once)')
+    return {'kernel': 'k_aggregate (engine mfma: segmented sum over the receiver-major lists)', 'bound': 'hbm',
+            'achieved': hbm / agg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm / agg_s / 1e9 / PEAK_HBM_GBS,
+            'frac_basis': basis, 'avg_launch_ms': agg_s * 1e3, 'launches': agg_n,
+            'algorithmic_bytes_per_launch': alg, 'algorithmic_gbs': alg / agg_s / 1e9,
+            'compulsory_bytes_per_launch': compulsory, 'cache_served': bool(alg > hbm), 'mean_in_degree': kbar,
+            'traffic': traffic_bytes, 'traffic_source': TRAFFIC_SOURCE if traffic_bytes else None}
+
+
+def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True):
+    """The gradient-descent planner's iteration (drp_gd_step) at traj x nb rows of N particles."""
+    eng, syn = rig.eng, rig.syn
+    rig.goal(N)
     B = traj * nb
-    eng = Engine(local_rank)
-    sd = weights.random_state_dict(seed=0)
-    eng.load_weights(weights.blob_from_state_dict(sd), 0.08)
-    cam = syn.demo_cam_params()
-    eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, cam)
-    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
-    G, goal_coor = eng.set_goal_image(obs_goal, 5 * N, fps_init=0, mode='cv5', want=True)
     s0, dens, attr = syn.make_pile(N, nb, seed=N)
     acts = np.repeat(np.stack([syn.nominal_pushes(H, seed=rank * 1000 + i) for i in range(traj)]), nb, axis=0).astype(np.float32)
     lo, hi = syn.action_limits()
@@ -194,13 +466,7 @@ def run_gd(args):
     def step():
         eng._ck(eng.lib.drp_gd_step(eng.h, None))
 
-    def fence():
-        eng.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
     per_class = {}
@@ -214,363 +480,281 @@ def run_gd(args):
     eng.probe_begin(dominant)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     dt = time.perf_counter() - t0
     dom_ms, dom_n = eng.probe_read()
     eng.probe_begin(None)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    per_iter = []
-    for _ in range(args.steps):
-        t1 = time.perf_counter()
-        step()
-        eng.sync()
-        per_iter.append(time.perf_counter() - t1)
-    med = float(np.median(per_iter))
-    if rank == 0:
-        avg_s = dom_ms / max(dom_n, 1) * 1e-3
-        if dominant == 'prop':
-            # the forward kernel of the tape-writing instantiation: the same MFMAs as bench's MPPI model
-            n_cu = eng.device_info()['n_cu']
-            spw = -(-B // n_cu)
-            tile_max = []
-            for w in range(0, B, spw):
-                r = cnt[w:w + spw].ravel()
-                if spw * N <= 4900 and (r == r.max()).sum() * 16 < r.size * 15:
-                    r = np.sort(r)[::-1]
-                r = np.pad(r, (0, (-r.size) % 32))
-                tile_max.append(r.reshape(-1, 32).max(-1))
-            tile_max = np.concatenate(tile_max).astype(np.float64)
-            mfmas = 3 * tile_max.size * ((tile_max - 1).clip(min=0).mean() * 78 + (2 * 144 + 96) / 3.0) + tile_max.size * 204
-            roof = {'bound': 'mfma', 'achieved': mfmas * 32768.0 / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                    'slot_iterations_per_tile': float((tile_max - 1).clip(min=0).mean()), 'tiles_per_step': int(tile_max.size)}
-        elif dominant == 'bwd_node' and per_class['bwd_edge'][1] == 0:
-            # kmb_step_bwd (the whole node / edge backward of a rollout step in one launch): algorithmic
-            # bytes per node -- phase P: effect row + reward gradient in, g_eff / g_cnode / g_agg rows out; per
-            # propagation step: own g_agg and g_eff rows, own masks, one (list entry, mask, g_agg row) per edge the
-            # node feeds; steps 2 and 1 also the effect row in, g_eff / g_agg rows out and g_cnode in and out; step 0
-            # g_cnode, encoder effect and impulse in, impulse gradient out
-            per_node = (256 + 12 + 3 * 256) + 3 * (2 * 256 + 8 * kbar + kbar * (4 + 8 + 256)) + 2 * (256 + 2 * 256 + 2 * 256) + (2 * 256 + 24)
-            work = B * N * per_node
-            roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'algorithmic_bytes_per_launch': work,
-                    'note': 'kmb_step_bwd: fp32 MFMA for the seven 64x64 products per node, bound by the rows it moves; the gathered g_agg rows mostly hit L2'}
-        elif dominant == 'bwd_edge':
-            # kb_edge_terms per node and propagation step: own g_agg row + own masks read, both g_proj halves written,
-            # then one (mask, g_agg row, list entry) per edge the node feeds
-            work = B * N * (256 + 8 * kbar + 512 + 8 + kbar * (8 + 256 + 4))
-            roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+    med = None
+    if want_median:
+        per_iter = []
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            step()
+            eng.sync()
+            per_iter.append(time.perf_counter() - t1)
+        med = float(np.median(per_iter))
+    avg_s = dom_ms / max(dom_n, 1) * 1e-3
+    traffic = load_traffic().get('gd-demo', {}) if (N, B, H) == (100, 1500, 1) else {}
+    tkey = None
+    if dominant == 'prop':
+        # the forward kernel of the tape-writing instantiation: the same MFMAs as the MPPI model
+        tiles, slots, _ = tile_slot_model(cnt, N, B, rig.n_cu, 'fused', True)
+        roof, _ = prop_roofline(tiles, slots, kbar, True, B, N, avg_s, dom_n, 3.0 * H * steps, per_class['node_encode'][1])
+        tkey = 'prop3_tape'
+    elif dominant == 'bwd_node' and per_class['bwd_edge'][1] == 0:
+        # kmb_step_bwd (the whole node / edge backward of a rollout step in one launch): algorithmic
+        # bytes per node -- phase P: effect row + reward gradient in, g_eff / g_cnode / g_agg rows out; per
+        # propagation step: own g_agg and g_eff rows, own masks, one (list entry, mask, g_agg row) per edge the
+        # node feeds; steps 2 and 1 also the effect row in, g_eff / g_agg rows out and g_cnode in and out; step 0
+        # g_cnode, encoder effect and impulse in, impulse gradient out
+        per_node = (256 + 12 + 3 * 256) + 3 * (2 * 256 + 8 * kbar + kbar * (4 + 8 + 256)) + 2 * (256 + 2 * 256 + 2 * 256) + (2 * 256 + 24)
+        work = B * N * per_node
+        roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'algorithmic_bytes_per_launch': work,
+                'note': 'kmb_step_bwd: fp32 MFMA for the seven 64x64 products per node; the byte model counts every gathered g_agg row, '
+                        'most of which are served by L2 -- traffic (when present) is the HBM side'}
+        tkey = 'step_bwd'
+    elif dominant == 'bwd_edge':
+        # kb_edge_terms per node and propagation step: own g_agg row + own masks read, both g_proj halves written,
+        # then one (mask, g_agg row, list entry) per edge the node feeds
+        work = B * N * (256 + 8 * kbar + 512 + 8 + kbar * (8 + 256 + 4))
+        roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+    else:
+        roof = {'bound': 'hbm', 'achieved': 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+    tb = traffic.get(tkey, {}).get('hbm_bytes_per_launch') if tkey else None
+    roof.update({'frac': roof['achieved'] / roof['peak'], 'kernel': dominant, 'avg_launch_ms': avg_s * 1e3,
+                 'launches': dom_n, 'traffic': tb, 'traffic_source': TRAFFIC_SOURCE if tb else None})
+    if tb and roof['bound'] == 'hbm':
+        # the HBM fraction proper: counter bytes over time (the algorithmic figure above counts L2-served gathers)
+        roof['algorithmic_frac'] = roof['frac']
+        roof['achieved'] = tb / avg_s / 1e9
+        roof['frac'] = roof['achieved'] / roof['peak']
+        roof['cache_served'] = bool(roof.get('algorithmic_bytes_per_launch', 0) > tb)
+    return {'dt': dt, 'median': med, 'per_class': per_class, 'dominant': dominant, 'roofline': roof, 'kbar': kbar,
+            'B': B, 's0': s0, 'dens': dens, 'attr': attr, 'acts': acts}
+
+
+def run_sweep(rig, fence):
+    """The other BASELINE workloads on this GPU, short: 2 warm-ups, 5 iterations each (no median pass)."""
+    out = []
+    for name in SWEEP:
+        N, ns, H, _, label = CONFIGS[name]
+        steps, warm = 5, 2
+        t_wall = time.perf_counter()
+        if name == 'gd-demo':
+            g = bench_gd(rig, N, ns // 30, 30, H, steps, warm, fence, want_median=False)
+            B, roof, per_class, dt = g['B'], g['roofline'], g['per_class'], g['dt']
+            kbar = g['kbar']
         else:
-            roof = {'bound': 'hbm', 'achieved': 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
-        roof.update({'frac': roof['achieved'] / roof['peak'], 'kernel': dominant, 'avg_launch_ms': avg_s * 1e3,
-                     'launches': dom_n, 'traffic': None, 'traffic_source': None})
-        total = world * B * N * H * args.steps
-        out = {'metric': 'MPC rollout-steps/sec (samples x particles x steps/sec)', 'value': total / dt,
-               'unit': 'particle-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-               'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'ms_per_step_median': med * 1e3, 'value_median': world * B * N * H / med,
-               'dtype': 'f32 (forward MLP products as split fp16 / bf16 MFMA terms, backward node stages on fp32 MFMA, fp32 accumulate)',
-               'data': 'synthetic',
-               'config': {'workload': args.workload, 'name': args.config_name, 'n_particles': N, 'n_trajectories_per_gpu': traj,
-                          'n_batch': nb, 'rows_per_gpu': B, 'n_look_ahead': H, 'engine': 'fused', 'mean_in_degree': kbar,
-                          'reference_time_model_ms': None},
-               'roofline': roof, 'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items()},
-               'cpu_baseline': None}
-        from dyn_res_pile_manip_amd.planners import particle_num_to_iter_time
-        out['config']['reference_time_model_ms'] = particle_num_to_iter_time(N)     # planners.py:25-28, batch 300 on its GPU
-        if world == 1 and not args.no_cpu_baseline:
-            import torch as _t
-            from oracle import propnet_dense as od
-            W = od.load_weights(sd)
-            cpu_traj = traj            # the whole demo batch: about 5 s of host work
-            a_cpu = acts[:cpu_traj * nb]
-            _t.set_num_threads(min(32, os.cpu_count() or 1))
-            od.gd_loss_and_grads(W, s0, dens, attr, a_cpu[:nb], G, cam, goal_coor, syn.demo_cam_extrinsics(), 24)   # warm-up
-            t0 = time.perf_counter()
-            od.gd_loss_and_grads(W, s0, dens, attr, a_cpu, G, cam, goal_coor, syn.demo_cam_extrinsics(), 24)
-            dtc = time.perf_counter() - t0
-            out['cpu_baseline'] = {'value': cpu_traj * nb * N * H / dtc, 'unit': 'particle-steps/s', 'cores': _t.get_num_threads(),
-                                   'kind': 'port', 'cpu_model': host_cpu_model(),
-                                   'sample': '%d trajectories x %d columns x %d particles, forward + autograd backward of '
-                                             'oracle/propnet_dense.py, %.1f s' % (cpu_traj, nb, N, dtc)}
-        print(json.dumps(out), flush=True)
-    eng.close()
-    if world > 1:
-        dist.destroy_process_group()
+            m = bench_mppi(rig, N, ns, H, 0, steps, warm, lambda e: e.mpc_update_device(), fence,
+                           ['graph', 'node_encode', 'prop', 'reward', 'mppi'], want_median=False)
+            B, roof, per_class, dt, kbar = ns, mppi_roofline(rig, m, N, ns, H, steps), m['per_class'], m['dt'], m['kbar']
+        out.append({'name': name, 'workload': label, 'n_particles': N, 'rows': B, 'n_look_ahead': H, 'steps': steps, 'warmup': warm,
+                    'ms_per_step': dt / steps * 1e3, 'value': B * N * H * steps / dt, 'unit': 'particle-steps/s',
+                    'mean_in_degree': kbar, 'dominant_kernel': roof['kernel'], 'avg_launch_ms': roof['avg_launch_ms'],
+                    'bound': roof['bound'], 'achieved': roof['achieved'], 'peak': roof['peak'], 'roofline_unit': roof['unit'],
+                    'frac': roof['frac'], 'traffic': roof.get('traffic'),
+                    'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items() if v[1] > 0},
+                    'wall_s': round(time.perf_counter() - t_wall, 2)})
+    return out
 
 
-def main():
-    args = parse()
-    if args.config_name == 'gd-demo':
-        return run_gd(args)
+def run_rank(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: WORLD_SIZE=%d but --gpus %d: the launcher and the flag must agree\n' % (world, args.gpus))
+        return EXIT_WORLD_MISMATCH
     if args.force_comm:
         os.environ['DRP_COMM_ALWAYS'] = '1'          # read at drp_create
+    import datetime
     import torch
     import torch.distributed as dist
-    from dyn_res_pile_manip_amd import synthetic as syn, weights, _lib
-    from dyn_res_pile_manip_amd.engine import Engine
-    from dyn_res_pile_manip_amd.planners import world2cam_affine
+    from dyn_res_pile_manip_amd.sharding import shard_range
 
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    use_comm = world > 1 or args.force_comm
     gloo = args.comm == 'gloo'
-    red_dev = 'cpu' if gloo else 'cuda'          # where the max-over-ranks timings are reduced
-    if use_comm:
+    use_rccl = (world > 1 or args.force_comm) and not gloo
+    if world > 1:
+        # rendezvous, id broadcast, barrier and timing reductions over gloo: torch's NCCL process group is never
+        # created, the only RCCL communicator of the process is the engine's
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        if gloo:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-        else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        dist.init_process_group('gloo', rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get('DRP_COMM_TIMEOUT_S', '120'))))
 
-    from dyn_res_pile_manip_amd.sharding import shard_range
-    N, H = args.particles, args.horizon
-    s_lo, s_hi = shard_range(args.samples_total_job, rank, world)      # this rank's contiguous block of samples
-    ns = s_hi - s_lo
-    eng = Engine(local_rank)
-    engine = args.engine
-    if engine == 'auto':
-        engine = 'fused'
-    eng.set_engine(_lib.ENGINES[engine])
-    sd = weights.random_state_dict(seed=0)
-    eng.load_weights(weights.blob_from_state_dict(sd), 0.08)
-    M34 = world2cam_affine(syn.demo_cam_extrinsics())
-    cam = syn.demo_cam_params()
-    eng.set_camera(M34, 24.0, cam)
-    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
-    # goal field (OpenCV's 5x5 chamfer, as the reference) and the farthest-point subsample of the goal
-    # pixels, built and kept on the device (rows f3); the copies feed the CPU baseline
-    G, goal_coor = eng.set_goal_image(obs_goal, 5 * N, fps_init=0, mode='cv5', want=True)
-    s0, dens, attr = syn.make_pile(N, 1, seed=0)
-    lo, hi = syn.action_limits()
-    nominal = syn.nominal_pushes(H, seed=0)
-    eng.mpc_begin(s0, attr, dens, nominal, n_sample=ns, sigma=0.3 * 24 / 12.0, beta_filter=0.7,
-                  reward_weight=0.1, act_lo=lo, act_hi=hi, seed=1234, sample_offset=s_lo)
-    if use_comm and not gloo:
+    rig = Rig(local_rank, args.engine)
+    eng, engine = rig.eng, rig.engine
+    comm_info = None
+    if use_rccl:
         uid = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
         eng.comm_init(uid[0], rank, world)
-    if gloo:
-        from dyn_res_pile_manip_amd.sharding import allgather_records
-
-    it = [0]
-
-    def step():
-        eng.mpc_sample(it[0])
-        eng.mpc_rollout(False)
-        if gloo and world > 1:
-            # host transport: this rank's record -> all-gather over gloo -> combine kernel
-            if args.update == 'elite':
-                eng.mpc_update_elite(allgather_records(eng.mpc_elite(args.elite).ravel()).reshape(world, args.elite, -1), args.elite)
-            else:
-                eng.mpc_update(allgather_records(eng.mpc_partials()))
-        elif args.update == 'elite':
-            eng.mpc_update_elite_device(args.elite)
-        else:
-            eng.mpc_update_device()
-        it[0] += 1
+        comm_info = eng.comm_info()
+        if comm_info['n_ranks'] != world:
+            sys.stderr.write('bench.py: ncclCommCount=%d, WORLD_SIZE=%d\n' % (comm_info['n_ranks'], world))
+            return EXIT_WORLD_MISMATCH
 
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if use_comm:
+        if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # untimed calibration: one iteration per kernel class with the HIP-event probe on
-    per_class = {}
-    for kc in KERNEL_CLASSES:
-        eng.probe_begin(kc)
-        step()
-        ms, n = eng.probe_read()
-        per_class[kc] = (ms, n)
-    dominant = max(per_class, key=lambda k: per_class[k][0])
-    cnt_last = eng.debug_fetch('nbr_cnt', (ns, N), np.uint8)
-    kbar = float(cnt_last.mean())
-    # slot iterations the propagation kernel runs per 32-receiver tile: the largest in-degree of the tile, minus the
-    # self loop when its encoder chain is replaced by the per-sample constant (attributes are zeros here).
-    # km_prop3 (chip-filling batches) cuts the rows of a workgroup's samples, ordered by in-degree, into tiles;
-    # km_prop cuts every sample on its own.
-    self_const = engine == 'fused' and os.environ.get('DRP_NO_SELF_CONST') is None
-    n_cu = eng.device_info()['n_cu']
-    spw = -(-ns // n_cu)
-    prop3 = (engine == 'fused' and os.environ.get('DRP_NO_PROP3') is None and ns >= n_cu and spw * ((N + 31) // 32) >= 8)
-    tile_max = []
-    if prop3:
-        ordered = os.environ.get('DRP_NO_PROP3_ORDER') is None and spw * N <= 4900
-        for w in range(0, ns, spw):
-            rows = cnt_last[w:w + spw].ravel()
-            if ordered and (rows == rows.max()).sum() * 16 < rows.size * 15:     # saturated piles keep the natural order
-                rows = np.sort(rows)[::-1]
-            rows = np.pad(rows, (0, (-rows.size) % 32))
-            tile_max.append(rows.reshape(-1, 32).max(-1))
-        tile_max = np.concatenate(tile_max).astype(np.float64)
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    N, H = args.particles, args.horizon
+    out = None
+    if args.config_name == 'gd-demo':
+        nb = 30
+        rows = args.samples_total_job // world
+        traj = max(1, rows // nb)
+        g = bench_gd(rig, N, traj, nb, H, args.steps, args.warmup, fence, rank=rank)
+        dt, med = max_over_ranks(g['dt']), max_over_ranks(g['median'])
+        if rank == 0:
+            from dyn_res_pile_manip_amd.planners import particle_num_to_iter_time
+            B = g['B']
+            out = {'metric': 'MPC rollout-steps/sec (samples x particles x steps/sec)', 'value': world * B * N * H * args.steps / dt,
+                   'unit': 'particle-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                   'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                   'ms_per_step_median': med * 1e3, 'value_median': world * B * N * H / med,
+                   'dtype': 'f32 (forward MLP products as split fp16 / bf16 MFMA terms, backward node stages on fp32 MFMA, fp32 accumulate)',
+                   'data': 'synthetic',
+                   'config': {'workload': args.workload, 'name': args.config_name, 'n_particles': N, 'n_trajectories_per_gpu': traj,
+                              'n_batch': nb, 'rows_per_gpu': B, 'n_look_ahead': H, 'engine': 'fused', 'mean_in_degree': g['kbar'],
+                              'parallelism': 'trajectories sharded x%d, no collective' % world,
+                              'reference_time_model_ms': particle_num_to_iter_time(N)},     # planners.py:25-28, batch 300 on its GPU
+                   'roofline': g['roofline'], 'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in g['per_class'].items()},
+                   'cpu_baseline': None}
+            if world == 1 and not args.no_cpu_baseline:
+                from oracle import propnet_dense as od
+                syn = rig.syn
+                W = od.load_weights(rig.sd)
+                torch.set_num_threads(min(32, os.cpu_count() or 1))
+                a_cpu = g['acts']            # the whole demo batch: about 5 s of host work
+                od.gd_loss_and_grads(W, g['s0'], g['dens'], g['attr'], a_cpu[:nb], rig.G, rig.cam, rig.goal_coor, syn.demo_cam_extrinsics(), 24)   # warm-up
+                t0 = time.perf_counter()
+                od.gd_loss_and_grads(W, g['s0'], g['dens'], g['attr'], a_cpu, rig.G, rig.cam, rig.goal_coor, syn.demo_cam_extrinsics(), 24)
+                dtc = time.perf_counter() - t0
+                out['cpu_baseline'] = {'value': traj * nb * N * H / dtc, 'unit': 'particle-steps/s', 'cores': torch.get_num_threads(),
+                                       'kind': 'port', 'cpu_model': host_cpu_model(),
+                                       'sample': '%d trajectories x %d columns x %d particles, forward + autograd backward of '
+                                                 'oracle/propnet_dense.py, %.1f s' % (traj, nb, N, dtc)}
     else:
-        tile_max = np.pad(cnt_last, ((0, 0), (0, (-N) % 32))).reshape(ns, -1, 32).max(-1).astype(np.float64).ravel()
-    n_tiles = int(tile_max.size)
-    slots_per_tile = float((tile_max - (1.0 if self_const else 0.0)).clip(min=0).mean())
-    eng.probe_begin(dominant)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    dom_ms, dom_n = eng.probe_read()
-    eng.probe_begin(None)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        s_lo, s_hi = shard_range(args.samples_total_job, rank, world)      # this rank's contiguous block of samples
+        ns = s_hi - s_lo
+        if gloo:
+            from dyn_res_pile_manip_amd.sharding import allgather_records
 
-    # per-iteration times (each iteration synchronised; SURVEY.md 8d asks for the median): a second pass, so the
-    # contract's K back-to-back iterations above stay un-synchronised
-    per_iter = []
-    for _ in range(args.steps):
-        t1 = time.perf_counter()
-        step()
-        eng.sync()
-        per_iter.append(time.perf_counter() - t1)
-    fence()
-    med = float(np.median(per_iter))
-    if world > 1:
-        t = torch.tensor([med], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        med = float(t.item())
+        def update(e):
+            if gloo and world > 1:
+                # host transport: this rank's record -> all-gather over gloo -> combine kernel
+                if args.update == 'elite':
+                    e.mpc_update_elite(allgather_records(e.mpc_elite(args.elite).ravel()).reshape(world, args.elite, -1), args.elite)
+                else:
+                    e.mpc_update(allgather_records(e.mpc_partials()))
+            elif args.update == 'elite':
+                e.mpc_update_elite_device(args.elite)
+            else:
+                e.mpc_update_device()
 
-    # the same K steps on the pure-fp32 MFMA engine (bit-for-bit an fp32 fma chain), for reference; its un-fused
-    # pipeline has the segmented sum ("scatter-add") as a kernel of its own, timed here with the HIP-event probe
-    alt, scatter = None, None
-    if engine != 'mfma' and not args.no_alt:
-        eng.set_engine(_lib.ENGINES['mfma'])
-        for _ in range(2):
-            step()
-        eng.probe_begin('aggregate')
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dta = time.perf_counter() - t0
-        agg_ms, agg_n = eng.probe_read()
-        eng.probe_begin(None)
-        kbar_alt = float(eng.debug_fetch('nbr_cnt', (ns, N), np.uint8).mean())
-        if agg_n > 0:
-            # per receiver and propagation step, own row + K sender rows + K edge-constant rows read,
-            # one row written, 256 B each
-            agg_bytes = ns * N * (2 * kbar_alt + 2) * 256.0
-            agg_s = agg_ms / agg_n * 1e-3
-            scatter = {'kernel': 'k_aggregate (engine mfma: segmented sum over the receiver-major lists)', 'bound': 'hbm',
-                       'achieved': agg_bytes / agg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                       'frac': agg_bytes / agg_s / 1e9 / PEAK_HBM_GBS, 'avg_launch_ms': agg_s * 1e3, 'launches': agg_n,
-                       'algorithmic_bytes_per_launch': agg_bytes, 'mean_in_degree': kbar_alt,
-                       'traffic': None, 'traffic_source': None}
-        if world > 1:
-            t = torch.tensor([dta], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dta = float(t.item())
-        alt = {'engine': 'mfma', 'dtype': 'f32', 'value': args.samples_total_job * N * H * args.steps / dta,
-               'ms_per_step': dta / args.steps * 1e3}
-        eng.set_engine(_lib.ENGINES[engine])
+        m = bench_mppi(rig, N, ns, H, s_lo, args.steps, args.warmup, update, fence, KERNEL_CLASSES, want_median=True,
+                       fault=(args.fault_rank == rank))
+        dt, med = max_over_ranks(m['dt']), max_over_ranks(m['median'])
+        step = m['step']
+        # the same K steps on the pure-fp32 MFMA engine (bit-for-bit an fp32 fma chain), for reference; its un-fused
+        # pipeline has the segmented sum ("scatter-add") as a kernel of its own, timed here with the HIP-event probe
+        alt, scatter = None, None
+        tj = load_traffic() if (N, ns) == (300, 1024) else {}
+        if engine != 'mfma' and not args.no_alt:
+            eng.set_engine(rig._lib.ENGINES['mfma'])
+            for _ in range(2):
+                step()
+            eng.probe_begin('aggregate')
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            dta = max_over_ranks(time.perf_counter() - t0)
+            agg_ms, agg_n = eng.probe_read()
+            eng.probe_begin(None)
+            kbar_alt = float(eng.debug_fetch('nbr_cnt', (ns, N), np.uint8).mean())
+            if agg_n > 0:
+                scatter = scatter_roofline(ns, N, kbar_alt, agg_ms, agg_n,
+                                           tj.get('mfma', {}).get('aggregate', {}).get('hbm_bytes_per_launch'))
+            alt = {'engine': 'mfma', 'dtype': 'f32', 'value': args.samples_total_job * N * H * args.steps / dta,
+                   'ms_per_step': dta / args.steps * 1e3}
+            eng.set_engine(rig._lib.ENGINES[engine])
+        if rank == 0:
+            roof = mppi_roofline(rig, m, N, ns, H, args.steps)
+            # HBM-side bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+            # profiles/summarize_pmc.py), collected on this same workload
+            roof['traffic'], roof['traffic_source'] = None, None
+            tkey = 'prop3' if (m['dominant'] == 'prop' and roof.get('propagation_steps_per_launch') == 3) else m['dominant']
+            tb = tj.get(engine, {}).get(tkey, {}).get('hbm_bytes_per_launch')
+            if tb:
+                roof['traffic'], roof['traffic_source'] = tb, TRAFFIC_SOURCE
+            comm_label = None
+            if use_rccl:
+                comm_label = 'rccl, %d rank%s' % (world, '' if world == 1 else 's')
+            elif world > 1:
+                comm_label = 'gloo, %d ranks%s' % (world, ', all on GPU 0' if args.share_gpu else '')
+            out = {
+                'metric': 'MPC rollout-steps/sec (samples x particles x steps/sec)',
+                'value': args.samples_total_job * N * H * args.steps / dt, 'unit': 'particle-steps/s', 'n_gpus': world,
+                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+                'scaling': args.scaling, 'vs_baseline': None,
+                'ms_per_step_median': med * 1e3, 'value_median': args.samples_total_job * N * H / med,
+                'dtype': 'f32' if engine in ('valu', 'mfma') else 'f32 (MLP products as split fp16 / bf16 MFMA terms, fp32 accumulate)',
+                'data': 'synthetic',
+                'config': {'workload': args.workload, 'name': args.config_name,
+                           'n_particles': N, 'n_sample_per_gpu': ns, 'n_sample_total': args.samples_total_job,
+                           'n_look_ahead': H, 'engine': engine, 'gpus_requested': args.gpus, 'world_size': world,
+                           'communicator': comm_label,
+                           'rccl': ({'comm_count': comm_info['n_ranks'], 'version': comm_info['version_str'],
+                                     'library': comm_info['path']} if comm_info else None),
+                           'rendezvous': 'gloo (id broadcast, barrier, timing reductions)' if world > 1 else None,
+                           'mean_in_degree': m['kbar'], 'parallelism': 'samples sharded x%d' % world,
+                           'update': 'softmax mean (optimize_action)' if args.update == 'mppi' else 'mean of the %d best (elite)' % args.elite},
+                'roofline': roof,
+                'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in m['per_class'].items()},
+                'roofline_scatter': scatter, 'alt_engine': alt,
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline(args, rig.sd, m['s0'], m['dens'], m['attr'], rig.G, rig.goal_coor, rig.cam)
+            else:
+                out['cpu_baseline'] = None
+    if rank == 0 and args.do_sweep and world == 1:
+        out['sweep'] = run_sweep(rig, fence)
     if rank == 0:
-        total = args.samples_total_job * N * H * args.steps
-        avg_s = dom_ms / max(dom_n, 1) * 1e-3
-        B = ns
-        tiles = n_tiles
-        if dominant == 'prop':
-            # km_prop: per 32-receiver tile, one 78-MFMA chain (the 3-term split
-            # relation encoder) per slot iteration + the 6-term split node layers (144 MFMAs, 96 in
-            # the last step); roofline on the 16-bit FLOPs actually EXECUTED, 2*32*32*16 per MFMA
-            # a launch covers one propagation step (km_prop) or all three of a rollout step (km_prop3,
-            # chip-filling batches): told apart by the launches the probe counted
-            psteps = max(1, int(round(3.0 * H * args.steps / max(dom_n, 1))))
-            mfmas = psteps * tiles * (slots_per_tile * 78 + (2 * 144 + 96) / 3.0)
-            alg = psteps * B * N * (kbar * FLOP_PER_EDGE_ENCODE + 2 * 64 * 64 * (1 + 2 * 2 / 3.0 + 1 / 3.0))
-            # the particle encoder runs as the first phase of km_prop3 when no launch of its own was counted:
-            # 12 + 4 x 48 bf16 MFMAs per tile (first layer + four 64x64 products on the 6-term split)
-            encoder_inside = psteps == 3 and per_class['node_encode'][1] == 0
-            if encoder_inside:
-                mfmas += tiles * 204
-                alg += B * N * FLOP_PER_NODE['node_encode'] + B * N * 2 * 2 * 64 * 64
-            work = mfmas * 32768.0
-            roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                    'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
-                    'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile,
-                    'tiles_per_step': tiles, 'mean_in_degree_minus_self': kbar - (1.0 if self_const else 0.0),
-                    'propagation_steps_per_launch': psteps, 'particle_encoder_in_launch': bool(encoder_inside)}
-        elif dominant == 'aggregate':
-            work = B * N * (2 * kbar + 2) * 256.0
-            roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
-        elif dominant == 'edge_encode':
-            work = B * N * kbar * FLOP_PER_EDGE_ENCODE
-            roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s'}
-        elif dominant in FLOP_PER_NODE:
-            work = B * N * FLOP_PER_NODE[dominant]
-            roof = {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s'}
-        else:
-            roof = {'bound': 'hbm', 'achieved': 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
-        roof['frac'] = roof['achieved'] / roof['peak']
-        roof['kernel'] = dominant
-        roof['avg_launch_ms'] = avg_s * 1e3
-        roof['launches'] = dom_n
-        roof['work_per_launch'] = work if dominant in ('prop', 'aggregate', 'edge_encode') or dominant in FLOP_PER_NODE else None
-        # HBM-side bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 +
-        # WRITE_SIZE, profiles/summarize_pmc.py); collected on this same workload
-        roof['traffic'] = None
-        roof['traffic_source'] = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath) and (N, ns) == (300, 1024):
-            try:
-                tj = json.load(open(tpath))
-                tkey = 'prop3' if (dominant == 'prop' and roof.get('propagation_steps_per_launch') == 3) else dominant
-                roof['traffic'] = tj[engine][tkey]['hbm_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/traffic.json (builder-side rocprofv3 --pmc passes of this command, not measured in this run)'
-                if scatter is not None:
-                    scatter['traffic'] = tj['mfma']['aggregate']['hbm_bytes_per_launch']
-                    scatter['traffic_source'] = roof['traffic_source']
-            except Exception:
-                pass
-        out = {
-            'metric': 'MPC rollout-steps/sec (samples x particles x steps/sec)',
-            'value': total / dt, 'unit': 'particle-steps/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': args.scaling, 'vs_baseline': None,
-            'ms_per_step_median': med * 1e3, 'value_median': args.samples_total_job * N * H / med,
-            'dtype': 'f32' if engine in ('valu', 'mfma') else 'f32 (MLP products as split fp16 / bf16 MFMA terms, fp32 accumulate)',
-            'data': 'synthetic',
-            'config': {'workload': args.workload, 'name': args.config_name,
-                       'n_particles': N, 'n_sample_per_gpu': ns, 'n_sample_total': args.samples_total_job,
-                       'n_look_ahead': H, 'engine': engine,
-                       'communicator': ('%s, %d rank%s%s' % (args.comm, world, '' if world == 1 else 's',
-                                                             ', all on GPU 0' if args.share_gpu else '')) if use_comm else None,
-                       'mean_in_degree': kbar, 'parallelism': 'samples sharded x%d' % world,
-                       'update': 'softmax mean (optimize_action)' if args.update == 'mppi' else 'mean of the %d best (elite)' % args.elite},
-            'roofline': roof,
-            'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items()},
-        }
-        out['roofline_scatter'] = scatter
-        out['alt_engine'] = alt
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam)
-        else:
-            out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
     eng.close()
-    if use_comm:
+    if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

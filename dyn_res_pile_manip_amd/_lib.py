@@ -118,6 +118,9 @@ SIGNATURES = {
     'drp_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'drp_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'drp_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'drp_comm_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                     ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_size_t]),
+    'drp_debug_stall': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'drp_comm_allgather': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'drp_probe_begin': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     'drp_probe_read': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_long)]),

@@ -3,14 +3,24 @@
 #include "../../include/drp.h"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>          // types and enums only: the library itself is bound at run time (RcclApi below)
 
+#include <dlfcn.h>
+#include <link.h>
+#include <sched.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "drp_common.h"
@@ -43,6 +53,87 @@ struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
 };
+
+// ---- RCCL, bound at run time -----------------------------------------------------------------------------------
+// libdrp.so does not link librccl: a process must not end up with two copies of it (PyTorch ships its own
+// librccl.so beside the one under /opt/rocm; which of two mapped copies answered a call used to depend on the import
+// order).  The first call that needs RCCL takes, in this order: $DRP_RCCL_LIB, the librccl the process has ALREADY
+// mapped (torch's, when the host imported torch), librccl.so.1 by the loader's search path, /opt/rocm/lib/librccl.so.1.
+// Only entry points whose ABI has been stable since NCCL 2.4 are used (no ncclConfig_t crosses the boundary).
+struct RcclApi {
+    void* handle = nullptr;
+    std::string path, error;
+    int version = 0;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+int rccl_find_mapped(struct dl_phdr_info* info, size_t, void* data) {
+    const char* name = info->dlpi_name;
+    if (name && *name) {
+        const char* base = strrchr(name, '/');
+        base = base ? base + 1 : name;
+        if (strncmp(base, "librccl.so", 10) == 0) {
+            *static_cast<std::string*>(data) = name;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+RcclApi g_rccl;
+RcclApi* rccl_api() {
+    RcclApi& api = g_rccl;
+    static std::once_flag once;
+    std::call_once(once, [&api] {
+        std::vector<std::string> tries;
+        if (const char* e = getenv("DRP_RCCL_LIB")) tries.push_back(e);
+        std::string mapped;
+        dl_iterate_phdr(rccl_find_mapped, &mapped);
+        if (!mapped.empty()) tries.push_back(mapped);
+        tries.push_back("librccl.so.1");
+        tries.push_back("/opt/rocm/lib/librccl.so.1");
+        tries.push_back("librccl.so");
+        for (const std::string& t : tries) {
+            api.handle = dlopen(t.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+            const char* de = dlerror();
+            api.error += t + ": " + (de ? de : "?") + "; ";
+        }
+        if (!api.handle) return;
+        bool ok = true;
+        auto sym = [&](const char* n) { void* p = dlsym(api.handle, n); if (!p) { ok = false; api.error += std::string(n) + " missing; "; } return p; };
+        api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(sym("ncclGetVersion"));
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(sym("ncclCommAbort"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+        api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
+        api.CommGetAsyncError = reinterpret_cast<decltype(api.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!ok) { dlclose(api.handle); api.handle = nullptr; return; }
+        Dl_info di;
+        if (dladdr(reinterpret_cast<void*>(api.AllGather), &di) && di.dli_fname) api.path = di.dli_fname;
+        (void)api.GetVersion(&api.version);
+    });
+    return api.handle ? &api : nullptr;
+}
+
+double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 }  // namespace
 
@@ -96,6 +187,8 @@ struct drp_ctx {
     DevBuf nominal, noise, partials, gathered, stats, elite, elite_all, xchg;
     int n_ranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    double comm_timeout_s = 60.0;        // DRP_COMM_TIMEOUT_S: a wait behind a collective gives up after this long (guarded_wait)
+    double comm_init_timeout_s = 300.0;  // DRP_COMM_INIT_TIMEOUT_S: ncclCommInitRank (every rank must arrive)
 
     // gradient-descent planner state
     bool gd_on = false;
@@ -190,6 +283,53 @@ int h2d(drp_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 int d2h(drp_ctx* c, void* dst, const void* src, size_t bytes) {
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     return DRP_OK;
+}
+
+// ---- waits that cannot hang on a dead peer --------------------------------------------------------------------
+// With a communicator attached, the stream may hold an ncclAllGather that never completes (a rank died, a rank took
+// another branch).  Every host wait of the context then polls instead of blocking: the stream / event, the
+// communicator's asynchronous error, and a deadline (DRP_COMM_TIMEOUT_S, default 60 s).  On error or timeout the
+// communicator is ABORTED (ncclCommAbort ends the collective's kernel on this rank), the context falls back to one
+// rank and the call returns DRP_ECOMM: the process can report and exit instead of sitting in hipStreamSynchronize.
+bool comm_live(const drp_ctx* c) { return c->comm != nullptr && (c->n_ranks > 1 || c->comm_always); }
+
+void comm_abort(drp_ctx* c) {
+    RcclApi* R = rccl_api();
+    if (c->comm && R) (void)R->CommAbort(c->comm);
+    c->comm = nullptr;
+    c->n_ranks = 1;
+    c->rank = 0;
+}
+
+int guarded_wait(drp_ctx* c, hipEvent_t ev) {
+    if (!comm_live(c)) {
+        const hipError_t e = ev ? hipEventSynchronize(ev) : hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(c, DRP_EHIP, "%s failed: %s", ev ? "hipEventSynchronize" : "hipStreamSynchronize", hipGetErrorString(e));
+        return DRP_OK;
+    }
+    RcclApi* R = rccl_api();
+    const double t0 = now_s();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(c->stream);
+        if (e == hipSuccess) return DRP_OK;
+        if (e != hipErrorNotReady) return fail(c, DRP_EHIP, "%s failed: %s", ev ? "hipEventQuery" : "hipStreamQuery", hipGetErrorString(e));
+        if ((spin & 63) == 63) {
+            ncclResult_t ae = ncclSuccess;
+            if (R && R->CommGetAsyncError(c->comm, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
+                comm_abort(c);
+                return fail(c, DRP_ECOMM, "RCCL reported an asynchronous error (%s); communicator aborted", R->GetErrorString(ae));
+            }
+            const double dt = now_s() - t0;
+            if (dt > c->comm_timeout_s) {
+                const int nr = c->n_ranks, rk = c->rank;
+                comm_abort(c);
+                return fail(c, DRP_ECOMM, "rank %d of %d waited %.1f s behind a collective (DRP_COMM_TIMEOUT_S=%g): a peer is gone "
+                            "or took another path; communicator aborted", rk, nr, dt, c->comm_timeout_s);
+            }
+            if (dt > 2e-3) usleep(50);            // past the length of any iteration's tail: stop burning the core
+            else sched_yield();
+        }
+    }
 }
 
 // RAII-less probe bracket
@@ -664,9 +804,32 @@ float max_abs(const float* p, size_t n) {
 // largest |s_delta| a push can cause (planners.py:238-254: the impulse is at most the push's own length in the
 // camera frame): actions [n][4] = (sx, sy, ex, ey) in world units
 float push_len_bound(const drp_ctx* c, const float* actions, size_t n) {
-    float fro = 0.0f;
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) fro += c->cam.m[i * 4 + j] * c->cam.m[i * 4 + j];
-    fro = sqrtf(fro);
+    // spectral norm of the world -> camera map's 3x3 part (1 for the rotation a camera is; the Frobenius norm used
+    // until round 2 is sqrt(3) too large, which put the DEFAULT clip box outside the proven envelope): power iteration
+    // on M^T M
+    double A[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+            for (int k = 0; k < 3; ++k) v += (double)c->cam.m[k * 4 + i] * (double)c->cam.m[k * 4 + j];
+            A[i][j] = v;
+        }
+    // the dominant eigenvector cannot be orthogonal to all three axes: the largest estimate of three starts
+    double lam = 0.0;
+    for (int s0 = 0; s0 < 3; ++s0) {
+        double x[3] = {s0 == 0 ? 1.0 : 0.0, s0 == 1 ? 1.0 : 0.0, s0 == 2 ? 1.0 : 0.0}, l = 0.0;
+        for (int it = 0; it < 64; ++it) {
+            double y[3];
+            for (int i = 0; i < 3; ++i) y[i] = A[i][0] * x[0] + A[i][1] * x[1] + A[i][2] * x[2];
+            l = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+            if (!(l > 0.0)) break;
+            for (int i = 0; i < 3; ++i) x[i] = y[i] / l;
+        }
+        if (l > lam) lam = l;
+    }
+    // an estimate from below, between the two largest eigenvalues at worst: one per cent of slack, never above Frobenius
+    const double frob = sqrt(A[0][0] + A[1][1] + A[2][2]);
+    const float fro = (float)fmin(frob, sqrt(lam) * 1.01);
     float l2 = 0.0f;
     for (size_t i = 0; i < n; ++i) {
         const float dx = actions[i * 4 + 2] - actions[i * 4 + 0], dy = actions[i * 4 + 3] - actions[i * 4 + 1];
@@ -734,6 +897,8 @@ int drp_create(int device, drp_ctx** out) {
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
+    if (const char* e = getenv("DRP_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_timeout_s = v; }
+    if (const char* e = getenv("DRP_COMM_INIT_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_init_timeout_s = v; }
     if (const char* e = getenv("DRP_SPLIT_SHIFT")) c->re_shift_env = atoi(e);
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -778,8 +943,8 @@ int drp_create(int device, drp_ctx** out) {
 void drp_destroy(drp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    if (c->comm) ncclCommDestroy(c->comm);
+    (void)guarded_wait(c, nullptr);           // a collective that cannot finish must not keep the destructor
+    if (c->comm) { RcclApi* R = rccl_api(); if (R) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
     DevBuf* bufs[] = {&c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
@@ -809,8 +974,7 @@ const char* drp_last_error(const drp_ctx* c) { return c ? c->err.c_str() : g_cre
 
 int drp_sync(drp_ctx* c) {
     if (!c) return DRP_EINVAL;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return DRP_OK;
+    return guarded_wait(c, nullptr);
 }
 
 int drp_set_engine(drp_ctx* c, int engine) {
@@ -849,15 +1013,16 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
         std::vector<float> mbv;
         pack_mfma_bwd(blob, mbv);
         CHK(h2d(c, c->w_mfma_bwd, mbv.data(), mbv.size() * sizeof(float)));
-        HIPCHK(c, hipStreamSynchronize(c->stream));     // mbv is about to go out of scope... kept alive until here
+        CHK(guarded_wait(c, nullptr));     // mbv is about to go out of scope... kept alive until here
         // range shift of the split relation encoder: proven for |attr| <= 2 (the reference's are 0), |s_r - s_s| <= 1.5
-        // per coordinate (radius 0.08 + two impulses of at most the workspace diagonal, 0.59 camera-frame units),
-        // density <= 10 000 (training range: 15 .. 6 500); calls beyond are re-checked one by one (range_check)
+        // per coordinate (radius 0.08 + two impulses; the default clip box's longest push is 8.5 sqrt(2) / 24 = 0.50
+        // camera-frame units, the whole workspace diagonal 0.59: 0.08 + 2 x 0.59 = 1.26), density <= 10 000 (training
+        // range: 15 .. 6 500); calls beyond are re-checked one by one (range_check)
         split_range_init(blob, c->re_range, 2.0, 1.5, 2.0);
         if (c->re_shift_env != 0x7fffffff) c->re_range.shift = c->re_shift_env;
         // weights no shift can carry (a matrix entry beyond fp16, NaN): the split engines refuse every call
         // (range_check); the fp32 engines are unaffected
-        c->re_ok = c->re_range.wmax < 6.0e4f &&
+        c->re_ok = c->re_range.finite && c->re_range.wmax < 6.0e4f &&
                    ldexp(split_range_bound(c->re_range, 2.0, 1.5, 2.0), c->re_range.shift) <= 65504.0;
         c->re_scale = ldexpf(1.0f, c->re_range.shift);
         c->re_inv = ldexpf(1.0f, -c->re_range.shift);
@@ -867,10 +1032,10 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
         std::vector<uint16_t> sp6;
         pack_split6(blob, sp6);
         CHK(h2d(c, c->w_split6, sp6.data(), sp6.size() * sizeof(uint16_t)));
-        HIPCHK(c, hipStreamSynchronize(c->stream));     // sp6 too
-        HIPCHK(c, hipStreamSynchronize(c->stream));     // m, sp are about to go out of scope
+        CHK(guarded_wait(c, nullptr));     // sp6 too
+        CHK(guarded_wait(c, nullptr));     // m, sp are about to go out of scope
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(guarded_wait(c, nullptr));
     c->w_host.assign(blob, blob + n_floats);
     c->adj_thresh = adj_thresh;
     // threshold = adj_thresh * adj_thresh in Python doubles, then an fp32 scalar
@@ -894,7 +1059,7 @@ int drp_set_goal(drp_ctx* c, const float* field, int h, int w, const float* goal
     HIPCHK(c, hipSetDevice(c->device));
     CHK(h2d(c, c->goal_field, field, (size_t)h * w * sizeof(float)));
     CHK(h2d(c, c->goal_coor, goal_coor, (size_t)m * 2 * sizeof(float)));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(guarded_wait(c, nullptr));
     c->goal_h = h; c->goal_w = w; c->goal_m = m;
     c->have_goal = true;
     return DRP_OK;
@@ -1047,7 +1212,7 @@ int drp_mpc_begin(drp_ctx* c, const drp_mpc_params* p, const float* s0, const fl
     CHK(ensure(c, c->states, (size_t)B * H * N * 3 * sizeof(float)));
     CHK(ensure(c, c->rewards, (size_t)B * H * sizeof(float)));
     CHK(ensure(c, c->scratch, (size_t)B * sizeof(float)));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(guarded_wait(c, nullptr));
     c->mpc_pending[0] = c->mpc_pending[1] = false;         // a new problem drops what the last one left in flight
     c->mpc_on = true;
     c->gd_on = false;
@@ -1146,8 +1311,9 @@ int drp_mpc_update_device(drp_ctx* c) {
     const int rec = 6 + 4 * c->mpc.n_look_ahead;
     if (c->comm && (c->n_ranks > 1 || c->comm_always)) {
         CHK(ensure(c, c->gathered, (size_t)rec * sizeof(double) * c->n_ranks));
-        ncclResult_t r = ncclAllGather(c->partials.p, c->gathered.p, rec, ncclDouble, c->comm, c->stream);
-        if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", ncclGetErrorString(r));
+        RcclApi* R = rccl_api();
+        ncclResult_t r = R->AllGather(c->partials.p, c->gathered.p, rec, ncclDouble, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", R->GetErrorString(r));
         return launch_update(c, ptr<double>(c->gathered), c->n_ranks);
     }
     return launch_update(c, ptr<double>(c->partials), 1);
@@ -1240,8 +1406,9 @@ int drp_mpc_update_elite_device(drp_ctx* c, int k) {
     int n_ranks = 1;
     if (c->comm && (c->n_ranks > 1 || c->comm_always)) {
         CHK(ensure(c, c->elite_all, (size_t)msg * sizeof(double) * c->n_ranks));
-        ncclResult_t r = ncclAllGather(c->elite.p, c->elite_all.p, msg, ncclDouble, c->comm, c->stream);
-        if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", ncclGetErrorString(r));
+        RcclApi* R = rccl_api();
+        ncclResult_t r = R->AllGather(c->elite.p, c->elite_all.p, msg, ncclDouble, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", R->GetErrorString(r));
         all = ptr<double>(c->elite_all);
         n_ranks = c->n_ranks;
     }
@@ -1298,8 +1465,8 @@ int drp_mpc_wait(drp_ctx* c, int slot, float* actions, float* rewards) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
     if (slot < 0 || slot > 1 || !c->mpc_pending[slot]) return fail(c, DRP_ESTATE, "no iteration in flight in slot %d", slot);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventSynchronize(c->mpc_ev[slot]));
     c->mpc_pending[slot] = false;
+    CHK(guarded_wait(c, c->mpc_ev[slot]));
     const drp_mpc_params& p = c->mpc;
     const size_t na = (size_t)p.n_sample * p.n_batch * p.n_look_ahead * 4, nr = (size_t)p.n_sample * p.n_batch;
     if (actions) memcpy(actions, c->mpc_pin[slot], na * sizeof(float));
@@ -1353,7 +1520,7 @@ int px_stage_pcd(drp_ctx* c, const float* d_depth, const uint8_t* d_mask, int h,
     HIPCHK(c, hipGetLastError());
     unsigned long long total = 0;
     CHK(d2h(c, &total, off + nblk, sizeof(total)));
-    HIPCHK(c, hipStreamSynchronize(st));
+    CHK(guarded_wait(c, nullptr));
     if (total > 0x7fffffffull) return fail(c, DRP_EINVAL, "too many foreground pixels");
     const int n = (int)total;
     *n_out = n;
@@ -1378,7 +1545,7 @@ int px_stage_down(drp_ctx* c, const double* d_pcd, int n, int nblk_bounds, doubl
     HIPCHK(c, hipGetLastError());
     PxGrid hg;
     CHK(d2h(c, &hg, g, sizeof(hg)));
-    HIPCHK(c, hipStreamSynchronize(st));
+    CHK(guarded_wait(c, nullptr));
     if (hg.cells <= 0 || hg.cells > PX_MAX_CELLS)
         return fail(c, DRP_EINVAL, "voxel grid %d x %d x %d exceeds %lld cells", hg.dims[0], hg.dims[1], hg.dims[2],
                     PX_MAX_CELLS);
@@ -1404,7 +1571,7 @@ int px_stage_down(drp_ctx* c, const double* d_pcd, int n, int nblk_bounds, doubl
     HIPCHK(c, hipGetLastError());
     unsigned long long total = 0;
     CHK(d2h(c, &total, boff + cblk, sizeof(total)));
-    HIPCHK(c, hipStreamSynchronize(st));
+    CHK(guarded_wait(c, nullptr));
     const int m = (int)(total >> 32);
     if ((int)(total & 0xffffffffull) != n) return fail(c, DRP_ESTATE, "voxel scan lost points");
     *m_out = m;
@@ -1518,7 +1685,7 @@ int drp_fps_rad(drp_ctx* c, const double* pcd, int n, double radius, int init_id
                        ptr<double>(c->px_dist), chosen, chosen + cap);
     HIPCHK(c, hipGetLastError());
     CHK(d2h(c, count_out, chosen + cap, sizeof(int)));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(guarded_wait(c, nullptr));
     CHK(d2h(c, idx_out, chosen, (size_t)*count_out * sizeof(int)));
     return drp_sync(c);
 }
@@ -1625,7 +1792,7 @@ int drp_set_goal_image(drp_ctx* c, const float* obs_goal, int h, int w, int mode
     HIPCHK(c, hipGetLastError());
     unsigned long long total = 0;
     CHK(d2h(c, &total, off + nblk, sizeof(total)));
-    HIPCHK(c, hipStreamSynchronize(st));
+    CHK(guarded_wait(c, nullptr));
     const int count = (int)total;
     if (count <= 0) return fail(c, DRP_EINVAL, "the goal image has no pixel below 0.5");
     if (count == (int)npix) return fail(c, DRP_EINVAL, "the goal image has no pixel at or above 0.5");
@@ -1655,7 +1822,7 @@ int drp_set_goal_image(drp_ctx* c, const float* obs_goal, int h, int w, int mode
     HIPCHK(c, hipGetLastError());
     if (field_out) CHK(d2h(c, field_out, c->goal_field.p, npix * sizeof(float)));
     if (goal_coor_out) CHK(d2h(c, goal_coor_out, c->goal_coor.p, (size_t)m * 2 * sizeof(float)));
-    HIPCHK(c, hipStreamSynchronize(st));
+    CHK(guarded_wait(c, nullptr));
     if (m_out) *m_out = m;
     c->goal_h = h; c->goal_w = w; c->goal_m = m;
     c->have_goal = true;
@@ -1891,7 +2058,7 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     CHK(ensure(c, c->adam_v, (size_t)B * H * 4 * sizeof(float)));
     HIPCHK(c, hipMemsetAsync(c->adam_m.p, 0, (size_t)B * H * 4 * sizeof(float), c->stream));
     HIPCHK(c, hipMemsetAsync(c->adam_v.p, 0, (size_t)B * H * 4 * sizeof(float), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(guarded_wait(c, nullptr));
     c->gd_nb = nb; c->gd_N = N; c->gd_B = B; c->gd_H = H; c->gd_iter = 0; c->gd_lr = lr;
     c->gd_pending[0] = c->gd_pending[1] = false;           // a new problem drops what the last one left in flight
     c->gd_cself_tag = 0;
@@ -1982,8 +2149,8 @@ int drp_gd_wait(drp_ctx* c, int slot, float* rewards_out, float* actions_out) {
     if (!c) return DRP_EINVAL;
     if (slot < 0 || slot > 1 || !c->gd_pending[slot]) return fail(c, DRP_ESTATE, "no iteration in flight in slot %d", slot);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventSynchronize(c->gd_ev[slot]));
     c->gd_pending[slot] = false;
+    CHK(guarded_wait(c, c->gd_ev[slot]));
     const size_t nr = (size_t)c->gd_B, na = (size_t)c->gd_B * c->gd_H * 4;
     if (rewards_out) memcpy(rewards_out, c->gd_pin[slot], nr * sizeof(float));
     if (actions_out) memcpy(actions_out, c->gd_pin[slot] + nr, na * sizeof(float));
@@ -2228,7 +2395,7 @@ int drp_train_begin(drp_ctx* c, int n_rollout, double lr, double beta1) {
     CHK(ensure(c, c->tr_part, (size_t)KT_WGRAD_MAX_JOBS * KT_WGRAD_MAX_BLOCKS * 66 * 64 * sizeof(float)));
     HIPCHK(c, hipMemsetAsync(c->tr_m.p, 0, (size_t)W_TOTAL * sizeof(float), c->stream));
     HIPCHK(c, hipMemsetAsync(c->tr_v.p, 0, (size_t)W_TOTAL * sizeof(float), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(guarded_wait(c, nullptr));
     c->tr_nroll = n_rollout; c->tr_lr = lr; c->tr_beta1 = beta1; c->tr_iter = 0;
     c->tr_on = true;
     c->gd_on = false;
@@ -2309,7 +2476,7 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         // the engines read packed copies of the weights: rebuild them from the updated blob
         std::vector<float> blob((size_t)W_TOTAL);
         CHK(d2h(c, blob.data(), c->w_raw.p, (size_t)W_TOTAL * sizeof(float)));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        CHK(guarded_wait(c, nullptr));
         CHK(install_weights(c, blob));
     }
     CHK(drp_sync(c));
@@ -2336,49 +2503,121 @@ int drp_get_weights(drp_ctx* c, float* blob_out, size_t n_floats) {
 }
 
 // ---- RCCL -------------------------------------------------------------------------------------
+namespace {
+RcclApi* need_rccl(drp_ctx* c) {
+    RcclApi* R = rccl_api();
+    if (!R) (void)fail(c, DRP_ECOMM, "RCCL is not available: %s", g_rccl.error.c_str());
+    return R;
+}
+// ids this process has already built a communicator from: a ncclUniqueId serves ONE ncclCommInitRank per rank --
+// a second one with the same id never completes
+std::mutex g_used_ids_mu;
+std::vector<std::string> g_used_ids;
+}  // namespace
+
 int drp_comm_unique_id(char* id128) {
     if (!id128) return DRP_EINVAL;
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    RcclApi* R = need_rccl(nullptr);
+    if (!R) return DRP_ECOMM;
     ncclUniqueId id;
-    ncclResult_t r = ncclGetUniqueId(&id);
-    if (r != ncclSuccess) return fail(nullptr, DRP_ECOMM, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    ncclResult_t r = R->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, DRP_ECOMM, "ncclGetUniqueId: %s", R->GetErrorString(r));
     memcpy(id128, &id, 128);
     return DRP_OK;
 }
 
 int drp_comm_init(drp_ctx* c, const char* id128, int rank, int n_ranks) {
     if (!c || !id128 || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(c, DRP_EINVAL, "bad comm args");
+    RcclApi* R = need_rccl(c);
+    if (!R) return DRP_ECOMM;
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    {
+        std::lock_guard<std::mutex> lk(g_used_ids_mu);
+        const std::string key(id128, 128);
+        for (const std::string& u : g_used_ids)
+            if (u == key) return fail(c, DRP_ECOMM, "this ncclUniqueId has already been used for a communicator in this process: "
+                                      "every communicator needs a fresh id from rank 0 (drp_comm_unique_id)");
+        g_used_ids.push_back(key);
+    }
+    if (c->comm) { CHK(guarded_wait(c, nullptr)); (void)R->CommDestroy(c->comm); c->comm = nullptr; }
+    // every rank has to arrive: the call runs on a helper thread so that a missing peer costs a deadline
+    // (DRP_COMM_INIT_TIMEOUT_S), not the process
+    struct InitState { std::atomic<int> done{0}; ncclComm_t comm = nullptr; ncclResult_t res = ncclSuccess; };
+    auto stt = std::make_shared<InitState>();
     ncclUniqueId id;
     memcpy(&id, id128, 128);
-    ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, id, rank);
-    if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
+    const int dev = c->device;
+    std::thread([stt, R, id, rank, n_ranks, dev] {
+        (void)hipSetDevice(dev);
+        stt->res = R->CommInitRank(&stt->comm, n_ranks, id, rank);
+        stt->done.store(1, std::memory_order_release);
+    }).detach();
+    const double t0 = now_s();
+    while (!stt->done.load(std::memory_order_acquire)) {
+        if (now_s() - t0 > c->comm_init_timeout_s)
+            return fail(c, DRP_ECOMM, "ncclCommInitRank: rank %d waited %.0f s for the other %d rank(s) (DRP_COMM_INIT_TIMEOUT_S)",
+                        rank, c->comm_init_timeout_s, n_ranks - 1);
+        usleep(200);
+    }
+    if (stt->res != ncclSuccess) return fail(c, DRP_ECOMM, "ncclCommInitRank: %s", R->GetErrorString(stt->res));
+    c->comm = stt->comm;
     c->rank = rank;
     c->n_ranks = n_ranks;
+    return DRP_OK;
+}
+
+int drp_comm_info(drp_ctx* c, int* n_ranks, int* rank, int* version, char* path, size_t path_len) {
+    if (!c) return DRP_EINVAL;
+    if (n_ranks) *n_ranks = 0;
+    if (rank) *rank = -1;
+    if (version) *version = 0;
+    if (path && path_len) path[0] = 0;
+    RcclApi* R = need_rccl(c);
+    if (!R) return DRP_ECOMM;
+    if (version) *version = R->version;
+    if (path && path_len) snprintf(path, path_len, "%s", R->path.c_str());
+    if (c->comm) {
+        int v = 0;
+        ncclResult_t r = R->CommCount(c->comm, &v);
+        if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclCommCount: %s", R->GetErrorString(r));
+        if (n_ranks) *n_ranks = v;
+        r = R->CommUserRank(c->comm, &v);
+        if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclCommUserRank: %s", R->GetErrorString(r));
+        if (rank) *rank = v;
+    }
     return DRP_OK;
 }
 
 int drp_comm_allgather(drp_ctx* c, const void* send, size_t bytes, void* recv) {
     if (!c || !send || !recv || bytes == 0) return fail(c, DRP_EINVAL, "bad all-gather arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->comm || (c->n_ranks <= 1 && !c->comm_always)) {
+    if (!comm_live(c)) {
         memcpy(recv, send, bytes);
         return DRP_OK;
     }
+    RcclApi* R = rccl_api();
     CHK(ensure(c, c->xchg, bytes * (size_t)(c->n_ranks + 1)));
     char* dsend = static_cast<char*>(c->xchg.p);
     char* drecv = dsend + bytes;
     HIPCHK(c, hipMemcpyAsync(dsend, send, bytes, hipMemcpyHostToDevice, c->stream));
-    ncclResult_t r = ncclAllGather(dsend, drecv, bytes, ncclChar, c->comm, c->stream);
-    if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", ncclGetErrorString(r));
+    ncclResult_t r = R->AllGather(dsend, drecv, bytes, ncclChar, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(c, DRP_ECOMM, "ncclAllGather: %s", R->GetErrorString(r));
     CHK(d2h(c, recv, drecv, bytes * (size_t)c->n_ranks));
     return drp_sync(c);
 }
 
 int drp_comm_destroy(drp_ctx* c) {
     if (!c) return DRP_EINVAL;
-    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm) {
+        RcclApi* R = rccl_api();
+        const int rc = guarded_wait(c, nullptr);      // aborts the communicator itself when the wait gives up
+        if (c->comm && R) (void)R->CommDestroy(c->comm);
+        c->comm = nullptr;
+        c->n_ranks = 1;
+        c->rank = 0;
+        return rc;
+    }
     c->n_ranks = 1;
     c->rank = 0;
     return DRP_OK;
@@ -2424,7 +2663,7 @@ int drp_probe_begin(drp_ctx* c, const char* kernel_class) {
 
 int drp_probe_read(drp_ctx* c, double* total_ms, long* launches) {
     if (!c) return DRP_EINVAL;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(guarded_wait(c, nullptr));
     double tot = 0.0;
     long n = 0;
     for (size_t i = 0; i + 1 < c->probe_used; i += 2) {
@@ -2436,6 +2675,22 @@ int drp_probe_read(drp_ctx* c, double* total_ms, long* launches) {
     c->probe_used = 0;
     if (total_ms) *total_ms = tot;
     if (launches) *launches = n;
+    return DRP_OK;
+}
+
+// holds the context's stream for `ms` milliseconds (a kernel spinning on the 100 MHz real-time counter): what a
+// collective waiting for a dead peer looks like to the host.  tests/test_gpu_errors.py drives the deadline of
+// guarded_wait with it.  ms <= 10 000.
+__global__ void k_debug_stall(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+int drp_debug_stall(drp_ctx* c, int ms) {
+    if (!c || ms < 0 || ms > 10000) return fail(c, DRP_EINVAL, "stall of %d ms outside 0..10000", ms);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_debug_stall, dim3(1), dim3(1), 0, c->stream, (unsigned long long)ms * 100000ull);
+    HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
 

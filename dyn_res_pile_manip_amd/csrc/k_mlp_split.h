@@ -61,6 +61,7 @@ struct SplitRange {
     float a1[64], d1[64], m1[64], b1[64];     // first layer: row coefficients of A, D, dm, |bias|
     float rs2[64], b2[64], rs4[64], b4[64];   // row abs sums and |bias| of the two hidden layers
     float wmax;                               // largest |weight| of the unscaled matrices packed as fp16
+    bool finite;                              // no NaN / Inf among the relation encoder's and propagator's parameters
     int shift;                                // k
     float env_attr, env_delta, env_dens;      // the envelope k was chosen for
 };
@@ -73,6 +74,14 @@ inline double split_range_bound(const SplitRange& r, double A, double D, double 
 }
 inline void split_range_init(const float* w, SplitRange& r, double A, double D, double dm) {
     r.wmax = 0.0f;
+    // fmaxf / fmax drop a NaN operand, so the sums and maxima below would let NaN weights through as a finite bound:
+    // look for them explicitly
+    r.finite = true;
+    const int spans[][2] = {{W_RE0_W, 64 * 6}, {W_RE0_B, 64}, {W_RE2_W, 4096}, {W_RE2_B, 64}, {W_RE4_W, 4096}, {W_RE4_B, 64},
+                            {W_RP_W, 64 * 193}, {W_RP_B, 64}};
+    for (const auto& sp : spans)
+        for (int i = 0; i < sp[1]; ++i)
+            if (!std::isfinite(w[sp[0] + i])) r.finite = false;
     for (int o = 0; o < 64; ++o) {
         const float* w1 = w + W_RE0_W + o * 6;
         r.a1[o] = fabsf(w1[0]) + fabsf(w1[1]);

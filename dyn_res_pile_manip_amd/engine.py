@@ -437,6 +437,22 @@ class Engine(object):
         self._ck(self.lib.drp_comm_init(self.h, uid, int(rank), int(n_ranks)))
         self._n_ranks = int(n_ranks)
 
+    def comm_destroy(self):
+        self._ck(self.lib.drp_comm_destroy(self.h))
+        self._n_ranks = 1
+
+    def comm_info(self):
+        """{'n_ranks': ncclCommCount (0 without a communicator), 'rank', 'version', 'path'} of the RCCL this process bound."""
+        n, r, v = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        path = ctypes.create_string_buffer(1024)
+        self._ck(self.lib.drp_comm_info(self.h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(v), path, 1024))
+        ver = v.value
+        return {'n_ranks': n.value, 'rank': r.value, 'version': ver, 'path': path.value.decode(),
+                'version_str': '%d.%d.%d' % (ver // 10000, (ver // 100) % 100, ver % 100) if ver >= 10000 else str(ver)}
+
+    def debug_stall(self, ms):
+        self._ck(self.lib.drp_debug_stall(self.h, int(ms)))
+
     def comm_allgather(self, arr):
         """All-gather one host array per rank over the context's communicator -> [n_ranks, *arr.shape]."""
         arr = np.ascontiguousarray(arr)

@@ -37,16 +37,36 @@ def relations_to_lists(Rr, Rs):
     B, E, N = Rr.shape
     idx = -np.ones((B, N, 10), dtype=np.int16)
     cnt = np.zeros((B, N), dtype=np.uint8)
-    bs, es = np.nonzero(Rr.sum(2) > 0.5)
+    bs, es = np.nonzero(Rr.sum(2) > 0.5)                 # edges in (sample, edge number) order
     recv = Rr[bs, es].argmax(1)
     send = Rs[bs, es].argmax(1)
-    for b, i, j in zip(bs, recv, send):
-        k = cnt[b, i]
-        if k >= 10:
-            raise ValueError('receiver %d of sample %d has more than 10 in-edges' % (i, b))
-        idx[b, i, k] = j
-        cnt[b, i] = k + 1
+    # slot of an edge = how many earlier edges of the sample have the same receiver: a stable sort by (sample,
+    # receiver) keeps the edge order inside a group, the position inside the group is the slot
+    key = bs.astype(np.int64) * N + recv
+    order = np.argsort(key, kind='stable')
+    ks = key[order]
+    first = np.ones(ks.shape, dtype=bool)
+    first[1:] = ks[1:] != ks[:-1]
+    start = np.maximum.accumulate(np.where(first, np.arange(ks.size), 0))
+    slot = np.arange(ks.size) - start
+    if slot.size and slot.max() >= 10:
+        w = order[np.argmax(slot >= 10)]
+        raise ValueError('receiver %d of sample %d has more than 10 in-edges' % (recv[w], bs[w]))
+    idx[bs[order], recv[order], slot] = send[order]
+    np.add.at(cnt, (bs, recv), 1)
     return idx, cnt
+
+
+def mask_lists(idx, particle_nums):
+    """model/gnn_dyn.py:238-241 on receiver-major lists: rows and columns beyond particle_nums[b] leave the graph.
+    idx [B,N,10] (-1 padded) -> (idx with the surviving senders compacted to the front in their order, cnt)."""
+    B, N, K = idx.shape
+    n = np.asarray(particle_nums).reshape(B, 1, 1).astype(np.int64)
+    keep = (idx >= 0) & (idx < n) & (np.arange(N).reshape(1, N, 1) < n)
+    order = np.argsort(~keep, axis=2, kind='stable')
+    out = np.take_along_axis(idx, order, 2)
+    out[~np.take_along_axis(keep, order, 2)] = -1
+    return np.ascontiguousarray(out, dtype=np.int16), keep.sum(2).astype(np.uint8)
 
 
 class PropModuleDiffDen(object):
@@ -120,15 +140,6 @@ class PropNetDiffDenModel(object):
             # Unused by the MPC path and by training: build the lists on the
             # device, mask them on the host, run forward with explicit relations.
             idx, cnt = self.engine.build_graph(s, sd)
-            for b in range(s.shape[0]):
-                n = int(particle_nums[b])
-                keep = idx[b] < n
-                keep[n:] = False
-                keep &= idx[b] >= 0
-                for i in range(s.shape[1]):
-                    js = idx[b, i][keep[i]]
-                    idx[b, i] = -1
-                    idx[b, i, :len(js)] = js
-                    cnt[b, i] = len(js)
+            idx, cnt = mask_lists(idx, particle_nums)
             return _like(self.engine.forward(a, s, sd, d, idx, cnt), proto)
         return _like(self.engine.step(a, s, sd, d), proto)

@@ -271,6 +271,13 @@ class PlannerGD(Planner):
         eng = self._bind(model_dy)
         self._eng = eng
         rank, n_ranks = (comm.rank, comm.n_ranks) if comm is not None else (0, 1)
+        mpc_type = self.config['mpc'].get('mpc_type', 'MPPI')
+        # what cannot be sharded is refused on EVERY rank, from the global arguments, before the first collective or
+        # rollout: a rank that raised alone would leave the others waiting in the exchange
+        n_units = traj_num if mpc_type == 'GD' else int(n_sample)
+        if n_ranks > n_units:
+            raise ValueError('%d %s cannot be sharded over %d ranks' %
+                             (n_units, 'trajectories' if mpc_type == 'GD' else 'samples', n_ranks))
         if comm is not None:
             comm.attach(eng)
 
@@ -328,7 +335,6 @@ class PlannerGD(Planner):
                     rew_mean[0, it] = r[:, 0].mean()
                     rew_std[0, it] = r[:, 0].std(ddof=1) if ns > 1 else 0.0
 
-        mpc_type = cfg.get('mpc_type', 'MPPI')
         i = 0
         if mpc_type == 'GD':
             # the reference's live loop (planners.py:661-764): every trajectory x batch column is an
@@ -340,9 +346,7 @@ class PlannerGD(Planner):
                 # the reference reaches its return statement with the loop variable unbound (planners.py:870)
                 raise ValueError('time_lim %.3g ms admits no iteration at %d particles (%d ms each, planners.py:25-28)'
                                  % (time_lim, N, particle_num_to_iter_time(N)))
-            t_lo, t_hi = sharding.shard_range(traj_num, rank, n_ranks)
-            if t_hi == t_lo:
-                raise ValueError('%d trajectories cannot be sharded over %d ranks' % (traj_num, n_ranks))
+            t_lo, t_hi = sharding.shard_range(traj_num, rank, n_ranks)      # never empty: n_ranks <= traj_num (above)
             cand = np.repeat(act_seq[:, t_lo:t_hi].transpose(1, 0, 2), n_batch, axis=0).astype(np.float32)
             eng.gd_begin(state_cur_np, attr_cur_np, state_param, cand, cfg['gd']['lr'], lo, hi)   # [traj*nb,H,4]
             reward_seqs = np.zeros((cand.shape[0],), np.float32)
@@ -387,9 +391,7 @@ class PlannerGD(Planner):
             r0 = reward_seqs.reshape(traj_num, n_batch)
             nominal = act_seq[:, int(np.argmax(r0.mean(1))), :].astype(np.float64)
             s_lo, s_hi = sharding.shard_range(n_sample, rank, n_ranks)
-            ns_loc = s_hi - s_lo
-            if ns_loc == 0:
-                raise ValueError('%d samples cannot be sharded over %d ranks' % (n_sample, n_ranks))
+            ns_loc = s_hi - s_lo                                           # > 0: n_ranks <= n_sample (above)
             if n_iter > 1:
                 eng.mpc_begin(state_cur_np, attr_cur_np, state_param, nominal, n_sample=ns_loc, sample_offset=s_lo, **mp)
             k_elite = int(cfg.get('cem', {}).get('n_elite', max(1, n_sample // 10)))

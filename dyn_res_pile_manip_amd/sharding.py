@@ -125,9 +125,15 @@ class RcclComm(object):
         self._eng = None
 
     def attach(self, eng):
-        if self._eng is not eng:
+        """Builds the communicator on first use.  A ncclUniqueId serves ONE ncclCommInitRank per rank, so the
+        object stays with the engine it was first attached to: handing it a second engine raises (make a new
+        RcclComm from a fresh id) instead of re-initialising with the spent id, which never returns."""
+        if self._eng is None:
             eng.comm_init(self.uid, self.rank, self.n_ranks)
             self._eng = eng
+        elif self._eng is not eng:
+            raise RuntimeError('this RcclComm is bound to another engine: a ncclUniqueId cannot be used for a second '
+                               'communicator -- create a new RcclComm from a fresh Engine.comm_unique_id()')
 
     def allgather(self, arr):
         return self._eng.comm_allgather(arr)

@@ -293,10 +293,22 @@ int drp_gd_get(drp_ctx* ctx, float* actions_out);
 int drp_gd_step_async(drp_ctx* ctx, int slot);
 int drp_gd_wait(drp_ctx* ctx, int slot, float* rewards_out, float* actions_out);
 
-/* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------ */
+/* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------
+ * The library does not link librccl: the first of these calls binds, at run time, $DRP_RCCL_LIB, else the librccl the
+ * process has already mapped (PyTorch's bundled copy when the host imported torch), else /opt/rocm's -- one RCCL per
+ * process whatever the import order.  drp_comm_info reports which one.
+ * Hang guard: while a communicator is attached, every host wait of the context (drp_sync, drp_mpc_wait, drp_gd_wait,
+ * the waits inside the blocking calls) polls the stream, the communicator's asynchronous error and a deadline
+ * (env DRP_COMM_TIMEOUT_S, default 60; DRP_COMM_INIT_TIMEOUT_S, default 300, for drp_comm_init).  On error or
+ * timeout the communicator is aborted (ncclCommAbort), the context is back to one rank and the call returns DRP_ECOMM. */
 int drp_comm_unique_id(char* id128);                       /* ncclGetUniqueId */
+/* ncclCommInitRank.  A ncclUniqueId serves one communicator: a second drp_comm_init with an id this process has
+ * already used returns DRP_ECOMM instead of never returning. */
 int drp_comm_init(drp_ctx* ctx, const char* id128, int rank, int n_ranks);
 int drp_comm_destroy(drp_ctx* ctx);
+/* n_ranks = ncclCommCount and rank = ncclCommUserRank of the attached communicator (0 / -1 without one),
+ * version = ncclGetVersion of the bound library, path = the file it was loaded from (each pointer nullable). */
+int drp_comm_info(drp_ctx* ctx, int* n_ranks, int* rank, int* version, char* path, size_t path_len);
 /* All-gather of one host buffer per rank over the context's communicator (upload, ncclAllGather, download):
  * recv [n_ranks][bytes] in rank order.  Without a communicator (or one rank) it copies send to recv.  The planner
  * mirror uses it for its per-iteration bookkeeping record (per-column best reward / index / pushes,
@@ -309,6 +321,9 @@ int drp_comm_allgather(drp_ctx* ctx, const void* send, size_t bytes, void* recv)
  * "mppi", "prop" (the fused propagation-step kernel of DRP_ENGINE_FUSED).  drp_probe_read returns total ms and launches since drp_probe_begin. */
 int drp_probe_begin(drp_ctx* ctx, const char* kernel_class);
 int drp_probe_read(drp_ctx* ctx, double* total_ms, long* launches);
+/* hold the context's stream for ms (<= 10 000) milliseconds -- what a collective waiting for a dead peer looks like to
+ * the host; the tests of the hang guard use it */
+int drp_debug_stall(drp_ctx* ctx, int ms);
 /* copy an intermediate device buffer to the host: "s_delta","nbr_idx","nbr_cnt",
  * "particle_encode"(eff0),"c_node","c_edge","proj","agg","effect". returns bytes. */
 long drp_debug_fetch(drp_ctx* ctx, const char* name, void* out, size_t out_bytes);

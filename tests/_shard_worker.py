@@ -1,5 +1,6 @@
-"""Worker of tests/test_gpu_sharded_planner.py: one rank of a world of processes that share GPU 0 and
-exchange through torch.distributed (gloo).  Runs the planner with comm=TorchComm and writes its result dict."""
+"""Worker of tests/test_gpu_sharded_planner.py: one rank of a world of processes.  Transport 'gloo' (default): the
+ranks share GPU 0 and exchange through torch.distributed (comm=TorchComm); 'rccl': one GPU per rank, the product
+transport (comm=RcclComm, the ncclUniqueId broadcast over the gloo group).  Writes the planner's result dict."""
 import os
 import sys
 
@@ -9,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run_planner(mpc_type, comm, n_sample=48, n_update_iter=4, traj=6, nb=2, N=40, H=2, seed=77):
+def run_planner(mpc_type, comm, n_sample=48, n_update_iter=4, traj=6, nb=2, N=40, H=2, seed=77, device=0):
     from dyn_res_pile_manip_amd import synthetic as syn, weights, flex_rewards
     from dyn_res_pile_manip_amd.gnn_dyn import PropNetDiffDenModel
     from dyn_res_pile_manip_amd.planners import PlannerGD
@@ -18,7 +19,7 @@ def run_planner(mpc_type, comm, n_sample=48, n_update_iter=4, traj=6, nb=2, N=40
     config['mpc']['mpc_type'] = mpc_type
     config['mpc']['cem'] = {'n_elite': 5}
     env = syn.SyntheticEnv(config)
-    model = PropNetDiffDenModel(config, True)
+    model = PropNetDiffDenModel(config, True, device=device)
     model.load_state_dict(weights.random_state_dict(seed=0), strict=False)
     planner = PlannerGD(config, env)
     s, dens, attr = syn.make_pile(N, n_batch=nb, seed=3)
@@ -38,8 +39,20 @@ def run_planner(mpc_type, comm, n_sample=48, n_update_iter=4, traj=6, nb=2, N=40
 if __name__ == '__main__':
     import torch.distributed as dist
     out_dir, mpc_type = sys.argv[1], sys.argv[2]
+    transport = sys.argv[3] if len(sys.argv) > 3 else 'gloo'
     dist.init_process_group('gloo')
-    from dyn_res_pile_manip_amd.sharding import TorchComm
-    res = run_planner(mpc_type, TorchComm())
+    from dyn_res_pile_manip_amd.sharding import RcclComm, TorchComm
+    if transport == 'rccl':
+        from dyn_res_pile_manip_amd.engine import Engine
+        rank, world = dist.get_rank(), dist.get_world_size()
+        uid = [None]
+        if rank == 0:
+            probe = Engine(0)
+            uid[0] = probe.comm_unique_id()
+            probe.close()
+        dist.broadcast_object_list(uid, src=0)
+        res = run_planner(mpc_type, RcclComm(uid[0], rank, world), device=rank)
+    else:
+        res = run_planner(mpc_type, TorchComm())
     np.savez(os.path.join(out_dir, '%s_rank%d.npz' % (mpc_type, dist.get_rank())), **res)
     dist.destroy_process_group()

@@ -36,31 +36,78 @@ def test_single_gpu_line_has_the_contract_fields():
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'cpu_model' in c
-    # algorithmic bytes over time: at this reduced size (256 samples) the edge rows fit the 256-MB infinity cache, so the
-    # figure can pass the HBM peak; the full-size line (1024 samples, 0.9) is what DESIGN quotes
-    assert d['roofline_scatter']['bound'] == 'hbm' and 0 < d['roofline_scatter']['frac'] < 3.0
+    # the segmented sum's fraction is of HBM-side bytes (PMC traffic at the profiled shape, compulsory bytes otherwise):
+    # a fraction of the HBM peak cannot pass 1; SURVEY 8d's algorithmic figure travels beside it under its own name
+    sc = d['roofline_scatter']
+    assert sc['bound'] == 'hbm' and 0 < sc['frac'] < 1 and sc['frac_basis'].startswith('compulsory')
+    assert sc['algorithmic_bytes_per_launch'] > sc['compulsory_bytes_per_launch'] and sc['cache_served'] is True
     assert 'workload' in d['config'] and 'model' not in d['config']
+    assert 'sweep' not in d                                   # a custom shape carries no sweep block
+
+
+def test_the_sweep_block_carries_the_other_baseline_workloads():
+    d = _run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--samples', '128', '--no-alt', '--no-cpu-baseline',
+              '--sweep'])
+    names = [e['name'] for e in d['sweep']]
+    assert names == ['c4-50', 'c4-150', 'c4-600', 'c5-share', 'gd-demo']
+    for e in d['sweep']:
+        assert e['steps'] == 5 and e['warmup'] == 2 and e['value'] > 0 and 0 < e['frac'] < 1, e
+        assert abs(e['value'] - e['rows'] * e['n_particles'] * e['n_look_ahead'] / (e['ms_per_step'] * 1e-3)) < 1e-6 * e['value']
+        assert e['dominant_kernel'] in e['kernel_ms_per_iteration']
+    assert d['sweep'][3]['n_particles'] == 1200 and d['sweep'][3]['rows'] == 512 and d['sweep'][3]['n_look_ahead'] == 20
 
 
 @pytest.mark.parametrize('mode', ['weak', 'strong', 'elite'])
 def test_two_ranks_sharing_the_gpu(mode):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    """`bench.py --gpus 2` with NO launcher around it: the parent spawns the two ranks itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
     extra = {'weak': ['--samples', '256'], 'strong': ['--samples-total', '512'],
              'elite': ['--samples', '256', '--update', 'elite', '--elite', '16']}[mode]
-    d = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-              '--master-port', str(29700 + os.getpid() % 200), 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1',
+    d = _run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1',
               '--comm', 'gloo', '--share-gpu', '--no-alt'] + extra, env)
     assert d['n_gpus'] == 2 and d['cpu_baseline'] is None
     assert d['scaling'] == ('strong' if mode == 'strong' else 'weak')
     assert d['config']['n_sample_total'] == 512 and d['config']['n_sample_per_gpu'] == 256
+    assert d['config']['world_size'] == 2 and d['config']['gpus_requested'] == 2
     assert abs(d['value'] - 512 * 300 * 10 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
     assert 'gloo' in d['config']['communicator']
 
 
-def test_one_rank_through_rccl():
-    """--force-comm: init_process_group('nccl'), ncclCommInitRank and ncclAllGather with one rank."""
+def test_two_ranks_under_the_drivers_launcher():
+    """The way the driver starts N > 1: torch.distributed.run around bench.py (ranks from the environment)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    d = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
-              '--master-port', str(29900 + os.getpid() % 90), 'bench.py', '--force-comm', '--steps', '3', '--warmup', '1',
+    d = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+              '--master-port', str(29700 + os.getpid() % 200), 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1',
+              '--comm', 'gloo', '--share-gpu', '--no-alt', '--samples', '256'], env)
+    assert d['n_gpus'] == 2 and d['config']['n_sample_total'] == 512
+
+
+def test_a_rank_that_dies_ends_the_run_with_an_error():
+    """Rank 1 exits before the first timed update (--fault-rank): rank 0 would wait in the exchange; the parent ends
+    the group and exits non-zero, promptly and without a JSON line."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', DRP_COMM_TIMEOUT_S='20')
+    t0 = time.time()
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--comm', 'gloo', '--share-gpu',
+                        '--no-alt', '--samples', '128', '--fault-rank', '1', '--timeout', '200'], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    assert p.returncode == 7, (p.returncode, p.stderr.decode()[-1500:])
+    assert 'rank 1 exited with status 7' in p.stderr.decode()
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert time.time() - t0 < 200
+
+
+def test_one_rank_through_rccl():
+    """--force-comm with no launcher: ncclCommInitRank and ncclAllGather with one rank; the line names the RCCL that
+    served it, and the communicator's own count."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    d = _run([sys.executable, 'bench.py', '--gpus', '1', '--force-comm', '--steps', '3', '--warmup', '1',
               '--samples', '256', '--no-alt', '--no-cpu-baseline'], env)
-    assert d['n_gpus'] == 1 and 'rccl' in d['config']['communicator'] and d['value'] > 0
+    assert d['n_gpus'] == 1 and d['config']['communicator'] == 'rccl, 1 rank' and d['value'] > 0
+    rc = d['config']['rccl']
+    assert rc['comm_count'] == 1 and 'librccl' in rc['library'] and rc['version'][0].isdigit()
+    # one RCCL per process: the bench imports torch, so the copy torch ships is the one the engine bound
+    assert os.sep + 'torch' + os.sep in rc['library']

@@ -51,3 +51,71 @@ def test_call_order_and_shape_errors(golden):
 def test_create_on_a_missing_device():
     with pytest.raises(DrpError, match='device'):
         Engine(63)
+
+
+def test_nan_weights_are_refused_by_the_split_engines(golden):
+    """fmaxf drops NaN operands: a NaN in the relation encoder used to pass the range check as a finite bound
+    (ADVICE round 2).  The split engines refuse such weights; the fp32 engines compute (and return NaN, as torch would)."""
+    eng = Engine(0)
+    blob = weights.blob_from_state_dict(golden.weights_seed0).copy()
+    off = 0
+    for k, shape in weights.STATE_DICT_KEYS:
+        if k == 'model.relation_encoder.model.2.weight':
+            break
+        off += int(np.prod(shape))
+    blob[off + 17] = np.nan
+    eng.load_weights(blob, 0.08)
+    eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+    s0, dens, attr = syn.make_pile(40, 1, seed=0)
+    acts = syn.sample_pushes(4, 2, seed=0)
+    with pytest.raises(DrpError, match='outside the range'):
+        eng.rollout(s0, attr, dens, acts)
+    eng.set_engine(_lib.ENGINES['mfma'])
+    states, _ = eng.rollout(s0, attr, dens, acts)
+    assert np.isnan(states).any()
+    eng.close()
+
+
+def test_default_clip_box_is_inside_the_proven_envelope(golden):
+    """The longest push of the default clip box is 8.5 sqrt(2) / 24 = 0.50 camera-frame units: with the rotation's
+    spectral norm (1) it sits inside the envelope the range shift was proven for (|s_r - s_s| <= 1.5); a workspace
+    three times as wide does not, and is still accepted by the per-call bound with seed-0 weights."""
+    eng = Engine(0)
+    eng.load_weights(weights.blob_from_state_dict(golden.weights_seed0), 0.08)
+    eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+    eng.set_goal_image(syn.goal_distance_image(syn.goal_mask('I')), 200, 0, 'exact')
+    s0, dens, attr = syn.make_pile(40, 1, seed=0)
+    lo, hi = syn.action_limits()
+    nominal = syn.nominal_pushes(2, seed=0)
+    for scale in (1.0, 3.0):
+        eng.mpc_begin(s0, attr, dens, nominal, n_sample=8, sigma=0.6, beta_filter=0.7, reward_weight=0.1,
+                      act_lo=lo * scale, act_hi=hi * scale, seed=1)
+    eng.close()
+
+
+def test_a_wait_behind_a_dead_collective_returns_an_error(golden, monkeypatch):
+    """Hang guard: with a communicator attached the host waits poll with a deadline.  drp_debug_stall holds the stream
+    the way a collective waiting for a vanished peer would: drp_sync must come back with DRP_ECOMM after
+    DRP_COMM_TIMEOUT_S, the communicator aborted, and the context usable again."""
+    import time
+    monkeypatch.setenv('DRP_COMM_ALWAYS', '1')
+    monkeypatch.setenv('DRP_COMM_TIMEOUT_S', '1')
+    eng = Engine(0)
+    eng.load_weights(weights.blob_from_state_dict(golden.weights_seed0), 0.08)
+    eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+    s0, dens, attr = syn.make_pile(40, 1, seed=0)
+    acts = syn.sample_pushes(4, 2, seed=0)
+    ref, _ = eng.rollout(s0, attr, dens, acts)
+    eng.comm_init(eng.comm_unique_id(), 0, 1)
+    assert eng.comm_info()['n_ranks'] == 1
+    eng.sync()                                          # nothing pending: the guarded wait returns at once
+    eng.debug_stall(3000)
+    t0 = time.time()
+    with pytest.raises(DrpError, match='waited'):
+        eng.sync()
+    assert 0.9 < time.time() - t0 < 2.5
+    assert eng.comm_info()['n_ranks'] == 0              # aborted: the context is back to one rank
+    eng.sync()                                          # no communicator: a plain wait, ends with the stall
+    again, _ = eng.rollout(s0, attr, dens, acts)
+    np.testing.assert_array_equal(again, ref)
+    eng.close()

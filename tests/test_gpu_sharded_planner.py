@@ -34,16 +34,61 @@ def test_one_rank_rccl_communicator_equals_no_communicator(mpc_type, monkeypatch
         np.testing.assert_array_equal(got_t[k], ref[k], err_msg=k)
 
 
-@pytest.mark.parametrize('mpc_type', ['MPPI', 'CEM', 'GD'])
-def test_two_processes_sharing_the_gpu_equal_one(mpc_type, tmp_path):
-    import _shard_worker as w
-    ref = w.run_planner(mpc_type, None)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + os.getpid() % 2000), WORLD_SIZE='2')
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, '_shard_worker.py'), str(tmp_path), mpc_type],
+def test_a_spent_unique_id_and_a_second_engine_are_refused(monkeypatch):
+    """A ncclUniqueId serves one ncclCommInitRank: re-initialising with it would never return."""
+    from dyn_res_pile_manip_amd._lib import DrpError
+    from dyn_res_pile_manip_amd.engine import Engine
+    from dyn_res_pile_manip_amd.sharding import RcclComm
+    a, b = Engine(0), Engine(0)
+    uid = a.comm_unique_id()
+    comm = RcclComm(uid, 0, 1)
+    comm.attach(a)
+    comm.attach(a)                                      # the same engine again: nothing to do
+    assert a.comm_info()['n_ranks'] == 1 and a.comm_info()['path'].find('librccl') >= 0
+    with pytest.raises(RuntimeError, match='fresh'):
+        comm.attach(b)
+    with pytest.raises(DrpError, match='already been used'):
+        b.comm_init(uid, 0, 1)
+    a.comm_destroy()
+    assert a.comm_info()['n_ranks'] == 0
+    a.close()
+    b.close()
+
+
+def _two_ranks(tmp_path, mpc_type, transport):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + os.getpid() % 2000), WORLD_SIZE='2',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, '_shard_worker.py'), str(tmp_path), mpc_type, transport],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+
+
+@pytest.mark.parametrize('mpc_type', ['MPPI', 'CEM', 'GD'])
+def test_two_gpus_over_rccl_equal_one(mpc_type, tmp_path):
+    """The product transport with MORE than one rank: RcclComm on two GPUs (the packed [statistics | k elite] message,
+    rank_stride, the one-exchange merge of the run records).  Needs two devices; a one-GPU box skips it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    import _shard_worker as w
+    ref = w.run_planner(mpc_type, None)
+    _two_ranks(tmp_path, mpc_type, 'rccl')
+    res = [np.load(os.path.join(str(tmp_path), '%s_rank%d.npz' % (mpc_type, r))) for r in range(2)]
+    for r in res:
+        assert int(r['iter_num']) == int(ref['iter_num'])
+        np.testing.assert_allclose(r['action_sequence'], ref['action_sequence'], atol=0 if mpc_type == 'GD' else 1e-5)
+        np.testing.assert_allclose(r['reward'], ref['reward'], rtol=1e-5)
+        np.testing.assert_allclose(r['rew_mean'], ref['rew_mean'], rtol=1e-5)
+    np.testing.assert_array_equal(res[0]['action_sequence'], res[1]['action_sequence'])
+
+
+@pytest.mark.parametrize('mpc_type', ['MPPI', 'CEM', 'GD'])
+def test_two_processes_sharing_the_gpu_equal_one(mpc_type, tmp_path):
+    import _shard_worker as w
+    ref = w.run_planner(mpc_type, None)
+    _two_ranks(tmp_path, mpc_type, 'gloo')
     res = [np.load(os.path.join(str(tmp_path), '%s_rank%d.npz' % (mpc_type, r))) for r in range(2)]
     for r in res:
         assert int(r['iter_num']) == int(ref['iter_num'])

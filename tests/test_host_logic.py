@@ -1,0 +1,89 @@
+"""CPU: host-side logic that needs no GPU -- the list conversions of the `model.forward` / `particle_nums`
+compatibility paths (model/gnn_dyn.py:238-251), and bench.py's launcher: `--gpus N` without a launcher around it
+spawns its own N rank processes, relays one JSON line, and exits non-zero when a rank fails or the world size and
+the flag disagree (nothing of that may leave a process behind)."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _random_lists(rng, B, N):
+    idx = -np.ones((B, N, 10), np.int16)
+    cnt = np.zeros((B, N), np.uint8)
+    for b in range(B):
+        for i in range(N):
+            k = int(rng.integers(0, min(10, N) + 1))
+            idx[b, i, :k] = np.sort(rng.choice(N, k, replace=False))
+            cnt[b, i] = k
+    return idx, cnt
+
+
+def test_dense_relations_become_the_lists_they_were_built_from():
+    from dyn_res_pile_manip_amd.gnn_dyn import relations_to_lists
+    rng = np.random.default_rng(0)
+    B, N = 3, 13
+    idx, cnt = _random_lists(rng, B, N)
+    E = int(cnt.astype(np.int64).sum(1).max()) + 2            # zero rows pad short samples (model/gnn_dyn.py:248-251)
+    Rr = np.zeros((B, E, N), np.float32)
+    Rs = np.zeros((B, E, N), np.float32)
+    for b in range(B):
+        e = 0
+        for i in range(N):                                    # nonzero() order: receiver-major, sender ascending (:247)
+            for j in idx[b, i, :cnt[b, i]]:
+                Rr[b, e, i] = 1
+                Rs[b, e, j] = 1
+                e += 1
+    got_idx, got_cnt = relations_to_lists(Rr, Rs)
+    np.testing.assert_array_equal(got_idx, idx)
+    np.testing.assert_array_equal(got_cnt, cnt)
+
+
+def test_particle_nums_masking_matches_the_row_by_row_rule():
+    from dyn_res_pile_manip_amd.gnn_dyn import mask_lists
+    rng = np.random.default_rng(1)
+    B, N = 4, 17
+    idx, cnt = _random_lists(rng, B, N)
+    nums = np.array([17, 9, 1, 12])
+    got_idx, got_cnt = mask_lists(idx.copy(), nums)
+    for b in range(B):
+        n = int(nums[b])
+        for i in range(N):
+            js = [j for j in idx[b, i] if 0 <= j < n] if i < n else []     # rows and columns >= n leave the graph (:238-241)
+            assert got_cnt[b, i] == len(js)
+            np.testing.assert_array_equal(got_idx[b, i, :len(js)], js)
+            assert (got_idx[b, i, len(js):] == -1).all()
+
+
+def _bench(argv, env=None, timeout=300):
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return p.returncode, p.stdout.decode(), p.stderr.decode(), time.time() - t0
+
+
+def test_world_size_and_gpus_flag_must_agree():
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    rc, out, err, _ = _bench(['--gpus', '1', '--steps', '1', '--warmup', '0'], env)
+    assert rc == 4 and 'WORLD_SIZE=2' in err and not out.strip()
+
+
+def test_self_launch_relays_failure_and_leaves_nobody_behind():
+    """No GPU here: both ranks fail in drp_create (there is no CPU fallback), the parent must notice, end the
+    group and exit non-zero -- not hang in a rendezvous, not print a line."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip('the failure path needs a box without a GPU')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    rc, out, err, dt = _bench(['--gpus', '2', '--share-gpu', '--comm', 'gloo', '--steps', '1', '--warmup', '0',
+                               '--timeout', '120'], env, timeout=200)
+    assert rc not in (0, 124), (rc, err[-500:])
+    assert 'exited with status' in err
+    assert not [l for l in out.splitlines() if l.startswith('{')]
+    assert dt < 120
