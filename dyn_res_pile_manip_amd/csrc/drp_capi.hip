@@ -295,7 +295,13 @@ bool comm_live(const drp_ctx* c) { return c->comm != nullptr && (c->n_ranks > 1 
 
 void comm_abort(drp_ctx* c) {
     RcclApi* R = rccl_api();
-    if (c->comm && R) (void)R->CommAbort(c->comm);
+    // ncclCommAbort raises the communicator's abort flag (a collective's kernel spinning on a peer sees it and ends) and
+    // then waits for the device to drain: on a helper thread, so that the caller gets its error code NOW
+    if (c->comm && R) {
+        ncclComm_t comm = c->comm;
+        const int dev = c->device;
+        std::thread([R, comm, dev] { (void)hipSetDevice(dev); (void)R->CommAbort(comm); }).detach();
+    }
     c->comm = nullptr;
     c->n_ranks = 1;
     c->rank = 0;

@@ -56,17 +56,19 @@ def build_neighbours(s_cur, s_delta, adj_thresh=0.08):
     nbr_idx = -np.ones((B, N, K), dtype=np.int32)
     nbr_cnt = np.zeros((B, N), dtype=np.int32)
     k = min(K, N)
+    col = np.arange(N, dtype=np.uint64)[None, :]
     for b in range(B):
         d = p[b][None, :, :] - p[b][:, None, :]          # [recv i, send j, 3] = p_j - p_i
         sq = d * d
         dis = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
-        order = np.argsort(dis, axis=1, kind='stable')[:, :k]
-        for i in range(N):
-            js = order[i]
-            js = js[(dis[i, js] - thr) < 0]
-            js = np.sort(js)
-            nbr_idx[b, i, :len(js)] = js
-            nbr_cnt[b, i] = len(js)
+        # topk(k, smallest) with ties to the lower sender index (what a stable sort by distance gives): the k smallest
+        # of the keys (distance bits, sender) -- a non-negative fp32's bit pattern orders like its value
+        key = (dis.view(np.uint32).astype(np.uint64) << np.uint64(32)) | col
+        js = (np.partition(key, k - 1, axis=1)[:, :k] & np.uint64(0xffffffff)).astype(np.int64)
+        keep = (np.take_along_axis(dis, js, 1) - thr) < 0
+        js = np.sort(np.where(keep, js, N + 1), axis=1)   # ascending sender, the dropped ones last
+        nbr_idx[b, :, :k] = np.where(js < N, js, -1)
+        nbr_cnt[b] = keep.sum(1)
     return nbr_idx, nbr_cnt
 
 

@@ -180,7 +180,10 @@ def main():
     cases = [('n64', 4, 64, 'uniform', True), ('n50', 2, 50, 'uniform', False),
              ('n150', 2, 150, 'uniform', False), ('n300', 2, 300, 'uniform', False),
              ('n600', 1, 600, 'uniform', False), ('n8', 2, 8, 'blob', True),
-             ('blob150', 2, 150, 'blob', False)]
+             ('blob150', 2, 150, 'blob', False),
+             # BASELINE configs[4]'s pile: the two-dimensional cell build and the natural-order rows of the whole-sample
+             # kernel against the reference itself (dense Rr / Rs of 2 x 12 000 x 1 200 floats: 115 MB each)
+             ('n1200', 2, 1200, 'uniform', False)]
     for name, B, N, kind, keep_mid in cases:
         s, dens, attr = syn.make_pile(N, n_batch=B, seed=11, kind=kind)
         acts = syn.sample_pushes(B, 1, seed=5)[:, 0]
@@ -239,7 +242,8 @@ def main():
     ro = {}
     for name, nb, N, ns, H, seed in [('c1', 1, 64, 16, 5, 0), ('c1_nb2', 2, 64, 8, 5, 1),
                                      ('n150', 1, 150, 4, 10, 2), ('n300', 1, 300, 2, 10, 3),
-                                     ('n50', 1, 50, 4, 10, 4)]:
+                                     ('n50', 1, 50, 4, 10, 4), ('n600', 1, 600, 2, 5, 5),
+                                     ('n1200', 1, 1200, 2, 4, 6)]:
         planner.particle_num = N
         s, dens, attr = syn.make_pile(N, n_batch=nb, seed=seed)
         acts = syn.sample_pushes(ns * nb, H, seed=seed)

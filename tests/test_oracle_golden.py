@@ -7,7 +7,7 @@ from oracle import propnet_dense as od
 from oracle import propnet_sparse as osp
 from dyn_res_pile_manip_amd import synthetic as syn
 
-ONE_STEP = ['n64', 'n50', 'n150', 'n300', 'n600', 'n8', 'blob150']
+ONE_STEP = ['n64', 'n50', 'n150', 'n300', 'n600', 'n8', 'blob150', 'n1200']
 MID = ['n64', 'n8']
 
 
@@ -76,7 +76,7 @@ def test_world2cam_and_s_delta(golden):
     np.testing.assert_allclose(sd2, g['s_delta'], rtol=0, atol=2e-7)
 
 
-@pytest.mark.parametrize('case', ['c1', 'c1_nb2', 'n150', 'n300', 'n50'])
+@pytest.mark.parametrize('case', ['c1', 'c1_nb2', 'n150', 'n300', 'n50', 'n600', 'n1200'])
 def test_rollout(golden, W, case):
     g = golden.rollout
     ext = syn.demo_cam_extrinsics()
