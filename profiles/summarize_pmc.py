@@ -8,7 +8,7 @@ read, WRITE_SIZE is exact for 16-B-per-lane stores.  Calibrated on this code's o
 pattern: km_update reads three [B*N,64] fp32 buffers with float4 loads = 230 400 KiB per
 launch at 1024 x 300 and FETCH_SIZE reports 115 461 KiB (x0.501).
 
-usage: summarize_pmc.py <engine> <fetch_counter_collection.csv> <write_counter_collection.csv>
+usage: summarize_pmc.py <engine | gd-demo> <fetch_counter_collection.csv> <write_counter_collection.csv>
 """
 import collections
 import csv
@@ -20,7 +20,8 @@ CLASS = {'k_graph': 'graph', 'k_graph_strips': 'graph', 'k_graph_sort': 'graph_s
          'k_project': 'project', 'k_aggregate': 'aggregate', 'k_aggregate_lds': 'aggregate', 'k_update': 'update',
          'k_predict': 'predict', 'km_node_encode': 'node_encode', 'km_node_encode_split': 'node_encode', 'km_edge_encode': 'edge_encode',
          'km_update<false>': 'update', 'km_update<true>': 'predict', 'k_reward': 'reward',
-         'km_prop<false>': 'prop', 'km_prop<true>': 'prop_last', 'km_prop3': 'prop3'}
+         'km_prop<false>': 'prop', 'km_prop<true>': 'prop_last', 'km_prop3': 'prop3',
+         'kmb_step_bwd': 'step_bwd', 'kb_reward': 'bwd_reward', 'kb_reverse_lists': 'bwd_lists', 'kb_sdelta': 'bwd_push'}
 
 
 def norm(name):
@@ -46,6 +47,8 @@ def per_kernel(path, counter):
 
 def main():
     engine, fpath, wpath = sys.argv[1:4]
+    if engine == 'gd-demo':
+        CLASS['km_prop3'] = 'prop3_tape'      # the tape-writing instantiation km_prop3<true> of the GD planner's forward
     fetch, nf = per_kernel(fpath, 'FETCH_SIZE')
     write, _ = per_kernel(wpath, 'WRITE_SIZE')
     out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'traffic.json')
