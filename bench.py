@@ -307,18 +307,20 @@ def prop_roofline(tiles, slots_per_tile, kbar, self_const, B, N, avg_s, launches
     psteps = max(1, int(round(float(prop_steps_total) / max(launches, 1))))
     mfmas = psteps * tiles * (slots_per_tile * 78 + (2 * 144 + 96) / 3.0)
     alg = psteps * B * N * (kbar * FLOP_PER_EDGE_ENCODE + 2 * 64 * 64 * (1 + 2 * 2 / 3.0 + 1 / 3.0))
-    # the particle encoder runs as the first phase of km_prop3 when no launch of its own was counted:
-    # 12 + 4 x 48 bf16 MFMAs per tile (first layer + four 64x64 products on the 6-term split)
-    encoder_inside = psteps == 3 and encoder_launches == 0
+    # the particle encoder runs as the first phase of km_prop3 (3 propagation steps per launch) or of every rollout step
+    # of km_rollout (3 H per launch: small piles, the whole rollout -- neighbour lists included -- in one launch) when
+    # no launch of its own was counted: 12 + 4 x 48 bf16 MFMAs per tile (first layer + four 64x64 products, 6-term split)
+    encoder_inside = psteps % 3 == 0 and encoder_launches == 0
     if encoder_inside:
-        mfmas += tiles * 204
-        alg += B * N * FLOP_PER_NODE['node_encode'] + B * N * 2 * 2 * 64 * 64
+        mfmas += (psteps // 3) * tiles * 204
+        alg += (psteps // 3) * (B * N * FLOP_PER_NODE['node_encode'] + B * N * 2 * 2 * 64 * 64)
     work = mfmas * 32768.0
     return {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
             'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile,
             'tiles_per_step': tiles, 'mean_in_degree_minus_self': kbar - (1.0 if self_const else 0.0),
-            'propagation_steps_per_launch': psteps, 'particle_encoder_in_launch': bool(encoder_inside)}, work
+            'propagation_steps_per_launch': psteps, 'particle_encoder_in_launch': bool(encoder_inside),
+            'graph_build_in_launch': bool(psteps > 3)}, work
 
 
 class Rig(object):
@@ -703,7 +705,7 @@ def run_rank(args):
             # HBM-side bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
             # profiles/summarize_pmc.py), collected on this same workload
             roof['traffic'], roof['traffic_source'] = None, None
-            tkey = 'prop3' if (m['dominant'] == 'prop' and roof.get('propagation_steps_per_launch') == 3) else m['dominant']
+            tkey = 'prop3' if (m['dominant'] == 'prop' and roof.get('propagation_steps_per_launch', 0) >= 3) else m['dominant']
             tb = tj.get(engine, {}).get(tkey, {}).get('hbm_bytes_per_launch')
             if tb:
                 roof['traffic'], roof['traffic_source'] = tb, TRAFFIC_SOURCE

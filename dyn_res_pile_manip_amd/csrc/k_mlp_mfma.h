@@ -224,11 +224,13 @@ __device__ __forceinline__ void mfma_layer8(const float4* __restrict__ wp, const
 // packed weights at the same moment; each starts at a different chunk (blockIdx.x / 8 = its rank within the
 // XCD under round-robin placement) so that the 32 CUs of an XCD do not queue on the same L2 channel, and keeps
 // eight 16-B loads in flight per thread.
-__device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ src, int n) {
+// `tid` = threadIdx.x (km_rollout hands in an opaque copy per rollout step, so that the per-thread addresses derived from it
+// are recomputed there instead of being kept -- spilled -- across the whole step loop).
+__device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ src, int n, int tid) {
     const int step = blockDim.x * 4;
     const int nfull = n / step;                      // whole chunks: no bounds test on their loads
     const int c0 = (int)(((blockIdx.x >> 3) & 31u) * (unsigned)nfull / 32u);
-    const int off = threadIdx.x * 4;
+    const int off = tid * 4;
     int u = 0;
     for (; u + 8 <= nfull; u += 8) {
         float4 t[8];
@@ -252,6 +254,7 @@ __device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ s
     const int i = nfull * step + off;                // the partial last chunk
     if (i < n) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
 }
+__device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ src, int n) { lds_fill(dst, src, n, (int)threadIdx.x); }
 
 // quotient and remainder of small non-negative integers through the fp32 reciprocal, corrected to be exact
 __device__ __forceinline__ void divmod_small(int x, int n, float inv_n, int& q, int& r) {

@@ -954,43 +954,85 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
 // shortcut needs every lane of a tile to qualify, which the order does not disturb for uniform batches.
 // Lists too long for the LDS left over (PROP3_PERM_MAX rows) keep the natural order.
 #define PROP3_PERM_MAX 4900
-template <bool TAPE>
-__global__ void __launch_bounds__(64 * PROP_WAVES)
-km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
-         const float* __restrict__ s_cur, int s_mod, size_t s_stride,
-         const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
-         const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
-         float* __restrict__ proj_a, float* __restrict__ proj_b, float* __restrict__ c_node,
-         float* __restrict__ eff /* !TAPE: in place; TAPE: effect history [4][B*N,64] */, int N, int B, int spw,
-         const float* __restrict__ s_delta /* not null: the particle encoder runs here first (phase E) */,
-         float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself, const uint8_t* __restrict__ cself_ok,
-         unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */,
-         float re_scale, float re_inv, int order_rows) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-#ifdef PROP_STAMPS
-    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
+#ifdef ROLLOUT_STAMPS
+// Diagnostic build only (tools/rollout_stamps.py): 100 MHz wall stamps between the phases of a rollout step, summed by
+// wave 0 of every 32nd workgroup; nothing the kernels compute reads them.
+__device__ unsigned long long g_roll_stamps[16];
+#define ROLL_STAMP(q) do { if (roll_on) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+                                          atomicAdd(&g_roll_stamps[q], now_ - roll_t); roll_t = now_; } } while (0)
+#else
+#define ROLL_STAMP(q) do { } while (0)
 #endif
-    float* wsp_f = lds;
-    float* w6_f = wsp_f + S_TOTAL * 4;               // AGG | RPR | RPS | PR0
-    float* rows = w6_f + 4 * 1536 * 4;               // 2^k b2, 2^k b4, b_rp, wd_rp | b_pr0, w_pr1[3], b_pr1
-    float* pe0_f = rows + 520;                       // phase E: first layer of the particle encoder, then b_pe2, b_pp, wd_pp;
-    float* rows_e = pe0_f + 384 * 4;                 // afterwards: the row order (perm, hist)
+// LDS map of the whole-sample kernels (km_prop3, km_rollout), in floats from the start of dynamic LDS
+struct Prop3Lds {
+    float* wsp_f;      // edge chain (S_TOTAL units); phase E borrows it for the particle encoder's two 64x64 layers
+    float* w6_f;       // AGG | RPR | RPS | PR0
+    float* rows;       // 2^k b2, 2^k b4, b_rp, wd_rp | b_pr0, w_pr1[3], b_pr1 | tile counter at +516
+    float* pe0_f;      // phase E: first layer of the particle encoder, then b_pe2, b_pp, wd_pp; afterwards the row order
+    float* rows_e;
+    int* tile_ctr;
+};
+__device__ __forceinline__ Prop3Lds prop3_lds(float* lds) {
+    Prop3Lds P;
+    P.wsp_f = lds;
+    P.w6_f = P.wsp_f + S_TOTAL * 4;
+    P.rows = P.w6_f + 4 * 1536 * 4;
+    P.pe0_f = P.rows + 520;
+    P.rows_e = P.pe0_f + 384 * 4;
+    P.tile_ctr = reinterpret_cast<int*>(P.rows + 516);
+    return P;
+}
+// the matrices and rows that stay put for a whole launch (S6_AGG, RPR, RPS, PR0 are consecutive in the packed blob)
+__device__ __forceinline__ void prop3_fill_resident(const Prop3Lds& P, const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6,
+                                                    const float* __restrict__ mw) {
+    lds_fill(P.w6_f, reinterpret_cast<const float*>(sw6) + S6_AGG * 4, 4 * 1536 * 4);
+    lds_fill(P.rows, reinterpret_cast<const float*>(sw) + S_ROWS * 4, 256);
+    lds_fill(P.rows + 256, mw + R_PR0_B, 260);
+}
+
+// One rollout step's MLP work for the workgroup's samples [b0, b0 + nb): [phase E: particle encoder] -> row order ->
+// three propagation steps, the last one writing s_out.  On entry the resident part of LDS is filled (or being filled:
+// `entry_sync` = the caller has not synchronised since) and the edge-chain region holds nothing this function relies
+// on; on exit every wave has passed its last tile (no barrier after it).
+template <bool TAPE>
+__device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6,
+                                           const float* __restrict__ mw,
+                                           const float* __restrict__ s_cur, int s_mod, size_t s_stride,
+                                           const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+                                           const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
+                                           float* __restrict__ proj_a, float* __restrict__ proj_b, float* __restrict__ c_node,
+                                           float* __restrict__ eff, int N, int B, int spw, const float* __restrict__ s_delta,
+                                           float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself,
+                                           const uint8_t* __restrict__ cself_ok, unsigned* __restrict__ mask_hist,
+                                           float* __restrict__ agg_hist, float re_scale, float re_inv, int order_rows, int tid /* tid */
+#ifdef PROP_STAMPS
+                                           , unsigned long long (&st_sum)[8]
+#endif
+) {
+    float* wsp_f = P.wsp_f;
+    float* w6_f = P.w6_f;
+    float* rows = P.rows;
+    float* pe0_f = P.pe0_f;
+    float* rows_e = P.rows_e;
+    int* tile_ctr = P.tile_ctr;
+#ifdef ROLLOUT_STAMPS
+    const bool roll_on = tid == 0 && (blockIdx.x & 31) == 0;
+    unsigned long long roll_t = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long roll_c0 = __builtin_amdgcn_s_memtime(), roll_r0 = roll_t;
+#endif
     const bool phase_e = s_delta != nullptr;
     if (phase_e) {
         // the particle encoder's two 64x64 layers borrow the edge chain's region; W_r and W_s are resident anyway
-        lds_fill(wsp_f, reinterpret_cast<const float*>(sw6) + S6_PE2 * 4, 2 * 1536 * 4);
-        lds_fill(pe0_f, reinterpret_cast<const float*>(sw6) + S6_PE0 * 4, 384 * 4);
-        lds_fill(rows_e, mw + R_PE2_B, 192);
+        lds_fill(wsp_f, reinterpret_cast<const float*>(sw6) + S6_PE2 * 4, 2 * 1536 * 4, tid);
+        lds_fill(pe0_f, reinterpret_cast<const float*>(sw6) + S6_PE0 * 4, 384 * 4, tid);
+        lds_fill(rows_e, mw + R_PE2_B, 192, tid);
     } else {
-        lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
+        lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4, tid);
     }
-    lds_fill(w6_f, reinterpret_cast<const float*>(sw6) + S6_AGG * 4, 4 * 1536 * 4);   // S6_AGG, RPR, RPS, PR0 are consecutive
-    lds_fill(rows, reinterpret_cast<const float*>(sw) + S_ROWS * 4, 256);
-    lds_fill(rows + 256, mw + R_PR0_B, 260);
-    int* tile_ctr = reinterpret_cast<int*>(rows + 516);
-    if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
+    if (tid == 0) *tile_ctr = PROP_WAVES;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ROLL_STAMP(3);                                   // encoder weights in LDS
+    const int lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * spw, nb = min(spw, B - b0);
     const int wg_rows = (nb > 0 ? nb : 0) * N;       // this workgroup's receivers: rows b0*N .. b0*N + wg_rows
     const int wg_tiles = (wg_rows + 31) >> 5;
@@ -1038,9 +1080,11 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
             if (lane == 0) qn = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             li = __builtin_amdgcn_readfirstlane(qn);
         }
+        ROLL_STAMP(4);                                   // wave 0's encoder tiles
         __syncthreads();                                 // the encoder's rows of this workgroup's samples are written
-        lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4);
-        if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
+        ROLL_STAMP(5);                                   // waiting for the other waves' encoder tiles
+        lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4, tid);
+        if (tid == 0) *tile_ctr = PROP_WAVES;
     }
     // ---- row order: in-degree descending, row ascending within a degree (deterministic; the encoder's LDS is free now)
     uint16_t* perm = reinterpret_cast<uint16_t*>(pe0_f);
@@ -1100,6 +1144,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
         }
     }
     __syncthreads();
+    ROLL_STAMP(6);                                   // edge-chain weights back in LDS, rows ordered
     // Waves w and w + 4 of a workgroup share a SIMD (tools/hwid.hip).  With no more tiles than waves every wave runs one
     // tile per step, and in the in-degree order tile t is heavier than tile t + 1: waves 4 ... 7 take the tiles from the
     // light end, so that a SIMD gets a heavy and a light one (4 x 50 particles, 7 tiles: 0 + 6, 1 + 5, 2 + 4, 3 instead
@@ -1128,10 +1173,6 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
         lr.b = b0 + m;
         return lr;
     };
-#ifdef PROP_STAMPS
-    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
-#endif
     const size_t bn64 = (size_t)B * N * 64;
     PropArgs A = {mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, c_node, eff, eff,
                   N, B, proj_b, s_out, out_stride, cself, cself_ok, nullptr, nullptr, re_scale, re_inv};
@@ -1141,7 +1182,8 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     for (int p = 0; p < DRP_PSTEP; ++p) {
         if (p > 0) {
             __syncthreads();                         // step p-1's rows of this workgroup's samples are written
-            if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
+            ROLL_STAMP(8);                           // waiting for the other waves at a propagation step's end
+            if (tid == 0) *tile_ctr = PROP_WAVES;
             __syncthreads();
         }
         A.proj = (p & 1) ? proj_b : proj_a;
@@ -1158,14 +1200,47 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
             L.w_x = reinterpret_cast<const bf16x8*>(w6_f) + 3 * 1536;
             prop_tiles<true, TAPE>(A, L, decode, row_of, lane, wave PROP_STAMPS_ARG);
         }
+        ROLL_STAMP(7);                               // wave 0's tiles of a propagation step
     }
+#ifdef ROLLOUT_STAMPS
+    if (roll_on) {                                   // shader clock over wall clock for the whole step
+        atomicAdd(&g_roll_stamps[9], __builtin_amdgcn_s_memtime() - roll_c0);
+        atomicAdd(&g_roll_stamps[10], __builtin_amdgcn_s_memrealtime() - roll_r0);
+    }
+#endif
+}
+
+template <bool TAPE>
+__global__ void __launch_bounds__(64 * PROP_WAVES)
+km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
+         const float* __restrict__ s_cur, int s_mod, size_t s_stride,
+         const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+         const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
+         float* __restrict__ proj_a, float* __restrict__ proj_b, float* __restrict__ c_node,
+         float* __restrict__ eff /* !TAPE: in place; TAPE: effect history [4][B*N,64] */, int N, int B, int spw,
+         const float* __restrict__ s_delta /* not null: the particle encoder runs here first (phase E) */,
+         float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself, const uint8_t* __restrict__ cself_ok,
+         unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */,
+         float re_scale, float re_inv, int order_rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef PROP_STAMPS
-    st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
-    st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // the three steps of this wave, barrier waits included
-    if (lane == 0 && blockIdx.x * PROP_WAVES + wave < 4096) {
-        g_prop_span[(blockIdx.x * PROP_WAVES + wave) * 2 + 0] = st_w0;
-        g_prop_span[(blockIdx.x * PROP_WAVES + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
-        for (int q = 0; q < 8; ++q) g_prop_stamps[(blockIdx.x * PROP_WAVES + wave) * 8 + q] += st_sum[q];
+    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const Prop3Lds P = prop3_lds(lds);
+    prop3_fill_resident(P, sw, sw6, mw);
+    prop3_step<TAPE>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
+                     eff, N, B, spw, s_delta, s_out, out_stride, cself, cself_ok, mask_hist, agg_hist, re_scale, re_inv, order_rows,
+                     (int)threadIdx.x PROP_STAMPS_ARG);
+#ifdef PROP_STAMPS
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        st_sum[7] = __builtin_amdgcn_s_memtime() - st_k0;        // the whole launch of this wave, fills and barrier waits included
+        if (lane == 0 && blockIdx.x * PROP_WAVES + wave < 4096) {
+            g_prop_span[(blockIdx.x * PROP_WAVES + wave) * 2 + 0] = st_w0;
+            g_prop_span[(blockIdx.x * PROP_WAVES + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+            for (int q = 0; q < 8; ++q) g_prop_stamps[(blockIdx.x * PROP_WAVES + wave) * 8 + q] += st_sum[q];
+        }
     }
 #endif
 }

@@ -146,10 +146,14 @@ def test_mpc_iteration_is_reproducible_and_improves(ctx):
                                   (100, 40),      # a batch far smaller than the chip: one sample per workgroup
                                   (5, 300)])      # less than one tile per sample
 def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch, N, ns):
-    """km_prop3 (a workgroup owns whole samples, the three propagation steps in one launch; chosen for
-    chip-filling batches and for every batch of small samples) against one km_prop launch per step
-    (DRP_NO_PROP3=1): same tiles, same arithmetic in the same order -> the same bits.  The second pass has
-    per-particle attributes (the self loop then runs the encoder chain like any other edge)."""
+    """Three ways to run the same rollout on the fused engine, all the same bits:
+      'rollout'  km_rollout: the WHOLE rollout in one launch (small piles: a workgroup owns its samples from the first
+                 step to the last, builds their neighbour lists itself and keeps the node matrices in LDS);
+      'prop3'    one graph launch + one km_prop3 launch per rollout step (DRP_NO_ROLLOUT_FUSED=1): a workgroup owns
+                 whole samples, the three propagation steps in one launch;
+      'steps'    one km_prop launch per propagation step (DRP_NO_PROP3=1).
+    Same tiles, same arithmetic in the same order.  The second pass has per-particle attributes (the self loop then
+    runs the encoder chain like any other edge).  Neighbour lists of the last step included."""
     from dyn_res_pile_manip_amd.engine import Engine
     H = 3
     s0, dens, attr = syn.make_pile(N, 1, seed=3)
@@ -157,21 +161,61 @@ def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch, N, ns)
     blob = weights.blob_from_state_dict(weights.random_state_dict(seed=0))
     M34 = world2cam_affine(syn.demo_cam_extrinsics())
     res = {}
-    for per_step in (False, True):
-        if per_step:
+    for mode in ('rollout', 'prop3', 'steps'):
+        monkeypatch.delenv('DRP_NO_PROP3', raising=False)
+        monkeypatch.delenv('DRP_NO_ROLLOUT_FUSED', raising=False)
+        if mode == 'steps':
             monkeypatch.setenv('DRP_NO_PROP3', '1')
-        else:
-            monkeypatch.delenv('DRP_NO_PROP3', raising=False)
+        elif mode == 'prop3':
+            monkeypatch.setenv('DRP_NO_ROLLOUT_FUSED', '1')
         eng = Engine(0)
         eng.load_weights(blob, 0.08)
         eng.set_camera(M34, 24.0, syn.demo_cam_params())
         for tag, at in (('uniform', attr), ('mixed', (np.arange(N, dtype=np.float32)[None] % 3) * 0.5)):
-            res[per_step, tag], _ = eng.rollout(s0, at.astype(np.float32), dens, acts)
+            res[mode, tag], _ = eng.rollout(s0, at.astype(np.float32), dens, acts)
+            res[mode, tag, 'idx'] = eng.debug_fetch('nbr_idx', (ns, N, 10), np.int16)
+            res[mode, tag, 'cnt'] = eng.debug_fetch('nbr_cnt', (ns, N), np.uint8)
         eng.close()
     for tag in ('uniform', 'mixed'):
-        assert np.isfinite(res[False, tag]).all()
-        assert np.array_equal(res[False, tag], res[True, tag]), tag
-    assert not np.array_equal(res[False, 'uniform'], res[False, 'mixed'])
+        assert np.isfinite(res['rollout', tag]).all()
+        for mode in ('prop3', 'steps'):
+            assert np.array_equal(res['rollout', tag], res[mode, tag]), (mode, tag)
+            assert np.array_equal(res['rollout', tag, 'idx'], res[mode, tag, 'idx']), (mode, tag)
+            assert np.array_equal(res['rollout', tag, 'cnt'], res[mode, tag, 'cnt']), (mode, tag)
+    assert not np.array_equal(res['rollout', 'uniform'], res['rollout', 'mixed'])
+
+
+@pytest.mark.parametrize('N,ns,H,nb', [(50, 1024, 10, 1), (20, 1024, 10, 1), (150, 600, 4, 1), (256, 1024, 2, 1),
+                                       (100, 300, 3, 30), (64, 16, 5, 2)])
+def test_whole_rollout_in_one_launch_equals_the_step_by_step_pipeline(monkeypatch, N, ns, H, nb):
+    """km_rollout at the reference's own sizes (the planner re-samples the pile at 10 - 100 particles) and beyond its
+    default limit of 80 particles (DRP_ROLLOUT_MAX_N lifts it: the kernel takes any workgroup of up to 3072 rows), with
+    several batch columns (row = sample * n_batch + column) and with rewards."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    s0, dens, attr = syn.make_pile(N, nb, seed=N)
+    acts = syn.sample_pushes(ns, H, seed=N + 1)
+    blob = weights.blob_from_state_dict(weights.random_state_dict(seed=0))
+    M34 = world2cam_affine(syn.demo_cam_extrinsics())
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setenv('DRP_ROLLOUT_MAX_N', '256')
+        if fused:
+            monkeypatch.delenv('DRP_NO_ROLLOUT_FUSED', raising=False)
+        else:
+            monkeypatch.setenv('DRP_NO_ROLLOUT_FUSED', '1')
+        eng = Engine(0)
+        eng.load_weights(blob, 0.08)
+        eng.set_camera(M34, 24.0, syn.demo_cam_params())
+        eng.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+        eng.probe_begin('prop')
+        res[fused] = eng.rollout(s0, attr, dens, acts, want_states=True, want_reward=True)
+        _, launches = eng.probe_read()
+        assert launches == (1 if fused else H)          # the path under test really is the one that ran
+        eng.close()
+    assert np.isfinite(res[True][0]).all()
+    assert np.array_equal(res[True][0], res[False][0])
+    assert np.array_equal(res[True][1], res[False][1])
 
 
 def test_config3_eight_logical_shards_equal_one_batch(ctx):
