@@ -229,6 +229,12 @@ struct drp_ctx {
     // goal pre-processing (row f3)
     DevBuf gl_goal, gl_seg, gl_tmp, gl_dist, gl_blk, gl_pix, gl_fps;
 
+    // re-packing after an optimiser step on the device (k_train.h): gather maps of the plain packers, pinned copy of the blob
+    DevBuf map_valu, map_mfma, map_mfma_bwd;
+    bool repack_maps_ready = false;
+    float* w_pin = nullptr;
+    bool repack_device = true;      // DRP_NO_REPACK_DEVICE=1: fetch the blob and run the host packers (the round-2 path)
+
     // km_rollout's argument block (device copy + what it holds)
     DevBuf roll_args;
     RolloutArgs roll_args_host{};
@@ -896,6 +902,21 @@ int range_check(drp_ctx* c, float max_attr, float max_dens, float max_sdelta) {
                 A, (double)max_dens, (double)max_sdelta, bound, r.shift);
 }
 
+// range shift of the split relation encoder: proven for |attr| <= 2 (the reference's are 0), |s_r - s_s| <= 1.5
+// per coordinate (radius 0.08 + two impulses; the default clip box's longest push is 8.5 sqrt(2) / 24 = 0.50
+// camera-frame units, the whole workspace diagonal 0.59: 0.08 + 2 x 0.59 = 1.26), density <= 10 000 (training
+// range: 15 .. 6 500); calls beyond are re-checked one by one (range_check)
+void set_split_range(drp_ctx* c, const float* blob) {
+    split_range_init(blob, c->re_range, 2.0, 1.5, 2.0);
+    if (c->re_shift_env != 0x7fffffff) c->re_range.shift = c->re_shift_env;
+    // weights no shift can carry (a matrix entry beyond fp16, NaN): the split engines refuse every call
+    // (range_check); the fp32 engines are unaffected
+    c->re_ok = c->re_range.finite && c->re_range.wmax < 6.0e4f &&
+               ldexp(split_range_bound(c->re_range, 2.0, 1.5, 2.0), c->re_range.shift) <= 65504.0;
+    c->re_scale = ldexpf(1.0f, c->re_range.shift);
+    c->re_inv = ldexpf(1.0f, -c->re_range.shift);
+}
+
 int check_bn(drp_ctx* c, int B, int N) {
     if (B <= 0 || N <= 0 || N > 4096) return fail(c, DRP_EINVAL, "bad shape B=%d N=%d (N <= 4096)", B, N);
     return DRP_OK;
@@ -938,6 +959,7 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_GRAPH_CELLS_HALO")) c->graph_cells_halo = (float)atof(e);
     c->prop3e = getenv("DRP_NO_PROP3E") == nullptr;
     c->rollout_fused = getenv("DRP_NO_ROLLOUT_FUSED") == nullptr;
+    c->repack_device = getenv("DRP_NO_REPACK_DEVICE") == nullptr;
     if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) c->rollout_max_n = atoi(e);
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
@@ -1002,7 +1024,7 @@ void drp_destroy(drp_ctx* c) {
                       &c->gl_goal, &c->gl_seg, &c->gl_tmp, &c->gl_dist, &c->gl_blk, &c->gl_pix, &c->gl_fps,
                       &c->tr_part, &c->tr_states, &c->tr_sdelta, &c->tr_nums, &c->tr_grad, &c->tr_m, &c->tr_v, &c->tr_loss, &c->agg_hist,
                       &c->tr_hact, &c->tr_gh, &c->tr_gpe, &c->tr_a1n, &c->tr_gh1, &c->tr_xn, &c->ed_re, &c->ed_a2, &c->ed_a1,
-                      &c->ed_x0, &c->ed_gce, &c->ed_g3, &c->ed_g2, &c->ed_g1, &c->roll_args};
+                      &c->ed_x0, &c->ed_gce, &c->ed_g3, &c->ed_g2, &c->ed_g1, &c->roll_args, &c->map_valu, &c->map_mfma, &c->map_mfma_bwd};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : c->probe_ev) (void)hipEventDestroy(ev);
@@ -1012,6 +1034,7 @@ void drp_destroy(drp_ctx* c) {
         if (c->mpc_pin[q]) (void)hipHostFree(c->mpc_pin[q]);
         if (c->mpc_ev[q]) (void)hipEventDestroy(c->mpc_ev[q]);
     }
+    if (c->w_pin) (void)hipHostFree(c->w_pin);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1060,18 +1083,7 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
         pack_mfma_bwd(blob, mbv);
         CHK(h2d(c, c->w_mfma_bwd, mbv.data(), mbv.size() * sizeof(float)));
         CHK(guarded_wait(c, nullptr));     // mbv is about to go out of scope... kept alive until here
-        // range shift of the split relation encoder: proven for |attr| <= 2 (the reference's are 0), |s_r - s_s| <= 1.5
-        // per coordinate (radius 0.08 + two impulses; the default clip box's longest push is 8.5 sqrt(2) / 24 = 0.50
-        // camera-frame units, the whole workspace diagonal 0.59: 0.08 + 2 x 0.59 = 1.26), density <= 10 000 (training
-        // range: 15 .. 6 500); calls beyond are re-checked one by one (range_check)
-        split_range_init(blob, c->re_range, 2.0, 1.5, 2.0);
-        if (c->re_shift_env != 0x7fffffff) c->re_range.shift = c->re_shift_env;
-        // weights no shift can carry (a matrix entry beyond fp16, NaN): the split engines refuse every call
-        // (range_check); the fp32 engines are unaffected
-        c->re_ok = c->re_range.finite && c->re_range.wmax < 6.0e4f &&
-                   ldexp(split_range_bound(c->re_range, 2.0, 1.5, 2.0), c->re_range.shift) <= 65504.0;
-        c->re_scale = ldexpf(1.0f, c->re_range.shift);
-        c->re_inv = ldexpf(1.0f, -c->re_range.shift);
+        set_split_range(c, blob);
         std::vector<uint16_t> sp;
         pack_split(blob, sp, c->re_range.shift);
         CHK(h2d(c, c->w_split, sp.data(), sp.size() * sizeof(uint16_t)));
@@ -2321,7 +2333,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             launch_wgrad<64>(c, ptr<float>(c->tr_gh), 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
                              nullptr, 1, 1);
             launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
-            hipLaunchKernelGGL(kt_colsum3, dim3(16), dim3(256), 0, st, g_out, (long)bn, G + W_PR1_B);
+            hipLaunchKernelGGL(kt_colsum3, dim3(1), dim3(1024), 0, st, g_out, (long)bn, G + W_PR1_B);
             // update of the last propagation step; then per step the edge terms and, in one launch, the
             // projection of this step with the update of the one before (k_backward_mfma.h)
             hipLaunchKernelGGL((kmb_node_step<false, true>), ngrid, nblk, KMB_STEP_LDS(false, true), st, mb, ptr<float>(c->g_eff),
@@ -2369,7 +2381,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             launch_wgrad<64>(c, ptr<float>(c->tr_gh), 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
                              nullptr, 1, 1);
             launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
-            hipLaunchKernelGGL(kt_colsum3, dim3(16), dim3(256), 0, st, g_out, (long)bn, G + W_PR1_B);
+            hipLaunchKernelGGL(kt_colsum3, dim3(1), dim3(1024), 0, st, g_out, (long)bn, G + W_PR1_B);
             for (int p = DRP_PSTEP - 1; p >= 0; --p) {
                 float* g_agg_p = gah + (size_t)p * bn64;
                 const unsigned* mask_p = mht + (size_t)p * bnk * 2;
@@ -2420,6 +2432,52 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         flush_wgrad(c);                                  // the next rollout step rewrites the dumps these jobs read
     }
     flush_wgrad(c);
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+// The packed copies of the weights follow an optimiser step without a round trip of the packers through the host
+// (k_train.h): only the blob itself comes back -- the split relation encoder's range shift is a function of the
+// weights (set_split_range), and drp_get_weights serves the host copy.
+int ensure_repack_maps(drp_ctx* c) {
+    if (c->repack_maps_ready) return DRP_OK;
+    std::vector<float> probe((size_t)W_TOTAL);
+    for (int i = 0; i < (int)W_TOTAL; ++i) probe[i] = (float)(i + 1);          // exact in fp32 (38 403 < 2^24)
+    auto to_map = [](const std::vector<float>& packed) {
+        std::vector<int> m(packed.size());
+        for (size_t i = 0; i < packed.size(); ++i)
+            m[i] = packed[i] == 0.0f ? 0 : (packed[i] < 0.0f ? -1 : (int)packed[i]);
+        return m;
+    };
+    std::vector<float> v, m, mb;
+    pack_valu(probe.data(), v);
+    pack_mfma(probe.data(), m);
+    pack_mfma_bwd(probe.data(), mb);
+    const std::vector<int> mv = to_map(v), mm = to_map(m), mmb = to_map(mb);
+    CHK(h2d(c, c->map_valu, mv.data(), mv.size() * sizeof(int)));
+    CHK(h2d(c, c->map_mfma, mm.data(), mm.size() * sizeof(int)));
+    CHK(h2d(c, c->map_mfma_bwd, mmb.data(), mmb.size() * sizeof(int)));
+    CHK(guarded_wait(c, nullptr));                   // the vectors go out of scope
+    if (!c->w_pin) HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->w_pin), (size_t)W_TOTAL * sizeof(float), hipHostMallocDefault));
+    c->repack_maps_ready = true;
+    return DRP_OK;
+}
+
+int repack_on_device(drp_ctx* c) {
+    CHK(ensure_repack_maps(c));
+    hipStream_t st = c->stream;
+    const float* w = ptr<float>(c->w_raw);
+    hipLaunchKernelGGL(kt_repack_gather, dim3((V_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_valu), ptr<float>(c->w_valu), (int)V_TOTAL);
+    hipLaunchKernelGGL(kt_repack_gather, dim3((M_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_mfma), ptr<float>(c->w_mfma), (int)M_TOTAL);
+    hipLaunchKernelGGL(kt_repack_gather, dim3((MB_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_mfma_bwd), ptr<float>(c->w_mfma_bwd), (int)MB_TOTAL);
+    hipLaunchKernelGGL(kt_repack_split6, dim3(7 * 16), dim3(256), 0, st, w, ptr<uint16_t>(c->w_split6));
+    // the relation encoder's range shift depends on the new weights: fetch the blob (it is the host copy
+    // drp_get_weights serves anyway), derive the shift, then pack the split-fp16 fragments with it
+    HIPCHK(c, hipMemcpyAsync(c->w_pin, c->w_raw.p, (size_t)W_TOTAL * sizeof(float), hipMemcpyDeviceToHost, st));
+    CHK(guarded_wait(c, nullptr));
+    c->w_host.assign(c->w_pin, c->w_pin + W_TOTAL);
+    set_split_range(c, c->w_host.data());
+    hipLaunchKernelGGL(kt_repack_split, dim3(4 * 16), dim3(256), 0, st, w, c->re_range.shift, ptr<uint16_t>(c->w_split));
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
@@ -2520,10 +2578,14 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
                            make_float4(inf, inf, inf, inf), (float)c->tr_beta1);
         HIPCHK(c, hipGetLastError());
         // the engines read packed copies of the weights: rebuild them from the updated blob
-        std::vector<float> blob((size_t)W_TOTAL);
-        CHK(d2h(c, blob.data(), c->w_raw.p, (size_t)W_TOTAL * sizeof(float)));
-        CHK(guarded_wait(c, nullptr));
-        CHK(install_weights(c, blob));
+        if (c->repack_device) {
+            CHK(repack_on_device(c));
+        } else {
+            std::vector<float> blob((size_t)W_TOTAL);
+            CHK(d2h(c, blob.data(), c->w_raw.p, (size_t)W_TOTAL * sizeof(float)));
+            CHK(guarded_wait(c, nullptr));
+            CHK(install_weights(c, blob));
+        }
     }
     CHK(drp_sync(c));
     if (loss_out) {
@@ -2754,6 +2816,13 @@ long drp_debug_fetch(drp_ctx* c, const char* name, void* out, size_t out_bytes) 
     else if (!strcmp(name, "proj")) { b = &c->proj; bytes = bn * 128 * 4; }
     else if (!strcmp(name, "agg")) { b = &c->agg; bytes = bn * 64 * 4; }
     else if (!strcmp(name, "stats")) { b = &c->stats; bytes = 8 * sizeof(double); }
+    // the blob and its packed copies (tests: the device re-pack after an optimiser step against the host packers)
+    else if (!strcmp(name, "w_raw")) { b = &c->w_raw; bytes = (size_t)W_TOTAL * 4; }
+    else if (!strcmp(name, "w_valu")) { b = &c->w_valu; bytes = (size_t)V_TOTAL * 4; }
+    else if (!strcmp(name, "w_mfma")) { b = &c->w_mfma; bytes = (size_t)M_TOTAL * 4; }
+    else if (!strcmp(name, "w_mfma_bwd")) { b = &c->w_mfma_bwd; bytes = (size_t)MB_TOTAL * 4; }
+    else if (!strcmp(name, "w_split")) { b = &c->w_split; bytes = (size_t)S_ALLOC * 16; }
+    else if (!strcmp(name, "w_split6")) { b = &c->w_split6; bytes = (size_t)S6_TOTAL * 16; }
     else return fail(c, DRP_EINVAL, "unknown buffer '%s'", name);
     // a GD session keeps every step's impulses and lists in its tape, not in the step workspace: the last step's
     DevBuf tape{};

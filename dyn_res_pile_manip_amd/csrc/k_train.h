@@ -9,6 +9,7 @@
 // workgroup in HBM, added up by a second launch in a fixed order (no atomics: deterministic).
 #pragma once
 #include "drp_common.h"
+#include "k_mlp_split.h"
 
 // d loss / d s_pred_t and the loss itself.  particle_nums[b] real particles per sample, the rest of
 // the N rows are padding (zero rows at the origin, never connected to a real particle).
@@ -212,15 +213,134 @@ kt_wgrad_reduce_multi(WgradJobs J) {
     else if (q.dwd != nullptr) q.dwd[(size_t)lane * q.lane_stride] += t;
 }
 
-// column sums of a [M,3] gradient (bias of the predictor's last layer)
-__global__ void __launch_bounds__(256) kt_colsum3(const float* __restrict__ g, long M, float* __restrict__ out) {
+// column sums of a [M,3] gradient (bias of the predictor's last layer): ONE workgroup, every partial sum in a fixed
+// order (a strided pass per thread, a wave reduction, the waves' sums in wave order) -- the first version added the
+// waves' sums of 16 workgroups with fp32 atomics, the one place where two runs of the same training step could differ
+// in the last bit (and, through Adam, drift apart by 1e-9 per step).
+__global__ void __launch_bounds__(1024) kt_colsum3(const float* __restrict__ g, long M, float* __restrict__ out) {
+    __shared__ float s_w[16][3];
     float a[3] = {0.f, 0.f, 0.f};
-    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+    for (long r = threadIdx.x; r < M; r += 1024) {
         a[0] += g[r * 3]; a[1] += g[r * 3 + 1]; a[2] += g[r * 3 + 2];
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float t = wave_sum(a[c]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(out + c, t);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6][c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; ++w) t += s_w[w][threadIdx.x];
+        out[threadIdx.x] += t;
+    }
+}
+
+
+// ---- re-packing the updated weights on the device -------------------------------------------------------------
+// After an optimiser step the engines' packed copies of the blob have to follow (w_valu, w_mfma, w_mfma_bwd: plain
+// re-arrangements; w_split, w_split6: re-arrangements of fp16 / bf16 split terms).  Round 2 fetched the blob and ran the
+// host packers again (five uploads, 0.4 of an iteration's 3.6 ms at the reference's batch of 4).  The plain copies are
+// GATHERS: the index map of a packer is what it makes of the probe blob w[i] = i + 1 (0 -> the constant 0, -1e30 ->
+// the sink row), built once from the host packer itself -- so the device copy cannot drift from it.  The split copies
+// repeat pack_split / pack_split6 element by element (same rounding: RNE to fp16 by the conversion instruction, RNE to
+// bf16 by the integer rule of host_bf16_rne; residuals in fp32); tests/test_gpu_train.py compares all five with the
+// host packers byte by byte.
+__global__ void kt_repack_gather(const float* __restrict__ w, const int* __restrict__ map, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int m = map[i];
+    dst[i] = m > 0 ? w[m - 1] : (m == 0 ? 0.0f : -1e30f);
+}
+
+__device__ __forceinline__ uint16_t dev_f16_rne(float f) {
+    const _Float16 h = (_Float16)f;                  // v_cvt_f16_f32, round to nearest even
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float dev_f16_to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+__device__ __forceinline__ uint16_t dev_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float dev_bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ int dev_split_feature(int s, int h, int jj) {
+    const int r = 8 * (s & 1) + jj;
+    return 32 * (s >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+// pack_split (k_mlp_split.h) on the device: grid.x = 4 jobs (RE0, RE2, RE4, RPE) x 16 blocks of 256 threads;
+// one thread per (ob, s, lane, jj) of a 64x64 matrix (4096), per (ob, lane, jj) of the first layer (1024)
+__global__ void __launch_bounds__(256)
+kt_repack_split(const float* __restrict__ w, int shift, uint16_t* __restrict__ out) {
+    const int job = blockIdx.x >> 4, e = (blockIdx.x & 15) * 256 + threadIdx.x;
+    if (job == 0) {
+        if (e < 1024) {
+            const int jj = e & 7, lane = (e >> 3) & 63, ob = e >> 9;
+            const int i = lane & 31, h = lane >> 5, o = 32 * ob + i;
+            float v = 0.0f;
+            if (h == 0 && jj < 6) v = w[W_RE0_W + o * 6 + jj];
+            else if (h == 0 && jj == 6) v = w[W_RE0_B + o];
+            v = ldexpf(v, shift);
+            const uint16_t hq = dev_f16_rne(v);
+            const float hi = dev_f16_to_f32(hq);
+            out[(size_t)(S_RE0 + (0 * 2 + ob) * 64 + lane) * 8 + jj] = hq;
+            out[(size_t)(S_RE0 + (1 * 2 + ob) * 64 + lane) * 8 + jj] = dev_f16_rne(v - hi);
+        } else if (e < 1024 + 64) {
+            // the chain's bias rows: 2^k b2, 2^k b4, b_rp, wd_rp (floats behind the fragments)
+            const int o = e - 1024;
+            float* srows = reinterpret_cast<float*>(out + (size_t)S_ROWS * 8);
+            srows[o] = ldexpf(w[W_RE2_B + o], shift);
+            srows[64 + o] = ldexpf(w[W_RE4_B + o], shift);
+            srows[128 + o] = w[W_RP_B + o];
+            srows[192 + o] = w[W_RP_W + o * 193 + 192];
+        }
+        return;
+    }
+    const int dst = job == 1 ? S_RE2 : (job == 2 ? S_RE4 : S_RPE);
+    const int src = job == 1 ? W_RE2_W : (job == 2 ? W_RE4_W : W_RP_W);
+    const int ld = job == 3 ? 193 : 64;
+    const int jj = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 3, ob = e >> 11;
+    const int i = lane & 31, h = lane >> 5;
+    const float v = w[src + (32 * ob + i) * ld + dev_split_feature(s, h, jj)];
+    const uint16_t hq = dev_f16_rne(v);
+    const float hi = dev_f16_to_f32(hq);
+    out[(size_t)(dst + ((0 * 2 + ob) * 4 + s) * 64 + lane) * 8 + jj] = hq;
+    out[(size_t)(dst + ((1 * 2 + ob) * 4 + s) * 64 + lane) * 8 + jj] = dev_f16_rne(v - hi);
+}
+
+// pack_split6 on the device: grid.x = 7 jobs (AGG, RPR, RPS, PR0, PE2, PPE, PE0) x 16 blocks
+__global__ void __launch_bounds__(256)
+kt_repack_split6(const float* __restrict__ w, uint16_t* __restrict__ out) {
+    const int job = blockIdx.x >> 4, e = (blockIdx.x & 15) * 256 + threadIdx.x;
+    if (job == 6) {
+        if (e >= 1024) return;
+        const int jj = e & 7, lane = (e >> 3) & 63, ob = e >> 9;
+        const int i = lane & 31, h = lane >> 5, o = 32 * ob + i;
+        float v = 0.0f;
+        if (h == 0 && jj < 5) v = w[W_PE0_W + o * 5 + jj];
+        else if (h == 0 && jj == 5) v = w[W_PE0_B + o];
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            const uint16_t q = dev_bf16_rne(v);
+            out[((size_t)S6_PE0 + (part * 2 + ob) * 64 + lane) * 8 + jj] = q;
+            v -= dev_bf16_to_f32(q);
+        }
+        return;
+    }
+    const int dsts[6] = {S6_AGG, S6_RPR, S6_RPS, S6_PR0, S6_PE2, S6_PPE};
+    const int srcs[6] = {W_PP_W, W_RP_W, W_RP_W, W_PR0_W, W_PE2_W, W_PP_W};
+    const int lds_[6] = {129, 193, 193, 64, 64, 129};
+    const int cols[6] = {64, 64, 128, 0, 0, 0};
+    const int dst = dsts[job], src = srcs[job], ld = lds_[job], col0 = cols[job];
+    const int jj = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 3, ob = e >> 11;
+    const int i = lane & 31, h = lane >> 5;
+    float v = w[src + (32 * ob + i) * ld + col0 + dev_split_feature(s, h, jj)];
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        const uint16_t q = dev_bf16_rne(v);
+        out[((size_t)dst + ((part * 2 + ob) * 4 + s) * 64 + lane) * 8 + jj] = q;
+        v -= dev_bf16_to_f32(q);
     }
 }

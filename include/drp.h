@@ -325,7 +325,8 @@ int drp_probe_read(drp_ctx* ctx, double* total_ms, long* launches);
  * the host; the tests of the hang guard use it */
 int drp_debug_stall(drp_ctx* ctx, int ms);
 /* copy an intermediate device buffer to the host: "s_delta","nbr_idx","nbr_cnt",
- * "particle_encode"(eff0),"c_node","c_edge","proj","agg","effect". returns bytes. */
+ * "particle_encode"(eff0),"c_node","c_edge","proj","agg","effect"; the weight blob "w_raw" and its packed copies
+ * "w_valu","w_mfma","w_mfma_bwd","w_split","w_split6" (byte sizes: the returned value). returns bytes. */
 long drp_debug_fetch(drp_ctx* ctx, const char* name, void* out, size_t out_bytes);
 
 #ifdef __cplusplus

@@ -126,7 +126,7 @@ def test_rollout_vs_reference(ctx, golden, case, engine):
 
 
 @pytest.mark.parametrize('goal', ['I', 'disc'])
-def test_reward(ctx, golden, goal):
+def test_reward(ctx, golden, goal, exact_goal_transform):
     g = golden.reward
     obs_goal = syn.goal_distance_image(syn.goal_mask(goal))
     ctx.set_goal(syn.goal_field(obs_goal), g[goal + '/goal_coor'])
@@ -134,7 +134,23 @@ def test_reward(ctx, golden, goal):
     np.testing.assert_allclose(r, g[goal + '/reward'], rtol=1e-5)
     r_un = ctx.reward(g[goal + '/state'], normalize=False)
     np.testing.assert_allclose(r_un, g[goal + '/reward_unnorm'], rtol=1e-5)
+    # the reference-named entry point (env/flex_rewards.py:156): goal IMAGE in, the field built on the device by the
+    # transform the fixture was captured with (exact Euclidean: make_golden.py's cv2 stub), torch tensors in and out
+    import torch
+    from dyn_res_pile_manip_amd import flex_rewards
+    flex_rewards.DIST_TRANSFORM = 'exact'           # the exact_goal_transform fixture restores it
+    r_t = flex_rewards.config_reward_ptcl(torch.from_numpy(g[goal + '/state']), torch.from_numpy(obs_goal), syn.demo_cam_params(),
+                                          torch.from_numpy(g[goal + '/goal_coor']), normalize=True, offset=(0, 0), engine=ctx)
+    assert isinstance(r_t, torch.Tensor) and r_t.shape == (g[goal + '/state'].shape[0],)
+    np.testing.assert_allclose(r_t.numpy(), g[goal + '/reward'], rtol=1e-5)
+    r_u = flex_rewards.config_reward_ptcl(g[goal + '/state'], obs_goal, syn.demo_cam_params(), g[goal + '/goal_coor'],
+                                          normalize=False, engine=ctx)
+    np.testing.assert_allclose(r_u, g[goal + '/reward_unnorm'], rtol=1e-5)
+    with pytest.raises(NotImplementedError):
+        flex_rewards.config_reward_ptcl(g[goal + '/state'], obs_goal, syn.demo_cam_params(), g[goal + '/goal_coor'],
+                                        offset=(3, 0), engine=ctx)
     # rollout + reward of every step == ptcl_evaluate_traj's next_r
+    ctx.set_goal(syn.goal_field(obs_goal), g[goal + '/goal_coor'])
     ro = golden.rollout
     _, rew = ctx.rollout(ro['c1/s_cur'], ro['c1/attr'], ro['c1/dens'], ro['c1/act_seqs'],
                          want_states=False, want_reward=True)

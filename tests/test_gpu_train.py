@@ -161,3 +161,49 @@ def test_checkpoint_round_trip_is_a_torch_state_dict(golden, tmp_path):
     m.load_state_dict(torch.load(path, map_location='cpu'), strict=True)
     np.testing.assert_array_equal(weights.blob_from_state_dict(m.state_dict()), blob)
     np.testing.assert_array_equal(weights.load_checkpoint(path), blob)
+
+
+def test_device_repack_equals_the_host_packers(golden, monkeypatch):
+    """After an optimiser step the packed copies of the weights are rebuilt ON THE DEVICE (gathers through index maps
+    derived from the host packers, and pack_split / pack_split6 repeated element by element).  Three Adam steps, then
+    every packed buffer byte by byte against a second context that was handed the same blob through
+    drp_load_weights (the host packers); and the whole trajectory against the round-2 path (DRP_NO_REPACK_DEVICE=1)."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    g = golden.train
+    case = 'b4_r3'
+    batch = _batch(g, case)
+    lr, beta1 = g[case + '/lr_beta1']
+    runs = {}
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv('DRP_NO_REPACK_DEVICE', '1')
+        else:
+            monkeypatch.delenv('DRP_NO_REPACK_DEVICE', raising=False)
+        model = _model(golden)
+        eng = model.engine
+        eng.train_begin(batch[0].shape[1] - 1, float(lr), float(beta1))
+        losses = [eng.train_step(*batch, mode='update')[0] for _ in range(3)]
+        blob = eng.get_weights()
+        packed = {}
+        for name, nbytes in (('w_raw', 38403 * 4), ('w_valu', None), ('w_mfma', None), ('w_mfma_bwd', None), ('w_split', None),
+                             ('w_split6', None)):
+            buf = np.zeros(1 << 20, np.uint8)
+            n = eng.lib.drp_debug_fetch(eng.h, name.encode(), buf.ctypes.data, buf.nbytes)
+            assert n > 0 and (nbytes is None or n == nbytes), (name, n)
+            packed[name] = buf[:n].copy()
+        runs[host] = (losses, blob, packed)
+        if not host:
+            np.testing.assert_array_equal(packed['w_raw'].view(np.float32), blob)      # the host copy follows the device's
+            ref = Engine(0)
+            ref.load_weights(blob, 0.08)
+            for name in ('w_valu', 'w_mfma', 'w_mfma_bwd', 'w_split', 'w_split6'):
+                buf = np.zeros(1 << 20, np.uint8)
+                n = ref.lib.drp_debug_fetch(ref.h, name.encode(), buf.ctypes.data, buf.nbytes)
+                assert n == packed[name].size, name
+                assert np.array_equal(buf[:n], packed[name]), name
+            ref.close()
+        eng.close()
+    assert runs[False][0] == runs[True][0]                       # the same losses, bit for bit
+    np.testing.assert_array_equal(runs[False][1], runs[True][1])
+    for name in runs[False][2]:
+        assert np.array_equal(runs[False][2][name], runs[True][2][name]), name
