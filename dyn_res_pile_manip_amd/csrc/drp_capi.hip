@@ -233,6 +233,7 @@ struct drp_ctx {
     DevBuf map_valu, map_mfma, map_mfma_bwd;
     bool repack_maps_ready = false;
     float* w_pin = nullptr;
+    bool bwd_edge_mfma = true;      // DRP_NO_BWD_EDGE_MFMA=1: the relation encoder's backward on the VALU kernel (kb_edge_encode)
     bool repack_device = true;      // DRP_NO_REPACK_DEVICE=1: fetch the blob and run the host packers (the round-2 path)
 
     // km_rollout's argument block (device copy + what it holds)
@@ -960,6 +961,7 @@ int drp_create(int device, drp_ctx** out) {
     c->prop3e = getenv("DRP_NO_PROP3E") == nullptr;
     c->rollout_fused = getenv("DRP_NO_ROLLOUT_FUSED") == nullptr;
     c->repack_device = getenv("DRP_NO_REPACK_DEVICE") == nullptr;
+    c->bwd_edge_mfma = getenv("DRP_NO_BWD_EDGE_MFMA") == nullptr;
     if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) c->rollout_max_n = atoi(e);
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
@@ -996,6 +998,7 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_prop3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_rollout, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kmb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kt_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
@@ -1889,6 +1892,17 @@ int drp_set_goal_image(drp_ctx* c, const float* obs_goal, int h, int w, int mode
 
 // ---- gradient-descent planner (row f1) ----------------------------------------------------------
 namespace {
+// relation encoder backward on the matrix cores (kmb_edge_encode): one tile of 32 edge slots per wave, the tiles of a
+// small batch spread one per CU
+void launch_edge_encode_mfma(drp_ctx* c, const float* s_prev, int prev_mod, size_t prev_stride, int nb, const int16_t* idx,
+                             const uint8_t* cnt, const float* gah, const unsigned* mht, size_t bn, int N, int B, float* gpos_edge,
+                             const KbEdgeDump& dump) {
+    const long ntiles = (long)B * (((long)N * DRP_K + 31) / 32);
+    const unsigned grid = (unsigned)(ntiles < (long)c->n_cu ? ntiles : (long)c->n_cu);
+    hipLaunchKernelGGL(kmb_edge_encode, dim3(grid), dim3(64 * MFMA_WAVES), KMB_EDGE_ENCODE_LDS, c->stream, ptr<float>(c->w_mfma),
+                       ptr<float>(c->w_mfma_bwd), s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx,
+                       cnt, gah, mht, bn, N, B, gpos_edge, dump);
+}
 int gd_forward_backward(drp_ctx* c) {
     const int nb = c->gd_nb, N = c->gd_N, B = c->gd_B, H = c->gd_H;
     const size_t bn = (size_t)B * N;
@@ -2054,13 +2068,16 @@ int gd_forward_backward(drp_ctx* c) {
             g_prev = g_state + (size_t)(t - 1) * bn * 3;
             CHK(d2d(g_prev, g_out, bn * 3 * sizeof(float)));
             { ProbeScope ps(c, KC_BWD_EDGE);
-            hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw,
-                               s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx, cnt,
-                               gah, mht, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), KbEdgeDump{}, 1);
+            if (c->bwd_edge_mfma)
+                launch_edge_encode_mfma(c, s_prev, prev_mod, prev_stride, nb, idx, cnt, gah, mht, bn, N, B, ptr<float>(c->gpos_edge), KbEdgeDump{});
+            else
+                hipLaunchKernelGGL(kb_edge_encode, dim3(B), dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw,
+                                   s_prev, prev_mod, prev_stride, ptr<float>(c->attr), nb, ptr<float>(c->dens), nb, idx, cnt,
+                                   gah, mht, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), KbEdgeDump{}, 1);
             }
             { ProbeScope ps(c, KC_BWD_EDGE);
             hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
-                               ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3);
+                               ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3, c->bwd_edge_mfma ? 1 : 0, cnt);
             }
         }
         { ProbeScope ps(c, KC_BWD_PUSH);
@@ -2419,11 +2436,15 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             g_prev = g_state + (size_t)(t - 1) * bn * 3;
             hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
         }
-        hipLaunchKernelGGL(kb_edge_encode, rgrid, dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw, s_prev, B,
-                           prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, gah, mht, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), ed, chunks);
+        if (c->bwd_edge_mfma)
+            launch_edge_encode_mfma(c, s_prev, B, prev_stride, B, idx, cnt, gah, mht, bn, N, B,
+                                    g_prev != nullptr ? ptr<float>(c->gpos_edge) : (float*)nullptr, ed);
+        else
+            hipLaunchKernelGGL(kb_edge_encode, rgrid, dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw, s_prev, B,
+                               prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, gah, mht, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), ed, chunks);
         if (g_prev != nullptr)
             hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
-                               ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3);
+                               ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3, c->bwd_edge_mfma ? 1 : 0, cnt);
         launch_wgrad<64>(c, ed.gce, 64, ed.re, 64, (long)bnk, G + W_RP_W, 193, 1, G + W_RP_B, G + W_RP_W + 192, dens, B,
                          (long)N * DRP_K);
         launch_wgrad<64>(c, ed.g3, 64, ed.a2, 64, (long)bnk, G + W_RE4_W, 64, 1, G + W_RE4_B, nullptr, nullptr, 1, 1);

@@ -714,20 +714,31 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
 // in the order of the reversed lists (no atomics)
 __global__ void __launch_bounds__(256)
 kb_gather_pos(const float* __restrict__ gpos_edge, const int* __restrict__ rev_off, const int* __restrict__ rev, int N,
-              float* __restrict__ g_pos, size_t gpos_stride) {
+              float* __restrict__ g_pos, size_t gpos_stride, int add_recv = 0, const uint8_t* __restrict__ nbr_cnt = nullptr) {
     const int b = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
     const int* ro = rev_off + (size_t)b * (N + 1);
     const int* rv = rev + (size_t)b * N * DRP_K;
     const float4* ge = reinterpret_cast<const float4*>(gpos_edge) + (size_t)b * N * DRP_K;
+    float* gp = g_pos + (size_t)b * gpos_stride + (size_t)j * 3;
+    float g0 = gp[0], g1 = gp[1], g2 = gp[2];
+    if (add_recv) {
+        // receiver part (kmb_edge_encode leaves it here): the sum over the node's own slots, in slot order
+        const int cnt = nbr_cnt[(size_t)b * N + j];
+        float rx = 0.0f, ry = 0.0f, rz = 0.0f;
+        for (int k = 0; k < cnt; ++k) {
+            const float4 v = ge[(size_t)j * DRP_K + k];
+            rx += v.x; ry += v.y; rz += v.z;
+        }
+        g0 += rx; g1 += ry; g2 += rz;
+    }
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
     for (int p = ro[j]; p < ro[j + 1]; ++p) {
         const float4 v = ge[rv[p]];
         ax += v.x; ay += v.y; az += v.z;
     }
-    float* gp = g_pos + (size_t)b * gpos_stride + (size_t)j * 3;
-    gp[0] -= ax; gp[1] -= ay; gp[2] -= az;
+    gp[0] = g0 - ax; gp[1] = g1 - ay; gp[2] = g2 - az;
 }
 
 // ---- Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8) + the clip box ------------

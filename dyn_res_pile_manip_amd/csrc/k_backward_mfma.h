@@ -18,7 +18,11 @@ enum {
     MB_PE2 = MB_PPE + 4096,     // particle encoder layer 2, transposed
     MB_PR0 = MB_PE2 + 4096,     // predictor layer 0, transposed
     RB_PE0 = MB_PR0 + 4096,     // particle encoder layer 0, columns 0..2 as three 64-rows (d / d s_delta)
-    MB_TOTAL = RB_PE0 + 192
+    MB_RPE = RB_PE0 + 192,      // W_e^T            } the relation encoder's backward (kmb_edge_encode)
+    MB_RE4 = MB_RPE + 4096,     // layer 4, transposed
+    MB_RE2 = MB_RE4 + 4096,     // layer 2, transposed
+    RB_RE0 = MB_RE2 + 4096,     // relation encoder layer 0, columns 2..4 as three 64-rows (d / d (s_r - s_s))
+    MB_TOTAL = RB_RE0 + 192
 };
 
 inline void pack_mfma_bwd(const float* w, std::vector<float>& m) {
@@ -40,6 +44,11 @@ inline void pack_mfma_bwd(const float* w, std::vector<float>& m) {
     PT64(MB_PR0, W_PR0_W, 64, 0);
     for (int c = 0; c < 3; ++c)
         for (int o = 0; o < 64; ++o) m[RB_PE0 + c * 64 + o] = w[W_PE0_W + o * 5 + c];
+    PT64(MB_RPE, W_RP_W, 193, 0);
+    PT64(MB_RE4, W_RE4_W, 64, 0);
+    PT64(MB_RE2, W_RE2_W, 64, 0);
+    for (int c = 0; c < 3; ++c)
+        for (int o = 0; o < 64; ++o) m[RB_RE0 + c * 64 + o] = w[W_RE0_W + o * 6 + 2 + c];
 }
 
 // One propagation step of the backward pass on the node rows:
@@ -483,6 +492,139 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                     g_sdelta[row * 3 + 2] = out[2];
                 }
             }
+        }
+    }
+}
+
+
+// ---- relation encoder backward on the matrix cores (horizons > 1 of the GD planner, training) -------------------
+// What kb_edge_encode (k_backward.h) computes per edge slot, as the forward chain of km_edge_encode run both ways on
+// tiles of 32 slots: the three Linear+ReLU layers forward (fp32 MFMA; only the SIGN of every pre-activation is kept:
+// 96 bits per lane instead of three fragments), the gradient at c_edge rebuilt from the three propagation steps' ReLU
+// masks and the receiver's g_agg rows (the mask words are in fragment order: word = half-wave, bit 31 - register),
+// then W_e^T, layer 4^T, layer 2^T under the kept signs, and the dot with the three position columns of layer 0.
+// The VALU kernel gave a wave one receiver and kept lane = feature: 5 x 16 KB of weights into LDS per FOUR receivers,
+// 106 us per launch at the reference's training batch (4 x 300 particles), the largest single item of an iteration.
+// Every sum has a fixed order (the MFMA's own k order): bit-reproducible.  Differences to kb_edge_encode: the
+// receiver's own position gradient (the sum over its slots) is left to kb_gather_pos (add_recv), which reads
+// gpos_edge anyway; the result agrees with the VALU kernel to fp32 rounding (another summation order), which the
+// tests against the reference's autograd cover (tests/test_gpu_gd.py horizon 2, tests/test_gpu_train.py).
+#define KMB_EDGE_ENCODE_LDS ((size_t)(512 + 5 * 4096 + 128 + 192) * sizeof(float))
+__global__ void __launch_bounds__(64 * MFMA_WAVES)
+kmb_edge_encode(const float* __restrict__ mw, const float* __restrict__ mb, const float* __restrict__ s_cur, int s_mod,
+                size_t s_stride, const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+                const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt,
+                const float* __restrict__ g_agg_hist /* [3][B*N,64] */, const unsigned* __restrict__ mask_hist /* [3][B*N*10][2] */,
+                size_t bn, int N, int B, float* __restrict__ gpos_edge /* nullable: [B,N,10,4] */, KbEdgeDump dump) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w1 = lds;                 // forward: layer 0 (K = 8, bias column), layers 2 and 4
+    float* w2 = w1 + 512;
+    float* w4 = w2 + 4096;
+    float* wet = w4 + 4096;          // backward: W_e^T, layer 4^T, layer 2^T
+    float* w4t = wet + 4096;
+    float* w2t = w4t + 4096;
+    float* rows = w2t + 4096;        // b2, b4
+    float* wxyz = rows + 128;        // layer 0, position columns
+    lds_fill(w1, mw + M_RE0, 512);
+    lds_fill(w2, mw + M_RE2, 2 * 4096);              // M_RE2, M_RE4 consecutive
+    lds_fill(wet, mb + MB_RPE, 3 * 4096);            // MB_RPE, MB_RE4, MB_RE2 consecutive
+    lds_fill(rows, mw + R_RE2_B, 128);               // R_RE2_B, R_RE4_B consecutive
+    lds_fill(wxyz, mb + RB_RE0, 192);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int nslots = N * DRP_K;
+    const int tps = (nslots + 31) >> 5;
+    const long ntiles = (long)B * tps;
+    const bool dumping = dump.re != nullptr;
+    // tiles are dealt block-cyclically FIRST (tile = block + grid * (wave + 8 round)): a handful of tiles (a training
+    // batch) spreads one wave per CU instead of eight waves on a few CUs
+    for (long gt = (long)blockIdx.x + (long)gridDim.x * wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+        const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
+        const bool live = (t * 32 + j) < nslots;
+        const int slot = min(t * 32 + j, nslots - 1);
+        const int i = slot / DRP_K, k = slot - i * DRP_K;
+        const size_t nrow = (size_t)b * N + i;
+        const size_t erow = nrow * DRP_K + k;
+        const int cnt = nbr_cnt[nrow];
+        const bool edge = k < cnt;
+        const int jn = edge ? (int)nbr_idx[erow] : i;
+        const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
+        const float* at = attr + (size_t)(b % attr_mod) * N;
+        const float d = dens[b % dens_mod] / DRP_DENS_SCALE;
+        const float ar = at[i], as = at[jn];
+        const float dx = s[i * 3 + 0] - s[jn * 3 + 0], dy = s[i * 3 + 1] - s[jn * 3 + 1], dz = s[i * 3 + 2] - s[jn * 3 + 2];
+        float x[4];
+        if (h == 0) { x[0] = ar; x[1] = dx; x[2] = dz; x[3] = 1.0f; }
+        else { x[0] = as; x[1] = dy; x[2] = d; x[3] = 0.0f; }
+        if (dumping && live && h == 0) {
+            float4* x0 = reinterpret_cast<float4*>(dump.x0 + erow * 8);
+            x0[0] = make_float4(ar, as, dx, dy);
+            x0[1] = make_float4(dz, d, 0.0f, 0.0f);
+        }
+        // ---- forward, keeping the signs
+        Frag a, c;
+        frag_zero(a);
+        mfma_layer8(reinterpret_cast<const float4*>(w1), x, a, lane);
+        const unsigned pos1 = frag_positive_bits_any(a);
+        frag_relu(a);
+        if (dumping && live) frag_to_row(dump.a1 + erow * 64, h, a);
+        frag_from_row(rows + 0, h, c);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(w2), a, c, lane);
+        const unsigned pos2 = frag_positive_bits_any(c);
+        frag_relu(c);
+        if (dumping && live) frag_to_row(dump.a2 + erow * 64, h, c);
+        frag_from_row(rows + 64, h, a);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(w4), c, a, lane);
+        const unsigned pos3 = frag_positive_bits_any(a);
+        if (dumping && live) { frag_relu(a); frag_to_row(dump.re + erow * 64, h, a); }
+        // ---- d loss / d c_edge of the slot: the three propagation steps share c_edge (zero for a padded slot)
+        Frag g;
+        frag_zero(g);
+        if (edge) {
+#pragma unroll
+            for (int p = 0; p < DRP_PSTEP; ++p) {
+                const unsigned m = mask_hist[((size_t)p * bn * DRP_K + erow) * 2 + h];
+                Frag ga;
+                frag_from_row(g_agg_hist + ((size_t)p * bn + nrow) * 64, h, ga);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((m >> (31 - (16 * ob + r))) & 1u) g.v[ob][r] += ga.v[ob][r];
+            }
+        }
+        if (dumping && live) frag_to_row(dump.gce + erow * 64, h, g);
+        // ---- backward through W_e and the three layers
+        Frag tt;
+        frag_zero(tt);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(wet), g, tt, lane);
+        frag_keep_bits(tt, pos3);
+        if (dumping && live) frag_to_row(dump.g3 + erow * 64, h, tt);
+        frag_zero(g);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(w4t), tt, g, lane);
+        frag_keep_bits(g, pos2);
+        if (dumping && live) frag_to_row(dump.g2 + erow * 64, h, g);
+        frag_zero(tt);
+        mfma_layer64<false>(reinterpret_cast<const float4*>(w2t), g, tt, lane);
+        frag_keep_bits(tt, pos1);
+        if (dumping && live) frag_to_row(dump.g1 + erow * 64, h, tt);
+        if (gpos_edge != nullptr) {
+            float o3[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                Frag w;
+                frag_from_row(wxyz + 64 * q, h, w);
+                float pdot = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pdot = fmaf(tt.v[0][r], w.v[0][r], pdot);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pdot = fmaf(tt.v[1][r], w.v[1][r], pdot);
+                o3[q] = pdot + __shfl_xor(pdot, 32, 64);
+            }
+            if (h == 0 && live)
+                *reinterpret_cast<float4*>(gpos_edge + erow * 4) = edge ? make_float4(o3[0], o3[1], o3[2], 0.0f)
+                                                                       : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
 }

@@ -142,6 +142,24 @@ __device__ __forceinline__ void frag_relu(Frag& f) {
     for (int r = 0; r < 16; ++r) { f.v[0][r] = relu1(f.v[0][r]); f.v[1][r] = relu1(f.v[1][r]); }
 }
 
+// bit 31 - (16 ob + r) = [register r of output block ob is > 0] (any float, not only relu'd ones), and the inverse:
+// keep the registers whose bit is set, zero the others -- a ReLU's derivative applied from 32 stored bits
+__device__ __forceinline__ unsigned frag_positive_bits_any(const Frag& f) {
+    unsigned m = 0;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = (m << 1) | (f.v[ob][r] > 0.0f ? 1u : 0u);
+    return m;
+}
+__device__ __forceinline__ void frag_keep_bits(Frag& f, unsigned m) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (!((m >> (31 - (16 * ob + r))) & 1u)) f.v[ob][r] = 0.0f;
+}
+
 // LDS accesses of one wave complete in order; this only stops the compiler from moving them.
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
