@@ -233,6 +233,7 @@ struct drp_ctx {
     DevBuf map_valu, map_mfma, map_mfma_bwd;
     bool repack_maps_ready = false;
     float* w_pin = nullptr;
+    bool prop_spread = true;        // DRP_NO_PROP_SPREAD=1: km_prop's tiles eight to a workgroup whatever their number
     bool bwd_edge_mfma = true;      // DRP_NO_BWD_EDGE_MFMA=1: the relation encoder's backward on the VALU kernel (kb_edge_encode)
     bool repack_device = true;      // DRP_NO_REPACK_DEVICE=1: fetch the blob and run the host packers (the round-2 path)
 
@@ -572,6 +573,9 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             const bool last = (p + 1 == DRP_PSTEP);
             ProbeScope ps(c, KC_PROP);
             long pb_ = (node_tiles + PROP_WAVES - 1) / PROP_WAVES;
+            // few tiles (up to four per CU): one per workgroup first, so that a tile has its SIMD to itself
+            const int spread = (c->prop_spread && node_tiles <= 4L * c->n_cu) ? 1 : 0;
+            if (spread) pb_ = node_tiles;
             const dim3 grid((unsigned)(pb_ < c->n_cu ? pb_ : c->n_cu)), pblk(64 * PROP_WAVES);
             const float* eff_in = tape ? a.eff_hist + (size_t)p * bn64 : ptr<float>(c->eff);
             float* eff_out = tape ? a.eff_hist + (size_t)(p + 1) * bn64 : ptr<float>(c->eff);
@@ -580,7 +584,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
 #define PROP_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
                   a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, \
                   ptr<float>(c->c_node), eff_in, eff_out, N, B, pb, a.s_out, a.out_stride, a.cself, a.cself_ok, mask_out, agg_out, \
-                  c->re_scale, c->re_inv
+                  c->re_scale, c->re_inv, spread
             if (!tape) {
                 if (!last) hipLaunchKernelGGL((km_prop<false, false>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS);
                 else hipLaunchKernelGGL((km_prop<true, false>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS);
@@ -962,6 +966,7 @@ int drp_create(int device, drp_ctx** out) {
     c->rollout_fused = getenv("DRP_NO_ROLLOUT_FUSED") == nullptr;
     c->repack_device = getenv("DRP_NO_REPACK_DEVICE") == nullptr;
     c->bwd_edge_mfma = getenv("DRP_NO_BWD_EDGE_MFMA") == nullptr;
+    c->prop_spread = getenv("DRP_NO_PROP_SPREAD") == nullptr;
     if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) c->rollout_max_n = atoi(e);
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;

@@ -864,7 +864,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         size_t out_stride, const float* __restrict__ cself /* nullable [B,64] */,
         const uint8_t* __restrict__ cself_ok,
         unsigned* __restrict__ mask_out /* TAPE: [B*N*10][2] */, float* __restrict__ agg_out /* TAPE, nullable: [B*N,64] */,
-        float re_scale, float re_inv) {
+        float re_scale, float re_inv, int spread /* few tiles: one per workgroup first (see decode) */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef PROP_STAMPS
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
@@ -897,9 +897,20 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     const long lt_step = (long)blocks_in_grp * PROP_WAVES;
     const long wg_base = (long)(blockIdx.x / ngroups) * PROP_WAVES;
     // the workgroup's share: what a static deal of the group's tiles over its waves would give it
+    // A batch of few tiles (training: 4 samples of 300 particles are 38) is latency, not throughput: `spread` deals the
+    // tiles workgroup-cyclically -- tile = block + grid x draw -- so that each runs alone on its CU (a wave that shares
+    // its SIMD with another runs a slot iteration in 3.3 us, alone in 2.2) instead of eight to a workgroup.
+    const long all_tiles = (long)B * tps;
     auto decode = [&](int li) {
-        const long lt = wg_base + (li & (PROP_WAVES - 1)) + (long)(li / PROP_WAVES) * lt_step;
         TileId id;
+        if (spread) {
+            const long lt = (long)blockIdx.x + (long)gridDim.x * li;
+            id.valid = lt < all_tiles;
+            id.b = (int)(lt / tps);
+            id.t = (int)(lt - (long)id.b * tps);
+            return id;
+        }
+        const long lt = wg_base + (li & (PROP_WAVES - 1)) + (long)(li / PROP_WAVES) * lt_step;
         id.valid = lt < grp_tiles;
         const int m = (int)(lt / tps);
         id.t = (int)(lt - (long)m * tps);
