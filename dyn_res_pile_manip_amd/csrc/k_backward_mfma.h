@@ -395,33 +395,57 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                 cmax = max(cmax, __shfl_xor(cmax, o, 64));
                 lmax = max(lmax, __shfl_xor(lmax, o, 64));
             }
-            for (int k = 0; k < cmax; ++k) {
-                const unsigned w = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + h] : 0u;
+            // the sender term's first entries are requested before the receiver term runs
+            const int nrev = p1 - p0;
+            int e0 = (0 < nrev) ? rv[p0] : 0;
+            int e1 = (1 < nrev) ? rv[p0 + 1] : 0;
+            {
+                // the row's ten mask words are independent loads: all in flight at once (a loop over k waited for each
+                // in turn -- ten L2 round trips per tile and phase), then the additions in slot order as before
+                unsigned wk[DRP_K];
 #pragma unroll
-                for (int ob = 0; ob < 2; ++ob)
+                for (int k = 0; k < DRP_K; ++k) wk[k] = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + h] : 0u;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        pr.v[ob][q] += ((w >> (31 - (16 * ob + q))) & 1u) ? gi.v[ob][q] : 0.0f;
+                for (int k = 0; k < DRP_K; ++k) {
+                    if (k >= cmax) break;                 // wave-uniform
+                    const unsigned w = wk[k];
+#pragma unroll
+                    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            pr.v[ob][q] += ((w >> (31 - (16 * ob + q))) & 1u) ? gi.v[ob][q] : 0.0f;
+                }
             }
-            // sender term over the reversed list (ascending receiver, then slot): the entry after next is
-            // requested while this one's mask word and row are in flight
-            int e0 = (0 < p1 - p0) ? rv[p0] : 0;
-            int e1 = (1 < p1 - p0) ? rv[p0 + 1] : 0;
-            for (int q0 = 0; q0 < lmax; ++q0) {
-                const bool on = q0 < p1 - p0;
-                const int e = e0;
-                e0 = e1;
-                e1 = (q0 + 2 < p1 - p0) ? rv[p0 + q0 + 2] : 0;
-                const unsigned w = on ? mk[(size_t)e * 2 + h] : 0u;
+            // sender term over the reversed list (ascending receiver, then slot), software-pipelined two deep: the
+            // mask word and the g_agg row of entry q0 + 1 and the index of entry q0 + 3 are requested before entry q0's
+            // row is added (the additions keep the list's order)
+            unsigned w_cur = (0 < nrev) ? mk[(size_t)e0 * 2 + h] : 0u;
+            Frag v_cur;
+            {
                 int er, ek;
-                divmod_small(e, DRP_K, 0.1f, er, ek);
-                Frag v;
-                frag_from_row(g_agg_p + (srow0 + (on ? er : i)) * 64, h, v);
+                divmod_small(e0, DRP_K, 0.1f, er, ek);
+                frag_from_row(g_agg_p + (srow0 + ((0 < nrev) ? er : i)) * 64, h, v_cur);
+            }
+            int e2 = (2 < nrev) ? rv[p0 + 2] : 0;
+            for (int q0 = 0; q0 < lmax; ++q0) {
+                const bool on_next = q0 + 1 < nrev;
+                const unsigned w_nxt = on_next ? mk[(size_t)e1 * 2 + h] : 0u;
+                Frag v_nxt;
+                {
+                    int er, ek;
+                    divmod_small(e1, DRP_K, 0.1f, er, ek);
+                    frag_from_row(g_agg_p + (srow0 + (on_next ? er : i)) * 64, h, v_nxt);
+                }
+                const int e3 = (q0 + 3 < nrev) ? rv[p0 + q0 + 3] : 0;
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        ps.v[ob][q] += ((w >> (31 - (16 * ob + q))) & 1u) ? v.v[ob][q] : 0.0f;
+                        ps.v[ob][q] += ((w_cur >> (31 - (16 * ob + q))) & 1u) ? v_cur.v[ob][q] : 0.0f;
+                w_cur = w_nxt;
+                v_cur = v_nxt;
+                e1 = e2;
+                e2 = e3;
             }
             // projection backward: g_eff += W_r^T (receiver term) + W_s^T (sender term)
             Frag ge;
