@@ -588,7 +588,8 @@ def run_rank(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('gloo', rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=float(os.environ.get('DRP_COMM_TIMEOUT_S', '120'))))
+                                # generous by default: on a fresh box the ranks' first `import torch` can differ by minutes
+                                timeout=datetime.timedelta(seconds=float(os.environ.get('DRP_BENCH_RENDEZVOUS_TIMEOUT_S', '900'))))
 
     rig = Rig(local_rank, args.engine)
     eng, engine = rig.eng, rig.engine
