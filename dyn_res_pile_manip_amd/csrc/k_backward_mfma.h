@@ -407,13 +407,14 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                 for (int k = 0; k < DRP_K; ++k) wk[k] = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + h] : 0u;
 #pragma unroll
                 for (int k = 0; k < DRP_K; ++k) {
-                    if (k >= cmax) break;                 // wave-uniform
-                    const unsigned w = wk[k];
+                    if (k < cmax) {                       // wave-uniform
+                        const unsigned w = wk[k];
 #pragma unroll
-                    for (int ob = 0; ob < 2; ++ob)
+                        for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-                        for (int q = 0; q < 16; ++q)
-                            pr.v[ob][q] += ((w >> (31 - (16 * ob + q))) & 1u) ? gi.v[ob][q] : 0.0f;
+                            for (int q = 0; q < 16; ++q)
+                                pr.v[ob][q] += ((w >> (31 - (16 * ob + q))) & 1u) ? gi.v[ob][q] : 0.0f;
+                    }
                 }
             }
             // sender term over the reversed list (ascending receiver, then slot), software-pipelined two deep: the
