@@ -161,8 +161,11 @@ struct drp_ctx {
     bool prop3_order = true;        // DRP_NO_PROP3_ORDER=1: km_prop3's tiles in the natural row order instead of by in-degree
     bool prop3e = true;             // DRP_NO_PROP3E=1: the particle encoder stays its own launch in front of km_prop3
     bool rollout_fused = true;      // DRP_NO_ROLLOUT_FUSED=1: one graph + one km_prop3 launch per rollout step for small piles too
-    int rollout_max_n = 80;         // DRP_ROLLOUT_MAX_N: km_rollout (the whole rollout in one launch) up to this many particles (measured:
-                                    // +18 % at 10 particles, +12 % at 20, +2 % at 50, +5 % at 64, even at 100, -10 % at 150 where the strip build wins)
+    int rollout_max_n = 64;         // DRP_ROLLOUT_MAX_N: km_rollout (the whole rollout in one launch) up to this many particles ...
+    int rollout_max_rows = 704;     // DRP_ROLLOUT_MAX_ROWS: ... and this many rows (samples x particles) per workgroup.  Measured
+                                    // against the step-by-step pipeline at 1024 samples: +18 % at 10 particles, +12 % at 20, +2 % at
+                                    // 50, +5 % at 64, -1 % at 80, -10 % at 150 (the strip build wins); 50 particles x 4096 samples
+                                    // (800 rows per workgroup) -5 %, 20 x 8192 (640 rows) +7 %
 
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
@@ -716,7 +719,7 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
     const int spw_r = (int)((B + c->n_cu - 1) / c->n_cu);
     const bool one_launch = c->engine == DRP_ENGINE_FUSED && c->rollout_fused && c->prop3 && c->prop3e && N <= c->rollout_max_n &&
                             whole_samples(c, B, N) && ((long)spw_r * N + 31) / 32 >= c->prop3_min_tiles &&
-                            (long)spw_r * N <= KM_ROLLOUT_MAX_ROWS;
+                            (long)spw_r * N <= KM_ROLLOUT_MAX_ROWS && (long)spw_r * N <= c->rollout_max_rows;
     if (one_launch) {
         RolloutArgs ra{};
         ra.sw = ptr<uint16_t>(c->w_split); ra.sw6 = ptr<uint16_t>(c->w_split6); ra.mw = ptr<float>(c->w_mfma);
@@ -967,7 +970,8 @@ int drp_create(int device, drp_ctx** out) {
     c->repack_device = getenv("DRP_NO_REPACK_DEVICE") == nullptr;
     c->bwd_edge_mfma = getenv("DRP_NO_BWD_EDGE_MFMA") == nullptr;
     c->prop_spread = getenv("DRP_NO_PROP_SPREAD") == nullptr;
-    if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) c->rollout_max_n = atoi(e);
+    if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) { c->rollout_max_n = atoi(e); c->rollout_max_rows = KM_ROLLOUT_MAX_ROWS; }
+    if (const char* e = getenv("DRP_ROLLOUT_MAX_ROWS")) c->rollout_max_rows = atoi(e);
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;

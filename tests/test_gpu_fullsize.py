@@ -161,6 +161,7 @@ def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch, N, ns)
     blob = weights.blob_from_state_dict(weights.random_state_dict(seed=0))
     M34 = world2cam_affine(syn.demo_cam_extrinsics())
     res = {}
+    monkeypatch.setenv('DRP_ROLLOUT_MAX_N', '256')      # every shape here through km_rollout (default: up to 64 particles)
     for mode in ('rollout', 'prop3', 'steps'):
         monkeypatch.delenv('DRP_NO_PROP3', raising=False)
         monkeypatch.delenv('DRP_NO_ROLLOUT_FUSED', raising=False)
@@ -189,7 +190,7 @@ def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch, N, ns)
                                        (100, 300, 3, 30), (64, 16, 5, 2)])
 def test_whole_rollout_in_one_launch_equals_the_step_by_step_pipeline(monkeypatch, N, ns, H, nb):
     """km_rollout at the reference's own sizes (the planner re-samples the pile at 10 - 100 particles) and beyond its
-    default limit of 80 particles (DRP_ROLLOUT_MAX_N lifts it: the kernel takes any workgroup of up to 3072 rows), with
+    default limit of 64 particles (DRP_ROLLOUT_MAX_N lifts it: the kernel takes any workgroup of up to 3072 rows), with
     several batch columns (row = sample * n_batch + column) and with rewards."""
     from dyn_res_pile_manip_amd.engine import Engine
     s0, dens, attr = syn.make_pile(N, nb, seed=N)
