@@ -501,6 +501,11 @@ void launch_aggregate(drp_ctx* c, int B, int N) {
                            ptr<float>(c->agg), chunks);
 }
 
+// kernels whose tile loop is workgroup-cyclic first (tile = block + grid x (wave + 8 round)): one workgroup per tile up to the chip
+int mfma_grid_spread(drp_ctx* c, long ntiles) {
+    const long cap = (long)c->n_cu;
+    return (int)(ntiles < cap ? (ntiles > 0 ? ntiles : 1) : cap);
+}
 int mfma_grid(drp_ctx* c, long ntiles) {
     long blocks = (ntiles + MFMA_WAVES - 1) / MFMA_WAVES;
     long cap = (long)c->n_cu;
@@ -528,7 +533,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     if (!phase_e) {
         ProbeScope ps(c, KC_NODE_ENCODE);
         if (c->engine == DRP_ENGINE_FUSED)
-            hipLaunchKernelGGL(km_node_encode_split, dim3(mfma_grid(c, node_tiles)), blk, KM_NODE_SPLIT_LDS, st,
+            hipLaunchKernelGGL(km_node_encode_split, dim3(mfma_grid_spread(c, node_tiles)), blk, KM_NODE_SPLIT_LDS, st,
                                ptr<uint16_t>(c->w_split6), mw, ptr<float>(c->s_delta), a.attr, a.attr_mod, a.dens,
                                a.dens_mod, N, B, eff0, ptr<float>(c->c_node), ptr<float>(c->proj));
         else
@@ -2006,7 +2011,7 @@ int gd_forward_backward(drp_ctx* c) {
             const float* mw = ptr<float>(c->w_mfma);
             const float* mb = ptr<float>(c->w_mfma_bwd);
             const long node_tiles = (long)B * ((N + 31) / 32);
-            const dim3 ngrid(mfma_grid(c, node_tiles)), nblk(64 * MFMA_WAVES);
+            const dim3 ngrid(mfma_grid_spread(c, node_tiles)), nblk(64 * MFMA_WAVES);
             { ProbeScope ps(c, KC_BWD_NODE);
             hipLaunchKernelGGL(kmb_predict, ngrid, nblk, KMB_PREDICT_LDS, st, mw, mb, eht + 3 * bn * 64, g_out, (size_t)N * 3, N, B,
                                ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr);
@@ -2352,7 +2357,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             const float* mw = ptr<float>(c->w_mfma);
             const float* mb = ptr<float>(c->w_mfma_bwd);
             const long node_tiles = (long)B * ((N + 31) / 32);
-            const dim3 ngrid(mfma_grid(c, node_tiles)), nblk(64 * MFMA_WAVES);
+            const dim3 ngrid(mfma_grid_spread(c, node_tiles)), nblk(64 * MFMA_WAVES);
             // predictor
             hipLaunchKernelGGL(kmb_predict, ngrid, nblk, KMB_PREDICT_LDS, st, mw, mb, eht + 3 * bn64, g_out, (size_t)N * 3, N, B,
                                ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh));

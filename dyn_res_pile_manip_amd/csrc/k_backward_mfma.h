@@ -71,7 +71,7 @@ kmb_node_step(const float* __restrict__ mb, float* __restrict__ g_eff, const flo
     const int j = lane & 31, h = lane >> 5;
     const int tps = (N + 31) >> 5;
     const long ntiles = (long)B * tps;
-    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+    for (long gt = (long)blockIdx.x + (long)gridDim.x * wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {   // workgroup-cyclic first: few tiles spread one per CU
         const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
         const int i = min(t * 32 + j, N - 1);
         const bool live = (t * 32 + j) < N;
@@ -130,7 +130,7 @@ kmb_predict(const float* __restrict__ mw, const float* __restrict__ mb, const fl
     const int j = lane & 31, h = lane >> 5;
     const int tps = (N + 31) >> 5;
     const long ntiles = (long)B * tps;
-    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+    for (long gt = (long)blockIdx.x + (long)gridDim.x * wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {   // workgroup-cyclic first: few tiles spread one per CU
         const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
         const int i = min(t * 32 + j, N - 1);
         const bool live = (t * 32 + j) < N;
@@ -190,7 +190,7 @@ kmb_node_encode(const float* __restrict__ mw, const float* __restrict__ mb, cons
     const int j = lane & 31, h = lane >> 5;
     const int tps = (N + 31) >> 5;
     const long ntiles = (long)B * tps;
-    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+    for (long gt = (long)blockIdx.x + (long)gridDim.x * wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {   // workgroup-cyclic first: few tiles spread one per CU
         const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
         const int i = min(t * 32 + j, N - 1);
         const bool live = (t * 32 + j) < N;
@@ -251,7 +251,7 @@ kmb_node_encode(const float* __restrict__ mw, const float* __restrict__ mb, cons
 }
 // below this many 32-row tiles the chunked VALU row kernels of k_backward.h are faster (a workgroup's
 // LDS fill of the packed weights is not amortised)
-#define KMB_MIN_TILES 1024
+#define KMB_MIN_TILES 1          // round 3: the tiles are dealt workgroup-cyclically, so a handful of them (a training batch) runs one per CU
 #define KMB_NODE_ENCODE_LDS ((size_t)(512 + 2 * 4096 + 192) * sizeof(float))
 
 // ---- the whole node / edge part of one rollout step's backward pass in ONE launch (the GD planner) ------------

@@ -1280,7 +1280,7 @@ km_node_encode_split(const uint16_t* __restrict__ sw6, const float* __restrict__
     const int j = lane & 31, h = lane >> 5;
     const int tps = (N + 31) >> 5;
     const long ntiles = (long)B * tps;
-    for (long gt = (long)blockIdx.x * MFMA_WAVES + wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {
+    for (long gt = (long)blockIdx.x + (long)gridDim.x * wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {   // workgroup-cyclic first: few tiles spread one per CU
         asm volatile("" ::: "memory");      // keep the packed-weight reads inside the loop (see km_prop)
         const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
         const int i = min(t * 32 + j, N - 1);
