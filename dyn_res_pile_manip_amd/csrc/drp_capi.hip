@@ -236,6 +236,7 @@ struct drp_ctx {
     DevBuf map_valu, map_mfma, map_mfma_bwd;
     bool repack_maps_ready = false;
     float* w_pin = nullptr;
+    bool wgrad_mfma = true;         // DRP_NO_WGRAD_MFMA=1: the weight gradients' outer-product sums on the VALU kernel (kt_wgrad_multi)
     bool prop_spread = true;        // DRP_NO_PROP_SPREAD=1: km_prop's tiles eight to a workgroup whatever their number
     bool bwd_edge_mfma = true;      // DRP_NO_BWD_EDGE_MFMA=1: the relation encoder's backward on the VALU kernel (kb_edge_encode)
     bool repack_device = true;      // DRP_NO_REPACK_DEVICE=1: fetch the blob and run the host packers (the round-2 path)
@@ -823,7 +824,10 @@ void flush_wgrad(drp_ctx* c) {
         J.j[q].part = static_cast<float*>(c->tr_part.p) + (size_t)q * KT_WGRAD_MAX_BLOCKS * 66 * 64;
         if (J.j[q].blocks > max_blocks) max_blocks = J.j[q].blocks;
     }
-    hipLaunchKernelGGL(kt_wgrad_multi, dim3((unsigned)max_blocks, (unsigned)n), dim3(256), KT_WGRAD_MULTI_LDS, c->stream, J);
+    if (c->wgrad_mfma)
+        hipLaunchKernelGGL(kt_wgrad_mfma_multi, dim3((unsigned)max_blocks, (unsigned)n), dim3(256), KT_WGRAD_MULTI_LDS, c->stream, J);
+    else
+        hipLaunchKernelGGL(kt_wgrad_multi, dim3((unsigned)max_blocks, (unsigned)n), dim3(256), KT_WGRAD_MULTI_LDS, c->stream, J);
     hipLaunchKernelGGL(kt_wgrad_reduce_multi, dim3(66, (unsigned)n), dim3(256), 0, c->stream, J);
     c->wg_jobs.clear();
 }
@@ -975,6 +979,7 @@ int drp_create(int device, drp_ctx** out) {
     c->repack_device = getenv("DRP_NO_REPACK_DEVICE") == nullptr;
     c->bwd_edge_mfma = getenv("DRP_NO_BWD_EDGE_MFMA") == nullptr;
     c->prop_spread = getenv("DRP_NO_PROP_SPREAD") == nullptr;
+    c->wgrad_mfma = getenv("DRP_NO_WGRAD_MFMA") == nullptr;
     if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) { c->rollout_max_n = atoi(e); c->rollout_max_rows = KM_ROLLOUT_MAX_ROWS; }
     if (const char* e = getenv("DRP_ROLLOUT_MAX_ROWS")) c->rollout_max_rows = atoi(e);
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
@@ -1014,6 +1019,7 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)kmb_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kt_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kt_wgrad_mfma_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_UPD_LDS) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);

@@ -213,6 +213,102 @@ kt_wgrad_reduce_multi(WgradJobs J) {
     else if (q.dwd != nullptr) q.dwd[(size_t)lane * q.lane_stride] += t;
 }
 
+// ---- the same outer-product sums on the fp32 matrix cores ----------------------------------------------------------
+// dW^T[k][o] = sum_rows x[row][k] g[row][o] is a GEMM whose contraction runs over the ROWS: v_mfma_f32_32x32x2_f32 with
+// A = x^T (32 input features x 2 rows), B = g (2 rows x 32 output features), so the accumulator's lane columns are
+// consecutive output features -- the [k][o] layout of the partials kt_wgrad_reduce_multi adds up.  A wave takes row pairs
+// (2p, 2p + 1), p = (block * 4 + wave) + 4 * blocks * t; bias and density column ride along as per-lane sums of the B operand.
+// Every sum has a fixed order (the wave's row pairs, the four waves in wave order, the blocks in block order): bit-reproducible,
+// as the VALU kernel -- in another order, so the last bits differ from it (the tests compare with the reference's autograd).
+__global__ void __launch_bounds__(256)
+kt_wgrad_mfma_multi(WgradJobs J) {
+    extern __shared__ float s_part[];                  // [3][66][64]
+    const WgradJob& q = J.j[blockIdx.y];
+    if ((int)blockIdx.x >= q.blocks) return;
+    const int IN = q.in;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const float* __restrict__ g = q.g;
+    const float* __restrict__ x = q.x;
+    const float* __restrict__ dens = q.dwd ? q.dens : nullptr;
+    const bool wide = IN > 32;                         // input features 32 .. 63 exist
+    f32x16 acc[2][2];                                  // [kb: input block][ob: output block]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float accb[2] = {0.0f, 0.0f}, accd[2] = {0.0f, 0.0f};
+    const long npairs = (q.M + 1) >> 1;
+    const long step = (long)q.blocks * 4;
+    // the operands of the next row pair are requested before this pair's MFMAs: a wave's pairs are a chain of L2 round trips otherwise
+    auto fetch = [&](long p, float& g0, float& g1, float& x0, float& x1, float& dv) {
+        const long row = 2 * p + h;
+        const bool on = p < npairs && row < q.M;
+        g0 = on ? g[row * q.ldg + j] : 0.0f;
+        g1 = on ? g[row * q.ldg + 32 + j] : 0.0f;
+        x0 = (on && j < IN) ? x[row * q.ldx + j] : 0.0f;
+        x1 = (on && wide && 32 + j < IN) ? x[row * q.ldx + 32 + j] : 0.0f;
+        dv = (dens != nullptr && on) ? dens[(row / q.rows_per_sample) % q.dens_mod] / DRP_DENS_SCALE : 0.0f;
+    };
+    float g0, g1, x0, x1, dv;
+    long p = (long)blockIdx.x * 4 + wave;
+    fetch(p, g0, g1, x0, x1, dv);
+    for (; p < npairs; p += step) {
+        float ng0, ng1, nx0, nx1, ndv;
+        fetch(p + step, ng0, ng1, nx0, nx1, ndv);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, g0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, g1, acc[0][1], 0, 0, 0);
+        if (wide) {
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, g0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, g1, acc[1][1], 0, 0, 0);
+        }
+        accb[0] += g0; accb[1] += g1;
+        accd[0] = fmaf(g0, dv, accd[0]); accd[1] = fmaf(g1, dv, accd[1]);
+        g0 = ng0; g1 = ng1; x0 = nx0; x1 = nx1; dv = ndv;
+    }
+    // the two half-waves hold the even and the odd rows' bias sums: even + odd, in that order
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+        const float ob_ = __shfl_xor(accb[ob], 32, 64), od_ = __shfl_xor(accd[ob], 32, 64);
+        accb[ob] = (h == 0) ? accb[ob] + ob_ : ob_ + accb[ob];
+        accd[ob] = (h == 0) ? accd[ob] + od_ : od_ + accd[ob];
+    }
+    // accumulator register r of acc[kb][ob] in lane (j, h) = dW^T[k = 32 kb + (r & 3) + 8 (r >> 2) + 4 h][o = 32 ob + j]
+    auto put = [&](float* dst) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dst[(32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + 32 * ob + j] = acc[kb][ob][r];
+        if (h == 0) {
+            dst[64 * 64 + j] = accb[0]; dst[64 * 64 + 32 + j] = accb[1];
+            dst[65 * 64 + j] = accd[0]; dst[65 * 64 + 32 + j] = accd[1];
+        }
+    };
+    if (wave > 0) put(s_part + (size_t)(wave - 1) * 66 * 64);
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float* src = s_part + (size_t)w * 66 * 64;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[kb][ob][r] += src[(32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + 32 * ob + j];
+            accb[0] += src[64 * 64 + j]; accb[1] += src[64 * 64 + 32 + j];
+            accd[0] += src[65 * 64 + j]; accd[1] += src[65 * 64 + 32 + j];
+        }
+        put(q.part + (size_t)blockIdx.x * 66 * 64);
+    }
+}
+
 // column sums of a [M,3] gradient (bias of the predictor's last layer): ONE workgroup, every partial sum in a fixed
 // order (a strided pass per thread, a wave reduction, the waves' sums in wave order) -- the first version added the
 // waves' sums of 16 workgroups with fp32 atomics, the one place where two runs of the same training step could differ
