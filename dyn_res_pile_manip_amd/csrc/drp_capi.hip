@@ -236,6 +236,8 @@ struct drp_ctx {
     DevBuf map_valu, map_mfma, map_mfma_bwd;
     bool repack_maps_ready = false;
     float* w_pin = nullptr;
+    int graph_q4 = 1;               // DRP_GRAPH_Q4=0 / 1 / 2: four threads per receiver in the plain neighbour sweep -- never / for a handful
+                                    // of samples (fewer workgroups than half the CUs) / whenever the plain sweep is chosen
     bool wgrad_mfma = true;         // DRP_NO_WGRAD_MFMA=1: the weight gradients' outer-product sums on the VALU kernel (kt_wgrad_multi)
     bool prop_spread = true;        // DRP_NO_PROP_SPREAD=1: km_prop's tiles eight to a workgroup whatever their number
     bool bwd_edge_mfma = true;      // DRP_NO_BWD_EDGE_MFMA=1: the relation encoder's backward on the VALU kernel (kb_edge_encode)
@@ -476,6 +478,12 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
             hipLaunchKernelGGL(k_graph_strips<GRAPH_THREADS>, dim3(SPREAD_GRID(B * graph_chunks(N))), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N, GRAPH_THREADS), st,
                                (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), B * graph_chunks(N), self_first);
         }
+    }
+    else if (c->graph_q4 != 0 && N >= 64 && (c->graph_q4 == 2 || (long)B * ((N + 127) / 128) * 2 <= c->n_cu)) {
+        // a handful of samples (training batches): four threads per receiver, each over a quarter of the senders
+        const int chunks = (N + 127) / 128;
+        hipLaunchKernelGGL(k_graph_q4, dim3((unsigned)(B * chunks)), dim3(GRAPH_Q4_THREADS), GRAPH_Q4_LDS(N), st, s_prev, prev_mod,
+                           prev_stride, actions, act_stride, s_delta, N, nbr_idx, nbr_cnt, c->cam, c->thr, chunks, self_first);
     }
     else
         hipLaunchKernelGGL(k_graph, dim3(SPREAD_GRID(B * graph_chunks(N))), dim3(GRAPH_THREADS), graph_lds(N), st, s_prev,
@@ -980,6 +988,7 @@ int drp_create(int device, drp_ctx** out) {
     c->bwd_edge_mfma = getenv("DRP_NO_BWD_EDGE_MFMA") == nullptr;
     c->prop_spread = getenv("DRP_NO_PROP_SPREAD") == nullptr;
     c->wgrad_mfma = getenv("DRP_NO_WGRAD_MFMA") == nullptr;
+    if (const char* e = getenv("DRP_GRAPH_Q4")) c->graph_q4 = atoi(e);
     if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) { c->rollout_max_n = atoi(e); c->rollout_max_rows = KM_ROLLOUT_MAX_ROWS; }
     if (const char* e = getenv("DRP_ROLLOUT_MAX_ROWS")) c->rollout_max_rows = atoi(e);
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
@@ -990,6 +999,7 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_SPLIT_SHIFT")) c->re_shift_env = atoi(e);
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_graph_q4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips<GRAPH_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||

@@ -212,6 +212,137 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
     graph_receiver(p4, N, i, thr, self_first, nbr_idx + ((size_t)b * N + i) * DRP_K, nbr_cnt + (size_t)b * N + i);
 }
 
+// ---- the plain sweep for a HANDFUL of samples: four threads per receiver -------------------------------------------
+// k_graph gives a receiver one thread that walks all N senders twice.  With a batch of thousands of samples that is what
+// fills the chip; with a training batch (4 samples of 300 - 1000 particles: a dozen workgroups) it is one long serial walk
+// per thread on an otherwise empty chip -- 57 us per rollout step at 300 particles, 144 us at 1000, a sixth of a training
+// iteration.  Here a workgroup of 512 threads owns the same 128 receivers and thread (r, q) walks only quarter q of the
+// senders (a quarter is wave-uniform: the reads stay broadcasts).  The four partial lists of ten meet in LDS:
+//   1. ten smallest in-radius distances of the own quarter (graph_receiver's first sweep)               -> LDS
+//   2. every thread of a receiver merges the four lists (30 insertions): kth and the tie budget
+//   3. own quarter again: senders strictly nearer than kth, and (separately, up to ten) senders AT kth    -> LDS
+//   4. thread q = 0 walks the quarters in order, merging each quarter's two ascending lists, under graph_receiver's own
+//      emission rule (strictly nearer: in; at kth: while the tie budget lasts; never more than ten) -- the quarters are
+//      ascending index ranges, so the walk meets the senders in ascending index, as the single sweep does.
+// The same lists as k_graph for every input, coincident particles and lattices included (tests/test_gpu_graph_strips.py).
+#define GRAPH_Q4_THREADS 512
+#define GRAPH_Q4_LDS(N) ((size_t)4 * ((N) + 3) * sizeof(float) + (size_t)128 * 4 * 10 * sizeof(float) + (size_t)128 * 4 * 22 * sizeof(int16_t))
+__global__ void __launch_bounds__(GRAPH_Q4_THREADS)
+k_graph_q4(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
+           const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
+           int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks, int self_first) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* p4 = reinterpret_cast<float4*>(lds);                       // [N] displaced positions
+    float* bestq = lds + 4 * ((N + 3) & ~3);                           // [128][4][10]
+    int16_t* listq = reinterpret_cast<int16_t*>(bestq + 128 * 4 * 10); // [128][4][22]: 10 strict, 10 ties, 2 counts
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const float* s = s_prev + (size_t)(b % prev_mod) * prev_stride;
+    float* sd = s_delta + (size_t)b * N * 3;
+    if (actions != nullptr) {
+        const PushFrame f = push_frame(cam, actions + (size_t)b * act_stride);
+        for (int i = threadIdx.x; i < N; i += GRAPH_Q4_THREADS) {
+            float x = s[i * 3 + 0], y = s[i * 3 + 1], z = s[i * 3 + 2];
+            float ox, oy, oz;
+            push_delta(f, x, y, z, ox, oy, oz);
+            if (chunk == 0) { sd[i * 3 + 0] = ox; sd[i * 3 + 1] = oy; sd[i * 3 + 2] = oz; }
+            p4[i] = make_float4(__fadd_rn(x, ox), __fadd_rn(y, oy), __fadd_rn(z, oz), 0.0f);
+        }
+    } else {
+        for (int i = threadIdx.x; i < N; i += GRAPH_Q4_THREADS)
+            p4[i] = make_float4(__fadd_rn(s[i * 3 + 0], sd[i * 3 + 0]), __fadd_rn(s[i * 3 + 1], sd[i * 3 + 1]),
+                                __fadd_rn(s[i * 3 + 2], sd[i * 3 + 2]), 0.0f);
+    }
+    __syncthreads();
+    const int r = threadIdx.x & 127, q = threadIdx.x >> 7;
+    const int i = chunk * 128 + r;
+    const bool have = i < N;
+    const int nq = (((N + 3) >> 2) + 3) & ~3;                          // senders per quarter, a multiple of 4
+    const int lo = min(q * nq, N), hi = min(lo + nq, N);
+    const float4 pi = p4[have ? i : 0];
+    float best[DRP_K];
+#pragma unroll
+    for (int t = 0; t < DRP_K; ++t) best[t] = thr;
+    {
+        int j = lo;
+        for (; j + 4 <= hi; j += 4) {
+            const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
+            const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
+                                 pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int t = DRP_K - 1; t > 0; --t) best[t] = __builtin_amdgcn_fmed3f(d4[u], best[t - 1], best[t]);
+                best[0] = min_nonneg(d4[u], best[0]);
+            }
+        }
+        for (; j < hi; ++j) {
+            const float4 pj = p4[j];
+            const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
+#pragma unroll
+            for (int t = DRP_K - 1; t > 0; --t) best[t] = __builtin_amdgcn_fmed3f(d, best[t - 1], best[t]);
+            best[0] = min_nonneg(d, best[0]);
+        }
+    }
+    float* mine = bestq + (r * 4 + q) * 10;
+#pragma unroll
+    for (int t = 0; t < DRP_K; ++t) mine[t] = best[t];
+    __syncthreads();
+    // 2. the other three quarters' lists into this one (every thread of the receiver: no broadcast needed afterwards)
+#pragma unroll
+    for (int o = 1; o < 4; ++o) {
+        const float* other = bestq + (r * 4 + ((q + o) & 3)) * 10;
+#pragma unroll
+        for (int t2 = 0; t2 < DRP_K; ++t2) {
+            const float d = other[t2];
+#pragma unroll
+            for (int t = DRP_K - 1; t > 0; --t) best[t] = __builtin_amdgcn_fmed3f(d, best[t - 1], best[t]);
+            best[0] = min_nonneg(d, best[0]);
+        }
+    }
+    const float kth = best[DRP_K - 1];
+    const int skip = (self_first && thr > 0.0f) ? i : -1;
+    // 3. the own quarter's senders: strictly nearer than kth / at kth (the first ten of either are all that can matter)
+    int16_t* ls = listq + (r * 4 + q) * 22;
+    int ns = 0, nt = 0;
+    for (int j = lo; j < hi; ++j) {
+        const float4 pj = p4[j];
+        const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
+        if (d <= kth && __fsub_rn(d, thr) < 0.0f && j != skip) {
+            if (d < kth) { if (ns < DRP_K) ls[ns++] = (int16_t)j; }
+            else if (nt < DRP_K) ls[10 + nt++] = (int16_t)j;
+        }
+    }
+    ls[20] = (int16_t)ns;
+    ls[21] = (int16_t)nt;
+    __syncthreads();
+    if (q != 0 || !have) return;
+    // 4. graph_receiver's emission rule over the four quarters in order
+    int16_t* out = nbr_idx + ((size_t)b * N + i) * DRP_K;
+    int cnt = 0;
+    int ties_left = DRP_K;
+#pragma unroll
+    for (int t = 0; t < DRP_K - 1; ++t) ties_left -= (best[t] < kth) ? 1 : 0;
+    if (skip >= 0) {
+        out[cnt++] = (int16_t)i;
+        if (!(0.0f < kth)) --ties_left;
+    }
+    for (int qq = 0; qq < 4; ++qq) {
+        const int16_t* l = listq + (r * 4 + qq) * 22;
+        const int n_s = l[20], n_t = l[21];
+        int a = 0, t = 0;
+        while ((a < n_s || t < n_t) && cnt < DRP_K) {
+            const bool take_s = a < n_s && (t >= n_t || l[a] < l[10 + t]);
+            if (take_s) out[cnt++] = l[a++];
+            else {
+                if (ties_left > 0) { out[cnt++] = l[10 + t]; --ties_left; }
+                ++t;
+            }
+        }
+    }
+    nbr_cnt[(size_t)b * N + i] = (uint8_t)cnt;
+    for (int t = cnt; t < DRP_K; ++t) out[t] = -1;
+}
+
 // ---- the same lists with the senders bucketed into x strips --------------------------------------------
 // An edge needs |dx| < radius, so a receiver only has to look at senders whose x is within the radius of
 // its own.  k_graph_sort (one workgroup per sample) writes the sample's displaced positions into 64 fixed

@@ -117,3 +117,51 @@ def test_cells_on_the_reference_cases(monkeypatch, golden):
     finally:
         for e in engs.values():
             e.close()
+
+
+@pytest.mark.parametrize('N,B,kind', [(64, 3, 'uniform'), (129, 2, 'uniform'), (300, 4, 'uniform'), (300, 4, 'blob'), (515, 2, 'lattice'),
+                                      (1000, 4, 'padded'), (257, 3, 'dupes'), (4096, 1, 'uniform'), (130, 5, 'padded')])
+def test_four_threads_per_receiver_give_the_plain_sweeps_lists(monkeypatch, N, B, kind):
+    """k_graph_q4 (a handful of samples: four threads per receiver, each over a quarter of the senders, the partial
+    lists merged in LDS) against k_graph, bit for bit, in both emission orders -- jittered piles, a lattice (exact
+    distance ties at the cut), clusters of coincident particles, and zero-padded training batches (hundreds of
+    coincident padding rows: every one of them ties with every other at distance 0)."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    rng = np.random.default_rng(N + B)
+    if kind == 'lattice':
+        g = int(np.ceil(np.sqrt(N)))
+        xy = np.stack(np.meshgrid(np.arange(g), np.arange(g)), -1).reshape(-1, 2)[:N].astype(np.float32) * 0.03 - 0.2
+        s0 = np.concatenate([xy, np.full((N, 1), 0.75, np.float32)], 1)[None]
+    elif kind == 'dupes':
+        base, _, _ = syn.make_pile(max(N // 8, 1), 1, seed=N)
+        s0 = np.repeat(base, 8, axis=1)[:, :N]
+        if s0.shape[1] < N:
+            s0 = np.concatenate([s0, s0[:, :N - s0.shape[1]]], 1)
+    else:
+        s0, _, _ = syn.make_pile(N, 1, seed=N, kind='blob' if kind == 'blob' else 'uniform')
+    s = np.tile(s0, (B, 1, 1)).astype(np.float32)
+    sd = np.zeros_like(s) if kind in ('lattice', 'dupes') else (0.004 * rng.standard_normal(s.shape)).astype(np.float32)
+    if kind == 'padded':
+        for b in range(B):
+            n_b = int(rng.integers(N // 3, N))
+            s[b, n_b:] = 0.0                       # collate_fn's zero rows: coincident particles at the camera origin
+            sd[b, n_b:] = 0.0
+    blob = weights.blob_from_state_dict(weights.random_state_dict(seed=0))
+    M34 = world2cam_affine(syn.demo_cam_extrinsics())
+    acts = syn.sample_pushes(B, 1, seed=N)
+    res = {}
+    for mode in ('0', '2'):
+        monkeypatch.setenv('DRP_NO_GRAPH_STRIPS', '1')
+        monkeypatch.setenv('DRP_NO_ROLLOUT_FUSED', '1')
+        monkeypatch.setenv('DRP_GRAPH_Q4', mode)
+        eng = Engine(0)
+        eng.load_weights(blob, 0.08)
+        eng.set_camera(M34, 24.0, syn.demo_cam_params())
+        idx, cnt = eng.build_graph(s, sd)                                  # ascending sender order
+        st, _ = eng.rollout(s0.astype(np.float32), np.zeros((1, N), np.float32), np.array([N / 0.16], np.float32), acts)
+        res[mode] = (idx, cnt, eng.debug_fetch('nbr_idx', (B, N, 10), np.int16), eng.debug_fetch('nbr_cnt', (B, N), np.uint8),
+                     eng.debug_fetch('s_delta', (B, N, 3)), st)           # self loop first, impulses from the push
+        eng.close()
+    for a, b in zip(res['0'], res['2']):
+        assert np.array_equal(a, b)
+    assert res['2'][1].max() <= 10 and res['2'][1].min() >= 1
