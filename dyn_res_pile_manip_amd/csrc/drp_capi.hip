@@ -159,6 +159,24 @@ struct drp_ctx {
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
     bool bwd_fused = true;          // DRP_NO_BWD_FUSED=1: the GD planner's backward pass as one launch per stage
     bool prop3_order = true;        // DRP_NO_PROP3_ORDER=1: km_prop3's tiles in the natural row order instead of by in-degree
+    int prop_pair_rows = 128;       // DRP_PROP_PAIR_ROWS: a workgroup of the whole-sample kernels with up to so many rows runs tiles of
+                                    // 16 receivers x two slots (0 = never)
+    int prop_pair_always = 64;      // DRP_PROP_PAIR_ALWAYS: ... whatever the in-degrees up to so many rows (four tiles of 16: a SIMD each),
+    int prop_pair_deg10 = 83;       // DRP_PROP_PAIR_DEG10: above that while the piles' mean in-degree (x 10) is at most this
+    // the mean in-degree the last lists of this shape had (k_deg_stat, every few launches): sum | rows << 24 | N << 48 in
+    // host memory the device writes; only ever a question of speed -- paired and unpaired tiles give the same bits
+    unsigned long long* deg_stat = nullptr;
+    unsigned long long* deg_stat_dev = nullptr;
+    unsigned deg_tick = 0;
+    bool prop_pair(long spw, long N, long B) const {
+        const long rows = spw * N;
+        if (rows > prop_pair_rows) return false;
+        if (rows <= prop_pair_always || deg_stat == nullptr) return true;
+        const unsigned long long v = *reinterpret_cast<volatile const unsigned long long*>(deg_stat);
+        const long sum = (long)(v & 0xffffffull), st_rows = (long)((v >> 24) & 0xffffffull), st_n = (long)(v >> 48);
+        if (st_n != N || st_rows != std::min(B * N, (long)DEG_STAT_MAX_ROWS) || st_rows == 0) return true;   // not known (yet)
+        return sum * 10 <= st_rows * (long)prop_pair_deg10;
+    }
     bool prop3e = true;             // DRP_NO_PROP3E=1: the particle encoder stays its own launch in front of km_prop3
     bool rollout_fused = true;      // DRP_NO_ROLLOUT_FUSED=1: one graph + one km_prop3 launch per rollout step for small piles too
     int rollout_max_n = 64;         // DRP_ROLLOUT_MAX_N: km_rollout (the whole rollout in one launch) up to this many particles ...
@@ -400,6 +418,30 @@ int ensure_step_ws(drp_ctx* c, int B, int N) {
     return DRP_OK;
 }
 
+// Every few launches whose pairing depends on it (prop_pair), the mean in-degree of the lists just built goes to host
+// memory behind the launch: the next launches of this shape read it there, without waiting for anything.
+static void note_degrees(drp_ctx* c, long spw, long N, long B) {
+    const long rows = spw * N;
+    if (rows > c->prop_pair_rows || rows <= c->prop_pair_always) return;
+    if ((c->deg_tick++ & 7u) != 0) return;
+    if (!c->deg_stat) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&c->deg_stat), sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) {
+            c->deg_stat = nullptr;
+            (void)hipGetLastError();
+            return;
+        }
+        *c->deg_stat = 0ull;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->deg_stat_dev), c->deg_stat, 0) != hipSuccess) {
+            (void)hipHostFree(c->deg_stat);
+            c->deg_stat = nullptr;
+            (void)hipGetLastError();
+            return;
+        }
+    }
+    hipLaunchKernelGGL(k_deg_stat, dim3(1), dim3(1024), 0, c->stream, ptr<uint8_t>(c->nbr_cnt),
+                       (int)std::min(B * N, (long)DEG_STAT_MAX_ROWS), (int)N, c->deg_stat_dev);
+}
+
 struct StepArgs {
     const float* s_prev; int prev_mod; size_t prev_stride;   // state read by sample b: row b % prev_mod
     const float* attr; int attr_mod;
@@ -581,9 +623,13 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
 #define PROP3_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
                    a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, pb, \
                    ptr<float>(c->c_node), eff_base, N, B, spw, phase_e ? (const float*)ptr<float>(c->s_delta) : (const float*)nullptr, \
-                   a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist, c->re_scale, c->re_inv, c->prop3_order ? 1 : 0
-            if (!tape) hipLaunchKernelGGL((km_prop3<false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
-            else hipLaunchKernelGGL((km_prop3<true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
+                   a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist, c->re_scale, c->re_inv, (c->prop3_order ? 1 : 0)
+            const bool pair = c->prop_pair(spw, N, B);
+            note_degrees(c, spw, N, B);
+            if (!tape && !pair) hipLaunchKernelGGL((km_prop3<false, false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
+            else if (!tape) hipLaunchKernelGGL((km_prop3<false, true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
+            else if (!pair) hipLaunchKernelGGL((km_prop3<true, false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
+            else hipLaunchKernelGGL((km_prop3<true, true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
 #undef PROP3_ARGS
         }
         for (int p = 0; p < DRP_PSTEP && !prop3; ++p) {
@@ -592,7 +638,10 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             long pb_ = (node_tiles + PROP_WAVES - 1) / PROP_WAVES;
             // few tiles (up to four per CU): one per workgroup first, so that a tile has its SIMD to itself
             const int spread = (c->prop_spread && node_tiles <= 4L * c->n_cu) ? 1 : 0;
-            if (spread) pb_ = node_tiles;
+            // fewer still (up to two per CU): tiles of 16 receivers x two slots, half the slot iterations each
+            const long tiles16 = (long)B * ((N + 15) / 16);
+            const bool pair = spread && c->prop_pair_rows > 0 && node_tiles <= 2L * c->n_cu;
+            if (spread) pb_ = pair ? tiles16 : node_tiles;
             const dim3 grid((unsigned)(pb_ < c->n_cu ? pb_ : c->n_cu)), pblk(64 * PROP_WAVES);
             const float* eff_in = tape ? a.eff_hist + (size_t)p * bn64 : ptr<float>(c->eff);
             float* eff_out = tape ? a.eff_hist + (size_t)(p + 1) * bn64 : ptr<float>(c->eff);
@@ -602,13 +651,17 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                   a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, \
                   ptr<float>(c->c_node), eff_in, eff_out, N, B, pb, a.s_out, a.out_stride, a.cself, a.cself_ok, mask_out, agg_out, \
                   c->re_scale, c->re_inv, spread
-            if (!tape) {
-                if (!last) hipLaunchKernelGGL((km_prop<false, false>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS);
-                else hipLaunchKernelGGL((km_prop<true, false>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS);
-            } else {
-                if (!last) hipLaunchKernelGGL((km_prop<false, true>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS);
-                else hipLaunchKernelGGL((km_prop<true, true>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS);
-            }
+#define PROP_LAUNCH(PAIR_) do { \
+                if (!tape) { \
+                    if (!last) hipLaunchKernelGGL((km_prop<false, false, PAIR_>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS); \
+                    else hipLaunchKernelGGL((km_prop<true, false, PAIR_>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS); \
+                } else { \
+                    if (!last) hipLaunchKernelGGL((km_prop<false, true, PAIR_>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS); \
+                    else hipLaunchKernelGGL((km_prop<true, true, PAIR_>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS); \
+                } } while (0)
+            if (pair) PROP_LAUNCH(true);
+            else PROP_LAUNCH(false);
+#undef PROP_LAUNCH
 #undef PROP_ARGS
             float* tmp = pa; pa = pb; pb = tmp;
         }
@@ -741,7 +794,7 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
         ra.actions = ptr<float>(c->actions); ra.s_delta = ptr<float>(c->s_delta); ra.nbr_idx = ptr<int16_t>(c->nbr_idx);
         ra.nbr_cnt = ptr<uint8_t>(c->nbr_cnt); ra.proj_a = ptr<float>(c->proj); ra.proj_b = ptr<float>(c->proj2);
         ra.c_node = ptr<float>(c->c_node); ra.eff = ptr<float>(c->eff); ra.cself = cself; ra.cself_ok = cself_ok;
-        ra.N = N; ra.B = B; ra.spw = spw_r; ra.nb = nb; ra.H = H; ra.order_rows = c->prop3_order ? 1 : 0;
+        ra.N = N; ra.B = B; ra.spw = spw_r; ra.nb = nb; ra.H = H; ra.order_rows = (c->prop3_order ? 1 : 0);
         ra.thr = c->thr; ra.re_scale = c->re_scale; ra.re_inv = c->re_inv; ra.cam = c->cam;
         // the argument block sits in device memory; it is uploaded when it changes (every iteration of an MPC session
         // passes the same one), behind whatever still runs on the stream
@@ -752,9 +805,14 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
             c->roll_args_valid = true;
         }
         ProbeScope ps(c, KC_PROP);
-        hipLaunchKernelGGL(km_rollout, dim3((unsigned)((B + spw_r - 1) / spw_r)), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS, c->stream,
-                           ptr<RolloutArgs>(c->roll_args));
+        if (c->prop_pair(spw_r, N, B))
+            hipLaunchKernelGGL(km_rollout<true>, dim3((unsigned)((B + spw_r - 1) / spw_r)), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS,
+                               c->stream, ptr<RolloutArgs>(c->roll_args));
+        else
+            hipLaunchKernelGGL(km_rollout<false>, dim3((unsigned)((B + spw_r - 1) / spw_r)), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS,
+                               c->stream, ptr<RolloutArgs>(c->roll_args));
         HIPCHK(c, hipGetLastError());
+        note_degrees(c, spw_r, N, B);           // the last step's lists
     }
     for (int t = 0; t < H && !one_launch; ++t) {
         StepArgs a{};
@@ -992,6 +1050,9 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) { c->rollout_max_n = atoi(e); c->rollout_max_rows = KM_ROLLOUT_MAX_ROWS; }
     if (const char* e = getenv("DRP_ROLLOUT_MAX_ROWS")) c->rollout_max_rows = atoi(e);
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
+    if (const char* e = getenv("DRP_PROP_PAIR_ROWS")) c->prop_pair_rows = std::max(0, atoi(e));
+    if (const char* e = getenv("DRP_PROP_PAIR_ALWAYS")) c->prop_pair_always = std::max(0, atoi(e));
+    if (const char* e = getenv("DRP_PROP_PAIR_DEG10")) c->prop_pair_deg10 = std::max(0, atoi(e));
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
     if (const char* e = getenv("DRP_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_timeout_s = v; }
@@ -1019,13 +1080,20 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_node_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_edge_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_SPLIT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_node_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_SPLIT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kt_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||
@@ -1068,6 +1136,7 @@ void drp_destroy(drp_ctx* c) {
         if (c->mpc_ev[q]) (void)hipEventDestroy(c->mpc_ev[q]);
     }
     if (c->w_pin) (void)hipHostFree(c->w_pin);
+    if (c->deg_stat) (void)hipHostFree(c->deg_stat);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -982,3 +982,24 @@ k_graph_cells(const float4* __restrict__ sorted, const int* __restrict__ starts,
     nbr_cnt[(size_t)b * N + i] = (uint8_t)w;
     for (int q = w; q < DRP_K; ++q) out[q] = -1;
 }
+
+// ---- mean in-degree of a batch's lists, for the host's choice between paired and unpaired tiles (prop_pair, drp_capi.hip)
+// one workgroup; out (host memory the device can write) = sum | rows << 24 | N << 48 in ONE 64-bit store
+#define DEG_STAT_MAX_ROWS 65536
+__global__ void __launch_bounds__(1024)
+k_deg_stat(const uint8_t* __restrict__ nbr_cnt, int rows, int N, unsigned long long* __restrict__ out) {
+    __shared__ int part[16];
+    int s = 0;
+    for (int r = threadIdx.x; r < rows; r += 1024) s += nbr_cnt[r];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        *out = (unsigned long long)(unsigned)t | ((unsigned long long)(unsigned)rows << 24) | ((unsigned long long)(unsigned)N << 48);
+        __threadfence_system();
+    }
+}
+

@@ -570,8 +570,18 @@ struct LaneRow {
     bool live;                // false: a clamped duplicate past the end (computed, never stored)
 };
 
-template <bool LAST, bool TAPE, class Decode, class RowOf>
-__device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, Decode decode, RowOf row_of, int lane, int wave
+// PAIR: a tile is 16 receivers, and the 32 item columns of the chain are 16 receivers x two CONSECUTIVE slots -- column j
+// belongs to receiver (j & 7) + 8 (j >> 4) and runs the slots of parity (j >> 3) & 1 -- so that a tile needs half the
+// slot iterations.  For batches of so few rows that most waves of the chip would have no tile at all (a workgroup's 128
+// rows are four tiles of 32 for eight waves; a training batch is one tile per CU) this halves the dependent chain that a
+// tile's latency is made of.  The receiver's lane adds its own column's term, then its partner's (eight lanes on, the
+// same DPP row: `row_ror:8` inside the add): slot k before slot k + 1, the order of the unpaired loop -- the same bits.
+__device__ __forceinline__ float dpp_ror8(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));
+}
+template <bool LAST, bool TAPE, bool PAIR, class First, class Decode, class RowOf>
+__device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, First first_of /* this wave's first tile */,
+                                           Decode decode /* the others: draws from the workgroup's queue */, RowOf row_of, int lane
 #ifdef PROP_STAMPS
                                            , unsigned long long (&st_sum)[8]
 #endif
@@ -589,6 +599,9 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
     const f16x8* wsp = L.wsp;
     const float* rows = L.rows;
     const int j = lane & 31, h = lane >> 5;
+    const int jr = PAIR ? ((j & 7) | ((j >> 4) << 3)) : j;      // the tile's receiver this column works for
+    const int par = PAIR ? ((j >> 3) & 1) : 0;                  // and which of an iteration's slots it runs
+    constexpr int KS = PAIR ? 2 : 1;
     // attr_mod == dens_mod (n_batch or B) for every caller; s_mod is one of the two as well
     const float inv_mod = 1.0f / (float)attr_mod;
     const bool s_by_sample = s_mod != attr_mod;            // states of a running rollout: one block per sample
@@ -622,7 +635,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
     };
     auto tile_head = [&](const TileId& id) {
         TileHead hd;
-        hd.lr = row_of(id, j);
+        hd.lr = row_of(id, jr);
         const int b = hd.lr.b, i = hd.lr.i;
         const size_t row = (size_t)b * N + i;
         hd.bs = bases_of(b);
@@ -639,14 +652,26 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         int ks, j0, j1;
         float p0x, p0y, p0z, p0a;
     };
-    auto tile_first = [&](const TileHead& hd) {
+    // PAIR: neighbours 4 and 5 of the head (a column's second slot can be slot 4), requested with it; kept beside the
+    // struct, whose layout the unpaired kernels' register allocation hangs on
+    auto head_nbw2 = [&](const TileHead& hd) {
+        return reinterpret_cast<const unsigned*>(nbr_idx + ((size_t)hd.lr.b * N + hd.lr.i) * DRP_K)[2];
+    };
+    auto tile_first = [&](const TileHead& hd, unsigned nbw2) {
         const int i = hd.lr.i;
         const int nb0 = (int)(hd.nbw0 & 0xffffu), nb1 = (int)(hd.nbw0 >> 16), nb2 = (int)(hd.nbw1 & 0xffffu);
         TileFirst f;
         // self slot first (k_graph self_first) and a per-sample self-edge constant: the self loop is skipped
         f.ks = __all(hd.ok && hd.cnt > 0 && nb0 == i) ? 1 : 0;
-        f.j0 = (f.ks < hd.cnt) ? (f.ks ? nb1 : nb0) : i;
-        f.j1 = (f.ks + 1 < hd.cnt) ? (f.ks ? nb2 : nb1) : i;
+        if (!PAIR) {
+            f.j0 = (f.ks < hd.cnt) ? (f.ks ? nb1 : nb0) : i;
+            f.j1 = (f.ks + 1 < hd.cnt) ? (f.ks ? nb2 : nb1) : i;
+        } else {                                          // this column's first two slots: ks + par, ks + par + 2
+            const int nb3 = (int)(hd.nbw1 >> 16), nb4 = (int)(nbw2 & 0xffffu);
+            const int s0 = f.ks + par;                    // 0 .. 2
+            f.j0 = (s0 < hd.cnt) ? (s0 == 0 ? nb0 : (s0 == 1 ? nb1 : nb2)) : i;
+            f.j1 = (s0 + 2 < hd.cnt) ? (s0 == 0 ? nb2 : (s0 == 1 ? nb3 : nb4)) : i;
+        }
         f.p0x = hd.bs.s[f.j0 * 3 + 0]; f.p0y = hd.bs.s[f.j0 * 3 + 1]; f.p0z = hd.bs.s[f.j0 * 3 + 2]; f.p0a = hd.bs.at[f.j0];
         return f;
     };
@@ -654,18 +679,21 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
     // waves of a SIMD do not advance evenly (tools/prop_stamps.py: with five tiles each the first wave of the
     // chip was done at 0.7 of the last one's time, and a SIMD with one wave left runs at about 0.6 of its
     // two-wave rate); on demand the waves end within 10 us of each other.
-    TileId cur = decode(wave), nxt = {false, 0, 0};
+    TileId cur = first_of(), nxt = {false, 0, 0};
     TileHead hd_next = {};
     TileFirst tf_next = {};
+    unsigned nbw2_next = 0u;
     if (cur.valid) {
         hd_next = tile_head(cur);
-        tf_next = tile_first(hd_next);
+        if (PAIR) nbw2_next = head_nbw2(hd_next);
+        tf_next = tile_first(hd_next, nbw2_next);
     }
     for (; cur.valid; cur = nxt) {
         const TileHead hd = hd_next;
         const TileFirst tf = tf_next;
         const int b = hd.lr.b, i = hd.lr.i;
-        const bool live = hd.lr.live;
+        const bool live_row = hd.lr.live;
+        const bool live = PAIR ? (live_row && par == 0) : live_row;   // the lanes that hold a receiver's aggregate
         const float* s = hd.bs.s;
         const float* at = hd.bs.at;
         const float d = hd.bs.d;
@@ -718,7 +746,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         int st_slots = 0;
 #endif
 #pragma unroll 1
-        for (int k = ks; k < DRP_K; ++k) {
+        for (int k = ks + par; k < DRP_K + par; k += KS) {     // k: this column's slot (PAIR: k may reach DRP_K, a padded slot)
             if (__all(k >= cnt)) break;              // no receiver of this tile has a slot k
 #ifdef PROP_STAMPS
             ++st_slots;
@@ -726,7 +754,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             asm volatile("" ::: "memory");          // keep the packed-weight reads inside the loop
             const int jcur = j0;
             const float p1x = s[j1 * 3 + 0], p1y = s[j1 * 3 + 1], p1z = s[j1 * 3 + 2], p1a = at[j1];
-            const int j2 = (k + 2 < cnt) ? (int)nb[min(k + 2, DRP_K - 1)] : i;
+            const int j2 = (k + 2 * KS < cnt) ? (int)nb[min(k + 2 * KS, DRP_K - 1)] : i;
             float x[8];
             x[0] = pia; x[1] = p0a;
             x[2] = pix - p0x; x[3] = piy - p0y; x[4] = piz - p0z;
@@ -755,8 +783,17 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             if (!TAPE) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    acc.v[0][r] += relu1(fmaf(c.v[0][r], inv, sv.v[0][r]));
-                    acc.v[1][r] += relu1(fmaf(c.v[1][r], inv, sv.v[1][r]));
+                    if (!PAIR) {
+                        acc.v[0][r] += relu1(fmaf(c.v[0][r], inv, sv.v[0][r]));
+                        acc.v[1][r] += relu1(fmaf(c.v[1][r], inv, sv.v[1][r]));
+                    } else {
+                        const float t0 = relu1(fmaf(c.v[0][r], inv, sv.v[0][r]));
+                        const float t1 = relu1(fmaf(c.v[1][r], inv, sv.v[1][r]));
+                        acc.v[0][r] += t0;
+                        acc.v[1][r] += t1;
+                        acc.v[0][r] += dpp_ror8(t0);
+                        acc.v[1][r] += dpp_ror8(t1);
+                    }
                 }
             } else {
 #pragma unroll
@@ -765,8 +802,12 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
                     c.v[1][r] = relu1(fmaf(c.v[1][r], inv, sv.v[1][r]));
                     acc.v[0][r] += c.v[0][r];
                     acc.v[1][r] += c.v[1][r];
+                    if (PAIR) {
+                        acc.v[0][r] += dpp_ror8(c.v[0][r]);
+                        acc.v[1][r] += dpp_ror8(c.v[1][r]);
+                    }
                 }
-                if (live) mask_out[(row * DRP_K + k) * 2 + h] = frag_positive_bits(c);
+                if (live_row && (!PAIR || k < DRP_K)) mask_out[(row * DRP_K + k) * 2 + h] = frag_positive_bits(c);
             }
             j0 = j1; j1 = j2;
             p0x = p1x; p0y = p1y; p0z = p1z; p0a = p1a;
@@ -783,6 +824,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         }
         const bool more = nxt.valid;
         if (more) hd_next = tile_head(nxt);
+        if (PAIR && more) nbw2_next = head_nbw2(hd_next);
         __builtin_amdgcn_sched_barrier(0);
         Frag e;
         {
@@ -800,7 +842,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         if (live) frag_to_row(eff + row * 64, h, e);
         split_frag6(e, f6);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) tf_next = tile_first(hd_next);          // the head has landed by now
+        if (more) tf_next = tile_first(hd_next, nbw2_next);          // the head has landed by now
         __builtin_amdgcn_sched_barrier(0);
         if (!LAST) {
             Frag p;
@@ -853,7 +895,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
 #define PROP_STAMPS_ARG
 #endif
 
-template <bool LAST, bool TAPE>
+template <bool LAST, bool TAPE, bool PAIR /* tiles of 16 receivers x two slots (prop_tiles); with `spread` only */>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
         const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -885,7 +927,8 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     if (threadIdx.x == 0) *tile_ctr = PROP_WAVES;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tps = (N + 31) >> 5;
+    constexpr int tile_rows = PAIR ? 16 : 32;
+    const int tps = PAIR ? (N + 15) >> 4 : (N + 31) >> 5;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
     // one and its L2), so the tiles of a sample -- which gather the same ~150 KB of sender rows -- all go
     // to workgroups of one residue class of blockIdx.  A placement guess only: wrong means slower, not wrong.
@@ -925,15 +968,15 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
                         N, B, proj_next, s_out, out_stride, cself, cself_ok, mask_out, agg_out, re_scale, re_inv};
     const PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
                        reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
-    // a tile = 32 consecutive receivers of one sample
+    // a tile = 32 (PAIR: 16) consecutive receivers of one sample
     auto row_of = [&](const TileId& id, int j) {
         LaneRow r;
         r.b = id.b;
-        r.live = (id.t * 32 + j) < N;
-        r.i = min(id.t * 32 + j, N - 1);
+        r.live = (id.t * tile_rows + j) < N;
+        r.i = min(id.t * tile_rows + j, N - 1);
         return r;
     };
-    prop_tiles<LAST, TAPE>(A, L, decode, row_of, lane, wave PROP_STAMPS_ARG);
+    prop_tiles<LAST, TAPE, PAIR>(A, L, [&]() { return decode(wave); }, decode, row_of, lane PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS
     st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
     st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // all tiles of this wave
@@ -1005,7 +1048,7 @@ __device__ __forceinline__ void prop3_fill_resident(const Prop3Lds& P, const uin
 // three propagation steps, the last one writing s_out.  On entry the resident part of LDS is filled (or being filled:
 // `entry_sync` = the caller has not synchronised since) and the edge-chain region holds nothing this function relies
 // on; on exit every wave has passed its last tile (no barrier after it).
-template <bool TAPE>
+template <bool TAPE, bool PAIR>
 __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6,
                                            const float* __restrict__ mw,
                                            const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1046,7 +1089,13 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
     const int lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * spw, nb = min(spw, B - b0);
     const int wg_rows = (nb > 0 ? nb : 0) * N;       // this workgroup's receivers: rows b0*N .. b0*N + wg_rows
-    const int wg_tiles = (wg_rows + 31) >> 5;
+    const int enc_tiles = (wg_rows + 31) >> 5;
+    // PAIR (the host's choice for a launch whose workgroups hold up to four tiles of 32 rows for their eight waves, see
+    // prop_pair() in drp_capi.hip): the propagation steps run tiles of 16 receivers x two slots (prop_tiles) -- twice
+    // the waves at work, half the slot iterations each.  A kernel of its own: the register allocation of the other one
+    // is not to move, and both tile loops in one kernel with a per-workgroup choice run 15 % slower, either of them.
+    constexpr int tile_rows = PAIR ? 16 : 32;
+    const int wg_tiles = PAIR ? (wg_rows + 15) >> 4 : enc_tiles;
     const float inv_N = 1.0f / (float)N;
     if (phase_e) {
         // ---- phase E: the particle encoder over this workgroup's rows (km_node_encode_split's arithmetic per row)
@@ -1055,7 +1104,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
         const bf16x8* wpe0 = reinterpret_cast<const bf16x8*>(pe0_f);
         const int j = lane & 31, h = lane >> 5;
         const float inv_mod = 1.0f / (float)attr_mod;
-        for (int li = wave; li < wg_tiles;) {
+        for (int li = wave; li < enc_tiles;) {
             asm volatile("" ::: "memory");
             const bool live = (li * 32 + j) < wg_rows;
             const int r = min(li * 32 + j, wg_rows - 1);
@@ -1157,9 +1206,27 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
     __syncthreads();
     ROLL_STAMP(6);                                   // edge-chain weights back in LDS, rows ordered
     // Waves w and w + 4 of a workgroup share a SIMD (tools/hwid.hip).  With no more tiles than waves every wave runs one
-    // tile per step, and in the in-degree order tile t is heavier than tile t + 1: waves 4 ... 7 take the tiles from the
-    // light end, so that a SIMD gets a heavy and a light one (4 x 50 particles, 7 tiles: 0 + 6, 1 + 5, 2 + 4, 3 instead
-    // of 0 + 4, 1 + 5, 2 + 6, 3).  With more tiles than waves the queue hands them out heaviest first as before.
+    // tile per step, and in the in-degree order tile t is heavier than tile t + 1.  A slot iteration takes 2.2 us with
+    // the SIMD to itself and 3.3 us next to another wave's, so a SIMD with tiles of a >= b slots needs about
+    // 2.2 a + 1.1 b: the 8 - wg_tiles heaviest tiles keep their SIMD to themselves and waves 4 ... 7 take the rest from
+    // the light end, the lightest next to the heaviest that gets company at all (4 x 50 particles, 7 tiles: 0, 1 + 6,
+    // 2 + 5, 3 + 4; eight tiles: 0 + 7, 1 + 6, 2 + 5, 3 + 4).  With more tiles than waves the queue hands them out
+    // heaviest first as before.
+    auto first_of = [&]() {
+        TileId first;
+        first.b = b0;
+        first.t = wave;
+        first.valid = wave < wg_tiles;
+        if (ordered && wg_tiles <= PROP_WAVES && wave >= PROP_WAVES / 2) {
+            const int sd = wave - PROP_WAVES / 2, alone = PROP_WAVES - wg_tiles;     // SIMDs 0 .. alone - 1 run one tile
+            first.t = wg_tiles - 1 - (sd - alone);
+            first.valid = sd >= alone && first.t >= PROP_WAVES / 2;
+        }
+        return first;
+    };
+    // (the queue's decoder keeps the branch it has always had -- dead now, a draw is past PROP_WAVES -- because the slot
+    // loop's register allocation moves with it: without the branch the 300-particle launch is 0.3 % slower, with the
+    // first tile's mapping inside it 7 %)
     const bool snake = ordered && wg_tiles <= PROP_WAVES;
     auto decode = [&](int li) {
         TileId id;
@@ -1175,7 +1242,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
     };
     auto row_of = [&](const TileId& id, int j) {
         LaneRow lr;
-        const int g = id.t * 32 + j;
+        const int g = id.t * tile_rows + j;
         lr.live = g < wg_rows;
         const int gc = min(g, wg_rows - 1);
         const int r = ordered ? (int)perm[gc] : gc;
@@ -1206,10 +1273,10 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
             A.agg_out = agg_hist ? agg_hist + (size_t)p * bn64 : nullptr;
         }
         if (p + 1 < DRP_PSTEP) {
-            prop_tiles<false, TAPE>(A, L, decode, row_of, lane, wave PROP_STAMPS_ARG);
+            prop_tiles<false, TAPE, PAIR>(A, L, first_of, decode, row_of, lane PROP_STAMPS_ARG);
         } else {
             L.w_x = reinterpret_cast<const bf16x8*>(w6_f) + 3 * 1536;
-            prop_tiles<true, TAPE>(A, L, decode, row_of, lane, wave PROP_STAMPS_ARG);
+            prop_tiles<true, TAPE, PAIR>(A, L, first_of, decode, row_of, lane PROP_STAMPS_ARG);
         }
         ROLL_STAMP(7);                               // wave 0's tiles of a propagation step
     }
@@ -1221,7 +1288,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
 #endif
 }
 
-template <bool TAPE>
+template <bool TAPE, bool PAIR>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
          const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1240,7 +1307,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
 #endif
     const Prop3Lds P = prop3_lds(lds);
     prop3_fill_resident(P, sw, sw6, mw);
-    prop3_step<TAPE>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
+    prop3_step<TAPE, PAIR>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
                      eff, N, B, spw, s_delta, s_out, out_stride, cself, cself_ok, mask_hist, agg_hist, re_scale, re_inv, order_rows,
                      (int)threadIdx.x PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS

@@ -2,6 +2,7 @@
   km_rollout (whole rollout in one launch)      vs  the step-by-step pipeline (DRP_NO_ROLLOUT_FUSED=1)      -- same bits
   km_prop with few tiles dealt one per workgroup vs  eight to a workgroup (DRP_NO_PROP_SPREAD=1)              -- same bits
   kmb_edge_encode (relation encoder backward, MFMA) vs kb_edge_encode (DRP_NO_BWD_EDGE_MFMA=1)               -- fp32 rounding
+  tiles of 16 receivers x two slots (small workgroups) vs tiles of 32 receivers (DRP_PROP_PAIR_ROWS=0)        -- same bits
 usage: python tools/fuzz_round3.py [cases] [seed]"""
 import os
 import sys
@@ -21,7 +22,7 @@ obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
 
 
 def engine(env):
-    for k in ('DRP_NO_ROLLOUT_FUSED', 'DRP_NO_PROP_SPREAD', 'DRP_NO_BWD_EDGE_MFMA', 'DRP_ROLLOUT_MAX_N'):
+    for k in ('DRP_NO_ROLLOUT_FUSED', 'DRP_NO_PROP_SPREAD', 'DRP_NO_BWD_EDGE_MFMA', 'DRP_ROLLOUT_MAX_N', 'DRP_PROP_PAIR_ROWS'):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = Engine(0)
@@ -32,7 +33,7 @@ def engine(env):
 
 bad = 0
 for c in range(cases):
-    kind = c % 3
+    kind = c % 4
     if kind == 0:
         # km_rollout: any sample size whose workgroup holds up to 3072 rows
         N = int(rng.integers(1, 257))
@@ -65,12 +66,39 @@ for c in range(cases):
         s0, dens, attr = syn.make_pile(N, 1, seed=c)
         acts = syn.sample_pushes(ns, H, seed=c)
         out = []
-        for env in ({}, {'DRP_NO_PROP_SPREAD': '1'}):
+        for env in ({}, {'DRP_NO_PROP_SPREAD': '1'}, {'DRP_PROP_PAIR_ROWS': '0'}):
             e = engine(env)
             out.append(e.rollout(s0, attr, dens, acts)[0])
             e.close()
-        ok = np.array_equal(out[0], out[1])
+        ok = np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
         print('spread   N=%3d ns=%3d  %s' % (N, ns, 'same bits' if ok else 'DIFFERENT'))
+    elif kind == 3:
+        # paired tiles: workgroups of up to 128 rows (whole-rollout launch, step-by-step whole-sample kernels, tape of the GD planner)
+        N = int(rng.integers(1, 129))
+        nb = int(rng.choice([1, 1, 2, 3]))
+        per_wg = max(1, 128 // N)
+        ns = int(rng.integers(1, 256 * per_wg + 1)) if rng.random() < 0.7 else int(rng.integers(1, 40))
+        H = int(rng.integers(1, 4))
+        B = ns * nb
+        s0, dens, attr = syn.make_pile(N, nb, seed=c)
+        if rng.random() < 0.3:
+            attr = rng.uniform(-1, 1, attr.shape).astype(np.float32)
+        acts = syn.sample_pushes(B, H, seed=c)
+        fused = rng.random() < 0.5
+        out = []
+        for env in ({}, {'DRP_PROP_PAIR_ROWS': '0'}):
+            if not fused:
+                env = dict(env, DRP_NO_ROLLOUT_FUSED='1')
+            e = engine(env)
+            e.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+            st, rw = e.rollout(s0, attr, dens, acts, want_states=True, want_reward=True)
+            lo, hi = syn.action_limits()
+            e.gd_begin(s0, attr, dens, acts, 0.05, lo, hi)
+            r, g = e.gd_grad()[:2]
+            out.append((st, rw, r, g))
+            e.close()
+        ok = all(np.array_equal(a, b_) for a, b_ in zip(out[0], out[1]))
+        print('pair     N=%3d nb=%d ns=%4d H=%d %s  %s' % (N, nb, ns, H, 'one launch' if fused else 'per step  ', 'same bits' if ok else 'DIFFERENT'))
     else:
         # relation encoder backward on the matrix cores: GD gradients at horizon 2 and 3
         N = int(rng.integers(5, 200))
