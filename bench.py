@@ -8,7 +8,7 @@ Workload at N=1: BASELINE.json configs[1] -- 300-particle pile, 1024 MPPI sample
 10-step horizon (inputs resident in HBM).  With --gpus N the sample axis is sharded,
 1024 samples per GPU (weak scaling, configs[2] at N=8).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4-50|c4-150|c4-300|c4-600|c5|c5-share|gd-demo]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|p20|c4-50|c4-150|c4-300|c4-600|c5|c5-share|gd-demo]
 
 `python bench.py --gpus N` with N > 1 and no launcher around it starts its own N rank processes (one per GPU) as
 CHILD processes -- before anything in this process has touched the GPU -- relays rank 0's JSON line and exits with
@@ -44,6 +44,7 @@ PEAK_BF16_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA (same rate)
 CONFIGS = {
     'c2': (300, 1024, 10, 'weak', 'BASELINE configs[1]: 300-particle pile, 1024 MPPI samples, 10-step horizon, 1 GPU'),
     'c3': (300, 1024, 10, 'weak', 'BASELINE configs[2]: 300-particle pile, 8192 MPPI samples at 8 GPUs (1024 per GPU), 10-step horizon, RCCL exchange'),
+    'p20': (20, 1024, 10, 'weak', "small piles (the reference re-samples the pile per MPC step at the particle count its resolution regressor asks for, env/flex_env.py:997-1020; its time model planners.py:25-28 is fitted over 10 - 100): 20 particles x 1024 samples x 10 steps"),
     'c4-50': (50, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 50 particles x 1024 samples x 10 steps'),
     'c4-150': (150, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 150 particles x 1024 samples x 10 steps'),
     'c4-300': (300, 1024, 10, 'weak', 'BASELINE configs[3]: dynamic-resolution sweep, 300 particles x 1024 samples x 10 steps'),
@@ -56,7 +57,7 @@ CONFIGS = {
     'gd-demo': (100, 1500, 1, 'weak', "the reference's live GD planner at its demo shape: 50 trajectories x 30 re-samplings x 100 particles, horizon 1 "
                                       '(config/mpc/config.yaml:38-43), one Adam iteration per step'),
 }
-SWEEP = ['c4-50', 'c4-150', 'c4-600', 'c5-share', 'gd-demo']     # the default run's extra block (configs[1] is the headline)
+SWEEP = ['p20', 'c4-50', 'c4-150', 'c4-600', 'c5-share', 'gd-demo']     # the default run's extra block (configs[1] is the headline)
 GD_CLASSES = ['graph', 'node_encode', 'prop', 'reward', 'tape_copy', 'bwd_reward', 'bwd_lists', 'bwd_node', 'bwd_edge',
               'bwd_push', 'opt']
 KERNEL_CLASSES = ['graph', 'node_encode', 'edge_encode', 'project', 'aggregate', 'update',
