@@ -180,6 +180,8 @@ struct drp_ctx {
     bool prop3e = true;             // DRP_NO_PROP3E=1: the particle encoder stays its own launch in front of km_prop3
     bool rollout_fused = true;      // DRP_NO_ROLLOUT_FUSED=1: one graph + one km_prop3 launch per rollout step for small piles too
     int rollout_max_n = 64;         // DRP_ROLLOUT_MAX_N: km_rollout (the whole rollout in one launch) up to this many particles ...
+    int rollout_mid_n = 96, rollout_mid_rows = 256;   // ... up to 96 particles for workgroups of up to 256 rows (small batches:
+                                    // 256 x 72 / 80 / 88 + 7 / + 11 / + 15 %, 512 x 80 / 96 + 8 / + 11 %; 1024 x 88: - 1 %, 2048 x 80: - 4 %)
     int rollout_max_rows = 704;     // DRP_ROLLOUT_MAX_ROWS: ... and this many rows (samples x particles) per workgroup.  Measured
                                     // against the step-by-step pipeline at 1024 samples: +18 % at 10 particles, +12 % at 20, +2 % at
                                     // 50, +5 % at 64, -1 % at 80, -10 % at 150 (the strip build wins); 50 particles x 4096 samples
@@ -784,7 +786,9 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
     // small piles on the fused engine: the whole rollout is ONE launch (km_rollout, k_rollout.h) -- a workgroup owns its
     // samples from the first step to the last, builds their neighbour lists itself and keeps the node matrices in LDS
     const int spw_r = (int)((B + c->n_cu - 1) / c->n_cu);
-    const bool one_launch = c->engine == DRP_ENGINE_FUSED && c->rollout_fused && c->prop3 && c->prop3e && N <= c->rollout_max_n &&
+    // up to rollout_max_n particles whatever the batch; up to rollout_mid_n while a workgroup holds no more than rollout_mid_rows
+    const bool roll_size = N <= c->rollout_max_n || (N <= c->rollout_mid_n && (long)spw_r * N <= c->rollout_mid_rows);
+    const bool one_launch = c->engine == DRP_ENGINE_FUSED && c->rollout_fused && c->prop3 && c->prop3e && roll_size &&
                             whole_samples(c, B, N) && ((long)spw_r * N + 31) / 32 >= c->prop3_min_tiles &&
                             (long)spw_r * N <= KM_ROLLOUT_MAX_ROWS && (long)spw_r * N <= c->rollout_max_rows;
     if (one_launch) {
@@ -1047,7 +1051,7 @@ int drp_create(int device, drp_ctx** out) {
     c->prop_spread = getenv("DRP_NO_PROP_SPREAD") == nullptr;
     c->wgrad_mfma = getenv("DRP_NO_WGRAD_MFMA") == nullptr;
     if (const char* e = getenv("DRP_GRAPH_Q4")) c->graph_q4 = atoi(e);
-    if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) { c->rollout_max_n = atoi(e); c->rollout_max_rows = KM_ROLLOUT_MAX_ROWS; }
+    if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) { c->rollout_max_n = atoi(e); c->rollout_mid_n = 0; c->rollout_max_rows = KM_ROLLOUT_MAX_ROWS; }
     if (const char* e = getenv("DRP_ROLLOUT_MAX_ROWS")) c->rollout_max_rows = atoi(e);
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
     if (const char* e = getenv("DRP_PROP_PAIR_ROWS")) c->prop_pair_rows = std::max(0, atoi(e));
