@@ -20,9 +20,9 @@ The ranks rendezvous over a gloo process group (the ncclUniqueId broadcast, the 
 timings); torch's NCCL process group is never created, so ONE RCCL serves the process: the one libdrp.so binds at
 run time (config.rccl in the line names its version and file).
 
-The default one-GPU run also carries a `sweep` block: the other BASELINE workloads (configs[3] 50 / 150 / 600
-particles, the per-GPU share of configs[4], the reference's live GD planner shape), 5 iterations each after 2
-warm-ups.  --config selects one of them as the headline instead; c5 is the strong-scaling one (4096 samples in
+The default one-GPU run also carries a `sweep` block: the other BASELINE workloads (20 particles -- the small-pile
+regime --, configs[3] 50 / 150 / 600 particles, the per-GPU share of configs[4], the reference's live GD planner
+shape), 20 iterations each after 5 warm-ups.  --config selects one of them as the headline instead; c5 is the strong-scaling one (4096 samples in
 total).  --force-comm attaches a one-rank RCCL communicator and runs the update through ncclAllGather.
 """
 import argparse
@@ -281,9 +281,35 @@ def tile_slot_model(cnt, N, ns, n_cu, engine, self_const):
     self loop when its encoder chain is replaced by the per-sample constant (attributes are zeros here).  km_prop3
     (whole_samples() in drp_capi.hip: chip-filling batches, or any batch of samples of up to 256 particles) cuts the
     rows of a workgroup's samples, ordered by in-degree unless the pile is saturated, into tiles; km_prop cuts every
-    sample on its own.  -> (tiles per propagation step, mean slot iterations per tile, whole-sample kernel?)"""
+    sample on its own.  Few rows run PAIRED tiles (prop_pair() in drp_capi.hip: a workgroup of up to 128 rows -- above 64
+    only while the mean in-degree is at most 8.3 --, a per-step batch of up to two tiles per CU): 16 receivers, two slots
+    per iteration of the chain; the particle encoder keeps tiles of 32.
+    -> (tiles per propagation step, mean slot iterations per tile, the particle encoder's tiles)"""
     spw = -(-ns // n_cu)
     prop3 = (engine == 'fused' and os.environ.get('DRP_NO_PROP3') is None and (ns >= n_cu - n_cu // 5 or N <= 256))
+    pair_rows = int(os.environ.get('DRP_PROP_PAIR_ROWS', '128'))
+    if prop3:
+        pair = spw * N <= pair_rows and (spw * N <= 64 or float(cnt.mean()) * 10 <= 83)
+    else:
+        pair = engine == 'fused' and pair_rows > 0 and ns * (-(-N // 32)) <= 2 * n_cu
+    if pair:
+        tile_max, enc_tiles = [], 0
+        self_ = 1.0 if self_const else 0.0
+        if prop3:
+            ordered = os.environ.get('DRP_NO_PROP3_ORDER') is None
+            for w in range(0, ns, spw):
+                rows = cnt[w:w + spw].ravel()
+                enc_tiles += -(-rows.size // 32)
+                if ordered and (rows == rows.max()).sum() * 16 < rows.size * 15:
+                    rows = np.sort(rows)[::-1]
+                rows = np.pad(rows, (0, (-rows.size) % 16))
+                tile_max.append(rows.reshape(-1, 16).max(-1))
+            tile_max = np.concatenate(tile_max).astype(np.float64)
+        else:
+            tile_max = np.pad(cnt, ((0, 0), (0, (-N) % 16))).reshape(ns, -1, 16).max(-1).astype(np.float64).ravel()
+            enc_tiles = ns * (-(-N // 32))
+        its = float(np.ceil((tile_max - self_).clip(min=0) / 2.0).mean())
+        return int(tile_max.size), its, enc_tiles
     tile_max = []
     if prop3:
         ordered = os.environ.get('DRP_NO_PROP3_ORDER') is None and spw * N <= 4900
@@ -297,10 +323,10 @@ def tile_slot_model(cnt, N, ns, n_cu, engine, self_const):
     else:
         tile_max = np.pad(cnt, ((0, 0), (0, (-N) % 32))).reshape(ns, -1, 32).max(-1).astype(np.float64).ravel()
     slots = float((tile_max - (1.0 if self_const else 0.0)).clip(min=0).mean())
-    return int(tile_max.size), slots, prop3
+    return int(tile_max.size), slots, int(tile_max.size)
 
 
-def prop_roofline(tiles, slots_per_tile, kbar, self_const, B, N, avg_s, launches, prop_steps_total, encoder_launches):
+def prop_roofline(tiles, slots_per_tile, kbar, self_const, B, N, avg_s, launches, prop_steps_total, encoder_launches, enc_tiles=None):
     """km_prop / km_prop3: per 32-receiver tile, one 78-MFMA chain (the 3-term split relation
     encoder) per slot iteration + the 6-term split node layers (144 MFMAs, 96 in the last step); roofline on the
     16-bit FLOPs actually EXECUTED, 2*32*32*16 per MFMA.  A launch covers one propagation step (km_prop) or all
@@ -313,13 +339,13 @@ def prop_roofline(tiles, slots_per_tile, kbar, self_const, B, N, avg_s, launches
     # no launch of its own was counted: 12 + 4 x 48 bf16 MFMAs per tile (first layer + four 64x64 products, 6-term split)
     encoder_inside = psteps % 3 == 0 and encoder_launches == 0
     if encoder_inside:
-        mfmas += (psteps // 3) * tiles * 204
+        mfmas += (psteps // 3) * (tiles if enc_tiles is None else enc_tiles) * 204
         alg += (psteps // 3) * (B * N * FLOP_PER_NODE['node_encode'] + B * N * 2 * 2 * 64 * 64)
     work = mfmas * 32768.0
     return {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
             'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile,
-            'tiles_per_step': tiles, 'mean_in_degree_minus_self': kbar - (1.0 if self_const else 0.0),
+            'tiles_per_step': tiles, 'paired_tiles': bool(enc_tiles is not None and enc_tiles != tiles), 'mean_in_degree_minus_self': kbar - (1.0 if self_const else 0.0),
             'propagation_steps_per_launch': psteps, 'particle_encoder_in_launch': bool(encoder_inside),
             'graph_build_in_launch': bool(psteps > 3)}, work
 
@@ -414,9 +440,9 @@ def mppi_roofline(rig, m, N, ns, H, steps):
     self_const = engine == 'fused' and os.environ.get('DRP_NO_SELF_CONST') is None
     work = None
     if dominant == 'prop':
-        tiles, slots, _ = tile_slot_model(m['cnt'], N, ns, rig.n_cu, engine, self_const)
+        tiles, slots, enc_tiles = tile_slot_model(m['cnt'], N, ns, rig.n_cu, engine, self_const)
         roof, work = prop_roofline(tiles, slots, kbar, self_const, ns, N, avg_s, m['dom_n'], 3.0 * H * steps,
-                                   m['per_class'].get('node_encode', (0, 0))[1])
+                                   m['per_class'].get('node_encode', (0, 0))[1], enc_tiles)
     elif dominant == 'aggregate':
         work = ns * N * (2 * kbar + 2) * 256.0
         roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
@@ -503,8 +529,8 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
     tkey = None
     if dominant == 'prop':
         # the forward kernel of the tape-writing instantiation: the same MFMAs as the MPPI model
-        tiles, slots, _ = tile_slot_model(cnt, N, B, rig.n_cu, 'fused', True)
-        roof, _ = prop_roofline(tiles, slots, kbar, True, B, N, avg_s, dom_n, 3.0 * H * steps, per_class['node_encode'][1])
+        tiles, slots, enc_tiles = tile_slot_model(cnt, N, B, rig.n_cu, 'fused', True)
+        roof, _ = prop_roofline(tiles, slots, kbar, True, B, N, avg_s, dom_n, 3.0 * H * steps, per_class['node_encode'][1], enc_tiles)
         tkey = 'prop3_tape'
     elif dominant == 'bwd_node' and per_class['bwd_edge'][1] == 0:
         # kmb_step_bwd (the whole node / edge backward of a rollout step in one launch): algorithmic
@@ -540,11 +566,12 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
 
 
 def run_sweep(rig, fence):
-    """The other BASELINE workloads on this GPU, short: 2 warm-ups, 5 iterations each (no median pass)."""
+    """The other BASELINE workloads on this GPU, short: 5 warm-ups, 20 iterations each (no median pass); ~3 s in all.
+    (Five iterations after two warm-ups, the first version, read 5 - 8 % low on the sub-millisecond workloads.)"""
     out = []
     for name in SWEEP:
         N, ns, H, _, label = CONFIGS[name]
-        steps, warm = 5, 2
+        steps, warm = 20, 5
         t_wall = time.perf_counter()
         if name == 'gd-demo':
             g = bench_gd(rig, N, ns // 30, 30, H, steps, warm, fence, want_median=False)

@@ -51,7 +51,7 @@ def test_the_sweep_block_carries_the_other_baseline_workloads():
     names = [e['name'] for e in d['sweep']]
     assert names == ['p20', 'c4-50', 'c4-150', 'c4-600', 'c5-share', 'gd-demo']
     for e in d['sweep']:
-        assert e['steps'] == 5 and e['warmup'] == 2 and e['value'] > 0 and 0 < e['frac'] < 1, e
+        assert e['steps'] == 20 and e['warmup'] == 5 and e['value'] > 0 and 0 < e['frac'] < 1, e
         assert abs(e['value'] - e['rows'] * e['n_particles'] * e['n_look_ahead'] / (e['ms_per_step'] * 1e-3)) < 1e-6 * e['value']
         assert e['dominant_kernel'] in e['kernel_ms_per_iteration']
     assert d['sweep'][4]['n_particles'] == 1200 and d['sweep'][4]['rows'] == 512 and d['sweep'][4]['n_look_ahead'] == 20
