@@ -246,6 +246,12 @@ struct drp_ctx {
     double tr_lr = 1e-3, tr_beta1 = 0.9;
     std::vector<float> w_host;
     std::vector<WgradJob> wg_jobs;  // weight-gradient jobs waiting for the next flush_wgrad
+    // DEFERRED weight gradients (training, DRP_NO_WGRAD_DEFER=1 turns it off): every operand of an iteration's jobs keeps a
+    // buffer of its own (per rollout step, per propagation step), the jobs queue up for the whole backward pass and go out
+    // in a handful of launches at its end (flush_wgrad_all) instead of 25 pairs in between
+    bool wgrad_defer = true, wg_defer_now = false;
+    DevBuf wg_jobs_dev, wg_idx_dev;
+    std::vector<unsigned char> wg_uploaded;     // what wg_jobs_dev / wg_idx_dev hold (re-uploaded when the iteration's jobs change)
     DevBuf tr_part, tr_states, tr_sdelta, tr_nums, tr_grad, tr_m, tr_v, tr_loss, agg_hist, tr_hact, tr_gh, tr_gpe, tr_a1n,
         tr_gh1, tr_xn, ed_re, ed_a2, ed_a1, ed_x0, ed_gce, ed_g3, ed_g2, ed_g1;
 
@@ -886,7 +892,7 @@ int need(drp_ctx* c, bool weights, bool cam, bool goal) {
 // inputs exist at that point of the stream.  flush_wgrad must run before a kernel overwrites a queued job's g or x.
 void flush_wgrad(drp_ctx* c) {
     const int n = (int)c->wg_jobs.size();
-    if (n == 0) return;
+    if (n == 0 || c->wg_defer_now) return;
     WgradJobs J{};
     int max_blocks = 1;
     for (int q = 0; q < n; ++q) {
@@ -902,13 +908,71 @@ void flush_wgrad(drp_ctx* c) {
     c->wg_jobs.clear();
 }
 
+// The deferred jobs of a whole backward pass.  Jobs of one size go through one launch (blockIdx.y walks that size's
+// slice of `order`); then ONE reduction launch in which a block owns a target dW and adds its jobs' sums in queue order
+// -- what the in-between flushes did launch after launch, so the gradients keep their bits.
+int flush_wgrad_all(drp_ctx* c) {
+    const int n = (int)c->wg_jobs.size();
+    c->wg_defer_now = false;
+    if (n == 0) return DRP_OK;
+    // partial sums: one slab per job
+    size_t part_floats = 0;
+    std::vector<size_t> part_off(n);
+    for (int q = 0; q < n; ++q) { part_off[q] = part_floats; part_floats += (size_t)c->wg_jobs[q].blocks * 66 * 64; }
+    CHK(ensure(c, c->tr_part, std::max(part_floats, (size_t)KT_WGRAD_MAX_JOBS * KT_WGRAD_MAX_BLOCKS * 66 * 64) * sizeof(float)));
+    for (int q = 0; q < n; ++q) c->wg_jobs[q].part = static_cast<float*>(c->tr_part.p) + part_off[q];
+    // launch order: by size; reduction lists: by target, in queue order
+    std::vector<int> order(n);
+    for (int q = 0; q < n; ++q) order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return c->wg_jobs[a].blocks > c->wg_jobs[b].blocks; });
+    std::vector<float*> targets;
+    std::vector<std::vector<int>> lists;
+    for (int q = 0; q < n; ++q) {
+        size_t k = 0;
+        while (k < targets.size() && targets[k] != c->wg_jobs[q].dW) ++k;
+        if (k == targets.size()) { targets.push_back(c->wg_jobs[q].dW); lists.emplace_back(); }
+        lists[k].push_back(q);
+    }
+    const int nt = (int)targets.size();
+    std::vector<int> idx;                      // order[n] | tgt_off[nt + 1] | tgt_jobs[n]
+    idx.insert(idx.end(), order.begin(), order.end());
+    int off = 0;
+    for (int k = 0; k < nt; ++k) { idx.push_back(off); off += (int)lists[k].size(); }
+    idx.push_back(off);
+    for (int k = 0; k < nt; ++k) idx.insert(idx.end(), lists[k].begin(), lists[k].end());
+    // upload when anything changed (the same shape queues the same jobs iteration after iteration)
+    const size_t jb = (size_t)n * sizeof(WgradJob), ib = idx.size() * sizeof(int);
+    std::vector<unsigned char> img(jb + ib);
+    memcpy(img.data(), c->wg_jobs.data(), jb);
+    memcpy(img.data() + jb, idx.data(), ib);
+    if (img != c->wg_uploaded) {
+        c->wg_uploaded.swap(img);               // the copies' source stays alive in the context
+        CHK(h2d(c, c->wg_jobs_dev, c->wg_uploaded.data(), jb));
+        CHK(h2d(c, c->wg_idx_dev, c->wg_uploaded.data() + jb, ib));
+    }
+    const WgradJob* jd = static_cast<const WgradJob*>(c->wg_jobs_dev.p);
+    const int* od = static_cast<const int*>(c->wg_idx_dev.p);
+    for (int a = 0; a < n;) {
+        int b = a;
+        while (b < n && c->wg_jobs[order[b]].blocks == c->wg_jobs[order[a]].blocks) ++b;
+        const dim3 grid((unsigned)c->wg_jobs[order[a]].blocks, (unsigned)(b - a));
+        if (c->wgrad_mfma) hipLaunchKernelGGL(kt_wgrad_mfma_list, grid, dim3(256), KT_WGRAD_MULTI_LDS, c->stream, jd, od, a);
+        else hipLaunchKernelGGL(kt_wgrad_list, grid, dim3(256), KT_WGRAD_MULTI_LDS, c->stream, jd, od, a);
+        a = b;
+    }
+    hipLaunchKernelGGL(kt_wgrad_reduce_lists, dim3(66, (unsigned)nt), dim3(256), 0, c->stream, jd, od + n, od + n + nt + 1);
+    c->wg_jobs.clear();
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
 template <int IN>
 void launch_wgrad(drp_ctx* c, const float* g, int ldg, const float* x, int ldx, long M, float* dW, int lane_stride,
                   int k_stride, float* db, float* dwd, const float* dens, int dens_mod, long rows_per_sample) {
     long blocks = (M + 63) / 64;
     if (blocks > KT_WGRAD_MAX_BLOCKS) blocks = KT_WGRAD_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
-    if ((int)c->wg_jobs.size() == KT_WGRAD_MAX_JOBS) flush_wgrad(c);
+    if ((int)c->wg_jobs.size() == KT_WGRAD_MAX_JOBS && !c->wg_defer_now) flush_wgrad(c);
     WgradJob q{};
     q.g = g; q.x = x; q.dW = dW; q.db = db; q.dwd = dwd; q.dens = dens; q.part = nullptr;
     q.M = M; q.rows_per_sample = rows_per_sample;
@@ -1050,6 +1114,7 @@ int drp_create(int device, drp_ctx** out) {
     c->bwd_edge_mfma = getenv("DRP_NO_BWD_EDGE_MFMA") == nullptr;
     c->prop_spread = getenv("DRP_NO_PROP_SPREAD") == nullptr;
     c->wgrad_mfma = getenv("DRP_NO_WGRAD_MFMA") == nullptr;
+    c->wgrad_defer = getenv("DRP_NO_WGRAD_DEFER") == nullptr;
     if (const char* e = getenv("DRP_GRAPH_Q4")) c->graph_q4 = atoi(e);
     if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) { c->rollout_max_n = atoi(e); c->rollout_mid_n = 0; c->rollout_max_rows = KM_ROLLOUT_MAX_ROWS; }
     if (const char* e = getenv("DRP_ROLLOUT_MAX_ROWS")) c->rollout_max_rows = atoi(e);
@@ -1129,7 +1194,8 @@ void drp_destroy(drp_ctx* c) {
                       &c->gl_goal, &c->gl_seg, &c->gl_tmp, &c->gl_dist, &c->gl_blk, &c->gl_pix, &c->gl_fps,
                       &c->tr_part, &c->tr_states, &c->tr_sdelta, &c->tr_nums, &c->tr_grad, &c->tr_m, &c->tr_v, &c->tr_loss, &c->agg_hist,
                       &c->tr_hact, &c->tr_gh, &c->tr_gpe, &c->tr_a1n, &c->tr_gh1, &c->tr_xn, &c->ed_re, &c->ed_a2, &c->ed_a1,
-                      &c->ed_x0, &c->ed_gce, &c->ed_g3, &c->ed_g2, &c->ed_g1, &c->roll_args, &c->map_valu, &c->map_mfma, &c->map_mfma_bwd};
+                      &c->ed_x0, &c->ed_gce, &c->ed_g3, &c->ed_g2, &c->ed_g1, &c->roll_args, &c->map_valu, &c->map_mfma, &c->map_mfma_bwd,
+                      &c->wg_jobs_dev, &c->wg_idx_dev};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : c->probe_ev) (void)hipEventDestroy(ev);
@@ -2109,7 +2175,7 @@ int gd_forward_backward(drp_ctx* c) {
             // projection of this step with the update of the one before
             { ProbeScope ps(c, KC_BWD_NODE);
             hipLaunchKernelGGL((kmb_node_step<false, true>), ngrid, nblk, KMB_STEP_LDS(false, true), st, mb, ptr<float>(c->g_eff),
-                               (const float*)nullptr, eht + (size_t)DRP_PSTEP * bn * 64, ptr<float>(c->g_cnode), 1,
+                               ptr<float>(c->g_eff), (const float*)nullptr, eht + (size_t)DRP_PSTEP * bn * 64, ptr<float>(c->g_cnode), 1,
                                gah + (size_t)(DRP_PSTEP - 1) * bn * 64, N, B);
             }
             for (int p = DRP_PSTEP - 1; p >= 0; --p) {
@@ -2122,13 +2188,13 @@ int gd_forward_backward(drp_ctx* c) {
                 if (p > 0)
                     { ProbeScope ps(c, KC_BWD_NODE);
                     hipLaunchKernelGGL((kmb_node_step<true, true>), ngrid, nblk, KMB_STEP_LDS(true, true), st, mb,
-                                       ptr<float>(c->g_eff), ptr<float>(c->g_proj), eht + (size_t)p * bn * 64,
+                                       ptr<float>(c->g_eff), ptr<float>(c->g_eff), ptr<float>(c->g_proj), eht + (size_t)p * bn * 64,
                                        ptr<float>(c->g_cnode), 0, gah + (size_t)(p - 1) * bn * 64, N, B);
                     }
                 else
                     { ProbeScope ps(c, KC_BWD_NODE);
                     hipLaunchKernelGGL((kmb_node_step<true, false>), ngrid, nblk, KMB_STEP_LDS(true, false), st, mb,
-                                       ptr<float>(c->g_eff), ptr<float>(c->g_proj), (const float*)nullptr, (float*)nullptr, 0,
+                                       ptr<float>(c->g_eff), ptr<float>(c->g_eff), ptr<float>(c->g_proj), (const float*)nullptr, (float*)nullptr, 0,
                                        (float*)nullptr, N, B);
                     }
             }
@@ -2422,9 +2488,25 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     const dim3 rgrid((unsigned)(B * chunks)), egrid((unsigned)(B * chunks16));
     const float* dens = ptr<float>(c->dens);
     HIPCHK(c, hipMemsetAsync(G, 0, (size_t)W_TOTAL * sizeof(float), st));
-    KbEdgeDump ed{ptr<float>(c->ed_re), ptr<float>(c->ed_a2), ptr<float>(c->ed_a1), ptr<float>(c->ed_x0),
-                  ptr<float>(c->ed_gce), ptr<float>(c->ed_g3), ptr<float>(c->ed_g2), ptr<float>(c->ed_g1)};
+    // deferred weight gradients: what a job reads keeps a buffer per rollout step t (g_eff and g_proj: per propagation step
+    // too; slot 0 of g_eff is the transient copy the predictor writes and the particle encoder reads)
+    const bool defer = c->wg_defer_now;
+    const size_t per_t = defer ? 1 : 0;
     for (int t = H - 1; t >= 0; --t) {
+        const size_t tt = per_t * (size_t)t;
+        float* const ge_tmp = ptr<float>(c->g_eff);
+        auto ge_v = [&](int v) { return ptr<float>(c->g_eff) + per_t * ((size_t)(t * 3 + v) + 1) * bn64; };   // v = 0, 1, 2: steps 2, 1, 0
+        auto gp_v = [&](int p) { return ptr<float>(c->g_proj) + per_t * (size_t)(t * 3 + p) * bn64 * 2; };
+        float* const g_cnode_t = ptr<float>(c->g_cnode) + tt * bn64;
+        float* const tr_hact_t = ptr<float>(c->tr_hact) + tt * bn64;
+        float* const tr_gh_t = ptr<float>(c->tr_gh) + tt * bn64;
+        float* const tr_gpe_t = ptr<float>(c->tr_gpe) + tt * bn64;
+        float* const tr_a1n_t = ptr<float>(c->tr_a1n) + tt * bn64;
+        float* const tr_gh1_t = ptr<float>(c->tr_gh1) + tt * bn64;
+        float* const tr_xn_t = ptr<float>(c->tr_xn) + tt * bn * 8;
+        KbEdgeDump ed{ptr<float>(c->ed_re) + tt * bnk * 64, ptr<float>(c->ed_a2) + tt * bnk * 64, ptr<float>(c->ed_a1) + tt * bnk * 64,
+                      ptr<float>(c->ed_x0) + tt * bnk * 8, ptr<float>(c->ed_gce) + tt * bnk * 64, ptr<float>(c->ed_g3) + tt * bnk * 64,
+                      ptr<float>(c->ed_g2) + tt * bnk * 64, ptr<float>(c->ed_g1) + tt * bnk * 64};
         const float* s_prev = (t == 0) ? given : states + (size_t)(t - 1) * N * 3;
         const size_t prev_stride = (t == 0) ? in_stride : hstride;
         float* eht = eh + (size_t)t * 4 * bn64;
@@ -2449,49 +2531,51 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             const dim3 ngrid(mfma_grid_spread(c, node_tiles)), nblk(64 * MFMA_WAVES);
             // predictor
             hipLaunchKernelGGL(kmb_predict, ngrid, nblk, KMB_PREDICT_LDS, st, mw, mb, eht + 3 * bn64, g_out, (size_t)N * 3, N, B,
-                               ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh));
-            launch_wgrad<64>(c, ptr<float>(c->tr_gh), 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
+                               ge_tmp, tr_hact_t, tr_gh_t);
+            launch_wgrad<64>(c, tr_gh_t, 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
                              nullptr, 1, 1);
-            launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
+            launch_wgrad<3>(c, tr_hact_t, 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
             hipLaunchKernelGGL(kt_colsum3, dim3(1), dim3(1024), 0, st, g_out, (long)bn, G + W_PR1_B);
             // update of the last propagation step; then per step the edge terms and, in one launch, the
             // projection of this step with the update of the one before (k_backward_mfma.h)
-            hipLaunchKernelGGL((kmb_node_step<false, true>), ngrid, nblk, KMB_STEP_LDS(false, true), st, mb, ptr<float>(c->g_eff),
-                               (const float*)nullptr, eht + (size_t)DRP_PSTEP * bn64, ptr<float>(c->g_cnode), 1,
+            hipLaunchKernelGGL((kmb_node_step<false, true>), ngrid, nblk, KMB_STEP_LDS(false, true), st, mb, ge_tmp, ge_v(0),
+                               (const float*)nullptr, eht + (size_t)DRP_PSTEP * bn64, g_cnode_t, 1,
                                gah + (size_t)(DRP_PSTEP - 1) * bn64, N, B);
             for (int p = DRP_PSTEP - 1; p >= 0; --p) {
                 float* g_agg_p = gah + (size_t)p * bn64;
                 const unsigned* mask_p = mht + (size_t)p * bnk * 2;
-                // particle propagator, aggregate columns: g_eff holds the pre-activation gradient of step p
-                launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
+                float* const ge_p = ge_v(DRP_PSTEP - 1 - p);     // the pre-activation gradient of step p
+                float* const gp_p = gp_v(p);
+                // particle propagator, aggregate columns
+                launch_wgrad<64>(c, ge_p, 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
                                  nullptr, nullptr, nullptr, 1, 1);
                 hipLaunchKernelGGL(kb_edge_terms, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, ptr<int>(c->rev_off),
-                                   ptr<int>(c->rev), N, ptr<float>(c->g_proj), chunks16);
+                                   ptr<int>(c->rev), N, gp_p, chunks16);
                 // relation propagator, receiver and sender columns
-                launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
+                launch_wgrad<64>(c, gp_p, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
                                  nullptr, nullptr, nullptr, 1, 1);
-                launch_wgrad<64>(c, ptr<float>(c->g_proj) + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
+                launch_wgrad<64>(c, gp_p + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
                                  1, nullptr, nullptr, nullptr, 1, 1);
-                flush_wgrad(c);                          // before the next kernel overwrites g_eff (and, next step, g_proj)
+                flush_wgrad(c);                          // (not deferred:) before the next kernel overwrites g_eff (and, next step, g_proj)
                 if (p > 0)
                     hipLaunchKernelGGL((kmb_node_step<true, true>), ngrid, nblk, KMB_STEP_LDS(true, true), st, mb,
-                                       ptr<float>(c->g_eff), ptr<float>(c->g_proj), eht + (size_t)p * bn64,
-                                       ptr<float>(c->g_cnode), 0, gah + (size_t)(p - 1) * bn64, N, B);
+                                       ge_p, ge_v(DRP_PSTEP - p), gp_p, eht + (size_t)p * bn64,
+                                       g_cnode_t, 0, gah + (size_t)(p - 1) * bn64, N, B);
                 else
                     hipLaunchKernelGGL((kmb_node_step<true, false>), ngrid, nblk, KMB_STEP_LDS(true, false), st, mb,
-                                       ptr<float>(c->g_eff), ptr<float>(c->g_proj), (const float*)nullptr, (float*)nullptr, 0,
+                                       ge_p, ge_tmp, gp_p, (const float*)nullptr, (float*)nullptr, 0,
                                        (float*)nullptr, N, B);
             }
             // particle propagator, encoder columns + density column + bias; particle encoder
-            launch_wgrad<64>(c, ptr<float>(c->g_cnode), 64, eht, 64, (long)bn, G + W_PP_W, 129, 1, G + W_PP_B, G + W_PP_W + 128,
+            launch_wgrad<64>(c, g_cnode_t, 64, eht, 64, (long)bn, G + W_PP_W, 129, 1, G + W_PP_B, G + W_PP_W + 128,
                              dens, B, (long)N);
             hipLaunchKernelGGL(kmb_node_encode, ngrid, nblk, KMB_NODE_ENCODE_LDS, st, mw, mb,
                                ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), B, dens, B, eht,
-                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, B, ptr<float>(c->g_sdelta), ptr<float>(c->tr_gpe),
-                               ptr<float>(c->tr_a1n), ptr<float>(c->tr_gh1), ptr<float>(c->tr_xn));
-            launch_wgrad<64>(c, ptr<float>(c->tr_gpe), 64, ptr<float>(c->tr_a1n), 64, (long)bn, G + W_PE2_W, 64, 1, G + W_PE2_B,
+                               ge_tmp, g_cnode_t, N, B, ptr<float>(c->g_sdelta), tr_gpe_t,
+                               tr_a1n_t, tr_gh1_t, tr_xn_t);
+            launch_wgrad<64>(c, tr_gpe_t, 64, tr_a1n_t, 64, (long)bn, G + W_PE2_W, 64, 1, G + W_PE2_B,
                              nullptr, nullptr, 1, 1);
-            launch_wgrad<5>(c, ptr<float>(c->tr_gh1), 64, ptr<float>(c->tr_xn), 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
+            launch_wgrad<5>(c, tr_gh1_t, 64, tr_xn_t, 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
                             nullptr, nullptr, 1, 1);
             flush_wgrad(c);
         } else {
@@ -2556,6 +2640,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         flush_wgrad(c);                                  // the next rollout step rewrites the dumps these jobs read
     }
     flush_wgrad(c);
+    if (defer) CHK(flush_wgrad_all(c));
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
@@ -2663,7 +2748,15 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     CHK(ensure_step_ws(c, B, N));
     CHK(ensure(c, c->states, (size_t)H * bn * 3 * sizeof(float)));
     CHK(ensure(c, c->g_state, (size_t)H * bn * 3 * sizeof(float)));
+    c->wg_defer_now = false;
+    c->wg_jobs.clear();
     if (backward) {
+        // deferred weight gradients keep every job's operands until the end of the backward pass: H copies of the node-level
+        // dumps (3 H + 1 of g_eff, 3 H of g_proj) and of the relation encoder's dumps -- 0.24 GB per rollout step at 32 x 300
+        const size_t keep_bytes = (size_t)H * (16 * bn64 + 7 * bnk * 64 + bnk * 8 + bn * 8) * sizeof(float);
+        const bool defer = c->wgrad_defer && (long)B * ((N + 31) / 32) >= KMB_MIN_TILES && keep_bytes <= ((size_t)8 << 30);
+        c->wg_defer_now = defer;
+        const size_t kt = defer ? (size_t)H : 1;
         CHK(ensure(c, c->eff_hist, (size_t)H * 4 * bn64 * sizeof(float)));
         CHK(ensure(c, c->agg_hist, (size_t)H * 3 * bn64 * sizeof(float)));
         CHK(ensure(c, c->tape_sdelta, (size_t)H * bn * 3 * sizeof(float)));
@@ -2674,17 +2767,17 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         CHK(ensure(c, c->rev_off, (size_t)B * (N + 1) * sizeof(int)));
         CHK(ensure(c, c->rev, bnk * sizeof(int)));
         CHK(ensure(c, c->gpos_edge, bnk * 4 * sizeof(float)));
-        CHK(ensure(c, c->g_eff, bn64 * sizeof(float)));
-        CHK(ensure(c, c->g_cnode, bn64 * sizeof(float)));
+        CHK(ensure(c, c->g_eff, (defer ? 3 * kt + 1 : 1) * bn64 * sizeof(float)));
+        CHK(ensure(c, c->g_cnode, kt * bn64 * sizeof(float)));
         CHK(ensure(c, c->g_agg, bn64 * sizeof(float)));
-        CHK(ensure(c, c->g_proj, bn64 * 2 * sizeof(float)));
+        CHK(ensure(c, c->g_proj, (defer ? 3 * kt : 1) * bn64 * 2 * sizeof(float)));
         CHK(ensure(c, c->g_sdelta, bn * 3 * sizeof(float)));
         DevBuf* node64[] = {&c->tr_hact, &c->tr_gh, &c->tr_gpe, &c->tr_a1n, &c->tr_gh1};
-        for (DevBuf* b : node64) CHK(ensure(c, *b, bn64 * sizeof(float)));
-        CHK(ensure(c, c->tr_xn, bn * 8 * sizeof(float)));
+        for (DevBuf* b : node64) CHK(ensure(c, *b, kt * bn64 * sizeof(float)));
+        CHK(ensure(c, c->tr_xn, kt * bn * 8 * sizeof(float)));
         DevBuf* edge64[] = {&c->ed_re, &c->ed_a2, &c->ed_a1, &c->ed_gce, &c->ed_g3, &c->ed_g2, &c->ed_g1};
-        for (DevBuf* b : edge64) CHK(ensure(c, *b, bnk * 64 * sizeof(float)));
-        CHK(ensure(c, c->ed_x0, bnk * 8 * sizeof(float)));
+        for (DevBuf* b : edge64) CHK(ensure(c, *b, kt * bnk * 64 * sizeof(float)));
+        CHK(ensure(c, c->ed_x0, kt * bnk * 8 * sizeof(float)));
     }
     CHK(ensure(c, c->tr_loss, (size_t)H * B * sizeof(double)));
     c->lastH = H;

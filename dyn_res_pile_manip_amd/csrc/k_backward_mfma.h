@@ -57,9 +57,9 @@ inline void pack_mfma_bwd(const float* w, std::vector<float>& m) {
 // PROJECT of step p and UPDATE of step p-1 touch the same rows only: one launch does both.
 template <bool PROJECT, bool UPDATE>
 __global__ void __launch_bounds__(64 * MFMA_WAVES)
-kmb_node_step(const float* __restrict__ mb, float* __restrict__ g_eff, const float* __restrict__ g_proj,
-              const float* __restrict__ eff_next, float* __restrict__ g_cnode, int first, float* __restrict__ g_agg,
-              int N, int B) {
+kmb_node_step(const float* __restrict__ mb, const float* g_eff_in, float* g_eff /* out; may be g_eff_in (row-local) */,
+              const float* __restrict__ g_proj, const float* __restrict__ eff_next, float* __restrict__ g_cnode, int first,
+              float* __restrict__ g_agg, int N, int B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wr = lds;
     float* ws = wr + (PROJECT ? 4096 : 0);
@@ -77,7 +77,7 @@ kmb_node_step(const float* __restrict__ mb, float* __restrict__ g_eff, const flo
         const bool live = (t * 32 + j) < N;
         const size_t row = (size_t)b * N + i;
         Frag ge;
-        frag_from_row(g_eff + row * 64, h, ge);
+        frag_from_row(g_eff_in + row * 64, h, ge);
         if (PROJECT) {
             Frag g;
             frag_from_row(g_proj + row * 128, h, g);

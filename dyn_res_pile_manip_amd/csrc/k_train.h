@@ -139,10 +139,7 @@ struct WgradJobs {
     WgradJob j[KT_WGRAD_MAX_JOBS];
 };
 
-__global__ void __launch_bounds__(256)
-kt_wgrad_multi(WgradJobs J) {
-    extern __shared__ float s_part[];                  // [3][66][64]
-    const WgradJob& q = J.j[blockIdx.y];
+__device__ __forceinline__ void wgrad_valu_body(const WgradJob& q, float* s_part /* [3][66][64] */) {
     if ((int)blockIdx.x >= q.blocks) return;
     const int IN = q.in;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -185,6 +182,18 @@ kt_wgrad_multi(WgradJobs J) {
         out[65 * 64 + lane] = accd;
     }
 }
+__global__ void __launch_bounds__(256)
+kt_wgrad_multi(WgradJobs J) {
+    extern __shared__ float s_part[];
+    wgrad_valu_body(J.j[blockIdx.y], s_part);
+}
+// the jobs of a whole training iteration, in device memory: blockIdx.y walks `order[base ...]` (jobs of one size)
+__global__ void __launch_bounds__(256)
+kt_wgrad_list(const WgradJob* __restrict__ jobs, const int* __restrict__ order, int base) {
+    extern __shared__ float s_part[];
+    const WgradJob q = jobs[order[base + blockIdx.y]];
+    wgrad_valu_body(q, s_part);
+}
 #define KT_WGRAD_MULTI_LDS ((size_t)3 * 66 * 64 * sizeof(float))
 
 __global__ void __launch_bounds__(256)
@@ -220,10 +229,7 @@ kt_wgrad_reduce_multi(WgradJobs J) {
 // (2p, 2p + 1), p = (block * 4 + wave) + 4 * blocks * t; bias and density column ride along as per-lane sums of the B operand.
 // Every sum has a fixed order (the wave's row pairs, the four waves in wave order, the blocks in block order): bit-reproducible,
 // as the VALU kernel -- in another order, so the last bits differ from it (the tests compare with the reference's autograd).
-__global__ void __launch_bounds__(256)
-kt_wgrad_mfma_multi(WgradJobs J) {
-    extern __shared__ float s_part[];                  // [3][66][64]
-    const WgradJob& q = J.j[blockIdx.y];
+__device__ __forceinline__ void wgrad_mfma_body(const WgradJob& q, float* s_part /* [3][66][64] */) {
     if ((int)blockIdx.x >= q.blocks) return;
     const int IN = q.in;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -252,21 +258,28 @@ kt_wgrad_mfma_multi(WgradJobs J) {
         x1 = (on && wide && 32 + j < IN) ? x[row * q.ldx + 32 + j] : 0.0f;
         dv = (dens != nullptr && on) ? dens[(row / q.rows_per_sample) % q.dens_mod] / DRP_DENS_SCALE : 0.0f;
     };
-    float g0, g1, x0, x1, dv;
+    // a wave's pairs are a chain of L2 round trips unless several are in flight: the operands of the next WG_AHEAD pairs are
+    // requested before this pair's MFMAs (one pair ahead: 1.5 us a pair at 750 rows per block; the sums keep their order)
+    constexpr int WG_AHEAD = 4;
+    float g0[WG_AHEAD], g1[WG_AHEAD], x0[WG_AHEAD], x1[WG_AHEAD], dv[WG_AHEAD];
     long p = (long)blockIdx.x * 4 + wave;
-    fetch(p, g0, g1, x0, x1, dv);
-    for (; p < npairs; p += step) {
-        float ng0, ng1, nx0, nx1, ndv;
-        fetch(p + step, ng0, ng1, nx0, nx1, ndv);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, g0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, g1, acc[0][1], 0, 0, 0);
-        if (wide) {
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, g0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, g1, acc[1][1], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < WG_AHEAD; ++a) fetch(p + a * step, g0[a], g1[a], x0[a], x1[a], dv[a]);
+    for (; p < npairs; p += WG_AHEAD * step) {
+#pragma unroll
+        for (int a = 0; a < WG_AHEAD; ++a) {
+            if (p + a * step < npairs) {               // wave-uniform
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[a], g0[a], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[a], g1[a], acc[0][1], 0, 0, 0);
+                if (wide) {
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[a], g0[a], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[a], g1[a], acc[1][1], 0, 0, 0);
+                }
+                accb[0] += g0[a]; accb[1] += g1[a];
+                accd[0] = fmaf(g0[a], dv[a], accd[0]); accd[1] = fmaf(g1[a], dv[a], accd[1]);
+            }
+            fetch(p + (a + WG_AHEAD) * step, g0[a], g1[a], x0[a], x1[a], dv[a]);
         }
-        accb[0] += g0; accb[1] += g1;
-        accd[0] = fmaf(g0, dv, accd[0]); accd[1] = fmaf(g1, dv, accd[1]);
-        g0 = ng0; g1 = ng1; x0 = nx0; x1 = nx1; dv = ndv;
     }
     // the two half-waves hold the even and the odd rows' bias sums: even + odd, in that order
 #pragma unroll
@@ -307,6 +320,55 @@ kt_wgrad_mfma_multi(WgradJobs J) {
         }
         put(q.part + (size_t)blockIdx.x * 66 * 64);
     }
+}
+
+__global__ void __launch_bounds__(256)
+kt_wgrad_mfma_multi(WgradJobs J) {
+    extern __shared__ float s_part[];
+    wgrad_mfma_body(J.j[blockIdx.y], s_part);
+}
+__global__ void __launch_bounds__(256)
+kt_wgrad_mfma_list(const WgradJob* __restrict__ jobs, const int* __restrict__ order, int base) {
+    extern __shared__ float s_part[];
+    const WgradJob q = jobs[order[base + blockIdx.y]];
+    wgrad_mfma_body(q, s_part);
+}
+
+// The reduction for a whole iteration's jobs: blockIdx.y = a TARGET (one dW), whose jobs -- the same matrix's gradient from
+// every rollout step and propagation step -- are added in list order, each job's partials as kt_wgrad_reduce_multi adds
+// them: what a sequence of kt_wgrad_reduce_multi launches in that order leaves in a zeroed dW, bit for bit.
+__global__ void __launch_bounds__(256)
+kt_wgrad_reduce_lists(const WgradJob* __restrict__ jobs, const int* __restrict__ tgt_off, const int* __restrict__ tgt_jobs) {
+    __shared__ float s_w[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = blockIdx.x;      // k: 0..63 columns, 64 bias, 65 density column
+    const int e0 = tgt_off[blockIdx.y], e1 = tgt_off[blockIdx.y + 1];
+    const WgradJob q0 = jobs[tgt_jobs[e0]];
+    if (k < 64 && k >= q0.in) return;
+    if (k == 64 && q0.db == nullptr) return;
+    if (k == 65 && q0.dwd == nullptr) return;
+    float tot = 0.0f;
+    for (int e = e0; e < e1; ++e) {
+        const WgradJob q = jobs[tgt_jobs[e]];
+        const float* __restrict__ part = q.part;
+        const int nblocks = q.blocks;
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        int b = wave;
+        for (; b + 12 < nblocks; b += 16) {
+            t0 += part[((size_t)b * 66 + k) * 64 + lane];
+            t1 += part[((size_t)(b + 4) * 66 + k) * 64 + lane];
+            t2 += part[((size_t)(b + 8) * 66 + k) * 64 + lane];
+            t3 += part[((size_t)(b + 12) * 66 + k) * 64 + lane];
+        }
+        for (; b < nblocks; b += 4) t0 += part[((size_t)b * 66 + k) * 64 + lane];
+        __syncthreads();                               // the previous job's sums have been read
+        s_w[wave][lane] = (t0 + t1) + (t2 + t3);
+        __syncthreads();
+        if (wave == 0) tot += (s_w[0][lane] + s_w[1][lane]) + (s_w[2][lane] + s_w[3][lane]);
+    }
+    if (wave != 0) return;
+    if (k < 64) q0.dW[(size_t)lane * q0.lane_stride + (size_t)k * q0.k_stride] += tot;
+    else if (k == 64) q0.db[lane] += tot;
+    else q0.dwd[(size_t)lane * q0.lane_stride] += tot;
 }
 
 // column sums of a [M,3] gradient (bias of the predictor's last layer): ONE workgroup, every partial sum in a fixed

@@ -207,3 +207,33 @@ def test_device_repack_equals_the_host_packers(golden, monkeypatch):
     np.testing.assert_array_equal(runs[False][1], runs[True][1])
     for name in runs[False][2]:
         assert np.array_equal(runs[False][2][name], runs[True][2][name]), name
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_deferred_weight_gradients_equal_the_flushed_ones(golden, monkeypatch, case):
+    """The weight gradients of an iteration go out at the END of the backward pass (every operand keeps a buffer per rollout
+    step and propagation step; one launch per job size + one reduction that adds a matrix's jobs in queue order) instead of
+    25 launch pairs in between (DRP_NO_WGRAD_DEFER=1): the same gradients and the same Adam trajectory, bit for bit --
+    with the matrix-core and the VALU outer products alike."""
+    g = golden.train
+    batch = _batch(g, case)
+    lr, beta1 = g[case + '/lr_beta1']
+    for valu in (False, True):
+        runs = []
+        for flushed in (False, True):
+            for k, on in (('DRP_NO_WGRAD_DEFER', flushed), ('DRP_NO_WGRAD_MFMA', valu)):
+                if on:
+                    monkeypatch.setenv(k, '1')
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            model = _model(golden)
+            eng = model.engine
+            eng.train_begin(batch[0].shape[1] - 1, float(lr), float(beta1))
+            loss, grad = eng.train_step(*batch, mode='grad', want_grad=True)
+            losses = [eng.train_step(*batch, mode='update')[0] for _ in range(3)]
+            runs.append((loss, grad, losses, eng.get_weights()))
+            eng.close()
+        assert np.isfinite(runs[0][1]).all() and np.abs(runs[0][1]).max() > 0
+        assert runs[0][0] == runs[1][0] and runs[0][2] == runs[1][2]
+        np.testing.assert_array_equal(runs[0][1], runs[1][1])
+        np.testing.assert_array_equal(runs[0][3], runs[1][3])
