@@ -2432,6 +2432,18 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     const uint8_t* cself_ok = nullptr;
     int rc = prepare_cself(c, B, N, B, &cself, &cself_ok);
     for (int t = 0; t < H && rc == DRP_OK; ++t) {
+        // with a backward pass to follow, the step's impulses and neighbour lists are part of the tape: its workspace
+        // pointers are lent the tape's slices for the call (as the GD planner does) instead of three copies afterwards
+        void* const save_sd = c->s_delta.p; void* const save_idx = c->nbr_idx.p; void* const save_cnt = c->nbr_cnt.p;
+        struct Lend {
+            drp_ctx* c; void* sd; void* idx; void* cnt;
+            ~Lend() { c->s_delta.p = sd; c->nbr_idx.p = idx; c->nbr_cnt.p = cnt; }
+        } lend{c, save_sd, save_idx, save_cnt};
+        if (backward) {
+            c->s_delta.p = ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3;
+            c->nbr_idx.p = ptr<int16_t>(c->tape_idx) + (size_t)t * bnk;
+            c->nbr_cnt.p = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
+        }
         // this step's impulses are data (train/train_gnn_dyn.py:181)
         hipError_t e = hipMemcpy2DAsync(c->s_delta.p, (size_t)N * 3 * sizeof(float),
                                         ptr<float>(c->tr_sdelta) + (size_t)t * N * 3, hstride * sizeof(float),
@@ -2455,15 +2467,6 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         }
         rc = run_step(c, a);
         if (rc != DRP_OK) break;
-        if (backward) {
-            auto d2d = [&](void* dst, const void* src, size_t bytes) {
-                return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
-            };
-            bool ok = d2d(ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, c->s_delta.p, bn * 3 * sizeof(float));
-            ok = ok && d2d(ptr<int16_t>(c->tape_idx) + (size_t)t * bnk, c->nbr_idx.p, bnk * sizeof(int16_t));
-            ok = ok && d2d(ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn, c->nbr_cnt.p, bn);
-            if (!ok) { rc = fail(c, DRP_EHIP, "tape copy failed"); break; }
-        }
         // loss of this step and d loss / d s_pred_t (train/train_gnn_dyn.py:184-186, :203)
         hipLaunchKernelGGL(kt_mse_grad, dim3(B), dim3(256), 0, st, states + (size_t)t * N * 3, hstride,
                            given + (size_t)(t + 1) * N * 3, in_stride, ptr<int>(c->tr_nums), N, scale,
@@ -2488,6 +2491,14 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     const dim3 rgrid((unsigned)(B * chunks)), egrid((unsigned)(B * chunks16));
     const float* dens = ptr<float>(c->dens);
     HIPCHK(c, hipMemsetAsync(G, 0, (size_t)W_TOTAL * sizeof(float), st));
+    // the reversed lists of ALL rollout steps in one launch (the tape holds every step's lists; a training batch is a handful
+    // of workgroups per step)
+    if (N <= 512)
+        hipLaunchKernelGGL(kb_reverse_lists<256>, dim3(B * H), dim3(256), KB_REV_LDS(N, rev_lds), st, ptr<int16_t>(c->tape_idx),
+                           ptr<uint8_t>(c->tape_cnt), N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums), B);
+    else
+        hipLaunchKernelGGL(kb_reverse_lists<1024>, dim3(B * H), dim3(1024), KB_REV_LDS(N, rev_lds), st, ptr<int16_t>(c->tape_idx),
+                           ptr<uint8_t>(c->tape_cnt), N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums), B);
     // deferred weight gradients: what a job reads keeps a buffer per rollout step t (g_eff and g_proj: per propagation step
     // too; slot 0 of g_eff is the transient copy the predictor writes and the particle encoder reads)
     const bool defer = c->wg_defer_now;
@@ -2516,12 +2527,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
         float* gah = ptr<float>(c->g_agg_hist);
-        if (N <= 512)
-            hipLaunchKernelGGL(kb_reverse_lists<256>, dim3(B), dim3(256), KB_REV_LDS(N, rev_lds), st, idx,
-                               cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums));
-        else
-            hipLaunchKernelGGL(kb_reverse_lists<1024>, dim3(B), dim3(1024), KB_REV_LDS(N, rev_lds), st, idx,
-                               cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums));
+        int* const rev_off_t = ptr<int>(c->rev_off) + (size_t)t * B * (N + 1);
+        int* const rev_t = ptr<int>(c->rev) + (size_t)t * bnk;
         // node-level stages: on the matrix cores when the batch has enough 32-row tiles to fill the chip,
         // otherwise the row kernels chunked over (sample, rows)
         if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES) {
@@ -2549,8 +2556,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                 // particle propagator, aggregate columns
                 launch_wgrad<64>(c, ge_p, 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
                                  nullptr, nullptr, nullptr, 1, 1);
-                hipLaunchKernelGGL(kb_edge_terms, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, ptr<int>(c->rev_off),
-                                   ptr<int>(c->rev), N, gp_p, chunks16);
+                hipLaunchKernelGGL(kb_edge_terms, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, rev_off_t,
+                                   rev_t, N, gp_p, chunks16);
                 // relation propagator, receiver and sender columns
                 launch_wgrad<64>(c, gp_p, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
                                  nullptr, nullptr, nullptr, 1, 1);
@@ -2594,8 +2601,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                 // particle propagator, aggregate columns: g_eff now holds the pre-activation gradient
                 launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
                                  nullptr, nullptr, nullptr, 1, 1);
-                hipLaunchKernelGGL(kb_edge_terms, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, ptr<int>(c->rev_off),
-                                   ptr<int>(c->rev), N, ptr<float>(c->g_proj), chunks16);
+                hipLaunchKernelGGL(kb_edge_terms, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, rev_off_t,
+                                   rev_t, N, ptr<float>(c->g_proj), chunks16);
                 // relation propagator, receiver and sender columns
                 launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
                                  nullptr, nullptr, nullptr, 1, 1);
@@ -2631,7 +2638,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                                prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, gah, mht, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), ed, chunks);
         if (g_prev != nullptr)
             hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
-                               ptr<int>(c->rev_off), ptr<int>(c->rev), N, g_prev, (size_t)N * 3, c->bwd_edge_mfma ? 1 : 0, cnt);
+                               rev_off_t, rev_t, N, g_prev, (size_t)N * 3, c->bwd_edge_mfma ? 1 : 0, cnt);
         launch_wgrad<64>(c, ed.gce, 64, ed.re, 64, (long)bnk, G + W_RP_W, 193, 1, G + W_RP_B, G + W_RP_W + 192, dens, B,
                          (long)N * DRP_K);
         launch_wgrad<64>(c, ed.g3, 64, ed.a2, 64, (long)bnk, G + W_RE4_W, 64, 1, G + W_RE4_B, nullptr, nullptr, 1, 1);
@@ -2764,8 +2771,8 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         CHK(ensure(c, c->tape_cnt, (size_t)H * bn));
         CHK(ensure(c, c->tape_mask, (size_t)H * DRP_PSTEP * bnk * 2 * sizeof(unsigned)));
         CHK(ensure(c, c->g_agg_hist, (size_t)DRP_PSTEP * bn64 * sizeof(float)));
-        CHK(ensure(c, c->rev_off, (size_t)B * (N + 1) * sizeof(int)));
-        CHK(ensure(c, c->rev, bnk * sizeof(int)));
+        CHK(ensure(c, c->rev_off, (size_t)H * B * (N + 1) * sizeof(int)));
+        CHK(ensure(c, c->rev, (size_t)H * bnk * sizeof(int)));
         CHK(ensure(c, c->gpos_edge, bnk * 4 * sizeof(float)));
         CHK(ensure(c, c->g_eff, (defer ? 3 * kt + 1 : 1) * bn64 * sizeof(float)));
         CHK(ensure(c, c->g_cnode, kt * bn64 * sizeof(float)));

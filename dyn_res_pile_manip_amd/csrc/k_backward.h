@@ -236,7 +236,8 @@ __global__ void __launch_bounds__(T)
 kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt, int N,
                  int* __restrict__ rev_off /* [B][N+1] */, int* __restrict__ rev /* [B][N*10] */, int in_lds,
                  const int* __restrict__ n_real /* nullable [B]: receivers >= n_real[b] are padding whose
-                                                   gradient is identically zero (training batches) */) {
+                                                   gradient is identically zero (training batches) */,
+                 int n_real_mod = 0 /* > 0: the grid runs over several rollout steps' lists, sample = block % n_real_mod */) {
     extern __shared__ int s_rev[];
     __shared__ int s_w[T / 64];
     int* deg = s_rev;
@@ -247,7 +248,7 @@ kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict_
     int* ro = rev_off + (size_t)b * (N + 1);
     int* rv = rev + (size_t)b * N * DRP_K;
     int* fill = in_lds ? s_rev + 2 * N : rv;
-    const int n_recv = n_real ? n_real[b] : N;
+    const int n_recv = n_real ? n_real[n_real_mod > 0 ? b % n_real_mod : b] : N;
     for (int i = tid; i < N; i += T) deg[i] = 0;
     __syncthreads();
     for (int e = tid; e < N * DRP_K; e += T) {
