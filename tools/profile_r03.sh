@@ -38,7 +38,7 @@ pmc gd_demo sq "$SQ" $G
 pmc gd_demo sq2 "$SQ2" $G
 python3 profiles/summarize_pmc.py gd-demo $(ls $O/gd_demo_fetch/*/*_counter_collection.csv | head -1) $(ls $O/gd_demo_write/*/*_counter_collection.csv | head -1) > $O/summ/traffic_gd.txt
 cp profiles/traffic.json $O/summ/traffic.json
-for c in c4-50 c5-share; do
+for c in p20 c4-50 c5-share; do
   run $c --config $c --steps 5 --warmup 2 --no-alt --no-cpu-baseline
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 tools/train_timing.py > $O/train_stats.log 2>&1
