@@ -570,6 +570,19 @@ struct LaneRow {
     bool live;                // false: a clamped duplicate past the end (computed, never stored)
 };
 
+// CARRY (the whole-sample kernels of small workgroups): what a wave's FIRST tile needs before its first slot -- in-degree,
+// first neighbours, own and first senders' positions: a chain of three dependent round trips, which later tiles have
+// requested during the previous tile's node part -- does not change between the propagation steps of a rollout step (the
+// lists and the positions are the step's, only the projections move).  The last tile's node part of step p requests it
+// again for the first tile of step p + 1 and hands it over the workgroup barrier in registers: the first tile of steps 2
+// and 3 starts like any other (1024 samples x 32 particles + 6 %, x 20 / 50 + 1 %; the same bits).
+struct HeadCarry {
+    bool ready;
+    int b, i, live, cnt, ok, ks, j0, j1;
+    const float* s; const float* at;
+    float d, pix, piy, piz, pia, p0x, p0y, p0z, p0a;
+    unsigned nbw0, nbw1, nbw2;
+};
 // PAIR: a tile is 16 receivers, and the 32 item columns of the chain are 16 receivers x two CONSECUTIVE slots -- column j
 // belongs to receiver (j & 7) + 8 (j >> 4) and runs the slots of parity (j >> 3) & 1 -- so that a tile needs half the
 // slot iterations.  For batches of so few rows that most waves of the chip would have no tile at all (a workgroup's 128
@@ -579,9 +592,10 @@ struct LaneRow {
 __device__ __forceinline__ float dpp_ror8(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));
 }
-template <bool LAST, bool TAPE, bool PAIR, class First, class Decode, class RowOf>
+template <bool LAST, bool TAPE, bool PAIR, bool CARRY, class First, class Decode, class RowOf>
 __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, First first_of /* this wave's first tile */,
-                                           Decode decode /* the others: draws from the workgroup's queue */, RowOf row_of, int lane
+                                           Decode decode /* the others: draws from the workgroup's queue */, RowOf row_of, int lane,
+                                           HeadCarry& hc
 #ifdef PROP_STAMPS
                                            , unsigned long long (&st_sum)[8]
 #endif
@@ -683,7 +697,18 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
     TileHead hd_next = {};
     TileFirst tf_next = {};
     unsigned nbw2_next = 0u;
-    if (cur.valid) {
+    const TileId first_id = cur;
+    if (CARRY && hc.ready) {
+        if (cur.valid) {
+            hd_next.lr.b = hc.b; hd_next.lr.i = hc.i; hd_next.lr.live = hc.live != 0;
+            hd_next.bs.s = hc.s; hd_next.bs.at = hc.at; hd_next.bs.d = hc.d;
+            hd_next.cnt = hc.cnt; hd_next.ok = hc.ok; hd_next.nbw0 = hc.nbw0; hd_next.nbw1 = hc.nbw1;
+            hd_next.pix = hc.pix; hd_next.piy = hc.piy; hd_next.piz = hc.piz; hd_next.pia = hc.pia;
+            tf_next.ks = hc.ks; tf_next.j0 = hc.j0; tf_next.j1 = hc.j1;
+            tf_next.p0x = hc.p0x; tf_next.p0y = hc.p0y; tf_next.p0z = hc.p0z; tf_next.p0a = hc.p0a;
+            nbw2_next = hc.nbw2;
+        }
+    } else if (cur.valid) {
         hd_next = tile_head(cur);
         if (PAIR) nbw2_next = head_nbw2(hd_next);
         tf_next = tile_first(hd_next, nbw2_next);
@@ -825,6 +850,10 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         const bool more = nxt.valid;
         if (more) hd_next = tile_head(nxt);
         if (PAIR && more) nbw2_next = head_nbw2(hd_next);
+        if (CARRY && !LAST && !more) {                     // the wave's last tile of this step: the head of its first tile of the next
+            hd_next = tile_head(first_id);
+            if (PAIR) nbw2_next = head_nbw2(hd_next);
+        }
         __builtin_amdgcn_sched_barrier(0);
         Frag e;
         {
@@ -842,7 +871,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         if (live) frag_to_row(eff + row * 64, h, e);
         split_frag6(e, f6);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) tf_next = tile_first(hd_next, nbw2_next);          // the head has landed by now
+        if (more || (CARRY && !LAST)) tf_next = tile_first(hd_next, nbw2_next);          // the head has landed by now
         __builtin_amdgcn_sched_barrier(0);
         if (!LAST) {
             Frag p;
@@ -886,6 +915,15 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             st_sum[5] += 1ull;
         }
 #endif
+    }
+    if (CARRY && !LAST && first_id.valid) {
+        hc.ready = true;
+        hc.b = hd_next.lr.b; hc.i = hd_next.lr.i; hc.live = hd_next.lr.live ? 1 : 0;
+        hc.s = hd_next.bs.s; hc.at = hd_next.bs.at; hc.d = hd_next.bs.d;
+        hc.cnt = hd_next.cnt; hc.ok = hd_next.ok; hc.nbw0 = hd_next.nbw0; hc.nbw1 = hd_next.nbw1; hc.nbw2 = nbw2_next;
+        hc.pix = hd_next.pix; hc.piy = hd_next.piy; hc.piz = hd_next.piz; hc.pia = hd_next.pia;
+        hc.ks = tf_next.ks; hc.j0 = tf_next.j0; hc.j1 = tf_next.j1;
+        hc.p0x = tf_next.p0x; hc.p0y = tf_next.p0y; hc.p0z = tf_next.p0z; hc.p0a = tf_next.p0a;
     }
 }
 
@@ -976,7 +1014,8 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         r.i = min(id.t * tile_rows + j, N - 1);
         return r;
     };
-    prop_tiles<LAST, TAPE, PAIR>(A, L, [&]() { return decode(wave); }, decode, row_of, lane PROP_STAMPS_ARG);
+    HeadCarry hc_none;
+    prop_tiles<LAST, TAPE, PAIR, false>(A, L, [&]() { return decode(wave); }, decode, row_of, lane, hc_none PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS
     st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
     st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // all tiles of this wave
@@ -1048,7 +1087,7 @@ __device__ __forceinline__ void prop3_fill_resident(const Prop3Lds& P, const uin
 // three propagation steps, the last one writing s_out.  On entry the resident part of LDS is filled (or being filled:
 // `entry_sync` = the caller has not synchronised since) and the edge-chain region holds nothing this function relies
 // on; on exit every wave has passed its last tile (no barrier after it).
-template <bool TAPE, bool PAIR>
+template <bool TAPE, bool PAIR, bool CARRY>
 __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6,
                                            const float* __restrict__ mw,
                                            const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1256,6 +1295,8 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
                   N, B, proj_b, s_out, out_stride, cself, cself_ok, nullptr, nullptr, re_scale, re_inv};
     PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
                  reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
+    HeadCarry hc;
+    hc.ready = false;
 #pragma unroll 1
     for (int p = 0; p < DRP_PSTEP; ++p) {
         if (p > 0) {
@@ -1273,10 +1314,10 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
             A.agg_out = agg_hist ? agg_hist + (size_t)p * bn64 : nullptr;
         }
         if (p + 1 < DRP_PSTEP) {
-            prop_tiles<false, TAPE, PAIR>(A, L, first_of, decode, row_of, lane PROP_STAMPS_ARG);
+            prop_tiles<false, TAPE, PAIR, CARRY>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
         } else {
             L.w_x = reinterpret_cast<const bf16x8*>(w6_f) + 3 * 1536;
-            prop_tiles<true, TAPE, PAIR>(A, L, first_of, decode, row_of, lane PROP_STAMPS_ARG);
+            prop_tiles<true, TAPE, PAIR, CARRY>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
         }
         ROLL_STAMP(7);                               // wave 0's tiles of a propagation step
     }
@@ -1307,7 +1348,8 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
 #endif
     const Prop3Lds P = prop3_lds(lds);
     prop3_fill_resident(P, sw, sw6, mw);
-    prop3_step<TAPE, PAIR>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
+    prop3_step<TAPE, PAIR, PAIR && !TAPE /* the tape's kernel has no register to spare for the carried head; the big kernel's
+                                            allocation is not to move (with it: 256 VGPRs) */>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
                      eff, N, B, spw, s_delta, s_out, out_stride, cself, cself_ok, mask_hist, agg_hist, re_scale, re_inv, order_rows,
                      (int)threadIdx.x PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS

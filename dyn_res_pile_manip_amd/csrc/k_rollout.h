@@ -117,7 +117,7 @@ km_rollout(const RolloutArgs* __restrict__ args) {
         }
         __syncthreads();                             // the lists are written, the positions no longer needed
         ROLL_STAMP(2);                               // neighbour lists
-        prop3_step<false, PAIR>(P, a->sw, a->sw6, a->mw, s_prev, prev_mod, prev_stride, a->attr, nbat, a->dens, nbat, nbr_idx, nbr_cnt,
+        prop3_step<false, PAIR, true>(P, a->sw, a->sw6, a->mw, s_prev, prev_mod, prev_stride, a->attr, nbat, a->dens, nbat, nbr_idx, nbr_cnt,
                           a->proj_a, a->proj_b, a->c_node, a->eff, N, B, spw, s_delta, states + (size_t)t * N * 3, hstride,
                           a->cself, a->cself_ok, nullptr, nullptr, a->re_scale, a->re_inv, a->order_rows, tid PROP_STAMPS_ARG);
 #ifdef ROLLOUT_STAMPS
