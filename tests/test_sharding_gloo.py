@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the N>1 path of the sampling planner -- contiguous sample
+"""CPU, world_size 2 / 3 / 8 over gloo: the N>1 path of the sampling planner -- contiguous sample
 shards, one all-gather of the per-rank records, combine == the unsharded
 optimize_action (planners.py:549-561).  The rollout/reward on each rank is played by the
 oracle here (no GPU in this container); on the GPU box the same records come from
@@ -32,7 +32,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from dyn_res_pile_manip_amd import sharding, synthetic as syn, weights
     from oracle import propnet_sparse as osp
-    N, H, ns_total = 24, 3, 10          # 10 samples over 2 ranks: 5 + 5; and 3 ranks would be 4+3+3
+    N, H, ns_total = 24, 3, 20          # 20 samples: 10 + 10 over 2 ranks, 7 + 7 + 6 over 3, 3 + 3 + 3 + 3 + 2 + 2 + 2 + 2 over 8
     sd = weights.random_state_dict(seed=0)
     W = osp.weights_np(sd)
     M34 = osp.world2cam_affine(syn.demo_cam_extrinsics(), 24)
@@ -48,7 +48,7 @@ def _worker(rank, world, port, out_dir):
     allrec = sharding.allgather_records(rec)
     nominal, stats = sharding.combine_records(allrec, ns_total)
     # the elite (CEM-style) form of the exchange: k best per rank, all-gathered, re-selected
-    k = 4
+    k = 2
     erec = sharding.make_elite_records(r, acts[lo:hi], k, sample_offset=lo)
     eall = sharding.allgather_records(erec.ravel()).reshape(world, k, -1)
     e_nominal, e_n, e_worst = sharding.combine_elite_records(eall, k)
@@ -58,27 +58,31 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_mppi_update_equals_single_rank(tmp_path):
-    world = 2
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_sharded_mppi_update_equals_single_rank(tmp_path, world):
+    """2 ranks; 3 (uneven shards); 8 -- the node BASELINE configs[2] and [4] are quoted on."""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     from dyn_res_pile_manip_amd import synthetic as syn
     from oracle import propnet_dense as od
     got = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(world)]
-    np.testing.assert_array_equal(got[0]['nominal'], got[1]['nominal'])     # every rank agrees
-    assert (int(got[0]['lo']), int(got[0]['hi']), int(got[1]['lo']), int(got[1]['hi'])) == (0, 5, 5, 10)
-    r_all = np.concatenate([got[0]['r'], got[1]['r']])
-    acts = syn.sample_pushes(10, 3, seed=3)
+    from dyn_res_pile_manip_amd.sharding import shard_range
+    for q in range(1, world):
+        np.testing.assert_array_equal(got[0]['nominal'], got[q]['nominal'])     # every rank agrees
+    assert [(int(g['lo']), int(g['hi'])) for g in got] == [shard_range(20, q, world) for q in range(world)]
+    r_all = np.concatenate([g['r'] for g in got])
+    acts = syn.sample_pushes(20, 3, seed=3)
     expect = od.optimize_action(acts, r_all, 0.1)
     np.testing.assert_allclose(got[0]['nominal'], expect, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(got[0]['mean'], r_all.astype(np.float64).mean(), rtol=1e-12)
     np.testing.assert_allclose(got[0]['std'], r_all.astype(np.float64).std(ddof=1), rtol=1e-9)
     assert int(got[0]['argmax']) == int(np.argmax(r_all))
-    # elite update: mean of the 4 best of all 10 samples, whichever rank held them
-    np.testing.assert_array_equal(got[0]['e_nominal'], got[1]['e_nominal'])
-    best = np.lexsort((np.arange(10), -r_all.astype(np.float64)))[:4]
+    # elite update: mean of the 2 best of all 20 samples, whichever rank held them
+    for q in range(1, world):
+        np.testing.assert_array_equal(got[0]['e_nominal'], got[q]['e_nominal'])
+    best = np.lexsort((np.arange(20), -r_all.astype(np.float64)))[:2]
     np.testing.assert_allclose(got[0]['e_nominal'], acts[best].astype(np.float64).mean(0), rtol=1e-12, atol=1e-12)
-    assert int(got[0]['e_n']) == 4 and float(got[0]['e_worst']) == float(r_all[best[-1]])
+    assert int(got[0]['e_n']) == 2 and float(got[0]['e_worst']) == float(r_all[best[-1]])
 
 
 def test_shard_range_covers_everything():
