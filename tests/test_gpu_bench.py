@@ -74,6 +74,19 @@ def test_two_ranks_sharing_the_gpu(mode):
     assert 'gloo' in d['config']['communicator']
 
 
+def test_eight_ranks_sharing_the_gpu():
+    """`bench.py --gpus 8` as the scaling run calls it (no launcher, configs[2]: 1024 samples per rank would be 8192 -- here
+    64 per rank): eight child ranks, gloo rendezvous, one exchange per iteration, max-over-ranks timing, ONE line."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    d = _run([sys.executable, 'bench.py', '--gpus', '8', '--steps', '3', '--warmup', '1', '--comm', 'gloo', '--share-gpu',
+              '--no-alt', '--samples', '64'], env)
+    assert d['n_gpus'] == 8 and d['config']['world_size'] == 8 and d['config']['gpus_requested'] == 8
+    assert d['config']['n_sample_total'] == 512 and d['config']['n_sample_per_gpu'] == 64
+    assert d['scaling'] == 'weak' and d['cpu_baseline'] is None
+    assert abs(d['value'] - 512 * 300 * 10 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+
+
 def test_two_ranks_under_the_drivers_launcher():
     """The way the driver starts N > 1: torch.distributed.run around bench.py (ranks from the environment)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
