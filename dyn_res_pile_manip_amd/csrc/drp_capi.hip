@@ -97,6 +97,22 @@ RcclApi* rccl_api() {
     std::call_once(once, [&api] {
         std::vector<std::string> tries;
         if (const char* e = getenv("DRP_RCCL_LIB")) tries.push_back(e);
+        // The RCCL that belongs to the HIP runtime THIS library runs on comes first: a process can hold two HIP runtimes
+        // (PyTorch's wheel ships its own copy next to its librccl; imported after this library it does not replace the
+        // system runtime this library is already bound to), and an RCCL talking to the other one finds no device
+        // (ncclCommInitRank: "no ROCm-capable device is detected").
+        {
+            Dl_info hi;
+            if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &hi) && hi.dli_fname) {
+                std::string dir(hi.dli_fname);
+                const size_t slash = dir.rfind('/');
+                if (slash != std::string::npos) {
+                    dir.resize(slash + 1);
+                    tries.push_back(dir + "librccl.so.1");
+                    tries.push_back(dir + "librccl.so");
+                }
+            }
+        }
         std::string mapped;
         dl_iterate_phdr(rccl_find_mapped, &mapped);
         if (!mapped.empty()) tries.push_back(mapped);
@@ -158,6 +174,7 @@ struct drp_ctx {
     bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
     bool bwd_fused = true;          // DRP_NO_BWD_FUSED=1: the GD planner's backward pass as one launch per stage
+    bool graph_strips_q = true;     // DRP_GRAPH_STRIPS_Q=0: k_graph_strips sweeps wave-wide ranges (round 2) instead of quarter-wave ones
     bool prop3_order = true;        // DRP_NO_PROP3_ORDER=1: km_prop3's tiles in the natural row order instead of by in-degree
     int prop_pair_rows = 128;       // DRP_PROP_PAIR_ROWS: a workgroup of the whole-sample kernels with up to so many rows runs tiles of
                                     // 16 receivers x two slots (0 = never)
@@ -522,8 +539,15 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
                            act_stride, s_delta, N, c->cam, sorted, starts);
         if (N >= 800) {
             const int chunks = (N + 255) / 256;
-            hipLaunchKernelGGL(k_graph_strips<256>, dim3(SPREAD_GRID(B * chunks)), dim3(256), GRAPH_STRIPS_LDS(N, 256), st,
-                               (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, chunks, B * chunks, self_first);
+            if (c->graph_strips_q)
+                hipLaunchKernelGGL(k_graph_strips_q<256>, dim3(SPREAD_GRID(B * chunks)), dim3(256), GRAPH_STRIPS_LDS(N, 256), st,
+                                   (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, chunks, B * chunks, self_first);
+            else
+                hipLaunchKernelGGL(k_graph_strips<256>, dim3(SPREAD_GRID(B * chunks)), dim3(256), GRAPH_STRIPS_LDS(N, 256), st,
+                                   (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, chunks, B * chunks, self_first);
+        } else if (c->graph_strips_q) {
+            hipLaunchKernelGGL(k_graph_strips_q<GRAPH_THREADS>, dim3(SPREAD_GRID(B * graph_chunks(N))), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N, GRAPH_THREADS), st,
+                               (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), B * graph_chunks(N), self_first);
         } else {
             hipLaunchKernelGGL(k_graph_strips<GRAPH_THREADS>, dim3(SPREAD_GRID(B * graph_chunks(N))), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N, GRAPH_THREADS), st,
                                (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), B * graph_chunks(N), self_first);
@@ -1119,6 +1143,7 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) { c->rollout_max_n = atoi(e); c->rollout_mid_n = 0; c->rollout_max_rows = KM_ROLLOUT_MAX_ROWS; }
     if (const char* e = getenv("DRP_ROLLOUT_MAX_ROWS")) c->rollout_max_rows = atoi(e);
     c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
+    if (const char* e = getenv("DRP_GRAPH_STRIPS_Q")) c->graph_strips_q = atoi(e) != 0;
     if (const char* e = getenv("DRP_PROP_PAIR_ROWS")) c->prop_pair_rows = std::max(0, atoi(e));
     if (const char* e = getenv("DRP_PROP_PAIR_ALWAYS")) c->prop_pair_always = std::max(0, atoi(e));
     if (const char* e = getenv("DRP_PROP_PAIR_DEG10")) c->prop_pair_deg10 = std::max(0, atoi(e));
@@ -1134,6 +1159,8 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)k_elite_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips<GRAPH_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_graph_strips_q<GRAPH_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_graph_strips_q<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REWARD_LDS(4096)) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reverse_lists<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REV_LDS(KB_REV_LDS_MAX_N, 1)) != hipSuccess ||

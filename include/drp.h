@@ -294,9 +294,11 @@ int drp_gd_step_async(drp_ctx* ctx, int slot);
 int drp_gd_wait(drp_ctx* ctx, int slot, float* rewards_out, float* actions_out);
 
 /* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------
- * The library does not link librccl: the first of these calls binds, at run time, $DRP_RCCL_LIB, else the librccl the
- * process has already mapped (PyTorch's bundled copy when the host imported torch), else /opt/rocm's -- one RCCL per
- * process whatever the import order.  drp_comm_info reports which one.
+ * The library does not link librccl: the first of these calls binds, at run time, $DRP_RCCL_LIB, else the librccl that
+ * sits NEXT TO THE HIP RUNTIME THIS LIBRARY RUNS ON (PyTorch's bundled pair when the host imported torch first, /opt/rocm's
+ * when torch came later or not at all: a wheel imported afterwards brings a second HIP runtime into the process, and its
+ * RCCL would talk to that one), else a librccl the process has already mapped, else /opt/rocm's.  drp_comm_info reports
+ * which one.
  * Hang guard: while a communicator is attached, every host wait of the context (drp_sync, drp_mpc_wait, drp_gd_wait,
  * the waits inside the blocking calls) polls the stream, the communicator's asynchronous error and a deadline
  * (env DRP_COMM_TIMEOUT_S, default 60; DRP_COMM_INIT_TIMEOUT_S, default 300, for drp_comm_init).  On error or

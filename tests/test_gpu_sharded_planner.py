@@ -109,3 +109,20 @@ def test_two_processes_sharing_the_gpu_equal_one(mpc_type, tmp_path):
     full = np.concatenate([res[0]['reward_full'], res[1]['reward_full']])
     assert full.shape == ref['reward_full'].shape
     np.testing.assert_allclose(full, ref['reward_full'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('order', ['drp_first', 'torch_first', 'no_torch'])
+def test_the_communicator_comes_up_whatever_the_import_order(order):
+    """PyTorch's wheel ships its own HIP runtime and its own RCCL.  Imported BEFORE this library the process runs on that
+    runtime and must use that RCCL; imported AFTER it (or not at all) the library is bound to the system runtime, and the
+    wheel's RCCL -- mapped by then -- would talk to a runtime nobody initialised (ncclCommInitRank: "no ROCm-capable device
+    is detected").  The library binds the RCCL that sits next to the HIP runtime it itself runs on."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(root, 'tests', '_rccl_order.py'), order], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and 'communicator up' in out and 'ERR' not in out, out[-2000:]
+    up = [l for l in out.splitlines() if l.startswith('communicator up')][0]
+    assert ("torch/lib/librccl" in up) == (order == 'torch_first'), up
