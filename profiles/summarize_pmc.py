@@ -32,6 +32,8 @@ def norm(name):
         return 'km_prop<true>'
     if name.startswith('km_prop3'):      # the three propagation steps of a rollout step in one launch
         return 'km_prop3'
+    if name.startswith('k_graph_strips'):     # <T>, and _q<T> (quarter-wave ranges, round 3)
+        return 'k_graph_strips'
     return name
 
 
