@@ -581,6 +581,12 @@ def run_sweep(rig, fence):
             m = bench_mppi(rig, N, ns, H, 0, steps, warm, lambda e: e.mpc_update_device(), fence,
                            ['graph', 'node_encode', 'prop', 'reward', 'mppi'], want_median=False)
             B, roof, per_class, dt, kbar = ns, mppi_roofline(rig, m, N, ns, H, steps), m['per_class'], m['dt'], m['kbar']
+            # HBM-side bytes per launch of the dominant kernel, where a PMC pass of this preset is on file (tools/profile_r03.sh)
+            tkey = ('rollout' if roof.get('graph_build_in_launch') else
+                    'prop3' if roof.get('propagation_steps_per_launch', 0) >= 3 else m['dominant'])
+            tb = load_traffic().get(name, {}).get(tkey, {}).get('hbm_bytes_per_launch')
+            if tb:
+                roof['traffic'] = tb
         out.append({'name': name, 'workload': label, 'n_particles': N, 'rows': B, 'n_look_ahead': H, 'steps': steps, 'warmup': warm,
                     'ms_per_step': dt / steps * 1e3, 'value': B * N * H * steps / dt, 'unit': 'particle-steps/s',
                     'mean_in_degree': kbar, 'dominant_kernel': roof['kernel'], 'avg_launch_ms': roof['avg_launch_ms'],

@@ -21,6 +21,7 @@ CLASS = {'k_graph': 'graph', 'k_graph_strips': 'graph', 'k_graph_sort': 'graph_s
          'k_predict': 'predict', 'km_node_encode': 'node_encode', 'km_node_encode_split': 'node_encode', 'km_edge_encode': 'edge_encode',
          'km_update<false>': 'update', 'km_update<true>': 'predict', 'k_reward': 'reward',
          'km_prop<false>': 'prop', 'km_prop<true>': 'prop_last', 'km_prop3': 'prop3',
+         'km_rollout': 'rollout', 'k_graph_cells': 'graph', 'k_graph_sort2': 'graph_sort',
          'kmb_step_bwd': 'step_bwd', 'kb_reward': 'bwd_reward', 'kb_reverse_lists': 'bwd_lists', 'kb_sdelta': 'bwd_push'}
 
 
@@ -34,6 +35,8 @@ def norm(name):
         return 'km_prop3'
     if name.startswith('k_graph_strips'):     # <T>, and _q<T> (quarter-wave ranges, round 3)
         return 'k_graph_strips'
+    if name.startswith('km_rollout'):         # <false> / <true> (paired tiles): the whole rollout of a small pile in one launch
+        return 'km_rollout'
     return name
 
 

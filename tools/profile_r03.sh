@@ -38,9 +38,15 @@ pmc gd_demo sq "$SQ" $G
 pmc gd_demo sq2 "$SQ2" $G
 python3 profiles/summarize_pmc.py gd-demo $(ls $O/gd_demo_fetch/*/*_counter_collection.csv | head -1) $(ls $O/gd_demo_write/*/*_counter_collection.csv | head -1) > $O/summ/traffic_gd.txt
 cp profiles/traffic.json $O/summ/traffic.json
-for c in p20 c4-50 c5-share; do
-  run $c --config $c --steps 5 --warmup 2 --no-alt --no-cpu-baseline
+# the sweep's workloads: kernel stats and HBM-side bytes of their dominant kernel (traffic.json entries under the preset's name)
+for c in p20 c4-50 c4-150 c4-600 c5-share; do
+  S="--config $c --steps 5 --warmup 2 --no-alt --no-cpu-baseline --no-sweep"
+  run $c $S
+  pmc $c fetch FETCH_SIZE $S
+  pmc $c write WRITE_SIZE $S
+  python3 profiles/summarize_pmc.py $c $(ls $O/${c}_fetch/*/*_counter_collection.csv | head -1) $(ls $O/${c}_write/*/*_counter_collection.csv | head -1) > $O/summ/traffic_$c.txt
 done
+cp profiles/traffic.json $O/summ/traffic.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 tools/train_timing.py > $O/train_stats.log 2>&1
 cp $(ls $O/train_stats/*/*_kernel_stats.csv | head -1) $O/summ/r03_train_kernel_stats.csv
 # the bench lines of this build on this box
