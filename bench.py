@@ -637,6 +637,13 @@ def run_rank(args):
         if comm_info['n_ranks'] != world:
             sys.stderr.write('bench.py: ncclCommCount=%d, WORLD_SIZE=%d\n' % (comm_info['n_ranks'], world))
             return EXIT_WORLD_MISMATCH
+        if world > 1:
+            # every rank must have bound the same RCCL (the library follows the HIP runtime the process runs on: include/drp.h)
+            seen = [None] * world
+            dist.all_gather_object(seen, (comm_info['version'], comm_info['path']))
+            if len(set(v for v, _ in seen)) != 1:
+                sys.stderr.write('bench.py: the ranks bound different RCCL versions: %r\n' % (seen,))
+                return EXIT_WORLD_MISMATCH
 
     def fence():
         eng.sync()
