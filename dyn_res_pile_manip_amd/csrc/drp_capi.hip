@@ -204,6 +204,20 @@ struct drp_ctx {
                                     // 50, +5 % at 64, -1 % at 80, -10 % at 150 (the strip build wins); 50 particles x 4096 samples
                                     // (800 rows per workgroup) -5 %, 20 x 8192 (640 rows) +7 %
 
+    // Edge-chain cache of the whole-sample kernels (prop_tiles, EC): the relation encoder's chain runs in the first propagation
+    // step only and its output is read back in the other two, from a workgroup-private buffer of 80 KB per tile of 32 receivers
+    // (2.5 KB per receiver).  Chosen while the whole launch's buffer is at most ecache_max_mb (DRP_ECACHE_MAX_MB; 0 = never).
+    int ecache_max_mb = 192;
+    DevBuf ecache;
+    // how many float4 a workgroup of `rows` receivers needs, and whether a launch of `grid` such workgroups takes the cached kernels
+    static size_t ecache_stride(long rows, bool pair) {
+        const long tiles = pair ? (rows + 15) / 16 : (rows + 31) / 32;
+        return (size_t)tiles * (pair ? 5 : DRP_K) * EC_UNITS;
+    }
+    bool use_ecache(long grid, long rows, bool pair) const {
+        return ecache_max_mb > 0 && (size_t)grid * ecache_stride(rows, pair) * 16 <= (size_t)ecache_max_mb << 20;
+    }
+
     // model constants
     bool have_weights = false, have_cam = false, have_goal = false;
     float adj_thresh = 0.08f, thr = 0.0064f;
@@ -658,10 +672,18 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                    a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist, c->re_scale, c->re_inv, (c->prop3_order ? 1 : 0)
             const bool pair = c->prop_pair(spw, N, B);
             note_degrees(c, spw, N, B);
-            if (!tape && !pair) hipLaunchKernelGGL((km_prop3<false, false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
-            else if (!tape) hipLaunchKernelGGL((km_prop3<false, true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
-            else if (!pair) hipLaunchKernelGGL((km_prop3<true, false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
-            else hipLaunchKernelGGL((km_prop3<true, true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS);
+            const bool ec = c->use_ecache(grid.x, (long)spw * N, pair);
+            const size_t ec_stride = drp_ctx::ecache_stride((long)spw * N, pair);
+            if (ec) CHK(ensure(c, c->ecache, (size_t)grid.x * ec_stride * 16));
+            float4* ecp = ec ? ptr<float4>(c->ecache) : nullptr;
+#define PROP3_LAUNCH(TAPE_, PAIR_) do { \
+                if (ec) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride); \
+                else hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride); } while (0)
+            if (!tape && !pair) PROP3_LAUNCH(false, false);
+            else if (!tape) PROP3_LAUNCH(false, true);
+            else if (!pair) PROP3_LAUNCH(true, false);
+            else PROP3_LAUNCH(true, true);
+#undef PROP3_LAUNCH
 #undef PROP3_ARGS
         }
         for (int p = 0; p < DRP_PSTEP && !prop3; ++p) {
@@ -830,6 +852,12 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
         ra.c_node = ptr<float>(c->c_node); ra.eff = ptr<float>(c->eff); ra.cself = cself; ra.cself_ok = cself_ok;
         ra.N = N; ra.B = B; ra.spw = spw_r; ra.nb = nb; ra.H = H; ra.order_rows = (c->prop3_order ? 1 : 0);
         ra.thr = c->thr; ra.re_scale = c->re_scale; ra.re_inv = c->re_inv; ra.cam = c->cam;
+        const bool pair_r = c->prop_pair(spw_r, N, B);
+        const unsigned grid_r = (unsigned)((B + spw_r - 1) / spw_r);
+        const bool ec = c->use_ecache(grid_r, (long)spw_r * N, pair_r);
+        ra.ec_stride = drp_ctx::ecache_stride((long)spw_r * N, pair_r);
+        if (ec) CHK(ensure(c, c->ecache, (size_t)grid_r * ra.ec_stride * 16));
+        ra.ecache = ec ? ptr<float4>(c->ecache) : nullptr;
         // the argument block sits in device memory; it is uploaded when it changes (every iteration of an MPC session
         // passes the same one), behind whatever still runs on the stream
         if (!c->roll_args_valid || memcmp(&ra, &c->roll_args_host, sizeof(ra)) != 0) {
@@ -839,12 +867,11 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
             c->roll_args_valid = true;
         }
         ProbeScope ps(c, KC_PROP);
-        if (c->prop_pair(spw_r, N, B))
-            hipLaunchKernelGGL(km_rollout<true>, dim3((unsigned)((B + spw_r - 1) / spw_r)), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS,
-                               c->stream, ptr<RolloutArgs>(c->roll_args));
-        else
-            hipLaunchKernelGGL(km_rollout<false>, dim3((unsigned)((B + spw_r - 1) / spw_r)), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS,
-                               c->stream, ptr<RolloutArgs>(c->roll_args));
+#define ROLLOUT_LAUNCH(PAIR_, EC_) hipLaunchKernelGGL((km_rollout<PAIR_, EC_>), dim3(grid_r), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS, \
+                                                      c->stream, ptr<RolloutArgs>(c->roll_args))
+        if (pair_r) { if (ec) ROLLOUT_LAUNCH(true, true); else ROLLOUT_LAUNCH(true, false); }
+        else { if (ec) ROLLOUT_LAUNCH(false, true); else ROLLOUT_LAUNCH(false, false); }
+#undef ROLLOUT_LAUNCH
         HIPCHK(c, hipGetLastError());
         note_degrees(c, spw_r, N, B);           // the last step's lists
     }
@@ -1153,6 +1180,7 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_COMM_INIT_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_init_timeout_s = v; }
     if (const char* e = getenv("DRP_SPLIT_SHIFT")) c->re_shift_env = atoi(e);
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
+    if (const char* e = getenv("DRP_ECACHE_MAX_MB")) c->ecache_max_mb = std::max(0, atoi(e));
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_q4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -1184,12 +1212,18 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_prop<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kt_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||
@@ -1210,7 +1244,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)guarded_wait(c, nullptr);           // a collective that cannot finish must not keep the destructor
     if (c->comm) { RcclApi* R = rccl_api(); if (R) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
-    DevBuf* bufs[] = {&c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
+    DevBuf* bufs[] = {&c->ecache, &c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,

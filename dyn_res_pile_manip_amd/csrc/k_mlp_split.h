@@ -549,6 +549,7 @@ struct PropArgs {
     const float* cself; const uint8_t* cself_ok;
     unsigned* mask_out; float* agg_out;
     float re_scale, re_inv;      // 2^k and 2^-k of the relation encoder's range shift
+    float4* ecache;              // EC != 0: this workgroup's edge-chain cache, [tile][iteration][8][64 lanes] float4
 };
 struct PropLds {
     const f16x8* wsp;         // edge chain, S_* offsets
@@ -592,7 +593,19 @@ struct HeadCarry {
 __device__ __forceinline__ float dpp_ror8(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));
 }
-template <bool LAST, bool TAPE, bool PAIR, bool CARRY, class First, class Decode, class RowOf>
+// EC (edge-chain cache; the whole-sample kernels of small piles).  The relation encoder's chain W_e . RelationEncoder(.) of an
+// edge depends on the rollout step's positions only -- model/gnn_dyn.py:179-180 computes it ONCE, in front of the loop over the
+// propagation steps (:182-193) -- so a workgroup that owns its samples can run it in the first propagation step only
+// (EC = 1: the chain starts from a zero accumulator and its raw output q = 2^k W_e h_3 goes to a workgroup-private buffer, in
+// the accumulator's own layout: eight coalesced 1-KB stores per slot iteration) and read it back in the other two (EC = 2: no
+// chain, no matrix work in the slot loop at all -- q and the sender's row are loaded two iterations ahead), with
+//     relu(q 2^-k + ((b + d w_d + P_r[i]) + P_s[j]))
+// in all three steps.  That differs from the recomputing loop (EC = 0: the bias and P_r ride in the chain's initial
+// accumulator) in the last place of a sum's rounding: EC kernels are compared with the oracle, not bit for bit with EC = 0.
+// Pays where the chain's LATENCY is the bound -- one tile per wave -- and the buffer (2.5 KB per receiver) stays in the
+// last-level cache; at 300 particles x 1024 samples it is 700 MB per rollout step and recomputing costs the same.
+#define EC_UNITS 512             // float4 per (tile, slot iteration): 8 per lane
+template <bool LAST, bool TAPE, bool PAIR, bool CARRY, int EC, class First, class Decode, class RowOf>
 __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, First first_of /* this wave's first tile */,
                                            Decode decode /* the others: draws from the workgroup's queue */, RowOf row_of, int lane,
                                            HeadCarry& hc
@@ -671,6 +684,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
     auto head_nbw2 = [&](const TileHead& hd) {
         return reinterpret_cast<const unsigned*>(nbr_idx + ((size_t)hd.lr.b * N + hd.lr.i) * DRP_K)[2];
     };
+
     auto tile_first = [&](const TileHead& hd, unsigned nbw2) {
         const int i = hd.lr.i;
         const int nb0 = (int)(hd.nbw0 & 0xffffu), nb1 = (int)(hd.nbw0 >> 16), nb2 = (int)(hd.nbw1 & 0xffffu);
@@ -726,6 +740,40 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         const float* pj = proj + ((size_t)b * N) * 128;
         const int cnt = hd.cnt;
         const int16_t* nb = nbr_idx + row * DRP_K;
+        const int ks = tf.ks;
+        const float inv = A.re_inv;
+        const int kfirst = ks + par;                       // this column's slots: kfirst, kfirst + KS, ... while below cnt
+        // EC: this tile's part of the workgroup's cache, one unit per slot ITERATION of the tile
+        float4* const ec = (EC != 0) ? A.ecache + (size_t)cur.t * (PAIR ? 5 : DRP_K) * EC_UNITS + lane : nullptr;
+        // ---- EC = 2: the chain's outputs come from the cache: a slot is 16 loads of 16 B and 130 vector instructions, no
+        // matrix work.  The slot loop (further down) works on HALF slots (one output block: 4 + 4 loads, 32 registers), two in
+        // flight: a half's registers are requested again, for the next slot, as soon as they have been added.  The first slot
+        // is requested HERE, with the tile's own rows: its addresses hang on nothing but the tile's number and the head's
+        // first sender.  A slot past the tile's last is still requested (from addresses that exist: the cache lines of the
+        // iteration before, its sender row the sink) -- a request under a branch would make the buffers merge points, i.e.
+        // copies behind a full wait; the loads go through global-address-space pointers (flat loads return out of order: a
+        // wait for one would be a wait for all).
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef const f32x4 __attribute__((address_space(1))) * GPtr4;
+        struct Half { f32x4 q[4], s[4]; };
+        Half ha, hb;
+        const GPtr4 ecg = (GPtr4)reinterpret_cast<const f32x4*>(ec);
+        const GPtr4 pjg = (GPtr4)reinterpret_cast<const f32x4*>(pj + 64 + 4 * h);
+        const GPtr4 sinkg = (GPtr4)reinterpret_cast<const f32x4*>(mw + R_SINK + 4 * h);
+        // the column's slot k with sender jc; it_q: the iteration whose cache lines are read
+        auto issue_half = [&](int k, int it_q, int ob, int jc, Half& H) {
+            const GPtr4 src = ecg + (size_t)it_q * EC_UNITS + ob * 4 * 64;
+            const GPtr4 rowp = ((k < cnt) ? pjg + (size_t)jc * 32 : sinkg) + 8 * ob;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                H.q[g] = src[g * 64];
+                H.s[g] = rowp[2 * g];
+            }
+        };
+        if constexpr (EC == 2) {
+            issue_half(kfirst, 0, 0, tf.j0, ha);
+            issue_half(kfirst, 0, 1, tf.j0, hb);
+        }
         Frag acc, bpr;
         {
             Frag pr;
@@ -735,7 +783,6 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
         }
         // the self loop's effect is relu(c_self + bias + P_r[i] + P_s[i]) without running the encoder chain
-        const int ks = tf.ks;
         if (ks) {
             const float* csr = cself + (size_t)b * 64;
             const float* psr = pj + (size_t)i * 128 + 64;
@@ -754,13 +801,12 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         } else {
             frag_zero(acc);
         }
-        {
+        if (EC == 0) {
             // the chain below runs on activations scaled by 2^k: so does its initial accumulator
             const float sc = A.re_scale;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { bpr.v[0][r] *= sc; bpr.v[1][r] *= sc; }
         }
-        const float inv = A.re_inv;
         const float pix = hd.pix, piy = hd.piy, piz = hd.piz, pia = hd.pia;
         // two-deep software pipeline on the dependent loads (index -> sender position): the
         // position of slot k+1 and the index of slot k+2 are requested while slot k computes
@@ -770,9 +816,44 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
         int st_slots = 0;
 #endif
+        if constexpr (EC == 2) {
+            unsigned mbits = 0u;
+            auto consume_half = [&](int k, int ob, const Half& H) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float qv[4] = {H.q[g].x, H.q[g].y, H.q[g].z, H.q[g].w};
+                    const float sv[4] = {H.s[g].x, H.s[g].y, H.s[g].z, H.s[g].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const float t = relu1(fmaf(qv[e], inv, bpr.v[ob][r] + sv[e]));
+                        acc.v[ob][r] += t;
+                        if (PAIR) acc.v[ob][r] += dpp_ror8(t);
+                        if (TAPE) mbits = (mbits << 1) | ((unsigned)(0 - __float_as_int(t)) >> 31);
+                    }
+                }
+                if (TAPE && ob == 1 && live_row && (!PAIR || k < DRP_K)) mask_out[(row * DRP_K + k) * 2 + h] = mbits;
+            };
+            int k = kfirst;
 #pragma unroll 1
-        for (int k = ks + par; k < DRP_K + par; k += KS) {     // k: this column's slot (PAIR: k may reach DRP_K, a padded slot)
-            if (__all(k >= cnt)) break;              // no receiver of this tile has a slot k
+            for (int it = 0; it < (PAIR ? 5 : DRP_K); ++it, k += KS) {
+                if (__all(k >= cnt)) break;                      // wave-uniform trip count (the columns move together)
+                const int j2 = (k + 2 * KS < cnt) ? (int)nb[min(k + 2 * KS, DRP_K - 1)] : i;
+                const int it_q = (it + 1 < (PAIR ? 5 : DRP_K) && !__all(k + KS >= cnt)) ? it + 1 : it;
+                consume_half(k, 0, ha);
+                issue_half(k + KS, it_q, 0, j1, ha);
+                consume_half(k, 1, hb);
+                issue_half(k + KS, it_q, 1, j1, hb);
+                j1 = j2;
+#ifdef PROP_STAMPS
+                ++st_slots;
+#endif
+            }
+        } else {
+        int it = 0;                                      // EC = 1: the iteration's unit of the cache
+#pragma unroll 1
+        for (int k = kfirst; k < DRP_K + par; k += KS) {     // k: this column's slot (PAIR: k may reach DRP_K, a padded slot)
+            if (__all(k >= cnt)) break;             // no column of this tile has a slot k
 #ifdef PROP_STAMPS
             ++st_slots;
 #endif
@@ -803,8 +884,19 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             frag_from_row(rows + 64, h, a);
             mfma_layer64_split(wsp + S_RE4, fb, a, lane, wn, wsp + S_RPE, w0);
             split_frag<true>(a, fb);
-            c = bpr;
+            if (EC == 0) c = bpr; else frag_zero(c);
             mfma_layer64_split(wsp + S_RPE, fb, c, lane, w0, nullptr, wn);
+            if (EC == 1) {
+                // the chain's raw output, for the other two propagation steps; and this step's term the way they form it
+                float4* dst = ec + (size_t)it * EC_UNITS;
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        dst[(ob * 4 + g) * 64] = make_float4(c.v[ob][4 * g + 0], c.v[ob][4 * g + 1], c.v[ob][4 * g + 2], c.v[ob][4 * g + 3]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sv.v[0][r] += bpr.v[0][r]; sv.v[1][r] += bpr.v[1][r]; }
+            }
             if (!TAPE) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -836,6 +928,8 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             }
             j0 = j1; j1 = j2;
             p0x = p1x; p0y = p1y; p0z = p1z; p0a = p1a;
+            if (EC == 1) ++it;
+        }
         }
         // ---- node update on the aggregate still in registers
         asm volatile("" ::: "memory");
@@ -907,7 +1001,8 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
 #ifdef PROP_STAMPS
         {
             const unsigned long long st_c2 = __builtin_amdgcn_s_memtime(), st_r2 = __builtin_amdgcn_s_memrealtime();
-            st_sum[0] += st_c1 - st_c0;        // shader cycles in slot loops
+            if (EC == 2) st_sum[6] += st_c1 - st_c0;   // shader cycles in the slot loops that read the cache
+            else st_sum[0] += st_c1 - st_c0;           // shader cycles in slot loops
             st_sum[1] += (unsigned long long)st_slots;
             st_sum[2] += st_c2 - st_c1;        // shader cycles in node parts
             st_sum[3] += st_c2 - st_c0;        // shader cycles, whole tile
@@ -1015,7 +1110,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         return r;
     };
     HeadCarry hc_none;
-    prop_tiles<LAST, TAPE, PAIR, false>(A, L, [&]() { return decode(wave); }, decode, row_of, lane, hc_none PROP_STAMPS_ARG);
+    prop_tiles<LAST, TAPE, PAIR, false, 0>(A, L, [&]() { return decode(wave); }, decode, row_of, lane, hc_none PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS
     st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
     st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // all tiles of this wave
@@ -1087,7 +1182,7 @@ __device__ __forceinline__ void prop3_fill_resident(const Prop3Lds& P, const uin
 // three propagation steps, the last one writing s_out.  On entry the resident part of LDS is filled (or being filled:
 // `entry_sync` = the caller has not synchronised since) and the edge-chain region holds nothing this function relies
 // on; on exit every wave has passed its last tile (no barrier after it).
-template <bool TAPE, bool PAIR, bool CARRY>
+template <bool TAPE, bool PAIR, bool CARRY, bool ECACHE>
 __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6,
                                            const float* __restrict__ mw,
                                            const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1097,7 +1192,8 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
                                            float* __restrict__ eff, int N, int B, int spw, const float* __restrict__ s_delta,
                                            float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself,
                                            const uint8_t* __restrict__ cself_ok, unsigned* __restrict__ mask_hist,
-                                           float* __restrict__ agg_hist, float re_scale, float re_inv, int order_rows, int tid /* tid */
+                                           float* __restrict__ agg_hist, float re_scale, float re_inv, int order_rows, int tid /* tid */,
+                                           float4* __restrict__ ecache /* ECACHE: this workgroup's edge-chain cache (prop_tiles) */
 #ifdef PROP_STAMPS
                                            , unsigned long long (&st_sum)[8]
 #endif
@@ -1292,7 +1388,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
     };
     const size_t bn64 = (size_t)B * N * 64;
     PropArgs A = {mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, c_node, eff, eff,
-                  N, B, proj_b, s_out, out_stride, cself, cself_ok, nullptr, nullptr, re_scale, re_inv};
+                  N, B, proj_b, s_out, out_stride, cself, cself_ok, nullptr, nullptr, re_scale, re_inv, ecache};
     PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
                  reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
     HeadCarry hc;
@@ -1313,12 +1409,17 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
             A.mask_out = mask_hist + (size_t)p * B * N * DRP_K * 2;
             A.agg_out = agg_hist ? agg_hist + (size_t)p * bn64 : nullptr;
         }
-        if (p + 1 < DRP_PSTEP) {
-            prop_tiles<false, TAPE, PAIR, CARRY>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
+        if (ECACHE && p == 0) {
+            prop_tiles<false, TAPE, PAIR, CARRY, 1>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
+        } else if (p + 1 < DRP_PSTEP) {
+            prop_tiles<false, TAPE, PAIR, CARRY, ECACHE ? 2 : 0>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
         } else {
             L.w_x = reinterpret_cast<const bf16x8*>(w6_f) + 3 * 1536;
-            prop_tiles<true, TAPE, PAIR, CARRY>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
+            prop_tiles<true, TAPE, PAIR, CARRY, ECACHE ? 2 : 0>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
         }
+#ifdef ROLLOUT_STAMPS
+        if (roll_on) atomicAdd(&g_roll_stamps[11 + p], __builtin_amdgcn_s_memrealtime() - roll_t);   // ... by propagation step
+#endif
         ROLL_STAMP(7);                               // wave 0's tiles of a propagation step
     }
 #ifdef ROLLOUT_STAMPS
@@ -1329,7 +1430,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
 #endif
 }
 
-template <bool TAPE, bool PAIR>
+template <bool TAPE, bool PAIR, bool ECACHE>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
          const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1340,7 +1441,8 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
          const float* __restrict__ s_delta /* not null: the particle encoder runs here first (phase E) */,
          float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself, const uint8_t* __restrict__ cself_ok,
          unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */,
-         float re_scale, float re_inv, int order_rows) {
+         float re_scale, float re_inv, int order_rows,
+         float4* __restrict__ ecache /* ECACHE: [workgroup][ec_stride] */, size_t ec_stride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef PROP_STAMPS
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
@@ -1349,9 +1451,9 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     const Prop3Lds P = prop3_lds(lds);
     prop3_fill_resident(P, sw, sw6, mw);
     prop3_step<TAPE, PAIR, PAIR && !TAPE /* the tape's kernel has no register to spare for the carried head; the big kernel's
-                                            allocation is not to move (with it: 256 VGPRs) */>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
+                                            allocation is not to move (with it: 256 VGPRs) */, ECACHE>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
                      eff, N, B, spw, s_delta, s_out, out_stride, cself, cself_ok, mask_hist, agg_hist, re_scale, re_inv, order_rows,
-                     (int)threadIdx.x PROP_STAMPS_ARG);
+                     (int)threadIdx.x, ECACHE ? ecache + (size_t)blockIdx.x * ec_stride : nullptr PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -38,12 +38,13 @@ struct RolloutArgs {
     float* s_delta; int16_t* nbr_idx; uint8_t* nbr_cnt;
     float* proj_a; float* proj_b; float* c_node; float* eff;
     const float* cself; const uint8_t* cself_ok;
+    float4* ecache; size_t ec_stride;        // ECACHE: the edge-chain cache (prop_tiles), ec_stride float4 per workgroup
     int N, B, spw, nb, H, order_rows;
     float thr, re_scale, re_inv;
     DrpCam cam;
 };
 
-template <bool PAIR>
+template <bool PAIR, bool ECACHE>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_rollout(const RolloutArgs* __restrict__ args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -117,9 +118,10 @@ km_rollout(const RolloutArgs* __restrict__ args) {
         }
         __syncthreads();                             // the lists are written, the positions no longer needed
         ROLL_STAMP(2);                               // neighbour lists
-        prop3_step<false, PAIR, true>(P, a->sw, a->sw6, a->mw, s_prev, prev_mod, prev_stride, a->attr, nbat, a->dens, nbat, nbr_idx, nbr_cnt,
+        prop3_step<false, PAIR, true, ECACHE>(P, a->sw, a->sw6, a->mw, s_prev, prev_mod, prev_stride, a->attr, nbat, a->dens, nbat, nbr_idx, nbr_cnt,
                           a->proj_a, a->proj_b, a->c_node, a->eff, N, B, spw, s_delta, states + (size_t)t * N * 3, hstride,
-                          a->cself, a->cself_ok, nullptr, nullptr, a->re_scale, a->re_inv, a->order_rows, tid PROP_STAMPS_ARG);
+                          a->cself, a->cself_ok, nullptr, nullptr, a->re_scale, a->re_inv, a->order_rows, tid,
+                          ECACHE ? a->ecache + (size_t)blockIdx.x * a->ec_stride : nullptr PROP_STAMPS_ARG);
 #ifdef ROLLOUT_STAMPS
         roll_t = __builtin_amdgcn_s_memrealtime();   // prop3_step keeps its own clock
         if (roll_on) atomicAdd(&g_roll_stamps[15], 1ull);

@@ -153,8 +153,11 @@ def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch, N, ns)
                  whole samples, the three propagation steps in one launch;
       'steps'    one km_prop launch per propagation step (DRP_NO_PROP3=1).
     Same tiles, same arithmetic in the same order.  The second pass has per-particle attributes (the self loop then
-    runs the encoder chain like any other edge).  Neighbour lists of the last step included."""
+    runs the encoder chain like any other edge).  Neighbour lists of the last step included.
+    (With the edge-chain cache of the whole-sample kernels switched off: it changes the last place of a sum --
+    `test_edge_cache_against_the_oracle` below is its test.)"""
     from dyn_res_pile_manip_amd.engine import Engine
+    monkeypatch.setenv('DRP_ECACHE_MAX_MB', '0')
     H = 3
     s0, dens, attr = syn.make_pile(N, 1, seed=3)
     acts = syn.sample_pushes(ns, H, seed=3)
@@ -184,6 +187,60 @@ def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch, N, ns)
             assert np.array_equal(res['rollout', tag, 'idx'], res[mode, tag, 'idx']), (mode, tag)
             assert np.array_equal(res['rollout', tag, 'cnt'], res[mode, tag, 'cnt']), (mode, tag)
     assert not np.array_equal(res['rollout', 'uniform'], res['rollout', 'mixed'])
+
+
+@pytest.mark.parametrize('N,ns,H,nb', [
+    (50, 1024, 4, 1),       # 200 rows a workgroup: 7 tiles for 8 waves, tiles of 2 ... 9 slot iterations
+    (40, 1024, 4, 1),
+    (20, 1024, 4, 1),       # paired tiles reading the cache
+    (64, 1024, 3, 1),       # eight full tiles
+    (30, 180, 3, 30),       # the planner's shape: 30 batch columns, one sample per workgroup
+    (100, 700, 2, 1)])      # three samples a workgroup, 10 tiles for 8 waves
+def test_edge_cache_against_the_oracle(monkeypatch, N, ns, H, nb):
+    """The whole-sample kernels of small piles with the relation encoder's chain run in the FIRST propagation step only and
+    its output read back in the other two -- model/gnn_dyn.py:179-193 computes relation_encode once, in front of the pstep
+    loop.  That changes the order of a sum (the bias and the receiver's term no longer ride in the chain's accumulator), not
+    its terms: checked against the oracle at the tolerance of every other engine (flat 1e-4 of the step's displacement,
+    2e-6 absolute), with the neighbour lists of the last step equal to the oracle's, and both launch structures (the whole
+    rollout in one launch / one launch per rollout step) the same bits."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    from oracle import propnet_sparse as osp
+    monkeypatch.setenv('DRP_ECACHE_MAX_MB', '4000')
+    monkeypatch.setenv('DRP_ROLLOUT_MAX_N', '256')
+    s0, dens, attr = syn.make_pile(N, nb, seed=N)
+    acts = syn.sample_pushes(ns, H, seed=N + 7)
+    sd = weights.random_state_dict(seed=0)
+    blob = weights.blob_from_state_dict(sd)
+    M34 = world2cam_affine(syn.demo_cam_extrinsics())
+    out = {}
+    for mode in ('rollout', 'prop3'):
+        monkeypatch.delenv('DRP_NO_ROLLOUT_FUSED', raising=False)
+        if mode == 'prop3':
+            monkeypatch.setenv('DRP_NO_ROLLOUT_FUSED', '1')
+        eng = Engine(0)
+        eng.load_weights(blob, 0.08)
+        eng.set_camera(M34, 24.0, syn.demo_cam_params())
+        out[mode], _ = eng.rollout(s0, attr, dens, acts)
+        out[mode, 'idx'] = eng.debug_fetch('nbr_idx', (ns, N, 10), np.int16)
+        out[mode, 'cnt'] = eng.debug_fetch('nbr_cnt', (ns, N), np.uint8)
+        eng.close()
+    assert np.array_equal(out['rollout'], out['prop3'])
+    W = osp.weights_np(sd)
+    pick = np.unique(np.linspace(0, ns - 1, 24).astype(int))          # samples spread over the batch (and its workgroups)
+    for b in pick:
+        c = int(b % nb)                                               # sample b of the batch starts from column b % nb
+        taps = {}
+        ref = osp.rollout(W, s0[c:c + 1], dens[c:c + 1], attr[c:c + 1], acts[b:b + 1], M34, 24.0, taps=taps)[0]
+        got = out['rollout'][b]
+        prev = np.concatenate([s0[c][None], ref[:-1]])
+        disp = np.abs(ref - prev).max(axis=(1, 2))
+        err = np.abs(got - ref).max(axis=(1, 2))
+        assert (err < 2e-6).all(), (b, err)
+        assert (err / np.maximum(disp, 1e-12) < 1e-4).all(), (b, err / disp)
+        ridx, rcnt = taps['nbr_idx'][-1][0], taps['nbr_cnt'][-1][0]
+        assert np.array_equal(out['rollout', 'cnt'][b], rcnt), b
+        for i in range(N):
+            assert sorted(out['rollout', 'idx'][b, i, :rcnt[i]]) == sorted(ridx[i, :rcnt[i]]), (b, i)
 
 
 @pytest.mark.parametrize('N,ns,H,nb', [(50, 1024, 10, 1), (20, 1024, 10, 1), (150, 600, 4, 1), (256, 1024, 2, 1),
