@@ -276,78 +276,38 @@ def load_traffic():
 TRAFFIC_SOURCE = 'profiles/traffic.json (builder-side rocprofv3 --pmc passes of this command, not measured in this run)'
 
 
-def tile_slot_model(cnt, N, ns, n_cu, engine, self_const):
-    """Slot iterations the propagation kernel runs per 32-receiver tile: the largest in-degree of the tile, minus the
-    self loop when its encoder chain is replaced by the per-sample constant (attributes are zeros here).  km_prop3
-    (whole_samples() in drp_capi.hip: chip-filling batches, or any batch of samples of up to 256 particles) cuts the
-    rows of a workgroup's samples, ordered by in-degree unless the pile is saturated, into tiles; km_prop cuts every
-    sample on its own.  Few rows run PAIRED tiles (prop_pair() in drp_capi.hip: a workgroup of up to 128 rows -- above 64
-    only while the mean in-degree is at most 8.3 --, a per-step batch of up to two tiles per CU): 16 receivers, two slots
-    per iteration of the chain; the particle encoder keeps tiles of 32.
-    -> (tiles per propagation step, mean slot iterations per tile, the particle encoder's tiles)"""
-    spw = -(-ns // n_cu)
-    prop3 = (engine == 'fused' and os.environ.get('DRP_NO_PROP3') is None and (ns >= n_cu - n_cu // 5 or N <= 256))
-    pair_rows = int(os.environ.get('DRP_PROP_PAIR_ROWS', '128'))
-    if prop3:
-        pair = spw * N <= pair_rows and (spw * N <= 64 or float(cnt.mean()) * 10 <= 83)
-    else:
-        pair = engine == 'fused' and pair_rows > 0 and ns * (-(-N // 32)) <= 2 * n_cu
-    if pair:
-        tile_max, enc_tiles = [], 0
-        self_ = 1.0 if self_const else 0.0
-        if prop3:
-            ordered = os.environ.get('DRP_NO_PROP3_ORDER') is None
-            for w in range(0, ns, spw):
-                rows = cnt[w:w + spw].ravel()
-                enc_tiles += -(-rows.size // 32)
-                if ordered and (rows == rows.max()).sum() * 16 < rows.size * 15:
-                    rows = np.sort(rows)[::-1]
-                rows = np.pad(rows, (0, (-rows.size) % 16))
-                tile_max.append(rows.reshape(-1, 16).max(-1))
-            tile_max = np.concatenate(tile_max).astype(np.float64)
-        else:
-            tile_max = np.pad(cnt, ((0, 0), (0, (-N) % 16))).reshape(ns, -1, 16).max(-1).astype(np.float64).ravel()
-            enc_tiles = ns * (-(-N // 32))
-        its = float(np.ceil((tile_max - self_).clip(min=0) / 2.0).mean())
-        return int(tile_max.size), its, enc_tiles
-    tile_max = []
-    if prop3:
-        ordered = os.environ.get('DRP_NO_PROP3_ORDER') is None and spw * N <= 4900
-        for w in range(0, ns, spw):
-            rows = cnt[w:w + spw].ravel()
-            if ordered and (rows == rows.max()).sum() * 16 < rows.size * 15:     # saturated piles keep the natural order
-                rows = np.sort(rows)[::-1]
-            rows = np.pad(rows, (0, (-rows.size) % 32))
-            tile_max.append(rows.reshape(-1, 32).max(-1))
-        tile_max = np.concatenate(tile_max).astype(np.float64)
-    else:
-        tile_max = np.pad(cnt, ((0, 0), (0, (-N) % 32))).reshape(ns, -1, 32).max(-1).astype(np.float64).ravel()
-    slots = float((tile_max - (1.0 if self_const else 0.0)).clip(min=0).mean())
-    return int(tile_max.size), slots, int(tile_max.size)
-
-
-def prop_roofline(tiles, slots_per_tile, kbar, self_const, B, N, avg_s, launches, prop_steps_total, encoder_launches, enc_tiles=None):
-    """km_prop / km_prop3: per 32-receiver tile, one 78-MFMA chain (the 3-term split relation
-    encoder) per slot iteration + the 6-term split node layers (144 MFMAs, 96 in the last step); roofline on the
-    16-bit FLOPs actually EXECUTED, 2*32*32*16 per MFMA.  A launch covers one propagation step (km_prop) or all
-    three of a rollout step (km_prop3): told apart by the launches the probe counted."""
-    psteps = max(1, int(round(float(prop_steps_total) / max(launches, 1))))
-    mfmas = psteps * tiles * (slots_per_tile * 78 + (2 * 144 + 96) / 3.0)
-    alg = psteps * B * N * (kbar * FLOP_PER_EDGE_ENCODE + 2 * 64 * 64 * (1 + 2 * 2 / 3.0 + 1 / 3.0))
-    # the particle encoder runs as the first phase of km_prop3 (3 propagation steps per launch) or of every rollout step
-    # of km_rollout (3 H per launch: small piles, the whole rollout -- neighbour lists included -- in one launch) when
-    # no launch of its own was counted: 12 + 4 x 48 bf16 MFMAs per tile (first layer + four 64x64 products, 6-term split)
-    encoder_inside = psteps % 3 == 0 and encoder_launches == 0
-    if encoder_inside:
-        mfmas += (psteps // 3) * (tiles if enc_tiles is None else enc_tiles) * 204
-        alg += (psteps // 3) * (B * N * FLOP_PER_NODE['node_encode'] + B * N * 2 * 2 * 64 * 64)
-    work = mfmas * 32768.0
-    return {'bound': 'mfma', 'achieved': work / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+def prop_roofline(work, kbar, self_const, B, N, avg_s, H):
+    """km_prop / km_prop3 / km_rollout.  `work` is what the kernels THEMSELVES counted over one
+    iteration (Engine.probe_work, include/drp.h drp_probe_work: slot iterations that ran the relation encoder's 78-MFMA
+    chain, slot iterations served by the edge-chain cache, node parts of 144 / 96 MFMAs, particle-encoder tiles of 204;
+    `launches` = the launches of that iteration) -- an iteration of its own, right before the timed ones: counting costs
+    time.  `frac` is the roofline on the 16-bit FLOPs actually EXECUTED, 2*32*32*16 per MFMA; nothing here re-derives
+    which kernel or tile shape the library chose.  Beside it `useful_frac`, on a FIXED count: SURVEY.md 8d's factored
+    formulation F_fac(K) = 116 096 + 25 472 K FLOP per particle-step at the measured mean in-degree K, times the
+    particle-steps of a launch -- removing redundant work (the self loop's constant, the cached chain) RAISES it.
+    A launch covers one propagation step (km_prop), the three of a rollout step (km_prop3) or a whole rollout."""
+    n = float(max(work['launches'], 1))
+    flops = work['mfmas'] / n * 32768.0
+    particle_steps = B * N * H / n
+    useful = particle_steps * (116096.0 + 25472.0 * kbar)
+    k_run = kbar - (1.0 if self_const else 0.0)                   # chains an average receiver runs: the self loop's is a constant
+    slots = work['chain_slots'] + work['cached_slots']
+    node_parts = work['tiles'] + work['tiles_last']
+    return {'bound': 'mfma', 'achieved': flops / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
-            'algorithmic_f32_tflops': alg / avg_s / 1e12, 'slot_iterations_per_tile': slots_per_tile,
-            'tiles_per_step': tiles, 'paired_tiles': bool(enc_tiles is not None and enc_tiles != tiles), 'mean_in_degree_minus_self': kbar - (1.0 if self_const else 0.0),
-            'propagation_steps_per_launch': psteps, 'particle_encoder_in_launch': bool(encoder_inside),
-            'graph_build_in_launch': bool(psteps > 3)}, work
+            'numerator': 'drp_probe_work: counted by the kernels over the iteration before the timed ones',
+            'executed_per_launch': {k: v / n for k, v in work.items() if k != 'launches'},
+            'useful_frac': useful / avg_s / 1e12 / PEAK_BF16_TFLOPS, 'useful_tflops': useful / avg_s / 1e12,
+            'useful_frac_of_f32_mfma_peak': useful / avg_s / 1e12 / PEAK_F32_TFLOPS,
+            'useful_basis': 'SURVEY 8d: F_fac(K) = 116096 + 25472 K FLOP per particle-step, K = %.2f; %.0f particle-steps per launch' % (kbar, particle_steps),
+            'algorithmic_f32_tflops': particle_steps * (116096.0 + 25472.0 * k_run) / avg_s / 1e12,
+            'slot_iterations_per_tile': slots / float(max(node_parts, 1)),
+            'cached_share_of_slot_iterations': work['cached_slots'] / float(max(slots, 1)),
+            'tiles_per_step': node_parts / float(3 * H),
+            'mean_in_degree_minus_self': k_run,
+            'propagation_steps_per_launch': 3.0 * H / n,
+            'particle_encoder_in_launch': bool(work['encoder_tiles'] > 0),
+            'graph_build_in_launch': bool(H / n > 1.5)}, flops
 
 
 class Rig(object):
@@ -401,10 +361,16 @@ def bench_mppi(rig, N, ns, H, s_lo, steps, warmup, step_extra, fence, classes, w
         os._exit(7)                     # a rank that is simply gone: no clean-up, no goodbye to the group
     fence()
     per_class = {}
+    dom_work = None
     for kc in classes:
-        eng.probe_begin(kc)
+        # one iteration per kernel class; the propagation kernels also COUNT what they execute in theirs (the counters
+        # cost time: never inside the timed region)
+        eng.probe_begin('prop+work' if kc == 'prop' else kc)
         step()
         per_class[kc] = eng.probe_read()
+        if kc == 'prop' and per_class[kc][1] > 0:
+            dom_work = eng.probe_work()
+            dom_work['launches'] = per_class[kc][1]
     dominant = max(per_class, key=lambda k: per_class[k][0])
     cnt_last = eng.debug_fetch('nbr_cnt', (ns, N), np.uint8)
     eng.probe_begin(dominant)
@@ -429,7 +395,7 @@ def bench_mppi(rig, N, ns, H, s_lo, steps, warmup, step_extra, fence, classes, w
         fence()
         med = float(np.median(per_iter))
     return {'dt': dt, 'median': med, 'per_class': per_class, 'dominant': dominant, 'dom_ms': dom_ms, 'dom_n': dom_n,
-            'cnt': cnt_last, 'kbar': float(cnt_last.mean()), 'step': step, 's0': s0, 'dens': dens, 'attr': attr}
+            'cnt': cnt_last, 'kbar': float(cnt_last.mean()), 'step': step, 's0': s0, 'dens': dens, 'attr': attr, 'work': dom_work}
 
 
 def mppi_roofline(rig, m, N, ns, H, steps):
@@ -440,9 +406,7 @@ def mppi_roofline(rig, m, N, ns, H, steps):
     self_const = engine == 'fused' and os.environ.get('DRP_NO_SELF_CONST') is None
     work = None
     if dominant == 'prop':
-        tiles, slots, enc_tiles = tile_slot_model(m['cnt'], N, ns, rig.n_cu, engine, self_const)
-        roof, work = prop_roofline(tiles, slots, kbar, self_const, ns, N, avg_s, m['dom_n'], 3.0 * H * steps,
-                                   m['per_class'].get('node_encode', (0, 0))[1], enc_tiles)
+        roof, work = prop_roofline(m['work'], kbar, self_const, ns, N, avg_s, H)
     elif dominant == 'aggregate':
         work = ns * N * (2 * kbar + 2) * 256.0
         roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
@@ -499,10 +463,14 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
         step()
     fence()
     per_class = {}
+    dom_work = None
     for kc in GD_CLASSES:
-        eng.probe_begin(kc)
+        eng.probe_begin('prop+work' if kc == 'prop' else kc)
         step()
         per_class[kc] = eng.probe_read()
+        if kc == 'prop' and per_class[kc][1] > 0:
+            dom_work = eng.probe_work()
+            dom_work['launches'] = per_class[kc][1]
     dominant = max(per_class, key=lambda k: per_class[k][0])
     cnt = eng.debug_fetch('nbr_cnt', (B, N), np.uint8)
     kbar = float(cnt.mean())
@@ -529,8 +497,7 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
     tkey = None
     if dominant == 'prop':
         # the forward kernel of the tape-writing instantiation: the same MFMAs as the MPPI model
-        tiles, slots, enc_tiles = tile_slot_model(cnt, N, B, rig.n_cu, 'fused', True)
-        roof, _ = prop_roofline(tiles, slots, kbar, True, B, N, avg_s, dom_n, 3.0 * H * steps, per_class['node_encode'][1], enc_tiles)
+        roof, _ = prop_roofline(dom_work, kbar, True, B, N, avg_s, H)
         tkey = 'prop3_tape'
     elif dominant == 'bwd_node' and per_class['bwd_edge'][1] == 0:
         # kmb_step_bwd (the whole node / edge backward of a rollout step in one launch): algorithmic
@@ -591,7 +558,8 @@ def run_sweep(rig, fence):
                     'ms_per_step': dt / steps * 1e3, 'value': B * N * H * steps / dt, 'unit': 'particle-steps/s',
                     'mean_in_degree': kbar, 'dominant_kernel': roof['kernel'], 'avg_launch_ms': roof['avg_launch_ms'],
                     'bound': roof['bound'], 'achieved': roof['achieved'], 'peak': roof['peak'], 'roofline_unit': roof['unit'],
-                    'frac': roof['frac'], 'traffic': roof.get('traffic'),
+                    'frac': roof['frac'], 'useful_frac': roof.get('useful_frac'), 'executed_per_launch': roof.get('executed_per_launch'),
+                    'traffic': roof.get('traffic'),
                     'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items() if v[1] > 0},
                     'wall_s': round(time.perf_counter() - t_wall, 2)})
     return out

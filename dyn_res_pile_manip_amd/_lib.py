@@ -124,6 +124,7 @@ SIGNATURES = {
     'drp_comm_allgather': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'drp_probe_begin': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     'drp_probe_read': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_long)]),
+    'drp_probe_work': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     'drp_debug_fetch': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p,
                                         ctypes.c_size_t]),
 }

@@ -309,6 +309,10 @@ struct drp_ctx {
     int lastB = 0, lastN = 0, lastH = 0;
 
     // probe
+    DevBuf probe_work;              // PROP_WORK_* counters of the propagation kernels while their class is probed
+    bool probe_count = false;       // drp_probe_begin("prop+work"): the kernels count what they execute (not for timed regions: the
+                                    // counting costs the 300-particle launch 8 %)
+    unsigned long long* work_ptr() const { return (probe_cls == KC_PROP && probe_count) ? static_cast<unsigned long long*>(probe_work.p) : nullptr; }
     int probe_cls = -1;
     std::vector<hipEvent_t> probe_ev;
     size_t probe_used = 0;
@@ -676,9 +680,12 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             const size_t ec_stride = drp_ctx::ecache_stride((long)spw * N, pair);
             if (ec) CHK(ensure(c, c->ecache, (size_t)grid.x * ec_stride * 16));
             float4* ecp = ec ? ptr<float4>(c->ecache) : nullptr;
+            unsigned long long* const wk = c->work_ptr();    // not null: the counting instantiations (drp_probe_begin("prop+work"))
 #define PROP3_LAUNCH(TAPE_, PAIR_) do { \
-                if (ec) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride); \
-                else hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride); } while (0)
+                if (ec && wk) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, true, true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); \
+                else if (ec) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, true, false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); \
+                else if (wk) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, false, true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); \
+                else hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, false, false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); } while (0)
             if (!tape && !pair) PROP3_LAUNCH(false, false);
             else if (!tape) PROP3_LAUNCH(false, true);
             else if (!pair) PROP3_LAUNCH(true, false);
@@ -704,17 +711,18 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
 #define PROP_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
                   a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, \
                   ptr<float>(c->c_node), eff_in, eff_out, N, B, pb, a.s_out, a.out_stride, a.cself, a.cself_ok, mask_out, agg_out, \
-                  c->re_scale, c->re_inv, spread
-#define PROP_LAUNCH(PAIR_) do { \
+                  c->re_scale, c->re_inv, spread, c->work_ptr()
+#define PROP_LAUNCH(PAIR_, WORK_) do { \
                 if (!tape) { \
-                    if (!last) hipLaunchKernelGGL((km_prop<false, false, PAIR_>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS); \
-                    else hipLaunchKernelGGL((km_prop<true, false, PAIR_>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS); \
+                    if (!last) hipLaunchKernelGGL((km_prop<false, false, PAIR_, WORK_>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS); \
+                    else hipLaunchKernelGGL((km_prop<true, false, PAIR_, WORK_>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS); \
                 } else { \
-                    if (!last) hipLaunchKernelGGL((km_prop<false, true, PAIR_>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS); \
-                    else hipLaunchKernelGGL((km_prop<true, true, PAIR_>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS); \
+                    if (!last) hipLaunchKernelGGL((km_prop<false, true, PAIR_, WORK_>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS); \
+                    else hipLaunchKernelGGL((km_prop<true, true, PAIR_, WORK_>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS); \
                 } } while (0)
-            if (pair) PROP_LAUNCH(true);
-            else PROP_LAUNCH(false);
+            if (c->work_ptr()) { if (pair) PROP_LAUNCH(true, true); else PROP_LAUNCH(false, true); }
+            else if (pair) PROP_LAUNCH(true, false);
+            else PROP_LAUNCH(false, false);
 #undef PROP_LAUNCH
 #undef PROP_ARGS
             float* tmp = pa; pa = pb; pb = tmp;
@@ -858,6 +866,7 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
         ra.ec_stride = drp_ctx::ecache_stride((long)spw_r * N, pair_r);
         if (ec) CHK(ensure(c, c->ecache, (size_t)grid_r * ra.ec_stride * 16));
         ra.ecache = ec ? ptr<float4>(c->ecache) : nullptr;
+        ra.work = c->work_ptr();
         // the argument block sits in device memory; it is uploaded when it changes (every iteration of an MPC session
         // passes the same one), behind whatever still runs on the stream
         if (!c->roll_args_valid || memcmp(&ra, &c->roll_args_host, sizeof(ra)) != 0) {
@@ -867,10 +876,12 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
             c->roll_args_valid = true;
         }
         ProbeScope ps(c, KC_PROP);
-#define ROLLOUT_LAUNCH(PAIR_, EC_) hipLaunchKernelGGL((km_rollout<PAIR_, EC_>), dim3(grid_r), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS, \
-                                                      c->stream, ptr<RolloutArgs>(c->roll_args))
+#define ROLLOUT_LAUNCH_W(PAIR_, EC_, WORK_) hipLaunchKernelGGL((km_rollout<PAIR_, EC_, WORK_>), dim3(grid_r), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS, \
+                                                               c->stream, ptr<RolloutArgs>(c->roll_args))
+#define ROLLOUT_LAUNCH(PAIR_, EC_) do { if (ra.work) ROLLOUT_LAUNCH_W(PAIR_, EC_, true); else ROLLOUT_LAUNCH_W(PAIR_, EC_, false); } while (0)
         if (pair_r) { if (ec) ROLLOUT_LAUNCH(true, true); else ROLLOUT_LAUNCH(true, false); }
         else { if (ec) ROLLOUT_LAUNCH(false, true); else ROLLOUT_LAUNCH(false, false); }
+#undef ROLLOUT_LAUNCH_W
 #undef ROLLOUT_LAUNCH
         HIPCHK(c, hipGetLastError());
         note_degrees(c, spw_r, N, B);           // the last step's lists
@@ -1204,26 +1215,46 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_node_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_edge_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_EDGE_SPLIT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_node_encode_split, hipFuncAttributeMaxDynamicSharedMemorySize, KM_NODE_SPLIT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(false)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kt_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||
@@ -1244,7 +1275,7 @@ void drp_destroy(drp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)guarded_wait(c, nullptr);           // a collective that cannot finish must not keep the destructor
     if (c->comm) { RcclApi* R = rccl_api(); if (R) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
-    DevBuf* bufs[] = {&c->ecache, &c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
+    DevBuf* bufs[] = {&c->probe_work, &c->ecache, &c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
@@ -3048,10 +3079,38 @@ int drp_probe_begin(drp_ctx* c, const char* kernel_class) {
     if (!c) return DRP_EINVAL;
     c->probe_cls = -1;
     c->probe_used = 0;
+    c->probe_count = false;
     if (!kernel_class || !*kernel_class) return DRP_OK;
+    if (strcmp(kernel_class, "prop+work") == 0) { kernel_class = "prop"; c->probe_count = true; }
     for (int i = 0; i < KC_COUNT; ++i)
-        if (strcmp(kernel_class, kclass_names[i]) == 0) { c->probe_cls = i; return DRP_OK; }
+        if (strcmp(kernel_class, kclass_names[i]) == 0) {
+            if (i == KC_PROP && c->probe_count) {
+                HIPCHK(c, hipSetDevice(c->device));
+                CHK(ensure(c, c->probe_work, PROP_WORK_SHARDS * PROP_WORK_STRIDE * sizeof(unsigned long long)));
+                HIPCHK(c, hipMemsetAsync(c->probe_work.p, 0, PROP_WORK_SHARDS * PROP_WORK_STRIDE * sizeof(unsigned long long), c->stream));
+            }
+            c->probe_cls = i;
+            return DRP_OK;
+        }
     return fail(c, DRP_EINVAL, "unknown kernel class '%s'", kernel_class);
+}
+
+int drp_probe_work(drp_ctx* c, unsigned long long out[8]) {
+    if (!c || !out) return fail(c, DRP_EINVAL, "null argument");
+    if (c->probe_cls != KC_PROP || !c->probe_count || !c->probe_work.p) return fail(c, DRP_ESTATE, "drp_probe_begin(\"prop+work\") not running");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<unsigned long long> sh((size_t)PROP_WORK_SHARDS * PROP_WORK_STRIDE);
+    CHK(d2h(c, sh.data(), c->probe_work.p, sh.size() * sizeof(unsigned long long)));
+    CHK(guarded_wait(c, nullptr));
+    unsigned long long w[PROP_WORK_COUNT] = {};
+    for (int q = 0; q < PROP_WORK_SHARDS; ++q)
+        for (int i = 0; i < PROP_WORK_COUNT; ++i) w[i] += sh[(size_t)q * PROP_WORK_STRIDE + i];
+    for (int i = 0; i < PROP_WORK_COUNT; ++i) out[i] = w[i];
+    // the matrix instructions those units are made of (k_mlp_split.h: the chain of an edge slot, the node layers of a tile)
+    out[5] = (unsigned long long)PROP_MFMA_CHAIN * w[PROP_WORK_CHAIN_SLOTS] + (unsigned long long)PROP_MFMA_NODE * w[PROP_WORK_TILES] +
+             (unsigned long long)PROP_MFMA_NODE_LAST * w[PROP_WORK_TILES_LAST] + (unsigned long long)PROP_MFMA_ENC * w[PROP_WORK_ENC_TILES];
+    out[6] = 0; out[7] = 0;
+    return DRP_OK;
 }
 
 int drp_probe_read(drp_ctx* c, double* total_ms, long* launches) {

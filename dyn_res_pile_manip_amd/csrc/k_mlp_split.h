@@ -550,7 +550,31 @@ struct PropArgs {
     unsigned* mask_out; float* agg_out;
     float re_scale, re_inv;      // 2^k and 2^-k of the relation encoder's range shift
     float4* ecache;              // EC != 0: this workgroup's edge-chain cache, [tile][iteration][8][64 lanes] float4
+    unsigned long long* work;    // WORK: counters of what the launch executes (PROP_WORK_*, drp_probe_work)
 };
+// What the WORK instantiations of the propagation kernels count (one wave-uniform pass over the tile's in-degrees and two
+// atomic adds per tile): the roofline's numerator is what the kernel EXECUTED, read from here.  Instantiations of their own,
+// launched for the iteration drp_probe_begin("prop+work") brackets: the same tiles, orders and loops as the kernels they
+// shadow, whose code (and register allocation: the 300-particle launch is 8 % slower with a dormant branch in it) stays as it is.
+enum {
+    PROP_WORK_CHAIN_SLOTS = 0,   // slot iterations that ran the relation encoder's chain (78 MFMAs: 6 + 3 x 24)
+    PROP_WORK_CACHED_SLOTS,      // slot iterations served by the edge-chain cache (no MFMA)
+    PROP_WORK_TILES,             // node parts of a propagation step that is not the last (144 MFMAs: W_agg, W_r, W_s, 6-term split)
+    PROP_WORK_TILES_LAST,        // node parts of the last step (96: W_agg, predictor layer 0)
+    PROP_WORK_ENC_TILES,         // particle-encoder tiles inside the launch (204: 12 + 4 x 48)
+    PROP_WORK_COUNT
+};
+// the counters are kept in PROP_WORK_SHARDS copies, a workgroup adding to copy blockIdx.x % PROP_WORK_SHARDS (every tile of the
+// chip adding to ONE address costs a fifth of the launch: the adds of one address are serial at the memory side)
+#define PROP_WORK_SHARDS 256
+#define PROP_WORK_STRIDE 8                     // 64-bit words per copy: a 64-B line of its own
+__device__ __forceinline__ unsigned long long* prop_work_shard(unsigned long long* work) {
+    return work + (size_t)(blockIdx.x % PROP_WORK_SHARDS) * PROP_WORK_STRIDE;
+}
+#define PROP_MFMA_CHAIN 78
+#define PROP_MFMA_NODE 144
+#define PROP_MFMA_NODE_LAST 96
+#define PROP_MFMA_ENC 204
 struct PropLds {
     const f16x8* wsp;         // edge chain, S_* offsets
     const bf16x8* w_agg;      // W_agg
@@ -605,7 +629,7 @@ __device__ __forceinline__ float dpp_ror8(float x) {
 // Pays where the chain's LATENCY is the bound -- one tile per wave -- and the buffer (2.5 KB per receiver) stays in the
 // last-level cache; at 300 particles x 1024 samples it is 700 MB per rollout step and recomputing costs the same.
 #define EC_UNITS 512             // float4 per (tile, slot iteration): 8 per lane
-template <bool LAST, bool TAPE, bool PAIR, bool CARRY, int EC, class First, class Decode, class RowOf>
+template <bool LAST, bool TAPE, bool PAIR, bool CARRY, int EC, bool WORK, class First, class Decode, class RowOf>
 __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, First first_of /* this wave's first tile */,
                                            Decode decode /* the others: draws from the workgroup's queue */, RowOf row_of, int lane,
                                            HeadCarry& hc
@@ -773,6 +797,15 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         if constexpr (EC == 2) {
             issue_half(kfirst, 0, 0, tf.j0, ha);
             issue_half(kfirst, 0, 1, tf.j0, hb);
+        }
+        if (WORK) {                                        // the counting instantiation: what this tile will execute
+            int n = 0;
+            for (int k = kfirst; (k - par) < DRP_K && !__all(k >= cnt); k += KS) ++n;
+            if (lane == 0) {
+                unsigned long long* w = prop_work_shard(A.work);
+                atomicAdd(w + (EC == 2 ? PROP_WORK_CACHED_SLOTS : PROP_WORK_CHAIN_SLOTS), (unsigned long long)n);
+                atomicAdd(w + (LAST ? PROP_WORK_TILES_LAST : PROP_WORK_TILES), 1ull);
+            }
         }
         Frag acc, bpr;
         {
@@ -1028,7 +1061,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
 #define PROP_STAMPS_ARG
 #endif
 
-template <bool LAST, bool TAPE, bool PAIR /* tiles of 16 receivers x two slots (prop_tiles); with `spread` only */>
+template <bool LAST, bool TAPE, bool PAIR /* tiles of 16 receivers x two slots (prop_tiles); with `spread` only */, bool WORK>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
         const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1039,7 +1072,8 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         size_t out_stride, const float* __restrict__ cself /* nullable [B,64] */,
         const uint8_t* __restrict__ cself_ok,
         unsigned* __restrict__ mask_out /* TAPE: [B*N*10][2] */, float* __restrict__ agg_out /* TAPE, nullable: [B*N,64] */,
-        float re_scale, float re_inv, int spread /* few tiles: one per workgroup first (see decode) */) {
+        float re_scale, float re_inv, int spread /* few tiles: one per workgroup first (see decode) */,
+        unsigned long long* __restrict__ work /* WORK: PROP_WORK_* counters */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef PROP_STAMPS
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
@@ -1098,7 +1132,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
 #endif
     const PropArgs A = {mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj, c_node, eff_in, eff,
-                        N, B, proj_next, s_out, out_stride, cself, cself_ok, mask_out, agg_out, re_scale, re_inv};
+                        N, B, proj_next, s_out, out_stride, cself, cself_ok, mask_out, agg_out, re_scale, re_inv, nullptr, WORK ? work : nullptr};
     const PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
                        reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
     // a tile = 32 (PAIR: 16) consecutive receivers of one sample
@@ -1110,7 +1144,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         return r;
     };
     HeadCarry hc_none;
-    prop_tiles<LAST, TAPE, PAIR, false, 0>(A, L, [&]() { return decode(wave); }, decode, row_of, lane, hc_none PROP_STAMPS_ARG);
+    prop_tiles<LAST, TAPE, PAIR, false, 0, WORK>(A, L, [&]() { return decode(wave); }, decode, row_of, lane, hc_none PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS
     st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
     st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // all tiles of this wave
@@ -1182,7 +1216,7 @@ __device__ __forceinline__ void prop3_fill_resident(const Prop3Lds& P, const uin
 // three propagation steps, the last one writing s_out.  On entry the resident part of LDS is filled (or being filled:
 // `entry_sync` = the caller has not synchronised since) and the edge-chain region holds nothing this function relies
 // on; on exit every wave has passed its last tile (no barrier after it).
-template <bool TAPE, bool PAIR, bool CARRY, bool ECACHE>
+template <bool TAPE, bool PAIR, bool CARRY, bool ECACHE, bool WORK>
 __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6,
                                            const float* __restrict__ mw,
                                            const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1193,7 +1227,8 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
                                            float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself,
                                            const uint8_t* __restrict__ cself_ok, unsigned* __restrict__ mask_hist,
                                            float* __restrict__ agg_hist, float re_scale, float re_inv, int order_rows, int tid /* tid */,
-                                           float4* __restrict__ ecache /* ECACHE: this workgroup's edge-chain cache (prop_tiles) */
+                                           float4* __restrict__ ecache /* ECACHE: this workgroup's edge-chain cache (prop_tiles) */,
+                                           unsigned long long* __restrict__ work /* WORK: PROP_WORK_* counters */
 #ifdef PROP_STAMPS
                                            , unsigned long long (&st_sum)[8]
 #endif
@@ -1274,6 +1309,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
             int qn = 0;
             if (lane == 0) qn = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             li = __builtin_amdgcn_readfirstlane(qn);
+            if (WORK && lane == 0) atomicAdd(prop_work_shard(work) + PROP_WORK_ENC_TILES, 1ull);
         }
         ROLL_STAMP(4);                                   // wave 0's encoder tiles
         __syncthreads();                                 // the encoder's rows of this workgroup's samples are written
@@ -1388,7 +1424,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
     };
     const size_t bn64 = (size_t)B * N * 64;
     PropArgs A = {mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, c_node, eff, eff,
-                  N, B, proj_b, s_out, out_stride, cself, cself_ok, nullptr, nullptr, re_scale, re_inv, ecache};
+                  N, B, proj_b, s_out, out_stride, cself, cself_ok, nullptr, nullptr, re_scale, re_inv, ecache, WORK ? work : nullptr};
     PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
                  reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
     HeadCarry hc;
@@ -1410,12 +1446,12 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
             A.agg_out = agg_hist ? agg_hist + (size_t)p * bn64 : nullptr;
         }
         if (ECACHE && p == 0) {
-            prop_tiles<false, TAPE, PAIR, CARRY, 1>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
+            prop_tiles<false, TAPE, PAIR, CARRY, 1, WORK>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
         } else if (p + 1 < DRP_PSTEP) {
-            prop_tiles<false, TAPE, PAIR, CARRY, ECACHE ? 2 : 0>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
+            prop_tiles<false, TAPE, PAIR, CARRY, ECACHE ? 2 : 0, WORK>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
         } else {
             L.w_x = reinterpret_cast<const bf16x8*>(w6_f) + 3 * 1536;
-            prop_tiles<true, TAPE, PAIR, CARRY, ECACHE ? 2 : 0>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
+            prop_tiles<true, TAPE, PAIR, CARRY, ECACHE ? 2 : 0, WORK>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
         }
 #ifdef ROLLOUT_STAMPS
         if (roll_on) atomicAdd(&g_roll_stamps[11 + p], __builtin_amdgcn_s_memrealtime() - roll_t);   // ... by propagation step
@@ -1430,7 +1466,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
 #endif
 }
 
-template <bool TAPE, bool PAIR, bool ECACHE>
+template <bool TAPE, bool PAIR, bool ECACHE, bool WORK>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
          const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1442,7 +1478,8 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
          float* __restrict__ s_out, size_t out_stride, const float* __restrict__ cself, const uint8_t* __restrict__ cself_ok,
          unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */,
          float re_scale, float re_inv, int order_rows,
-         float4* __restrict__ ecache /* ECACHE: [workgroup][ec_stride] */, size_t ec_stride) {
+         float4* __restrict__ ecache /* ECACHE: [workgroup][ec_stride] */, size_t ec_stride,
+         unsigned long long* __restrict__ work /* WORK: PROP_WORK_* counters */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef PROP_STAMPS
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
@@ -1451,9 +1488,9 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     const Prop3Lds P = prop3_lds(lds);
     prop3_fill_resident(P, sw, sw6, mw);
     prop3_step<TAPE, PAIR, PAIR && !TAPE /* the tape's kernel has no register to spare for the carried head; the big kernel's
-                                            allocation is not to move (with it: 256 VGPRs) */, ECACHE>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
+                                            allocation is not to move (with it: 256 VGPRs) */, ECACHE, WORK>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
                      eff, N, B, spw, s_delta, s_out, out_stride, cself, cself_ok, mask_hist, agg_hist, re_scale, re_inv, order_rows,
-                     (int)threadIdx.x, ECACHE ? ecache + (size_t)blockIdx.x * ec_stride : nullptr PROP_STAMPS_ARG);
+                     (int)threadIdx.x, ECACHE ? ecache + (size_t)blockIdx.x * ec_stride : nullptr, work PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

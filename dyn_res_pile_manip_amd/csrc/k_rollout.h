@@ -39,12 +39,13 @@ struct RolloutArgs {
     float* proj_a; float* proj_b; float* c_node; float* eff;
     const float* cself; const uint8_t* cself_ok;
     float4* ecache; size_t ec_stride;        // ECACHE: the edge-chain cache (prop_tiles), ec_stride float4 per workgroup
+    unsigned long long* work;                // WORK: PROP_WORK_* counters
     int N, B, spw, nb, H, order_rows;
     float thr, re_scale, re_inv;
     DrpCam cam;
 };
 
-template <bool PAIR, bool ECACHE>
+template <bool PAIR, bool ECACHE, bool WORK>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_rollout(const RolloutArgs* __restrict__ args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -118,10 +119,10 @@ km_rollout(const RolloutArgs* __restrict__ args) {
         }
         __syncthreads();                             // the lists are written, the positions no longer needed
         ROLL_STAMP(2);                               // neighbour lists
-        prop3_step<false, PAIR, true, ECACHE>(P, a->sw, a->sw6, a->mw, s_prev, prev_mod, prev_stride, a->attr, nbat, a->dens, nbat, nbr_idx, nbr_cnt,
+        prop3_step<false, PAIR, true, ECACHE, WORK>(P, a->sw, a->sw6, a->mw, s_prev, prev_mod, prev_stride, a->attr, nbat, a->dens, nbat, nbr_idx, nbr_cnt,
                           a->proj_a, a->proj_b, a->c_node, a->eff, N, B, spw, s_delta, states + (size_t)t * N * 3, hstride,
                           a->cself, a->cself_ok, nullptr, nullptr, a->re_scale, a->re_inv, a->order_rows, tid,
-                          ECACHE ? a->ecache + (size_t)blockIdx.x * a->ec_stride : nullptr PROP_STAMPS_ARG);
+                          ECACHE ? a->ecache + (size_t)blockIdx.x * a->ec_stride : nullptr, a->work PROP_STAMPS_ARG);
 #ifdef ROLLOUT_STAMPS
         roll_t = __builtin_amdgcn_s_memrealtime();   // prop3_step keeps its own clock
         if (roll_on) atomicAdd(&g_roll_stamps[15], 1ull);

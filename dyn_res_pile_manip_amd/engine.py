@@ -474,6 +474,13 @@ class Engine(object):
         self._ck(self.lib.drp_probe_read(self.h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
+    def probe_work(self):
+        """What the propagation kernels executed since probe_begin('prop'), counted by the kernels (include/drp.h)."""
+        out = (ctypes.c_ulonglong * 8)()
+        self._ck(self.lib.drp_probe_work(self.h, out))
+        keys = ('chain_slots', 'cached_slots', 'tiles', 'tiles_last', 'encoder_tiles', 'mfmas')
+        return {k: int(out[i]) for i, k in enumerate(keys)}
+
     def debug_fetch(self, name, shape, dtype=np.float32):
         out = np.empty(shape, dtype=dtype)
         self._ck(self.lib.drp_debug_fetch(self.h, name.encode(), out.ctypes.data_as(ctypes.c_void_p),

@@ -323,6 +323,13 @@ int drp_comm_allgather(drp_ctx* ctx, const void* send, size_t bytes, void* recv)
  * "mppi", "prop" (the fused propagation-step kernel of DRP_ENGINE_FUSED).  drp_probe_read returns total ms and launches since drp_probe_begin. */
 int drp_probe_begin(drp_ctx* ctx, const char* kernel_class);
 int drp_probe_read(drp_ctx* ctx, double* total_ms, long* launches);
+/* What the propagation kernels (km_prop, km_prop3, km_rollout) EXECUTED since drp_probe_begin(ctx, "prop+work") -- the "prop"
+ * probe with the kernels' own counters switched on (two atomic adds per tile: they cost the 300-particle launch 8 %, so a
+ * timed region runs under the plain "prop" probe and the counters over an iteration of their own): out[0] slot iterations that ran the relation
+ * encoder's chain (78 16-bit MFMAs each), [1] slot iterations served by the edge-chain cache (none), [2] / [3] tiles of
+ * propagation steps that are not / are the last (144 / 96), [4] particle-encoder tiles inside the launch (204),
+ * [5] the 16-bit MFMAs (32x32x16, 32 768 FLOP each) those add up to; [6], [7] zero.  bench.py's roofline numerator. */
+int drp_probe_work(drp_ctx* ctx, unsigned long long out[8]);
 /* hold the context's stream for ms (<= 10 000) milliseconds -- what a collective waiting for a dead peer looks like to
  * the host; the tests of the hang guard use it */
 int drp_debug_stall(drp_ctx* ctx, int ms);

@@ -43,6 +43,57 @@ def test_single_gpu_line_has_the_contract_fields():
     assert sc['algorithmic_bytes_per_launch'] > sc['compulsory_bytes_per_launch'] and sc['cache_served'] is True
     assert 'workload' in d['config'] and 'model' not in d['config']
     assert 'sweep' not in d                                   # a custom shape carries no sweep block
+    # the numerator of `frac` is what the kernels counted themselves (drp_probe_work), and a fraction on SURVEY 8d's fixed
+    # count travels beside it
+    ex = r['executed_per_launch']
+    assert r['numerator'].startswith('drp_probe_work')
+    assert ex['mfmas'] == 78 * ex['chain_slots'] + 144 * ex['tiles'] + 96 * ex['tiles_last'] + 204 * ex['encoder_tiles']
+    assert abs(r['achieved'] - ex['mfmas'] * 32768.0 / (r['avg_launch_ms'] * 1e-3) / 1e12) < 1e-6 * r['achieved']
+    assert 0 < r['useful_frac'] < r['frac']
+
+
+def test_the_propagation_kernels_count_what_they_execute():
+    """drp_probe_work against a count made here from the lists the rollout leaves behind: 8 samples of 300 particles are one
+    sample per workgroup, ten tiles of 32 receivers in the natural order (a saturated pile) or ordered by in-degree, every
+    tile running as many slot iterations as its largest in-degree minus the self loop -- for every propagation step of
+    every rollout step; with the edge-chain cache the chain runs in a third of them."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from dyn_res_pile_manip_amd import synthetic as syn, weights
+    from dyn_res_pile_manip_amd.engine import Engine
+    from dyn_res_pile_manip_amd.planners import world2cam_affine
+    eng = Engine(0)
+    eng.load_weights(weights.blob_from_state_dict(weights.random_state_dict(seed=0)), 0.08)
+    eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+    n_cu = eng.device_info()['n_cu']
+    for N, ns, H in ((300, n_cu, 1), (50, 2 * n_cu, 2), (20, 2 * n_cu, 2)):
+        s0, dens, attr = syn.make_pile(N, 1, seed=1)
+        acts = syn.sample_pushes(ns, H, seed=2)
+        eng.probe_begin('prop+work')
+        eng.rollout(s0, attr, dens, acts)
+        ms, launches = eng.probe_read()
+        w = eng.probe_work()
+        eng.probe_begin(None)
+        assert launches >= 1 and ms > 0
+        assert w['mfmas'] == 78 * w['chain_slots'] + 144 * w['tiles'] + 96 * w['tiles_last'] + 204 * w['encoder_tiles']
+        assert w['tiles'] == 2 * w['tiles_last'] and w['tiles_last'] % H == 0
+        spw = ns // n_cu
+        rows = spw * N
+        if N == 300:
+            # one sample per workgroup, ten tiles of 32 receivers: in the natural order when the pile is saturated, by
+            # in-degree (largest first) otherwise; the self loop is a constant, not a slot
+            assert w['tiles_last'] == ns * 10 and w['encoder_tiles'] == ns * 10 and w['cached_slots'] == 0
+            cnt = eng.debug_fetch('nbr_cnt', (ns, N), np.uint8).astype(int)
+            slots = 0
+            for c in cnt:
+                order = c if (c == c.max()).sum() * 16 >= c.size * 15 else np.sort(c)[::-1]
+                slots += int((np.pad(order, (0, 20)).reshape(10, 32).max(-1) - 1).sum())
+            assert w['chain_slots'] == 3 * slots
+        else:
+            tiles = (ns // spw) * (-(-rows // (16 if rows <= 128 else 32)))
+            assert w['tiles_last'] == H * tiles, (w, tiles)
+            assert w['cached_slots'] == 2 * w['chain_slots'] > 0            # these shapes run the cached kernels
+    eng.close()
 
 
 def test_the_sweep_block_carries_the_other_baseline_workloads():
