@@ -132,8 +132,15 @@ SIGNATURES = {
 _lib = None
 
 
+DRP_ERANGE = -6
+
+
 class DrpError(RuntimeError):
     pass
+
+
+class DrpRangeError(DrpError):
+    """DRP_ERANGE: weights or inputs outside the range the split-fp16 relation encoder is scaled for (include/drp.h)."""
 
 
 def load():

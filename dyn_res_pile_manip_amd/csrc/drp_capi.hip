@@ -1067,8 +1067,8 @@ float max_abs(const float* p, size_t n) {
 // camera frame): actions [n][4] = (sx, sy, ex, ey) in world units
 float push_len_bound(const drp_ctx* c, const float* actions, size_t n) {
     // spectral norm of the world -> camera map's 3x3 part (1 for the rotation a camera is; the Frobenius norm used
-    // until round 2 is sqrt(3) too large, which put the DEFAULT clip box outside the proven envelope): power iteration
-    // on M^T M
+    // until round 2 is sqrt(3) too large, which put the DEFAULT clip box outside the proven envelope): sqrt of the
+    // largest eigenvalue of M^T M
     double A[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
@@ -1076,22 +1076,27 @@ float push_len_bound(const drp_ctx* c, const float* actions, size_t n) {
             for (int k = 0; k < 3; ++k) v += (double)c->cam.m[k * 4 + i] * (double)c->cam.m[k * 4 + j];
             A[i][j] = v;
         }
-    // the dominant eigenvector cannot be orthogonal to all three axes: the largest estimate of three starts
-    double lam = 0.0;
-    for (int s0 = 0; s0 < 3; ++s0) {
-        double x[3] = {s0 == 0 ? 1.0 : 0.0, s0 == 1 ? 1.0 : 0.0, s0 == 2 ? 1.0 : 0.0}, l = 0.0;
-        for (int it = 0; it < 64; ++it) {
-            double y[3];
-            for (int i = 0; i < 3; ++i) y[i] = A[i][0] * x[0] + A[i][1] * x[1] + A[i][2] * x[2];
-            l = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
-            if (!(l > 0.0)) break;
-            for (int i = 0; i < 3; ++i) x[i] = y[i] / l;
-        }
-        if (l > lam) lam = l;
+    // largest eigenvalue of the symmetric 3x3 in closed form (the trigonometric solution of its cubic): an upper bound of
+    // the impulse must not come from an iteration that converges from BELOW (a map with two close singular values)
+    double lam;
+    const double p1 = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double q = (A[0][0] + A[1][1] + A[2][2]) / 3.0;
+    if (p1 == 0.0) {
+        lam = fmax(A[0][0], fmax(A[1][1], A[2][2]));
+    } else {
+        const double p2 = (A[0][0] - q) * (A[0][0] - q) + (A[1][1] - q) * (A[1][1] - q) + (A[2][2] - q) * (A[2][2] - q) + 2.0 * p1;
+        const double p = sqrt(p2 / 6.0);
+        double Bm[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Bm[i][j] = (A[i][j] - (i == j ? q : 0.0)) / p;
+        double r = 0.5 * (Bm[0][0] * (Bm[1][1] * Bm[2][2] - Bm[1][2] * Bm[2][1]) - Bm[0][1] * (Bm[1][0] * Bm[2][2] - Bm[1][2] * Bm[2][0]) +
+                          Bm[0][2] * (Bm[1][0] * Bm[2][1] - Bm[1][1] * Bm[2][0]));
+        r = fmin(1.0, fmax(-1.0, r));
+        lam = q + 2.0 * p * cos(acos(r) / 3.0);
     }
-    // an estimate from below, between the two largest eigenvalues at worst: one per cent of slack, never above Frobenius
+    // rounding slack of the formula, never above the Frobenius norm (itself a bound)
     const double frob = sqrt(A[0][0] + A[1][1] + A[2][2]);
-    const float fro = (float)fmin(frob, sqrt(lam) * 1.01);
+    const float fro = (float)fmin(frob, sqrt(fmax(lam, 0.0)) * (1.0 + 1e-6));
     float l2 = 0.0f;
     for (size_t i = 0; i < n; ++i) {
         const float dx = actions[i * 4 + 2] - actions[i * 4 + 0], dy = actions[i * 4 + 3] - actions[i * 4 + 1];
@@ -1100,8 +1105,10 @@ float push_len_bound(const drp_ctx* c, const float* actions, size_t n) {
     }
     return fro * sqrtf(l2) / c->cam.gs;
 }
-int range_check(drp_ctx* c, float max_attr, float max_dens, float max_sdelta) {
-    if (c->engine != DRP_ENGINE_FUSED && c->engine != DRP_ENGINE_SPLIT) return DRP_OK;
+// tape: the caller runs the fused engine whatever drp_set_engine chose (the gradient-descent planner's and the trainer's
+// forward pass write their tape with it)
+int range_check(drp_ctx* c, float max_attr, float max_dens, float max_sdelta, bool tape = false) {
+    if (!tape && c->engine != DRP_ENGINE_FUSED && c->engine != DRP_ENGINE_SPLIT) return DRP_OK;
     const double A = max_attr, dm = max_dens / DRP_DENS_SCALE, D = (double)c->adj_thresh + 2.0 * max_sdelta;
     const SplitRange& r = c->re_range;
     if (!c->re_ok)
@@ -2364,7 +2371,7 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
         // Adam moves the pushes, the clip keeps them in the box: bound by the box's diagonals and by the initial pushes
         const float box[8] = {act_lo[0], act_lo[1], act_hi[2], act_hi[3], act_hi[0], act_hi[1], act_lo[2], act_lo[3]};
         CHK(range_check(c, max_abs(attr, (size_t)nb * N), max_abs(dens, (size_t)nb),
-                        fmaxf(push_len_bound(c, box, 2), push_len_bound(c, actions, (size_t)B * H))));
+                        fmaxf(push_len_bound(c, box, 2), push_len_bound(c, actions, (size_t)B * H)), true));
     }
     const size_t bn = (size_t)B * N;
     CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
@@ -2830,7 +2837,7 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     {
         float amax = 0.0f;                                    // a_cur = attrs[:, 0]
         for (int b = 0; b < B; ++b) amax = fmaxf(amax, max_abs(attrs + (size_t)b * (c->tr_nroll + 1) * N, (size_t)N));
-        CHK(range_check(c, amax, max_abs(particle_dens, (size_t)B), max_abs(states_delta, (size_t)B * c->tr_nroll * N * 3)));
+        CHK(range_check(c, amax, max_abs(particle_dens, (size_t)B), max_abs(states_delta, (size_t)B * c->tr_nroll * N * 3), true));
     }
     const int H = c->tr_nroll;
     const size_t bn = (size_t)B * N, bn64 = bn * 64, bnk = bn * DRP_K;

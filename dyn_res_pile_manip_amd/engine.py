@@ -22,10 +22,38 @@ def _dp(a):
     return a.ctypes.data_as(L.c_double_p)
 
 
-class Engine(object):
-    """Owns a `drp_ctx`.  Every method takes/returns numpy arrays (fp32)."""
+_DEFAULT = {}
 
-    def __init__(self, device=0, engine=None):
+
+def default_engine(device=0):
+    """The process's ONE context of a device, created on first use: what the reference-named mirrors (the model of
+    gnn_dyn.py, the helpers of utils.py, config_reward_ptcl of flex_rewards.py) run on unless they are handed an Engine --
+    one stream, one set of workspaces, one installed camera, as the reference's modules share one CUDA device.  It
+    serves what its fused engine refuses (DRP_ERANGE) on the fp32 matrix engine by itself (`auto_engine`)."""
+    device = int(device)
+    eng = _DEFAULT.get(device)
+    if eng is None or getattr(eng, 'h', None) is None:
+        eng = _DEFAULT[device] = Engine(device, auto_engine=True)
+    return eng
+
+
+def set_default_engine(engine):
+    """Make `engine` the context default_engine(engine.device) returns (None: forget it)."""
+    if engine is None:
+        _DEFAULT.clear()
+    else:
+        _DEFAULT[int(engine.device)] = engine
+
+
+class Engine(object):
+    """Owns a `drp_ctx`.  Every method takes/returns numpy arrays (fp32).
+
+    auto_engine: a call the fused (or split) engine refuses with DRP_ERANGE -- weights with an entry beyond fp16, inputs
+    whose proven activation bound leaves it: include/drp.h -- is repeated on the fp32 matrix engine (`mfma`), which has no
+    such limit; the engine stays switched and a warning is issued once.  (The gradient-descent planner and the trainer
+    write their tape with the fused engine only: there the error stands.)"""
+
+    def __init__(self, device=0, engine=None, auto_engine=False):
         self.lib = L.load()
         h = ctypes.c_void_p()
         rc = self.lib.drp_create(int(device), ctypes.byref(h))
@@ -35,6 +63,8 @@ class Engine(object):
         self.h = h
         self.device = int(device)
         self.H = 0
+        self.auto_engine = bool(auto_engine)
+        self.engine_id = L.ENGINE_FUSED              # drp_create's choice
         if engine is not None:
             self.set_engine(engine)
 
@@ -51,12 +81,27 @@ class Engine(object):
 
     def _ck(self, rc):
         if rc < 0:
-            raise L.DrpError('drp error %d: %s' % (rc, self.lib.drp_last_error(self.h).decode()))
+            msg = 'drp error %d: %s' % (rc, self.lib.drp_last_error(self.h).decode())
+            raise (L.DrpRangeError if rc == L.DRP_ERANGE else L.DrpError)(msg)
         return rc
+
+    def _ranged(self, call):
+        """`call()` -> return code of an entry point that checks the split engine's range."""
+        try:
+            return self._ck(call())
+        except L.DrpRangeError as e:
+            if not self.auto_engine or self.engine_id not in (L.ENGINE_FUSED, L.ENGINE_SPLIT):
+                raise
+            import warnings
+            warnings.warn('the split-fp16 engine refused the call (%s): continuing on the fp32 matrix engine' % e,
+                          RuntimeWarning, stacklevel=3)
+            self.set_engine(L.ENGINE_MFMA)
+            return self._ck(call())
 
     # ---- constants ----------------------------------------------------------------
     def set_engine(self, engine):
         self._ck(self.lib.drp_set_engine(self.h, int(engine)))
+        self.engine_id = int(engine)
 
     def device_info(self):
         name = ctypes.create_string_buffer(256)
@@ -139,8 +184,7 @@ class Engine(object):
         B, N, _ = s_cur.shape
         assert a_cur.shape == (B, N) and s_delta.shape == (B, N, 3) and dens.shape == (B,)
         out = np.empty((B, N, 3), dtype=np.float32)
-        self._ck(self.lib.drp_step(self.h, _fp(a_cur), _fp(s_cur), _fp(s_delta), _fp(dens), B, N,
-                                   _fp(out)))
+        self._ranged(lambda: self.lib.drp_step(self.h, _fp(a_cur), _fp(s_cur), _fp(s_delta), _fp(dens), B, N, _fp(out)))
         return out
 
     def forward(self, a_cur, s_cur, s_delta, dens, nbr_idx, nbr_cnt):
@@ -150,9 +194,9 @@ class Engine(object):
         B, N, _ = s_cur.shape
         assert nbr_idx.shape == (B, N, L.DRP_K) and nbr_cnt.shape == (B, N)
         out = np.empty((B, N, 3), dtype=np.float32)
-        self._ck(self.lib.drp_forward(self.h, _fp(a_cur), _fp(s_cur), _fp(s_delta), _fp(dens),
-                                      nbr_idx.ctypes.data_as(L.c_int16_p),
-                                      nbr_cnt.ctypes.data_as(L.c_uint8_p), B, N, _fp(out)))
+        self._ranged(lambda: self.lib.drp_forward(self.h, _fp(a_cur), _fp(s_cur), _fp(s_delta), _fp(dens),
+                                                  nbr_idx.ctypes.data_as(L.c_int16_p),
+                                                  nbr_cnt.ctypes.data_as(L.c_uint8_p), B, N, _fp(out)))
         return out
 
     def rollout(self, s0, attr, dens, actions, want_states=True, want_reward=False):
@@ -161,9 +205,9 @@ class Engine(object):
         B, H, _ = actions.shape
         states = np.empty((B, H, N, 3), dtype=np.float32) if want_states else None
         rew = np.empty((B, H), dtype=np.float32) if want_reward else None
-        self._ck(self.lib.drp_rollout(self.h, _fp(s0), _fp(attr), _fp(dens), nb, N, _fp(actions), B, H,
-                                      _fp(states) if want_states else None,
-                                      _fp(rew) if want_reward else None))
+        self._ranged(lambda: self.lib.drp_rollout(self.h, _fp(s0), _fp(attr), _fp(dens), nb, N, _fp(actions), B, H,
+                                                  _fp(states) if want_states else None,
+                                                  _fp(rew) if want_reward else None))
         return states, rew
 
     def reward(self, state, normalize=True):
@@ -188,21 +232,19 @@ class Engine(object):
             p.act_hi[i] = float(act_hi[i])
         p.seed, p.sample_offset = int(seed), int(sample_offset)
         p.noise_type, p.reserved = L.NOISE_TYPES[noise_type], 0
-        self._ck(self.lib.drp_mpc_begin(self.h, ctypes.byref(p), _fp(s0), _fp(attr), _fp(dens),
-                                        _dp(nominal)))
+        self._ranged(lambda: self.lib.drp_mpc_begin(self.h, ctypes.byref(p), _fp(s0), _fp(attr), _fp(dens), _dp(nominal)))
         self.H, self.nb, self.N, self.ns = H, nb, N, int(n_sample)
 
     def mpc_sample(self, iteration, noise=None):
         if noise is not None:
             noise = _f32(noise)
             assert noise.shape == (self.ns, self.H, 4)
-        self._ck(self.lib.drp_mpc_sample(self.h, _fp(noise) if noise is not None else None,
-                                         int(iteration)))
+        self._ranged(lambda: self.lib.drp_mpc_sample(self.h, _fp(noise) if noise is not None else None, int(iteration)))
 
     def mpc_set_actions(self, actions):
         actions = _f32(actions)
         assert actions.shape == (self.ns * self.nb, self.H, 4)
-        self._ck(self.lib.drp_mpc_set_actions(self.h, _fp(actions)))
+        self._ranged(lambda: self.lib.drp_mpc_set_actions(self.h, _fp(actions)))
 
     def mpc_rollout(self, reward_all_steps=False):
         self._ck(self.lib.drp_mpc_rollout(self.h, int(bool(reward_all_steps))))

@@ -13,7 +13,7 @@ libdrp.so raises.
 import numpy as np
 
 from . import weights as _weights
-from .engine import Engine
+from .engine import default_engine
 
 
 def _to_np(x):
@@ -82,6 +82,7 @@ class PropModuleDiffDen(object):
         sd, _ = _to_np(s_delta)
         d, _ = _to_np(particle_dens)
         idx, cnt = relations_to_lists(Rr, Rs)
+        self._owner._claim()
         return _like(self._owner.engine.forward(a, s, sd, d, idx, cnt), proto)
 
     __call__ = forward
@@ -93,9 +94,28 @@ class PropNetDiffDenModel(object):
             raise NotImplementedError('the HIP kernels are built for nf_effect = 64')
         self.config = config
         self.adj_thresh = config['train']['particle']['adj_thresh']
-        self.engine = engine if engine is not None else Engine(device)
+        # the process's one context of the device (shared with utils.py's helpers and flex_rewards.config_reward_ptcl)
+        # unless the caller brings its own
+        self.engine = engine if engine is not None else default_engine(device)
         self.model = PropModuleDiffDen(self)
         self._blob = None
+        self._device_ahead = False      # the engine's copy of the weights is newer than _blob (training steps)
+
+    def _claim(self):
+        """Models share the process's context: the one about to compute makes sure the engine holds ITS weights (another
+        model's load_state_dict may have come in between), saving the outgoing model's first if a training step has moved
+        them on the device."""
+        import weakref
+        eng = self.engine
+        ref = getattr(eng, '_weights_owner', None)
+        owner = ref() if ref is not None else None
+        if owner is self or self._blob is None:
+            return
+        if owner is not None and owner._device_ahead:
+            owner._blob = eng.get_weights()
+            owner._device_ahead = False
+        eng.load_weights(self._blob, self.adj_thresh)
+        eng._weights_owner = weakref.ref(self)
 
     # nn.Module look-alikes used by the reference's scripts
     def cuda(self, *a, **k):
@@ -109,8 +129,11 @@ class PropNetDiffDenModel(object):
         return self
 
     def load_state_dict(self, state_dict, strict=True):
+        import weakref
         self._blob = _weights.blob_from_state_dict(state_dict, strict=strict)
         self.engine.load_weights(self._blob, self.adj_thresh)
+        self.engine._weights_owner = weakref.ref(self)
+        self._device_ahead = False
         return self
 
     def state_dict(self):
@@ -119,7 +142,9 @@ class PropNetDiffDenModel(object):
         for the reference's `load_state_dict` / visualize_mpc.py:36-41 to read it back."""
         if self._blob is None:
             raise RuntimeError('no weights loaded')
+        self._claim()
         self._blob = self.engine.get_weights()       # training updates them on the device
+        self._device_ahead = False
         import torch
         from collections import OrderedDict
         return OrderedDict((k, torch.from_numpy(v)) for k, v in _weights.state_dict_from_blob(self._blob).items())
@@ -135,6 +160,7 @@ class PropNetDiffDenModel(object):
         d, _ = _to_np(particle_dens)
         assert a.shape == s.shape[:2]            # model/gnn_dyn.py:218-219
         assert s.shape == sd.shape
+        self._claim()
         if particle_nums is not None:
             # model/gnn_dyn.py:238-241: rows/columns beyond particle_nums[b] leave the graph.
             # Unused by the MPC path and by training: build the lists on the

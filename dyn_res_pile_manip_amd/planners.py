@@ -80,6 +80,7 @@ class PlannerGD(Planner):
     def _bind(self, model_dy):
         if not isinstance(model_dy, PropNetDiffDenModel):
             raise NotImplementedError      # planners.py:355
+        model_dy._claim()                  # models share the process's context: this one's weights in
         eng = model_dy.engine
         eng.set_camera(self._m34, float(self.global_scale), self.cam_params)
         return eng

@@ -74,6 +74,9 @@ def run_batch(model, optimizer, data, phase='train', n_rollout=None):
     if n_rollout is not None:
         assert length == n_rollout + 1                  # :166 (n_history = 1)
     mode = 'update' if phase == 'train' else 'eval'
+    if hasattr(model, '_claim'):
+        model._claim()                                  # models share the process's context: this one's weights in
+        model._device_ahead = model._device_ahead or mode == 'update'
     loss, _ = model.engine.train_step(states, _np(states_delta), _np(attrs), _np(particle_nums, np.int32),
                                       _np(particle_dens), mode=mode)
     return loss

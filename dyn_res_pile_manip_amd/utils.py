@@ -9,9 +9,7 @@ reproducible; pass explicit indices for bit-for-bit comparisons.
 """
 import numpy as np
 
-from .engine import Engine
-
-_ENGINE = None
+from .engine import default_engine, set_default_engine
 
 FG_DEPTH = 0.599 / 0.8      # env/flex_env.py:945
 VOXEL = 0.01                # env/flex_env.py:947
@@ -19,16 +17,12 @@ RECENTER_R = 0.02           # env/flex_env.py:949
 
 
 def get_engine(device=0):
-    """One shared context for the helpers of this module (created on first use)."""
-    global _ENGINE
-    if _ENGINE is None:
-        _ENGINE = Engine(device)
-    return _ENGINE
+    """The process's one context (engine.default_engine): the model, the planner bound to it and these helpers share it."""
+    return default_engine(device)
 
 
 def set_engine(engine):
-    global _ENGINE
-    _ENGINE = engine
+    set_default_engine(engine)
 
 
 def depth2fgpcd(depth, mask, cam_params):

@@ -186,7 +186,7 @@ def test_one_mpc_step_end_to_end(stack):
     config = dict(config)
     config['mpc'] = dict(config['mpc'], mpc_type='GD')
     planner = PlannerGD(config, env)
-    dev.set_engine(model.engine)
+    assert dev.get_engine() is model.engine             # utils.py's helpers and the model share the process's context
     obs = syn.render_depth(1500, seed=3, kind='uniform')
     subgoal = syn.goal_distance_image(syn.goal_mask('I'))
     act_seq = np.stack([syn.nominal_pushes(1, seed=20 + i) for i in range(6)], axis=1)
@@ -196,7 +196,6 @@ def test_one_mpc_step_end_to_end(stack):
     lo, hi = syn.action_limits()
     assert (out['action_sequence'][0] >= lo - 1e-6).all() and (out['action_sequence'][0] <= hi + 1e-6).all()
     assert out['iter_num'] == 3 and np.isfinite(out['reward']).all()
-    dev.set_engine(None)
 
 
 @pytest.mark.parametrize('mpc_type', ['MPPI', 'CEM', 'GD'])
@@ -220,3 +219,111 @@ def test_pipelined_loop_returns_what_the_blocking_loop_returns(stack, golden, mp
     assert res[0]['iter_num'] == res[1]['iter_num']
     for k in ('action_sequence', 'action_full', 'reward_full', 'observation_sequence', 'reward', 'next_r', 'rew_mean', 'rew_std'):
         np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
+
+
+def test_config_reward_ptcl_with_the_references_own_arguments(stack, golden):
+    """env/flex_env.py:1032-1036,1102 calls `config_reward_ptcl(state, goal, cam_params=..., goal_coor=..., normalize=True)`:
+    no engine argument.  The mirror runs it on the process's one context -- the model's, the planner's and utils.py's --
+    and installs `cam_params` on every call."""
+    _, env, model, planner = stack
+    from dyn_res_pile_manip_amd import flex_rewards, utils
+    from dyn_res_pile_manip_amd.engine import default_engine
+    assert utils.get_engine() is model.engine is default_engine()          # one context per process, not two
+    g = golden.reward
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    state, goal_coor = torch.from_numpy(g['I/state']), torch.from_numpy(g['I/goal_coor'])
+    r = flex_rewards.config_reward_ptcl(state, torch.from_numpy(obs_goal), cam_params=env.get_cam_params(),
+                                        goal_coor=goal_coor, normalize=True)
+    assert isinstance(r, torch.Tensor)
+    np.testing.assert_allclose(r.numpy(), g['I/reward'], rtol=1e-5)
+    # other intrinsics give another reward, and the reference's give the reference's again: cam_params is applied, every call
+    fx, fy, cx, cy = env.get_cam_params()
+    r2 = flex_rewards.config_reward_ptcl(state, obs_goal, cam_params=[0.9 * fx, 0.9 * fy, cx, cy], goal_coor=goal_coor, normalize=True)
+    assert np.abs(r2.numpy() - g['I/reward']).max() > 1e-3
+    r3 = flex_rewards.config_reward_ptcl(state, obs_goal, env.get_cam_params(), goal_coor)
+    np.testing.assert_allclose(r3.numpy(), g['I/reward'], rtol=1e-5)
+    # the planner still finds its own camera after that (it installs it whenever it binds a model)
+    out = planner.ptcl_model_rollout(golden.rollout['c1/s_cur'], golden.rollout['c1/dens'], golden.rollout['c1/attr'], model,
+                                     golden.rollout['c1/act_seqs'])
+    assert np.abs(out['model_rollout']['state_pred'] - golden.rollout['c1/state_pred']).max() < 5e-6
+
+
+def _scaled_relation_encoder(golden, f2, f4):
+    """seed-0 weights with the relation encoder's second layer (weight and bias) times f2 and its third layer's weight times
+    f4: for f2 * f4 = 1 the same function (ReLU is positively homogeneous) up to fp32 rounding."""
+    sd = {k[2:]: np.array(golden.weights_seed0[k]) for k in golden.weights_seed0.files if k.startswith('w/')}
+    sd['model.relation_encoder.model.2.weight'] = sd['model.relation_encoder.model.2.weight'] * np.float32(f2)
+    sd['model.relation_encoder.model.2.bias'] = sd['model.relation_encoder.model.2.bias'] * np.float32(f2)
+    sd['model.relation_encoder.model.4.weight'] = sd['model.relation_encoder.model.4.weight'] * np.float32(f4)
+    return sd
+
+
+def test_weights_the_fused_engine_cannot_serve_fall_back_by_themselves(golden):
+    """A checkpoint with a matrix entry beyond fp16 (the split-fp16 relation encoder packs W2, W3, W_e as they are): the
+    fused engine refuses every call with DRP_ERANGE.  The host mirror -- model and planner with NO engine argument, as
+    visualize_mpc.py:36-41,70-84 build them -- switches to the fp32 matrix engine by itself, warns once and keeps working;
+    the results are the oracle's for those weights.  (Weights merely far from a fresh network's, x 50 in every layer of
+    the relation encoder, stay on the fused engine: its range shift covers them.)"""
+    from oracle import propnet_sparse as osp
+    from dyn_res_pile_manip_amd import _lib
+    from dyn_res_pile_manip_amd.engine import set_default_engine
+    set_default_engine(None)                                   # a fresh process-wide context for this test
+    config = syn.default_config()
+    env = syn.SyntheticEnv(config)
+    g = golden.one_step
+    a, s, sdl, d = (g['n64/' + k] for k in ('attr', 's_cur', 's_delta', 'dens'))
+    try:
+        # (1) every layer of the relation encoder x 50 (edge effects 125 000 times a fresh network's): inside the fused
+        # engine's reach -- its range shift follows the weights --, no warning, the oracle's answer
+        sd50 = {k[2:]: np.array(golden.weights_seed0[k]) for k in golden.weights_seed0.files if k.startswith('w/')}
+        for lyr in ('0', '2', '4'):
+            sd50['model.relation_encoder.model.%s.weight' % lyr] *= np.float32(50.0)
+            sd50['model.relation_encoder.model.%s.bias' % lyr] *= np.float32(50.0)
+        model = PropNetDiffDenModel(config, True)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd50.items()}, strict=False)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')
+            out = model.predict_one_step(a, s, sdl, d)
+        assert model.engine.engine_id == _lib.ENGINE_FUSED
+        ref = osp.predict_one_step(osp.weights_np(sd50), a, s, sdl, d)
+        assert np.abs(out - ref).max() < 1e-4 * np.abs(ref - s).max()
+        # (2) an entry beyond fp16: DRP_ERANGE -> the fp32 matrix engine, one warning, the oracle's answer
+        sdx = _scaled_relation_encoder(golden, 1e6, 1e-6)
+        assert np.abs(sdx['model.relation_encoder.model.2.weight']).max() > 65504.0
+        model2 = PropNetDiffDenModel(config, True)
+        model2.load_state_dict({k: torch.from_numpy(v) for k, v in sdx.items()}, strict=False)
+        with pytest.warns(RuntimeWarning, match='fp32 matrix engine'):
+            out2 = model2.predict_one_step(torch.from_numpy(a), torch.from_numpy(s), torch.from_numpy(sdl), torch.from_numpy(d))
+        assert model2.engine.engine_id == _lib.ENGINE_MFMA
+        ref2 = osp.predict_one_step(osp.weights_np(sdx), a, s, sdl, d)
+        assert np.abs(out2.numpy() - ref2).max() < 2e-6
+        # the sampling planner on that model, no engine anywhere in sight: rollouts and a whole planner call
+        planner = PlannerGD(config, env)
+        ro = golden.rollout
+        sp = planner.ptcl_model_rollout(ro['c1/s_cur'], ro['c1/dens'], ro['c1/attr'], model2, ro['c1/act_seqs'])['model_rollout']['state_pred']
+        refr = osp.rollout(osp.weights_np(sdx), ro['c1/s_cur'], ro['c1/dens'], ro['c1/attr'], ro['c1/act_seqs'],
+                           osp.world2cam_affine(syn.demo_cam_extrinsics(), 24), 24.0)
+        assert np.abs(sp - refr).max() < 5e-6
+        gp = golden.gd_planner
+        lo, hi = syn.action_limits()
+        np.random.seed(0)
+        res = planner.trajectory_optimization_ptcl_multi_traj(
+            gp['s_cur'], gp['dens'], gp['attr'], syn.goal_distance_image(syn.goal_mask('I')), model2, gp['act_seq'], np.zeros(1),
+            n_sample=32, n_look_ahead=1, n_update_iter=3, action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=1e9)
+        assert np.isfinite(res['reward']).all() and res['action_sequence'].shape == (1, 4)
+        # the model of part (1) takes the shared context back with ITS weights (and the engine stays where it is)
+        out_again = model.predict_one_step(a, s, sdl, d)
+        assert np.abs(out_again - ref).max() < 1e-4 * np.abs(ref - s).max()
+        # the gradient-descent planner writes its tape with the fused engine only: there the refusal stands
+        cfg_gd = syn.default_config()
+        cfg_gd['mpc']['mpc_type'] = 'GD'
+        with pytest.raises(_lib.DrpRangeError):
+            PlannerGD(cfg_gd, env).trajectory_optimization_ptcl_multi_traj(
+                gp['s_cur'], gp['dens'], gp['attr'], syn.goal_distance_image(syn.goal_mask('I')), model2, gp['act_seq'], np.zeros(1),
+                n_sample=gp['act_seq'].shape[1], n_look_ahead=1, n_update_iter=3, action_lower_lim=lo, action_upper_lim=hi,
+                use_gpu=True, time_lim=1e9)
+    finally:
+        from dyn_res_pile_manip_amd.engine import default_engine
+        default_engine().close()
+        set_default_engine(None)

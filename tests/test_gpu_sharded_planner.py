@@ -121,7 +121,7 @@ def test_the_communicator_comes_up_whatever_the_import_order(order):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     p = subprocess.run([sys.executable, os.path.join(root, 'tests', '_rccl_order.py'), order], cwd=root, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     out = p.stdout.decode()
     assert p.returncode == 0 and 'communicator up' in out and 'ERR' not in out, out[-2000:]
     up = [l for l in out.splitlines() if l.startswith('communicator up')][0]
