@@ -137,6 +137,44 @@ def _free_port():
     return port
 
 
+def visible_gpu_count():
+    """GPUs this process could use, WITHOUT touching HIP (the parent of the ranks must not initialise the GPU): the DRM
+    render nodes it can open -- a container is handed the nodes of its GPUs only -- cut down by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES.  0 without the compute driver's device node, None when the box does not say."""
+    import glob
+    if not os.path.exists('/dev/kfd'):
+        return 0
+    nodes = glob.glob('/dev/dri/renderD*')
+    if not nodes:
+        return None
+    n = 0
+    for f in nodes:
+        try:
+            os.close(os.open(f, os.O_RDWR))
+            n += 1
+        except OSError:
+            pass
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
+
+
+def preflight(args, out=sys.stderr):
+    """--gpus N on a box with fewer GPUs must fail NOW (exit 4, one clear line), not after the ranks have waited out a
+    rendezvous: checked by the parent of self-launched ranks and by every rank a launcher started.  --share-gpu (all ranks
+    on GPU 0: the one-GPU dry run) lifts it."""
+    if args.gpus <= 1 or args.share_gpu:
+        return 0
+    have = visible_gpu_count()
+    if have is not None and have < args.gpus:
+        out.write('bench.py: --gpus %d but this box shows %d GPU(s) (render nodes / *_VISIBLE_DEVICES): not starting; '
+                  '--share-gpu --comm gloo runs the N-rank code path on one GPU\n' % (args.gpus, have))
+        return EXIT_WORLD_MISMATCH
+    return 0
+
+
 def launch_ranks(args):
     """Start one child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, as
     torch.distributed.run would set them), relay rank 0's JSON line, return the exit status.  The parent imports
@@ -145,6 +183,9 @@ def launch_ranks(args):
     process group, killed by its pgid -- never by pattern)."""
     import signal
     import tempfile
+    rc = preflight(args)
+    if rc:
+        return rc
     n = args.gpus
     port = _free_port()
     procs, outs = [], []
@@ -574,6 +615,9 @@ def run_rank(args):
         return EXIT_WORLD_MISMATCH
     if args.force_comm:
         os.environ['DRP_COMM_ALWAYS'] = '1'          # read at drp_create
+    rc = preflight(args)                             # under a launcher every rank checks for itself, before any rendezvous
+    if rc:
+        return rc
     import datetime
     import torch
     import torch.distributed as dist
@@ -627,6 +671,16 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def per_rank_ms(dt_own):
+        """Every rank's own ms per step of the timed region (the line's ms_per_step is their maximum): a straggler shows."""
+        ms = dt_own / args.steps * 1e3
+        if world == 1:
+            return {'min': ms, 'max': ms, 'all': [round(ms, 4)]}
+        t = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(t, torch.tensor([ms], dtype=torch.float64))
+        v = [float(x.item()) for x in t]
+        return {'min': min(v), 'max': max(v), 'all': [round(x, 4) for x in v]}
+
     N, H = args.particles, args.horizon
     out = None
     if args.config_name == 'gd-demo':
@@ -635,13 +689,14 @@ def run_rank(args):
         traj = max(1, rows // nb)
         g = bench_gd(rig, N, traj, nb, H, args.steps, args.warmup, fence, rank=rank)
         dt, med = max_over_ranks(g['dt']), max_over_ranks(g['median'])
+        rank_ms = per_rank_ms(g['dt'])
         if rank == 0:
             from dyn_res_pile_manip_amd.planners import particle_num_to_iter_time
             B = g['B']
             out = {'metric': 'MPC rollout-steps/sec (samples x particles x steps/sec)', 'value': world * B * N * H * args.steps / dt,
                    'unit': 'particle-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                    'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                   'ms_per_step_median': med * 1e3, 'value_median': world * B * N * H / med,
+                   'ms_per_step_median': med * 1e3, 'value_median': world * B * N * H / med, 'rank_ms_per_step': rank_ms,
                    'dtype': 'f32 (forward MLP products as split fp16 / bf16 MFMA terms, backward node stages on fp32 MFMA, fp32 accumulate)',
                    'data': 'synthetic',
                    'config': {'workload': args.workload, 'name': args.config_name, 'n_particles': N, 'n_trajectories_per_gpu': traj,
@@ -685,6 +740,7 @@ def run_rank(args):
         m = bench_mppi(rig, N, ns, H, s_lo, args.steps, args.warmup, update, fence, KERNEL_CLASSES, want_median=True,
                        fault=(args.fault_rank == rank))
         dt, med = max_over_ranks(m['dt']), max_over_ranks(m['median'])
+        rank_ms = per_rank_ms(m['dt'])
         step = m['step']
         # the same K steps on the pure-fp32 MFMA engine (bit-for-bit an fp32 fma chain), for reference; its un-fused
         # pipeline has the segmented sum ("scatter-add") as a kernel of its own, timed here with the HIP-event probe
@@ -729,7 +785,7 @@ def run_rank(args):
                 'value': args.samples_total_job * N * H * args.steps / dt, 'unit': 'particle-steps/s', 'n_gpus': world,
                 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
                 'scaling': args.scaling, 'vs_baseline': None,
-                'ms_per_step_median': med * 1e3, 'value_median': args.samples_total_job * N * H / med,
+                'ms_per_step_median': med * 1e3, 'value_median': args.samples_total_job * N * H / med, 'rank_ms_per_step': rank_ms,
                 'dtype': 'f32' if engine in ('valu', 'mfma') else 'f32 (MLP products as split fp16 / bf16 MFMA terms, fp32 accumulate)',
                 'data': 'synthetic',
                 'config': {'workload': args.workload, 'name': args.config_name,

@@ -11,6 +11,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -58,8 +59,9 @@ struct DevBuf {
 // ---- RCCL, bound at run time -----------------------------------------------------------------------------------
 // libdrp.so does not link librccl: a process must not end up with two copies of it (PyTorch ships its own
 // librccl.so beside the one under /opt/rocm; which of two mapped copies answered a call used to depend on the import
-// order).  The first call that needs RCCL takes, in this order: $DRP_RCCL_LIB, the librccl the process has ALREADY
-// mapped (torch's, when the host imported torch), librccl.so.1 by the loader's search path, /opt/rocm/lib/librccl.so.1.
+// order).  The first call that needs RCCL takes, in this order: $DRP_RCCL_LIB, the librccl that sits NEXT TO THE HIP RUNTIME
+// this library itself runs on (dladdr of hipGetDeviceCount), a librccl the process has already mapped (dl_iterate_phdr),
+// /opt/rocm/lib/librccl.so.1 (include/drp.h says the same).
 // Only entry points whose ABI has been stable since NCCL 2.4 are used (no ncclConfig_t crosses the boundary).
 struct RcclApi {
     void* handle = nullptr;
@@ -245,6 +247,8 @@ struct drp_ctx {
     DevBuf nominal, noise, partials, gathered, stats, elite, elite_all, xchg;
     int n_ranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    bool comm_failed = false;            // a wait gave up or RCCL reported an error: the communicator is gone and every entry point
+    int comm_failed_ranks = 0;           // that would use it answers DRP_ECOMM until drp_comm_destroy / a fresh drp_comm_init
     double comm_timeout_s = 60.0;        // DRP_COMM_TIMEOUT_S: a wait behind a collective gives up after this long (guarded_wait)
     double comm_init_timeout_s = 300.0;  // DRP_COMM_INIT_TIMEOUT_S: ncclCommInitRank (every rank must arrive)
 
@@ -344,8 +348,11 @@ int fail(drp_ctx* c, int code, const char* fmt, ...) {
         if (rc_ != DRP_OK) return rc_; \
     } while (0)
 
+int guarded_wait(drp_ctx* c, hipEvent_t ev);
 int ensure(drp_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return DRP_OK;
+    // hipFree waits for the device: behind a collective that cannot finish it would never return
+    if (b.p && c && c->comm != nullptr && (c->n_ranks > 1 || c->comm_always)) CHK(guarded_wait(c, nullptr));
     if (b.p) HIPCHK(c, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -377,6 +384,42 @@ int d2h(drp_ctx* c, void* dst, const void* src, size_t bytes) {
 // rank and the call returns DRP_ECOMM: the process can report and exit instead of sitting in hipStreamSynchronize.
 bool comm_live(const drp_ctx* c) { return c->comm != nullptr && (c->n_ranks > 1 || c->comm_always); }
 
+// Helper threads (ncclCommAbort behind a dead collective, ncclCommInitRank waiting for its peers) are tracked: drp_destroy,
+// drp_comm_destroy and process exit give them a bounded time to finish, so that none is still inside RCCL when the stream,
+// the context or the HIP / RCCL libraries' own statics go away.
+struct HelperState { std::atomic<int> done{0}; };
+std::mutex g_helpers_mu;
+std::vector<std::shared_ptr<HelperState>> g_helpers;
+std::shared_ptr<HelperState> helper_register() {
+    auto h = std::make_shared<HelperState>();
+    std::lock_guard<std::mutex> lk(g_helpers_mu);
+    static bool at_exit = false;
+    if (!at_exit) {
+        at_exit = true;
+        atexit([] {
+            const double t0 = now_s();
+            for (;;) {
+                bool busy = false;
+                { std::lock_guard<std::mutex> lk2(g_helpers_mu); for (auto& q : g_helpers) busy = busy || !q->done.load(std::memory_order_acquire); }
+                if (!busy || now_s() - t0 > 5.0) return;
+                usleep(1000);
+            }
+        });
+    }
+    g_helpers.erase(std::remove_if(g_helpers.begin(), g_helpers.end(), [](const std::shared_ptr<HelperState>& q) { return q->done.load() != 0; }), g_helpers.end());
+    g_helpers.push_back(h);
+    return h;
+}
+void helpers_wait(double seconds) {
+    const double t0 = now_s();
+    for (;;) {
+        bool busy = false;
+        { std::lock_guard<std::mutex> lk(g_helpers_mu); for (auto& q : g_helpers) busy = busy || !q->done.load(std::memory_order_acquire); }
+        if (!busy || now_s() - t0 > seconds) return;
+        usleep(500);
+    }
+}
+
 void comm_abort(drp_ctx* c) {
     RcclApi* R = rccl_api();
     // ncclCommAbort raises the communicator's abort flag (a collective's kernel spinning on a peer sees it and ends) and
@@ -384,11 +427,20 @@ void comm_abort(drp_ctx* c) {
     if (c->comm && R) {
         ncclComm_t comm = c->comm;
         const int dev = c->device;
-        std::thread([R, comm, dev] { (void)hipSetDevice(dev); (void)R->CommAbort(comm); }).detach();
+        auto h = helper_register();
+        std::thread([R, comm, dev, h] { (void)hipSetDevice(dev); (void)R->CommAbort(comm); h->done.store(1, std::memory_order_release); }).detach();
     }
+    // the failure is STICKY: the ranks' shards are no longer combined, so nothing that would have used the communicator may
+    // quietly carry on with this rank's data alone
+    c->comm_failed = true;
+    c->comm_failed_ranks = c->n_ranks;
     c->comm = nullptr;
     c->n_ranks = 1;
     c->rank = 0;
+}
+int comm_failed_error(drp_ctx* c) {
+    return fail(c, DRP_ECOMM, "the communicator of %d ranks was aborted after a failed wait or an RCCL error: call drp_comm_destroy "
+                "(continue alone) or drp_comm_init with a fresh id before the next collective step", c->comm_failed_ranks);
 }
 
 int guarded_wait(drp_ctx* c, hipEvent_t ev) {
@@ -1281,6 +1333,7 @@ void drp_destroy(drp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)guarded_wait(c, nullptr);           // a collective that cannot finish must not keep the destructor
+    helpers_wait(5.0);                        // no helper thread (an abort, an init) inside RCCL while the stream goes away
     if (c->comm) { RcclApi* R = rccl_api(); if (R) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
     DevBuf* bufs[] = {&c->probe_work, &c->ecache, &c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
@@ -1636,6 +1689,7 @@ int drp_mpc_update(drp_ctx* c, const double* partials, int n_ranks, double* nomi
 int drp_mpc_update_device(drp_ctx* c) {
     if (!c || !c->mpc_on) return fail(c, DRP_ESTATE, "drp_mpc_begin not called");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm_failed) return comm_failed_error(c);
     CHK(launch_partials(c, ptr<double>(c->partials)));
     const int rec = 6 + 4 * c->mpc.n_look_ahead;
     if (c->comm && (c->n_ranks > 1 || c->comm_always)) {
@@ -1726,6 +1780,7 @@ int drp_mpc_update_elite_device(drp_ctx* c, int k) {
     // written side by side by the two local kernels, all-gathered with ONE RCCL call, read in place by the
     // two combine kernels (the softmax combine supplies mean / std / max / argmax; its nominal is then replaced
     // by the elite mean).
+    if (c->comm_failed) return comm_failed_error(c);
     const int H = c->mpc.n_look_ahead, rec_s = 6 + 4 * H, rec_e = k * (2 + 4 * H), msg = rec_s + rec_e;
     CHK(ensure(c, c->elite, (size_t)msg * sizeof(double)));
     double* mine = ptr<double>(c->elite);
@@ -2963,32 +3018,47 @@ int drp_comm_init(drp_ctx* c, const char* id128, int rank, int n_ranks) {
     RcclApi* R = need_rccl(c);
     if (!R) return DRP_ECOMM;
     HIPCHK(c, hipSetDevice(c->device));
+    // an id serves ONE ncclCommInitRank per rank (a second one with the same id never returns): keyed on (id, rank) -- the
+    // ranks of one process, a context per GPU, share their id --, looked up first, recorded when the call is about to go out
+    const std::string key = std::string(id128, 128) + ":" + std::to_string(rank);
     {
         std::lock_guard<std::mutex> lk(g_used_ids_mu);
-        const std::string key(id128, 128);
         for (const std::string& u : g_used_ids)
-            if (u == key) return fail(c, DRP_ECOMM, "this ncclUniqueId has already been used for a communicator in this process: "
-                                      "every communicator needs a fresh id from rank 0 (drp_comm_unique_id)");
-        g_used_ids.push_back(key);
+            if (u == key) return fail(c, DRP_ECOMM, "this ncclUniqueId has already been used for rank %d's communicator in this process: "
+                                      "every communicator needs a fresh id from rank 0 (drp_comm_unique_id)", rank);
     }
-    if (c->comm) { CHK(guarded_wait(c, nullptr)); (void)R->CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm) { CHK(guarded_wait(c, nullptr)); if (c->comm) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
+    c->comm_failed = false;
+    c->n_ranks = 1;
+    c->rank = 0;
     // every rank has to arrive: the call runs on a helper thread so that a missing peer costs a deadline
-    // (DRP_COMM_INIT_TIMEOUT_S), not the process
-    struct InitState { std::atomic<int> done{0}; ncclComm_t comm = nullptr; ncclResult_t res = ncclSuccess; };
+    // (DRP_COMM_INIT_TIMEOUT_S), not the process; a helper nobody waits for any more aborts what it finally gets
+    struct InitState { std::atomic<int> state{0} /* 0 waiting, 1 finished, 2 given up */; ncclComm_t comm = nullptr; ncclResult_t res = ncclSuccess; };
     auto stt = std::make_shared<InitState>();
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     const int dev = c->device;
-    std::thread([stt, R, id, rank, n_ranks, dev] {
+    {
+        std::lock_guard<std::mutex> lk(g_used_ids_mu);
+        g_used_ids.push_back(key);
+    }
+    auto hs = helper_register();
+    std::thread([stt, R, id, rank, n_ranks, dev, hs] {
         (void)hipSetDevice(dev);
         stt->res = R->CommInitRank(&stt->comm, n_ranks, id, rank);
-        stt->done.store(1, std::memory_order_release);
+        int waiting = 0;
+        if (!stt->state.compare_exchange_strong(waiting, 1, std::memory_order_acq_rel) && stt->res == ncclSuccess && stt->comm)
+            (void)R->CommAbort(stt->comm);            // the caller has given up: nobody will ever own this communicator
+        hs->done.store(1, std::memory_order_release);
     }).detach();
     const double t0 = now_s();
-    while (!stt->done.load(std::memory_order_acquire)) {
-        if (now_s() - t0 > c->comm_init_timeout_s)
+    while (stt->state.load(std::memory_order_acquire) == 0) {
+        if (now_s() - t0 > c->comm_init_timeout_s) {
+            int waiting = 0;
+            if (!stt->state.compare_exchange_strong(waiting, 2, std::memory_order_acq_rel)) break;    // it arrived just now
             return fail(c, DRP_ECOMM, "ncclCommInitRank: rank %d waited %.0f s for the other %d rank(s) (DRP_COMM_INIT_TIMEOUT_S)",
                         rank, c->comm_init_timeout_s, n_ranks - 1);
+        }
         usleep(200);
     }
     if (stt->res != ncclSuccess) return fail(c, DRP_ECOMM, "ncclCommInitRank: %s", R->GetErrorString(stt->res));
@@ -3023,6 +3093,7 @@ int drp_comm_info(drp_ctx* c, int* n_ranks, int* rank, int* version, char* path,
 int drp_comm_allgather(drp_ctx* c, const void* send, size_t bytes, void* recv) {
     if (!c || !send || !recv || bytes == 0) return fail(c, DRP_EINVAL, "bad all-gather arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm_failed) return comm_failed_error(c);
     if (!comm_live(c)) {
         memcpy(recv, send, bytes);
         return DRP_OK;
@@ -3040,6 +3111,8 @@ int drp_comm_allgather(drp_ctx* c, const void* send, size_t bytes, void* recv) {
 
 int drp_comm_destroy(drp_ctx* c) {
     if (!c) return DRP_EINVAL;
+    c->comm_failed = false;                           // the caller has seen the failure and goes on alone
+    helpers_wait(5.0);                                // an abort still draining the device
     if (c->comm) {
         RcclApi* R = rccl_api();
         const int rc = guarded_wait(c, nullptr);      // aborts the communicator itself when the wait gives up
@@ -3185,9 +3258,9 @@ long drp_debug_fetch(drp_ctx* c, const char* name, void* out, size_t out_bytes) 
     }
     if (!b->p || bytes == 0 || bytes > b->cap) return fail(c, DRP_ESTATE, "buffer '%s' not populated", name);
     if (out_bytes < bytes) return fail(c, DRP_EINVAL, "buffer '%s' needs %zu bytes", name, bytes);
-    if (hipMemcpyAsync(out, b->p, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
+    if (hipMemcpyAsync(out, b->p, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
         return fail(c, DRP_EHIP, "debug fetch failed");
+    { const int rc = guarded_wait(c, nullptr); if (rc != DRP_OK) return rc; }
     return (long)bytes;
 }
 

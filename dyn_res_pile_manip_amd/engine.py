@@ -498,7 +498,8 @@ class Engine(object):
     def comm_allgather(self, arr):
         """All-gather one host array per rank over the context's communicator -> [n_ranks, *arr.shape]."""
         arr = np.ascontiguousarray(arr)
-        out = np.empty((getattr(self, '_n_ranks', 1),) + arr.shape, arr.dtype)
+        # the communicator's own count, not a cached one: an aborted communicator is gone (and the call below says so)
+        out = np.empty((max(1, self.comm_info()['n_ranks']),) + arr.shape, arr.dtype)
         self._ck(self.lib.drp_comm_allgather(self.h, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes,
                                              out.ctypes.data_as(ctypes.c_void_p)))
         return out

@@ -302,10 +302,16 @@ int drp_gd_wait(drp_ctx* ctx, int slot, float* rewards_out, float* actions_out);
  * Hang guard: while a communicator is attached, every host wait of the context (drp_sync, drp_mpc_wait, drp_gd_wait,
  * the waits inside the blocking calls) polls the stream, the communicator's asynchronous error and a deadline
  * (env DRP_COMM_TIMEOUT_S, default 60; DRP_COMM_INIT_TIMEOUT_S, default 300, for drp_comm_init).  On error or
- * timeout the communicator is aborted (ncclCommAbort), the context is back to one rank and the call returns DRP_ECOMM. */
+ * timeout the communicator is aborted (ncclCommAbort) and the call returns DRP_ECOMM.  The failure is STICKY: until
+ * drp_comm_destroy (continue alone) or a fresh drp_comm_init, every entry point that would have combined the ranks' shards
+ * (drp_mpc_update_device, drp_mpc_update_elite_device, drp_comm_allgather) returns DRP_ECOMM too -- none of them quietly
+ * carries on with this rank's data.  What needs no other rank (rollouts, rewards, fetches) keeps working.  The helper
+ * threads behind an abort or an init are given a bounded time to finish by drp_comm_destroy, drp_destroy and at exit. */
 int drp_comm_unique_id(char* id128);                       /* ncclGetUniqueId */
-/* ncclCommInitRank.  A ncclUniqueId serves one communicator: a second drp_comm_init with an id this process has
- * already used returns DRP_ECOMM instead of never returning. */
+/* ncclCommInitRank.  A ncclUniqueId serves one communicator per rank: a second drp_comm_init of the same (id, rank) in
+ * this process returns DRP_ECOMM instead of never returning (several contexts of one process, one per GPU, share an id).
+ * A rank whose peers do not arrive within DRP_COMM_INIT_TIMEOUT_S gets DRP_ECOMM; a communicator that comes up after that
+ * is aborted by the helper that was waiting for it. */
 int drp_comm_init(drp_ctx* ctx, const char* id128, int rank, int n_ranks);
 int drp_comm_destroy(drp_ctx* ctx);
 /* n_ranks = ncclCommCount and rank = ncclCommUserRank of the attached communicator (0 / -1 without one),

@@ -175,3 +175,18 @@ def test_one_rank_through_rccl():
     assert rc['comm_count'] == 1 and 'librccl' in rc['library'] and rc['version'][0].isdigit()
     # one RCCL per process: the bench imports torch, so the copy torch ships is the one the engine bound
     assert os.sep + 'torch' + os.sep in rc['library']
+
+
+def test_more_ranks_than_gpus_is_refused_before_any_rank_starts():
+    """One GPU here: `--gpus 2` without --share-gpu exits 4 at once with one line that says why (a driver's scaling run on a
+    smaller box must not sit in a rendezvous); the count comes from the render nodes, no HIP call in the parent."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.visible_gpu_count()
+    assert have is not None and have >= 1
+    t0 = time.time()
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', str(have + 1), '--steps', '1', '--warmup', '0'], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 4 and b'not starting' in p.stderr and not p.stdout.strip()
+    assert time.time() - t0 < 60

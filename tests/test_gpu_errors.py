@@ -115,8 +115,28 @@ def test_a_wait_behind_a_dead_collective_returns_an_error(golden, monkeypatch):
     with pytest.raises(DrpError, match='waited'):
         eng.sync()
     assert 0.9 < time.time() - t0 < 2.5
-    assert eng.comm_info()['n_ranks'] == 0              # aborted: the context is back to one rank
+    assert eng.comm_info()['n_ranks'] == 0              # aborted: no communicator any more
     eng.sync()                                          # no communicator: a plain wait, ends with the stall
-    again, _ = eng.rollout(s0, attr, dens, acts)
+    again, _ = eng.rollout(s0, attr, dens, acts)        # what needs no other rank still works
     np.testing.assert_array_equal(again, ref)
+    # the failure is sticky: every step that would have combined the ranks' shards answers DRP_ECOMM -- it must not carry
+    # on with this rank's data alone -- until the caller destroys the communicator (or attaches a fresh one)
+    lo, hi = syn.action_limits()
+    eng.set_goal_image(syn.goal_distance_image(syn.goal_mask('I')), 200, fps_init=0, mode='cv5', want=False)
+    eng.mpc_begin(s0, attr, dens, syn.nominal_pushes(2, seed=0), n_sample=8, sigma=0.6, beta_filter=0.7, reward_weight=0.1,
+                  act_lo=lo, act_hi=hi, seed=1, sample_offset=0)
+    eng.mpc_sample(0)
+    eng.mpc_rollout(False)
+    for call in (eng.mpc_update_device, lambda: eng.mpc_update_elite_device(2), lambda: eng.comm_allgather(np.arange(4.0))):
+        with pytest.raises(DrpError, match='aborted'):
+            call()
+    eng.comm_destroy()
+    eng.mpc_update_device()                             # alone, by the caller's decision
+    assert eng.comm_allgather(np.arange(4.0)).shape == (1, 4)
+    eng.comm_init(eng.comm_unique_id(), 0, 1)           # and a fresh communicator attaches
+    assert eng.comm_info()['n_ranks'] == 1
+    eng.mpc_sample(1)
+    eng.mpc_rollout(False)
+    eng.mpc_update_device()
+    eng.sync()
     eng.close()

@@ -87,3 +87,31 @@ def test_self_launch_relays_failure_and_leaves_nobody_behind():
     assert 'exited with status' in err
     assert not [l for l in out.splitlines() if l.startswith('{')]
     assert dt < 120
+
+
+def test_more_gpus_asked_for_than_the_box_has_fails_at_once():
+    """`bench.py --gpus N` on a box with fewer GPUs (this container shows none) must not start ranks that then wait out a
+    rendezvous: exit 4 and one line that says why, within seconds -- from the self-launching parent, and from a rank a
+    launcher started (WORLD_SIZE in the environment).  --share-gpu lifts the check."""
+    import bench
+    have = bench.visible_gpu_count()
+    if have is not None and have >= 8:
+        import pytest
+        pytest.skip('this box has 8 GPUs')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    rc, out, err, dt = _bench(['--gpus', '8', '--steps', '1', '--warmup', '0'], env, timeout=60)
+    assert rc == 4 and '--gpus 8' in err and 'not starting' in err and not out.strip(), (rc, err[-300:])
+    assert dt < 30
+    env_l = dict(env, WORLD_SIZE='8', RANK='3', LOCAL_RANK='3', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999')
+    rc, out, err, dt = _bench(['--gpus', '8', '--steps', '1', '--warmup', '0'], env_l, timeout=60)
+    assert rc == 4 and 'not starting' in err and not out.strip() and dt < 30
+
+
+def test_visible_gpu_count_follows_the_visibility_variables(monkeypatch):
+    import bench
+    have = bench.visible_gpu_count()
+    if have is None or have == 0:
+        import pytest
+        pytest.skip('no KFD topology with GPUs here')
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0')
+    assert bench.visible_gpu_count() == 1
