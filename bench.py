@@ -606,6 +606,71 @@ def run_sweep(rig, fence):
     return out
 
 
+def run_mpc_step(rig, fence):
+    """One whole MPC step the way env/flex_env.py:1016-1106 runs it, on a synthetic observation: obs2ptcl_fixed_num_batch
+    (720 x 720 depth image, 30 re-samplings; :1020) -> density (:1022) -> goal field + goal pixels (planners.py:620-624,
+    env/flex_rewards.py:172-177; cached per goal: miss and hit timed apart) -> trajectory_optimization_ptcl_multi_traj with the
+    shipped planner configuration (config/mpc/config.yaml:38-43: GD, 50 trajectories x 30 columns, horizon 1, 200 update
+    iterations, time_lim 2000 ms -> the reference's iteration count) -> the best push's re-rollout and reward (planners.py:
+    821-851).  Wall ms per phase, the process's CPU time beside it; the reference's budget for the planner call is its own
+    time_lim.  The simulator step is out of scope."""
+    import copy
+    from dyn_res_pile_manip_amd import synthetic as syn, utils as dev
+    from dyn_res_pile_manip_amd.gnn_dyn import PropNetDiffDenModel
+    from dyn_res_pile_manip_amd.planners import PlannerGD, gd_iteration_count
+    config = copy.deepcopy(syn.default_config())
+    config['mpc']['mpc_type'] = 'GD'
+    env = syn.SyntheticEnv(config)
+    model = PropNetDiffDenModel(config, True, engine=rig.eng)
+    model.load_state_dict(rig.sd, strict=False)
+    dev.set_engine(rig.eng)
+    planner = PlannerGD(config, env)
+    subgoal = syn.goal_distance_image(syn.goal_mask('I'))
+    obs = syn.render_depth(4000, seed=1, kind='uniform')
+    cam = syn.demo_cam_params()
+    lo, hi = syn.action_limits()
+    out = []
+    for N in (20, 50, 100):
+        act_seq = np.stack([syn.nominal_pushes(1, seed=10 + i) for i in range(50)], axis=1)           # [1, 50, 4]
+
+        def one(n_update_iter=200):
+            t = {}
+            c0 = time.process_time()
+            fence()
+            t0 = time.perf_counter()
+            np.random.seed(0)
+            obs_cur, particle_r = dev.obs2ptcl_fixed_num_batch(obs, N, 30, cam, 24.0)
+            particle_den = 1.0 / (particle_r * particle_r)
+            t['particles'] = time.perf_counter() - t0
+            attr_cur = np.zeros((obs_cur.shape[0], N), np.float32)
+            t1 = time.perf_counter()
+            res = planner.trajectory_optimization_ptcl_multi_traj(
+                obs_cur.astype(np.float32), particle_den.astype(np.float32), attr_cur, subgoal, model, act_seq,
+                np.zeros(act_seq.shape[0]), n_sample=act_seq.shape[1], n_look_ahead=1, n_update_iter=n_update_iter,
+                action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=2000.0)
+            t['planner'] = time.perf_counter() - t1
+            t['total'] = time.perf_counter() - t0
+            t['cpu'] = time.process_time() - c0
+            return res, t
+
+        planner._goal_key = None                                   # this pile size's goal pixels are not installed yet
+        res_first, t_first = one()                                 # goal cache MISS (and the first launch of these shapes)
+        runs = [one() for _ in range(3)]                           # goal cache hits
+        tm = {k: float(np.median([t[k] for _, t in runs])) for k in runs[0][1]}
+        r = runs[-1][0]
+        tt = r['times']
+        out.append({'n_particles': N, 'rows': 50 * 30, 'iterations': int(r['iter_num']) + 1,
+                    'reference_iteration_count': gd_iteration_count(200, 2000.0, N),
+                    'ms_total': tm['total'] * 1e3, 'ms_particles': tm['particles'] * 1e3, 'ms_planner_call': tm['planner'] * 1e3,
+                    'ms_goal_install_hit': tt.get('goal_time', 0.0) * 1e3, 'ms_goal_install_miss': res_first['times'].get('goal_time', 0.0) * 1e3,
+                    'ms_optimisation_loop': float(tt['optim_time']), 'ms_best_push_rollout_and_reward': float(tt['best_rollout_time']),
+                    'ms_total_first_call_goal_miss': t_first['total'] * 1e3,
+                    'host_cpu_ms': tm['cpu'] * 1e3,
+                    'reference_budget_ms': 2000.0, 'budget_source': 'config/mpc/config.yaml:40 time_lim (the planner call alone)',
+                    'push': [round(float(x), 3) for x in r['action_sequence'][0]], 'predicted_reward': float(r['reward'][0])})
+    return out
+
+
 def run_rank(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -807,6 +872,7 @@ def run_rank(args):
                 out['cpu_baseline'] = None
     if rank == 0 and args.do_sweep and world == 1:
         out['sweep'] = run_sweep(rig, fence)
+        out['mpc_step'] = run_mpc_step(rig, fence)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -285,7 +285,13 @@ class PlannerGD(Planner):
         obs_goal = obs_goal.astype(np.float32)
         # planners.py:620-624 + env/flex_rewards.py:172-177: goal pixels (col,row), their
         # farthest-point subsample to 5N and the distance field, all on the device
+        t_goal = time.time()
+        goal_was = self._goal_key
         self._set_goal(eng, obs_goal, goal_coor, max_goal_pts=N * 5)
+        goal_cached = self._goal_key is goal_was
+        if not goal_cached:
+            eng.sync()                                           # the install's kernels, so that its time is its own
+        goal_time = time.time() - t_goal
 
         lo, hi = self._clip_box(0)
         cfg = self.config['mpc']
@@ -454,6 +460,7 @@ class PlannerGD(Planner):
         best_seq = best_actions_of_samples[idx_best_sample][None]       # [1,H,4]
 
         obs_seq_best, reward_best, next_r = None, None, None
+        t_best = time.perf_counter()
         if rollout_best_action_sequence:
             # planners.py:821-851: B=1 re-rollout of the winner on column 0 + all-step reward
             states, rew = eng.rollout(state_cur_np[0:1], attr_cur_np[0:1], state_param[0:1], best_seq,
@@ -473,7 +480,10 @@ class PlannerGD(Planner):
                 'rew_std': rew_std,
                 'nominal_sequence': nominal,
                 'times': {'total_time': time.time() - start, 'rollout_time': rollout_time,
-                          'optim_time': optim_time},
+                          'optim_time': optim_time,
+                          # this build's own: goal install (s; cached per goal image), the winner's re-rollout + reward (ms)
+                          'goal_time': goal_time, 'goal_cached': goal_cached,
+                          'best_rollout_time': (time.perf_counter() - t_best) * 1e3},
                 'iter_num': i}
 
 

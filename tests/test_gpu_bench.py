@@ -106,6 +106,14 @@ def test_the_sweep_block_carries_the_other_baseline_workloads():
         assert abs(e['value'] - e['rows'] * e['n_particles'] * e['n_look_ahead'] / (e['ms_per_step'] * 1e-3)) < 1e-6 * e['value']
         assert e['dominant_kernel'] in e['kernel_ms_per_iteration']
     assert d['sweep'][4]['n_particles'] == 1200 and d['sweep'][4]['rows'] == 512 and d['sweep'][4]['n_look_ahead'] == 20
+    # one whole MPC step (env/flex_env.py:1016-1106) per pile size of the planner's regime, phases in ms, next to the
+    # reference's budget for the planner call
+    assert [e['n_particles'] for e in d['mpc_step']] == [20, 50, 100]
+    for e in d['mpc_step']:
+        assert e['iterations'] == e['reference_iteration_count'] and e['rows'] == 1500
+        assert 0 < e['ms_particles'] < e['ms_total'] and 0 < e['ms_optimisation_loop'] <= e['ms_planner_call'] < e['reference_budget_ms']
+        assert e['ms_goal_install_hit'] < e['ms_goal_install_miss']
+        assert all(s.syn_lo <= v <= s.syn_hi for v, s in zip(e['push'], [type('b', (), {'syn_lo': -5.01, 'syn_hi': 5.01})] * 4))
 
 
 @pytest.mark.parametrize('mode', ['weak', 'strong', 'elite'])
