@@ -162,13 +162,13 @@ struct drp_ctx {
     std::string err;
     int engine = DRP_ENGINE_VALU;
     int n_cu = 256;
-    bool agg_global_only = false;   // DRP_AGG_GLOBAL=1: always gather sender rows from L2/HBM
+    bool agg_global_only = false;   // always gather sender rows from L2/HBM (timing builds)
     bool rev_global_only = false;   // DRP_REV_GLOBAL=1: reversed neighbour lists built in global memory (the N > 3072 path)
     bool self_const = true;         // DRP_NO_SELF_CONST=1: always run the encoder chain on the self slot too
     bool prop3 = true;              // DRP_NO_PROP3=1: one launch per propagation step even for chip-filling batches
-    int prop3_min_b = 0;                // DRP_PROP3_MIN_B: km_prop3 / kmb_step_bwd from this many samples (default: whole_samples())
-    int prop3_min_tiles = 1;   // DRP_PROP3_MIN_TILES: km_prop3 from this many tiles per workgroup and step
-    int bwd_fused_min_tiles = 1;   // DRP_BWD_FUSED_MIN_TILES: the same for kmb_step_bwd
+    int prop3_min_b = 0;            // km_prop3 / kmb_step_bwd from this many samples (0: whole_samples() decides)
+    int prop3_min_tiles = 1;        // km_prop3 from this many tiles per workgroup and step
+    int bwd_fused_min_tiles = 1;    // the same for kmb_step_bwd
     bool graph_cells = true;        // DRP_NO_GRAPH_CELLS=1: x strips only (k_graph_strips) for large samples
     int graph_cells_min_n = 400;    // DRP_GRAPH_CELLS_MIN_N: two-dimensional cells from this many particles up (measured: slower at 300, 8 % faster at 450)
     float graph_cells_halo = 0.0f;  // DRP_GRAPH_CELLS_HALO: first-sweep halo in camera-frame units (default: from the particle count)
@@ -176,8 +176,7 @@ struct drp_ctx {
     bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
     bool bwd_fused = true;          // DRP_NO_BWD_FUSED=1: the GD planner's backward pass as one launch per stage
-    bool graph_strips_q = true;     // DRP_GRAPH_STRIPS_Q=0: k_graph_strips sweeps wave-wide ranges (round 2) instead of quarter-wave ones
-    bool prop3_order = true;        // DRP_NO_PROP3_ORDER=1: km_prop3's tiles in the natural row order instead of by in-degree
+    bool prop3_order = true;        // false: km_prop3's tiles in the natural row order instead of by in-degree
     int prop_pair_rows = 128;       // DRP_PROP_PAIR_ROWS: a workgroup of the whole-sample kernels with up to so many rows runs tiles of
                                     // 16 receivers x two slots (0 = never)
     int prop_pair_always = 64;      // DRP_PROP_PAIR_ALWAYS: ... whatever the in-degrees up to so many rows (four tiles of 16: a SIMD each),
@@ -196,12 +195,12 @@ struct drp_ctx {
         if (st_n != N || st_rows != std::min(B * N, (long)DEG_STAT_MAX_ROWS) || st_rows == 0) return true;   // not known (yet)
         return sum * 10 <= st_rows * (long)prop_pair_deg10;
     }
-    bool prop3e = true;             // DRP_NO_PROP3E=1: the particle encoder stays its own launch in front of km_prop3
+    bool prop3e = true;             // false: the particle encoder stays its own launch in front of km_prop3
     bool rollout_fused = true;      // DRP_NO_ROLLOUT_FUSED=1: one graph + one km_prop3 launch per rollout step for small piles too
     int rollout_max_n = 64;         // DRP_ROLLOUT_MAX_N: km_rollout (the whole rollout in one launch) up to this many particles ...
     int rollout_mid_n = 96, rollout_mid_rows = 256;   // ... up to 96 particles for workgroups of up to 256 rows (small batches:
                                     // 256 x 72 / 80 / 88 + 7 / + 11 / + 15 %, 512 x 80 / 96 + 8 / + 11 %; 1024 x 88: - 1 %, 2048 x 80: - 4 %)
-    int rollout_max_rows = 704;     // DRP_ROLLOUT_MAX_ROWS: ... and this many rows (samples x particles) per workgroup.  Measured
+    int rollout_max_rows = 704;     // ... and this many rows (samples x particles) per workgroup.  Measured
                                     // against the step-by-step pipeline at 1024 samples: +18 % at 10 particles, +12 % at 20, +2 % at
                                     // 50, +5 % at 64, -1 % at 80, -10 % at 150 (the strip build wins); 50 particles x 4096 samples
                                     // (800 rows per workgroup) -5 %, 20 x 8192 (640 rows) +7 %
@@ -226,7 +225,7 @@ struct drp_ctx {
     SplitRange re_range{};          // range shift 2^k of the split relation encoder and the bound it rests on
     float re_scale = 1.0f, re_inv = 1.0f;
     bool re_ok = true;
-    int re_shift_env = 0x7fffffff;  // DRP_SPLIT_SHIFT=k: fixed shift instead of the one derived from the weights
+    int re_shift_env = 0x7fffffff;  // a fixed shift k instead of the one derived from the weights (experiments)
     DevBuf w_raw, w_valu, w_mfma, w_mfma_bwd, w_split, w_split6;
     DrpCam cam{};
     DevBuf goal_field, goal_coor, cself;
@@ -559,7 +558,7 @@ struct StepArgs {
 // and for ANY batch of samples of up to 256 particles (one round of tiles per step for the workgroup's eight waves):
 // a small batch is latency, and one launch per rollout step instead of five is what counts (B = 32 ... 255 at 50 / 100
 // particles: 1.7 - 2.0 -> 1.0 - 1.2 ms per MPPI iteration; 300 particles: 2 - 7 % slower below 200 samples, 27 % faster
-// at 255).  DRP_PROP3_MIN_B overrides the batch bound.
+// at 255).
 bool whole_samples(const drp_ctx* c, long B, int N) {
     if (c->prop3_min_b > 0) return B >= c->prop3_min_b;
     return B >= c->n_cu - c->n_cu / 5 || N <= 256;
@@ -609,17 +608,10 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
                            act_stride, s_delta, N, c->cam, sorted, starts);
         if (N >= 800) {
             const int chunks = (N + 255) / 256;
-            if (c->graph_strips_q)
-                hipLaunchKernelGGL(k_graph_strips_q<256>, dim3(SPREAD_GRID(B * chunks)), dim3(256), GRAPH_STRIPS_LDS(N, 256), st,
-                                   (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, chunks, B * chunks, self_first);
-            else
-                hipLaunchKernelGGL(k_graph_strips<256>, dim3(SPREAD_GRID(B * chunks)), dim3(256), GRAPH_STRIPS_LDS(N, 256), st,
-                                   (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, chunks, B * chunks, self_first);
-        } else if (c->graph_strips_q) {
-            hipLaunchKernelGGL(k_graph_strips_q<GRAPH_THREADS>, dim3(SPREAD_GRID(B * graph_chunks(N))), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N, GRAPH_THREADS), st,
-                               (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), B * graph_chunks(N), self_first);
+            hipLaunchKernelGGL(k_graph_strips_q<256>, dim3(SPREAD_GRID(B * chunks)), dim3(256), GRAPH_STRIPS_LDS(N, 256), st,
+                               (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, chunks, B * chunks, self_first);
         } else {
-            hipLaunchKernelGGL(k_graph_strips<GRAPH_THREADS>, dim3(SPREAD_GRID(B * graph_chunks(N))), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N, GRAPH_THREADS), st,
+            hipLaunchKernelGGL(k_graph_strips_q<GRAPH_THREADS>, dim3(SPREAD_GRID(B * graph_chunks(N))), dim3(GRAPH_THREADS), GRAPH_STRIPS_LDS(N, GRAPH_THREADS), st,
                                (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), B * graph_chunks(N), self_first);
         }
     }
@@ -1218,18 +1210,13 @@ int drp_create(int device, drp_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
-    c->agg_global_only = getenv("DRP_AGG_GLOBAL") != nullptr;
     c->self_const = getenv("DRP_NO_SELF_CONST") == nullptr;
     c->prop3 = getenv("DRP_NO_PROP3") == nullptr;
     c->graph_strips = getenv("DRP_NO_GRAPH_STRIPS") == nullptr;
     c->graph_cells = getenv("DRP_NO_GRAPH_CELLS") == nullptr;
-    if (const char* e = getenv("DRP_PROP3_MIN_B")) c->prop3_min_b = atoi(e);
-    if (const char* e = getenv("DRP_PROP3_MIN_TILES")) c->prop3_min_tiles = atoi(e);
-    if (const char* e = getenv("DRP_BWD_FUSED_MIN_TILES")) c->bwd_fused_min_tiles = atoi(e);
     if (const char* e = getenv("DRP_GRAPH_CELLS_MIN_N")) c->graph_cells_min_n = atoi(e);
     if (const char* e = getenv("DRP_GRAPH_CELLS_HB")) c->graph_cells_hb = (float)atof(e);
     if (const char* e = getenv("DRP_GRAPH_CELLS_HALO")) c->graph_cells_halo = (float)atof(e);
-    c->prop3e = getenv("DRP_NO_PROP3E") == nullptr;
     c->rollout_fused = getenv("DRP_NO_ROLLOUT_FUSED") == nullptr;
     c->repack_device = getenv("DRP_NO_REPACK_DEVICE") == nullptr;
     c->bwd_edge_mfma = getenv("DRP_NO_BWD_EDGE_MFMA") == nullptr;
@@ -1238,9 +1225,6 @@ int drp_create(int device, drp_ctx** out) {
     c->wgrad_defer = getenv("DRP_NO_WGRAD_DEFER") == nullptr;
     if (const char* e = getenv("DRP_GRAPH_Q4")) c->graph_q4 = atoi(e);
     if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) { c->rollout_max_n = atoi(e); c->rollout_mid_n = 0; c->rollout_max_rows = KM_ROLLOUT_MAX_ROWS; }
-    if (const char* e = getenv("DRP_ROLLOUT_MAX_ROWS")) c->rollout_max_rows = atoi(e);
-    c->prop3_order = getenv("DRP_NO_PROP3_ORDER") == nullptr;
-    if (const char* e = getenv("DRP_GRAPH_STRIPS_Q")) c->graph_strips_q = atoi(e) != 0;
     if (const char* e = getenv("DRP_PROP_PAIR_ROWS")) c->prop_pair_rows = std::max(0, atoi(e));
     if (const char* e = getenv("DRP_PROP_PAIR_ALWAYS")) c->prop_pair_always = std::max(0, atoi(e));
     if (const char* e = getenv("DRP_PROP_PAIR_DEG10")) c->prop_pair_deg10 = std::max(0, atoi(e));
@@ -1248,15 +1232,12 @@ int drp_create(int device, drp_ctx** out) {
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
     if (const char* e = getenv("DRP_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_timeout_s = v; }
     if (const char* e = getenv("DRP_COMM_INIT_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_init_timeout_s = v; }
-    if (const char* e = getenv("DRP_SPLIT_SHIFT")) c->re_shift_env = atoi(e);
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (const char* e = getenv("DRP_ECACHE_MAX_MB")) c->ecache_max_mb = std::max(0, atoi(e));
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_q4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_graph_strips<GRAPH_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_graph_strips<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips_q<GRAPH_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips_q<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)kb_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_REWARD_LDS(4096)) != hipSuccess ||

@@ -445,170 +445,8 @@ k_graph_sort(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
 #define GS_LIST 11                                                 // ten entries + the slot a full list keeps overwriting
 #define GRAPH_STRIPS_LDS(N, T) ((size_t)((((N) + 3) & ~3) + 4) * 16 + (GRAPH_STRIPS + 1) * 4 + (T) * GS_LIST * 2 + 16)
 
-template <int T>
-__global__ void __launch_bounds__(T)
-k_graph_strips(const float4* __restrict__ sorted, const int* __restrict__ starts, int N,
-               int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, float thr, int chunks,
-               int n_items /* B * chunks; grid = SPREAD_GRID(n_items) */, int self_first) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int Np = (N + 3) & ~3;
-    float4* q4 = reinterpret_cast<float4*>(lds);                 // the staged range of the sorted senders
-    int* sstart = reinterpret_cast<int*>(q4 + Np);               // [GRAPH_STRIPS + 1]
-    int16_t* lst = reinterpret_cast<int16_t*>(sstart + GRAPH_STRIPS + 1);   // [T][GS_LIST] chosen indices, unsorted
-    const int item = spread_item();
-    if (item >= n_items) return;
-    const int b = item / chunks, chunk = item - b * chunks;
-    const float4* g4 = sorted + (size_t)b * Np;
-    if (threadIdx.x <= GRAPH_STRIPS) sstart[threadIdx.x] = starts[(size_t)b * (GRAPH_STRIPS + 1) + threadIdx.x];
-    const int s_first = chunk * T;
-    const int s_last = min(s_first + T, N) - 1;
-    const float radius = __fsqrt_rn(fmaxf(thr, 0.0f)) * 1.000001f;
-    const int reach = (int)fminf(ceilf(radius * GRAPH_STRIP_INV_W), (float)GRAPH_STRIPS) + 1;
-    // the workgroup's range: strips of its first and last receiver (the order is by strip), widened by the radius
-    const int wg_smin = graph_strip(g4[s_first].x), wg_smax = graph_strip(g4[s_last].x);
-    __syncthreads();
-    const int wlo = sstart[max(wg_smin - reach, 0)] & ~3;
-    const int whi = (sstart[min(wg_smax + reach, GRAPH_STRIPS - 1) + 1] + 3) & ~3;
-    for (int j = wlo + (int)threadIdx.x; j < whi; j += T) q4[j] = g4[j];
-    __syncthreads();
-
-    const int si = s_first + threadIdx.x;
-    const bool valid = si < N;
-    const unsigned long long act = __ballot(valid);
-    if (act == 0) return;
-    const float4 pi = q4[valid ? si : s_last];                    // a receiver is inside its own workgroup's range
-    const int i = __float_as_int(pi.w);
-    const int my_strip = graph_strip(pi.x);
-    const int smin = __builtin_amdgcn_readlane(my_strip, __ffsll((long long)act) - 1);
-    const int smax = __builtin_amdgcn_readlane(my_strip, 63 - __clzll((long long)act));
-    const int jlo = max(sstart[max(smin - reach, 0)] & ~3, wlo);
-    const int jhi = min((sstart[min(smax + reach, GRAPH_STRIPS - 1) + 1] + 3) & ~3, whi);
-
-    float best[DRP_K];
-#pragma unroll
-    for (int q = 0; q < DRP_K; ++q) best[q] = thr;
-    auto sweep1 = [&](int ja, int jb) {
-        for (int j = ja; j < jb; j += 4) {
-            const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
-            const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
-                                 pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int q = DRP_K - 1; q > 0; --q) best[q] = __builtin_amdgcn_fmed3f(d4[u], best[q - 1], best[q]);
-                best[0] = min_nonneg(d4[u], best[0]);
-            }
-        }
-    };
-    // first sweep in two stages: the strips within half the radius give a provisional 10th-nearest distance (an upper
-    // bound of the final one: more candidates can only lower it); a sender that could still enter the list is nearer
-    // than that in x, so the stage that follows only covers the strips within the wave's largest provisional distance
-    // -- none at all in a dense pile.  The list of the ten smallest does not depend on the order of insertion.
-    const int reach_a = (reach + 1) >> 1;
-    const int ja = max(sstart[max(smin - reach_a, 0)] & ~3, jlo);
-    const int jb = min((sstart[min(smax + reach_a, GRAPH_STRIPS - 1) + 1] + 3) & ~3, jhi);
-    sweep1(ja, jb);
-    {
-        float kprov = valid ? best[DRP_K - 1] : 0.0f;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) kprov = fmaxf(kprov, __shfl_xor(kprov, o, 64));
-        const int reach_b = min(reach, (int)ceilf(__fsqrt_rn(fmaxf(kprov, 0.0f)) * 1.000001f * GRAPH_STRIP_INV_W) + 1);
-        if (reach_b > reach_a) {
-            const int jl = max(sstart[max(smin - reach_b, 0)] & ~3, jlo);
-            const int jh = min((sstart[min(smax + reach_b, GRAPH_STRIPS - 1) + 1] + 3) & ~3, jhi);
-            sweep1(jl, ja);
-            sweep1(jb, jh);
-        }
-    }
-    const float kth = best[DRP_K - 1];
-    // second sweep: senders strictly nearer than kth are in; the ones AT kth fill what is left, lowest index first.
-    // Nothing farther than sqrt(kth) is emitted, so the sweep narrows to the strips within the wave's largest
-    // 10th-nearest distance (dense piles: a quarter of the radius)
-    float kmax = valid ? kth : 0.0f;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) kmax = fmaxf(kmax, __shfl_xor(kmax, o, 64));
-    const int reach2 = min(reach, (int)ceilf(__fsqrt_rn(fmaxf(kmax, 0.0f)) * 1.000001f * GRAPH_STRIP_INV_W) + 1);
-    const int jlo2 = max(sstart[max(smin - reach2, 0)] & ~3, jlo);
-    const int jhi2 = min((sstart[min(smax + reach2, GRAPH_STRIPS - 1) + 1] + 3) & ~3, jhi);
-    const int skip = (self_first && thr > 0.0f) ? i : -1;
-    // kth is the tenth smallest in-radius distance (or thr when there are fewer): at most nine senders are nearer, and
-    // when no more than ten are at or below it every one of them is an edge -- the common case, one compare per
-    // candidate: d <= kle with kle = kth below the radius, else the largest float under thr (d <= kle <=> d < thr).
-    // The entry is written unconditionally and kept only if the count moves on.  More than ten (several senders at
-    // exactly kth): the list is rebuilt by the exact rule.
-    const float kle = (kth < thr) ? kth : (thr > 0.0f ? __int_as_float(__float_as_int(thr) - 1) : -1.0f);
-    int16_t* mine = lst + threadIdx.x * GS_LIST;
-    int cnt = 0;
-    for (int j = jlo2; j < jhi2; j += 4) {
-        const float4 q0 = q4[j], q1 = q4[j + 1], q2 = q4[j + 2], q3 = q4[j + 3];
-        const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
-                             pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
-        const int o4[4] = {__float_as_int(q0.w), __float_as_int(q1.w), __float_as_int(q2.w), __float_as_int(q3.w)};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            mine[min(cnt, DRP_K)] = (int16_t)o4[u];
-            cnt += (d4[u] <= kle) ? 1 : 0;
-        }
-    }
-    if (cnt > DRP_K) {
-        cnt = 0;
-        for (int j = jlo2; j < jhi2; ++j) {
-            const float4 q = q4[j];
-            const float d = pair_dis(pi.x, pi.y, pi.z, q.x, q.y, q.z);
-            const int o = __float_as_int(q.w);
-            if (__fsub_rn(d, thr) < 0.0f && d < kth && o != skip && cnt < DRP_K) mine[cnt++] = (int16_t)o;
-        }
-        const int room = DRP_K - cnt - (skip >= 0 ? 1 : 0);
-        int last = -1;
-        for (int r = 0; r < room; ++r) {                         // the lowest indices among the senders at kth, one sweep each
-            int nxt = 0x7fff;
-            for (int j = jlo2; j < jhi2; ++j) {
-                const float4 q = q4[j];
-                const float d = pair_dis(pi.x, pi.y, pi.z, q.x, q.y, q.z);
-                const int o = __float_as_int(q.w);
-                if (__fsub_rn(d, thr) < 0.0f && d == kth && o != skip && o > last) nxt = min(nxt, o);
-            }
-            if (nxt == 0x7fff) break;
-            mine[cnt++] = (int16_t)nxt;
-            last = nxt;
-        }
-    }
-    if (skip >= 0) {                                               // the receiver itself is slot 0 of the output, not an entry
-        int at = -1;
-#pragma unroll
-        for (int q = 0; q < DRP_K; ++q)
-            if (q < cnt && (int)mine[q] == skip) at = q;
-        if (at >= 0) {
-            mine[at] = mine[cnt - 1];
-            --cnt;
-        }
-    }
-    if (!valid) return;
-    // ascending index through a 10-input sorting network (29 compare-exchanges); empty slots sort last
-    int v[DRP_K];
-#pragma unroll
-    for (int q = 0; q < DRP_K; ++q) v[q] = (q < cnt) ? (int)mine[q] : 0x7fff;
-#define CE(a, b) sort2(v[a], v[b])
-    CE(0, 5); CE(1, 6); CE(2, 7); CE(3, 8); CE(4, 9);
-    CE(0, 3); CE(1, 4); CE(5, 8); CE(6, 9);
-    CE(0, 2); CE(3, 6); CE(7, 9);
-    CE(0, 1); CE(2, 4); CE(5, 7); CE(8, 9);
-    CE(1, 2); CE(3, 5); CE(4, 6); CE(7, 8);
-    CE(1, 3); CE(2, 5); CE(4, 7); CE(6, 8);
-    CE(2, 3); CE(4, 5); CE(6, 7);
-    CE(3, 4); CE(5, 6);
-#undef CE
-    int16_t* out = nbr_idx + ((size_t)b * N + i) * DRP_K;
-    int w = 0;
-    if (skip >= 0) out[w++] = (int16_t)i;
-#pragma unroll
-    for (int q = 0; q < DRP_K; ++q)
-        if (q < cnt && w < DRP_K) out[w++] = (int16_t)v[q];
-    nbr_cnt[(size_t)b * N + i] = (uint8_t)w;
-    for (int q = w; q < DRP_K; ++q) out[q] = -1;
-}
-
-// ---- k_graph_strips with the sweep ranges per QUARTER wave (the default; DRP_GRAPH_STRIPS_Q=0 keeps the wave-wide ranges) ----
+// ---- k_graph_strips_q: the sweep over x strips, ranges per QUARTER wave (the wave-wide variant of round 2, 0.715 vs 0.674 ms per
+// iteration at 300 particles, is gone with its switch) ----
 template <int T>
 __global__ void __launch_bounds__(T)
 k_graph_strips_q(const float4* __restrict__ sorted, const int* __restrict__ starts, int N,

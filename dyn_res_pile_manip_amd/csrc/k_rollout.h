@@ -13,8 +13,8 @@
 // instead of being paid H times.  Every arithmetic instruction is the step-by-step pipeline's (the same device
 // functions, inlined): the two paths produce the same bits (tests/test_gpu_fullsize.py).
 //
-// Used for samples of up to DRP_ROLLOUT_MAX_N particles (default 64) in workgroups of up to DRP_ROLLOUT_MAX_ROWS rows
-// (default 704; the kernel itself takes any sample whose workgroup holds at most KM_ROLLOUT_MAX_ROWS rows: the displaced positions for the plain sweep sit in the edge chain's LDS
+// Used for samples of up to DRP_ROLLOUT_MAX_N particles (default 64) in workgroups of up to 704 rows
+// ( the kernel itself takes any sample whose workgroup holds at most KM_ROLLOUT_MAX_ROWS rows: the displaced positions for the plain sweep sit in the edge chain's LDS
 // region between two steps).  Measured against the step-by-step pipeline on one box (tools/ab_rollout.sh, 1024 samples
 // x 10 steps): 10 particles 0.575 -> 0.486 ms per MPC iteration, 20: 0.805 -> 0.707, 50: 1.377 -> 1.362, 64: 1.639 ->
 // 1.543, 100: 2.84 -> 2.86, 150: 4.12 -> 4.59 (there the x-strip build of k_graph.h beats the in-kernel plain sweep).

@@ -48,6 +48,9 @@ def spread(ns, k=32):
     return np.unique(np.linspace(0, ns - 1, k).astype(int))
 
 
+ENGINES_APART_SEEN = 0   # samples of the 1024 in which the two engines' trajectories part on a flipped neighbour: measured
+
+
 def test_config2_engines_agree_and_samples_are_independent(ctx):
     """1024 samples x 300 particles x 10 steps (BASELINE configs[1])."""
     N, ns, H = 300, 1024, 10
@@ -62,7 +65,8 @@ def test_config2_engines_agree_and_samples_are_independent(ctx):
     # split-bf16 vs fp32 MLPs: ~1e-8; a flipped neighbour (distance within an ulp of the radius or
     # of the 10th/11th order) may cascade in a handful of samples
     assert np.median(d) < 5e-7
-    assert (d > 1e-4).mean() < 0.01
+    print('configs[1], engines mfma vs fused: %d of %d samples differ by more than 1e-4 somewhere (a flipped neighbour)' % ((d > 1e-4).sum(), ns))
+    assert (d > 1e-4).sum() <= ENGINES_APART_SEEN + 2
     # step-0 graphs are identical (same inputs, integer/byte work is bit-exact)
     # no cross-sample state: a 64-sample rollout == the first 64 rows of the 1024-sample one
     sub, _ = ctx.rollout(s0, attr, dens, acts[:64])
@@ -396,6 +400,9 @@ def free_running_check(ctx, s0, dens, attr, acts, dev, tol=1e-4, margin=1e-6):
     return int(alive.sum()), parted
 
 
+PARTED_SEEN = 0     # samples of the 48 whose edge sets part from the oracle's on a coin-toss edge: measured, see the test's print
+
+
 def test_config2_free_running_against_the_oracle(ctx):
     """BASELINE configs[1], NOT teacher-forced: 48 samples spread over the 1024, ten steps, each from its own
     previous state on both sides."""
@@ -406,7 +413,10 @@ def test_config2_free_running_against_the_oracle(ctx):
     out, _ = ctx.rollout(s0, attr, dens, acts)
     rows = spread(ns, 48)
     kept, parted = free_running_check(ctx, s0, dens, attr, acts[rows], out[rows])
-    assert kept >= len(rows) * 3 // 4, parted          # a coin-toss neighbour in more than a quarter of the samples would be news
+    print('free-running configs[1]: %d of %d samples kept the oracle\'s edge sets for all %d steps; parted at steps %s'
+          % (kept, len(rows), H, sorted(parted.values()) if isinstance(parted, dict) else parted))
+    # round 4's libraries part in PARTED_SEEN samples (each on a coin-toss edge, checked inside): two more would be news
+    assert len(rows) - kept <= PARTED_SEEN + 2, parted
 
 
 def test_config5_whole_job_as_eight_logical_shards(ctx):
