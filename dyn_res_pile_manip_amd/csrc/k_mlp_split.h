@@ -925,8 +925,15 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                    for (int g = 0; g < 4; ++g) {
+#ifdef EC_NT_STORE
+                        typedef float f32x4s __attribute__((ext_vector_type(4)));
+                        f32x4s v4 = {c.v[ob][4 * g + 0], c.v[ob][4 * g + 1], c.v[ob][4 * g + 2], c.v[ob][4 * g + 3]};
+                        __builtin_nontemporal_store(v4, reinterpret_cast<f32x4s*>(dst + (ob * 4 + g) * 64));
+#else
                         dst[(ob * 4 + g) * 64] = make_float4(c.v[ob][4 * g + 0], c.v[ob][4 * g + 1], c.v[ob][4 * g + 2], c.v[ob][4 * g + 3]);
+#endif
+                    }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sv.v[0][r] += bpr.v[0][r]; sv.v[1][r] += bpr.v[1][r]; }
             }
