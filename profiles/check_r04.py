@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Round 4: every `frac` of the driver line's sweep block against the counters on file.  The bench line's numerator is what
+the kernels counted themselves (drp_probe_work); here the same quantity comes from the SQ pass of the same preset:
+(SQ_INSTS_VALU_MFMA_MOPS_F16 + _BF16) / 64 = 16-bit MFMA instructions per launch of the dominant kernel.
+usage: python3 profiles/check_r04.py   (reads profiles/r04_bench_default.json and profiles/r04_<preset>_pmc_sq_per_kernel.csv)"""
+import csv
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def mfmas_from_sq(tag, prefixes):
+    best = None
+    for r in csv.DictReader(open(os.path.join(HERE, 'r04_%s_pmc_sq_per_kernel.csv' % tag))):
+        name = r['Kernel_Name']
+        if not name.startswith(prefixes) or name.rstrip().endswith(', true>') or not r['Counter_Name'].startswith('SQ_INSTS_VALU_MFMA_MOPS'):
+            continue
+        best = best or {}
+        best.setdefault(name, 0.0)
+        best[name] += float(r['Mean_Counter_Value']) / 64.0
+    return best
+
+
+line = [json.loads(l) for l in open(os.path.join(HERE, 'r04_bench_default.json')) if l.startswith('{')][0]
+rows = [('fused', line['roofline'], ('km_prop3',))]
+for e in line['sweep']:
+    if e['name'] == 'gd-demo':
+        continue
+    rows.append((e['name'], e, ('km_rollout', 'km_prop3')))
+print('%-10s %-44s %14s %14s %8s' % ('preset', 'dominant kernel (SQ pass)', 'SQ MFMAs', 'counted MFMAs', 'ratio'))
+for tag, e, pre in rows:
+    sq = mfmas_from_sq(tag, pre)
+    name = max(sq, key=sq.get)
+    counted = e['executed_per_launch']['mfmas']
+    print('%-10s %-44s %14.0f %14.0f %8.4f' % (tag, name[:44], sq[name], counted, counted / sq[name]))
