@@ -720,7 +720,8 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                    a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist, c->re_scale, c->re_inv, (c->prop3_order ? 1 : 0)
             const bool pair = c->prop_pair(spw, N, B);
             note_degrees(c, spw, N, B);
-            const bool ec = c->use_ecache(grid.x, (long)spw * N, pair);
+            // (the cached kernel of paired tiles hands a tile's own rows from step to step in registers: one tile per wave)
+            const bool ec = c->use_ecache(grid.x, (long)spw * N, pair) && (!pair || tape || ((long)spw * N + 15) / 16 <= PROP_WAVES);
             const size_t ec_stride = drp_ctx::ecache_stride((long)spw * N, pair);
             if (ec) CHK(ensure(c, c->ecache, (size_t)grid.x * ec_stride * 16));
             float4* ecp = ec ? ptr<float4>(c->ecache) : nullptr;
@@ -920,11 +921,15 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
             c->roll_args_valid = true;
         }
         ProbeScope ps(c, KC_PROP);
-#define ROLLOUT_LAUNCH_W(PAIR_, EC_, WORK_) hipLaunchKernelGGL((km_rollout<PAIR_, EC_, WORK_>), dim3(grid_r), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS, \
-                                                               c->stream, ptr<RolloutArgs>(c->roll_args))
-#define ROLLOUT_LAUNCH(PAIR_, EC_) do { if (ra.work) ROLLOUT_LAUNCH_W(PAIR_, EC_, true); else ROLLOUT_LAUNCH_W(PAIR_, EC_, false); } while (0)
-        if (pair_r) { if (ec) ROLLOUT_LAUNCH(true, true); else ROLLOUT_LAUNCH(true, false); }
-        else { if (ec) ROLLOUT_LAUNCH(false, true); else ROLLOUT_LAUNCH(false, false); }
+        // ONE: no more tiles than waves in a workgroup -- the cached kernel then hands a tile's own rows (P_r, its own P_s, its
+        // effect) from one propagation step to the next in registers
+        const long tiles_r = pair_r ? ((long)spw_r * N + 15) / 16 : ((long)spw_r * N + 31) / 32;
+        const bool one = ec && tiles_r <= PROP_WAVES;
+#define ROLLOUT_LAUNCH_W(PAIR_, EC_, WORK_, ONE_) hipLaunchKernelGGL((km_rollout<PAIR_, EC_, WORK_, ONE_>), dim3(grid_r), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS, \
+                                                                     c->stream, ptr<RolloutArgs>(c->roll_args))
+#define ROLLOUT_LAUNCH(PAIR_, EC_, ONE_) do { if (ra.work) ROLLOUT_LAUNCH_W(PAIR_, EC_, true, ONE_); else ROLLOUT_LAUNCH_W(PAIR_, EC_, false, ONE_); } while (0)
+        if (pair_r) { if (one) ROLLOUT_LAUNCH(true, true, true); else if (ec) ROLLOUT_LAUNCH(true, true, false); else ROLLOUT_LAUNCH(true, false, false); }
+        else { if (one) ROLLOUT_LAUNCH(false, true, true); else if (ec) ROLLOUT_LAUNCH(false, true, false); else ROLLOUT_LAUNCH(false, false, false); }
 #undef ROLLOUT_LAUNCH_W
 #undef ROLLOUT_LAUNCH
         HIPCHK(c, hipGetLastError());
@@ -1287,14 +1292,18 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_prop3<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop3<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop3<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_rollout<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_rollout<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kt_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||

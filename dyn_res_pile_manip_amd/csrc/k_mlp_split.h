@@ -607,6 +607,13 @@ struct HeadCarry {
     const float* s; const float* at;
     float d, pix, piy, piz, pia, p0x, p0y, p0z, p0a;
     unsigned nbw0, nbw1, nbw2;
+    // ROWS (the cached kernels with one tile per wave): what a tile's node part produces for its OWN rows -- the receiver's
+    // projection P_r, its own sender projection P_s (the self loop's term) and its effect -- is what the same wave's same
+    // tile starts the next propagation step with: handed over in registers instead of stored, waited for at the workgroup
+    // barrier and loaded again (two round trips of 1.5 - 2 us per step where a step is 10 - 25 us; the same values, the
+    // same bits).  rows_ok: the workgroup has no more tiles than waves (a wave keeps its tile: first_of); rows_ready: filled.
+    bool rows_ok, rows_ready;
+    Frag rpr, rps, re;
 };
 // PAIR: a tile is 16 receivers, and the 32 item columns of the chain are 16 receivers x two CONSECUTIVE slots -- column j
 // belongs to receiver (j & 7) + 8 (j >> 4) and runs the slots of parity (j >> 3) & 1 -- so that a tile needs half the
@@ -629,7 +636,7 @@ __device__ __forceinline__ float dpp_ror8(float x) {
 // Pays where the chain's LATENCY is the bound -- one tile per wave -- and the buffer (2.5 KB per receiver) stays in the
 // last-level cache; at 300 particles x 1024 samples it is 700 MB per rollout step and recomputing costs the same.
 #define EC_UNITS 512             // float4 per (tile, slot iteration): 8 per lane
-template <bool LAST, bool TAPE, bool PAIR, bool CARRY, int EC, bool WORK, class First, class Decode, class RowOf>
+template <bool LAST, bool TAPE, bool PAIR, bool CARRY, int EC, bool WORK, bool ONE /* a wave has at most ONE tile per step: no queue, no loop */, class First, class Decode, class RowOf>
 __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, First first_of /* this wave's first tile */,
                                            Decode decode /* the others: draws from the workgroup's queue */, RowOf row_of, int lane,
                                            HeadCarry& hc
@@ -731,6 +738,8 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
     // waves of a SIMD do not advance evenly (tools/prop_stamps.py: with five tiles each the first wave of the
     // chip was done at 0.7 of the last one's time, and a SIMD with one wave left runs at about 0.6 of its
     // two-wave rate); on demand the waves end within 10 us of each other.
+    constexpr bool ROWS = CARRY && EC != 0 && ONE;    // HeadCarry's rows: the cached kernels whose waves keep one tile
+    bool first_tile = true;
     TileId cur = first_of(), nxt = {false, 0, 0};
     TileHead hd_next = {};
     TileFirst tf_next = {};
@@ -807,11 +816,13 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
                 atomicAdd(w + (LAST ? PROP_WORK_TILES_LAST : PROP_WORK_TILES), 1ull);
             }
         }
+        const bool use_rows = ROWS && EC == 2 && first_tile && hc.rows_ready;      // wave-uniform
         Frag acc, bpr;
         {
             Frag pr;
             frag_bias_dens(rows + 128, rows + 192, d, h, bpr);
-            frag_from_row(pj + (size_t)i * 128, h, pr);
+            if (use_rows) pr = hc.rpr;
+            else frag_from_row(pj + (size_t)i * 128, h, pr);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { bpr.v[0][r] += pr.v[0][r]; bpr.v[1][r] += pr.v[1][r]; }
         }
@@ -824,7 +835,9 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 cs = *reinterpret_cast<const float4*>(csr + 32 * ob + 8 * g + 4 * h);
-                    const float4 ps = *reinterpret_cast<const float4*>(psr + 32 * ob + 8 * g + 4 * h);
+                    float4 ps;
+                    if (use_rows) ps = make_float4(hc.rps.v[ob][4 * g + 0], hc.rps.v[ob][4 * g + 1], hc.rps.v[ob][4 * g + 2], hc.rps.v[ob][4 * g + 3]);
+                    else ps = *reinterpret_cast<const float4*>(psr + 32 * ob + 8 * g + 4 * h);
                     acc.v[ob][4 * g + 0] = relu1((bpr.v[ob][4 * g + 0] + cs.x) + ps.x);
                     acc.v[ob][4 * g + 1] = relu1((bpr.v[ob][4 * g + 1] + cs.y) + ps.y);
                     acc.v[ob][4 * g + 2] = relu1((bpr.v[ob][4 * g + 2] + cs.z) + ps.z);
@@ -926,13 +939,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
                 for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-#ifdef EC_NT_STORE
-                        typedef float f32x4s __attribute__((ext_vector_type(4)));
-                        f32x4s v4 = {c.v[ob][4 * g + 0], c.v[ob][4 * g + 1], c.v[ob][4 * g + 2], c.v[ob][4 * g + 3]};
-                        __builtin_nontemporal_store(v4, reinterpret_cast<f32x4s*>(dst + (ob * 4 + g) * 64));
-#else
                         dst[(ob * 4 + g) * 64] = make_float4(c.v[ob][4 * g + 0], c.v[ob][4 * g + 1], c.v[ob][4 * g + 2], c.v[ob][4 * g + 3]);
-#endif
                     }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sv.v[0][r] += bpr.v[0][r]; sv.v[1][r] += bpr.v[1][r]; }
@@ -976,10 +983,12 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
 #ifdef PROP_STAMPS
         const unsigned long long st_c1 = __builtin_amdgcn_s_memtime();
 #endif
-        {
+        if (!ONE) {
             int li = 0;
             if (lane == 0) li = __hip_atomic_fetch_add(L.tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             nxt = decode(__builtin_amdgcn_readfirstlane(li));        // past the share: invalid, and so is every later draw
+        } else {
+            nxt.valid = false;                                       // the tile loop runs once: straight-line code
         }
         const bool more = nxt.valid;
         if (more) hd_next = tile_head(nxt);
@@ -992,7 +1001,8 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         Frag e;
         {
             Frag cn;
-            frag_from_row((TAPE ? eff_in : eff) + row * 64, h, e);    // in place unless a tape is written
+            if (use_rows) e = hc.re;
+            else frag_from_row((TAPE ? eff_in : eff) + row * 64, h, e);    // in place unless a tape is written
             frag_from_row(c_node + row * 64, h, cn);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { e.v[0][r] += cn.v[0][r]; e.v[1][r] += cn.v[1][r]; }
@@ -1003,6 +1013,12 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         mfma_layer64_split6(L.w_agg, f6, e, lane);
         frag_relu(e);
         if (live) frag_to_row(eff + row * 64, h, e);
+        const bool keep_rows = ROWS && !LAST && first_tile && hc.rows_ok;        // wave-uniform
+        // (PAIR: a receiver's second column keeps its OWN copies -- its aggregate was summed odd slot first, so they equal the
+        // first column's to the last place only, where a reload would have fetched the first column's stores: with the rows
+        // kept, paired and unpaired tiles agree to the last place of a sum, not bit for bit; copying the first column's over
+        // (`row_ror:8` + select, 96 registers) costs more than the kept rows save at 20 - 32 particles)
+        if (keep_rows) hc.re = e;
         split_frag6(e, f6);
         __builtin_amdgcn_sched_barrier(0);
         if (more || (CARRY && !LAST)) tf_next = tile_first(hd_next, nbw2_next);          // the head has landed by now
@@ -1012,9 +1028,11 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             frag_zero(p);
             mfma_layer64_split6(L.w_x, f6, p, lane);
             if (live) frag_to_row(proj_next + row * 128, h, p);
+            if (keep_rows) hc.rpr = p;
             frag_zero(p);
             mfma_layer64_split6(L.w_x + 1536, f6, p, lane);
             if (live) frag_to_row(proj_next + row * 128 + 64, h, p);
+            if (keep_rows) hc.rps = p;
         } else {
             Frag hp;
             frag_from_row(L.rows_pr, h, hp);
@@ -1050,7 +1068,9 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             st_sum[5] += 1ull;
         }
 #endif
+        first_tile = false;
     }
+    if (ROWS) hc.rows_ready = !LAST && hc.rows_ok && first_id.valid;
     if (CARRY && !LAST && first_id.valid) {
         hc.ready = true;
         hc.b = hd_next.lr.b; hc.i = hd_next.lr.i; hc.live = hd_next.lr.live ? 1 : 0;
@@ -1151,7 +1171,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         return r;
     };
     HeadCarry hc_none;
-    prop_tiles<LAST, TAPE, PAIR, false, 0, WORK>(A, L, [&]() { return decode(wave); }, decode, row_of, lane, hc_none PROP_STAMPS_ARG);
+    prop_tiles<LAST, TAPE, PAIR, false, 0, WORK, false>(A, L, [&]() { return decode(wave); }, decode, row_of, lane, hc_none PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS
     st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
     st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // all tiles of this wave
@@ -1223,7 +1243,7 @@ __device__ __forceinline__ void prop3_fill_resident(const Prop3Lds& P, const uin
 // three propagation steps, the last one writing s_out.  On entry the resident part of LDS is filled (or being filled:
 // `entry_sync` = the caller has not synchronised since) and the edge-chain region holds nothing this function relies
 // on; on exit every wave has passed its last tile (no barrier after it).
-template <bool TAPE, bool PAIR, bool CARRY, bool ECACHE, bool WORK>
+template <bool TAPE, bool PAIR, bool CARRY, bool ECACHE, bool WORK, bool ONE /* the workgroup has no more tiles than waves (the host's promise) */>
 __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6,
                                            const float* __restrict__ mw,
                                            const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1436,35 +1456,51 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
                  reinterpret_cast<const bf16x8*>(w6_f) + 1536, rows, rows + 256, tile_ctr};
     HeadCarry hc;
     hc.ready = false;
-#pragma unroll 1
-    for (int p = 0; p < DRP_PSTEP; ++p) {
-        if (p > 0) {
-            __syncthreads();                         // step p-1's rows of this workgroup's samples are written
-            ROLL_STAMP(8);                           // waiting for the other waves at a propagation step's end
-            if (tid == 0) *tile_ctr = PROP_WAVES;
-            __syncthreads();
-        }
-        A.proj = (p & 1) ? proj_b : proj_a;
-        A.proj_next = (p & 1) ? proj_a : proj_b;
-        if (TAPE) {
-            A.eff_in = eff + (size_t)p * bn64;
-            A.eff = eff + (size_t)(p + 1) * bn64;
-            A.mask_out = mask_hist + (size_t)p * B * N * DRP_K * 2;
-            A.agg_out = agg_hist ? agg_hist + (size_t)p * bn64 : nullptr;
-        }
-        if (ECACHE && p == 0) {
-            prop_tiles<false, TAPE, PAIR, CARRY, 1, WORK>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
-        } else if (p + 1 < DRP_PSTEP) {
-            prop_tiles<false, TAPE, PAIR, CARRY, ECACHE ? 2 : 0, WORK>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
-        } else {
-            L.w_x = reinterpret_cast<const bf16x8*>(w6_f) + 3 * 1536;
-            prop_tiles<true, TAPE, PAIR, CARRY, ECACHE ? 2 : 0, WORK>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG);
-        }
+    hc.rows_ready = false;
+    hc.rows_ok = ONE;                                // every wave keeps its one tile from step to step (first_of)
 #ifdef ROLLOUT_STAMPS
-        if (roll_on) atomicAdd(&g_roll_stamps[11 + p], __builtin_amdgcn_s_memrealtime() - roll_t);   // ... by propagation step
+#define PROP3_STEP_STAMP(p_) do { if (roll_on) atomicAdd(&g_roll_stamps[11 + (p_)], __builtin_amdgcn_s_memrealtime() - roll_t); } while (0)   /* ... by propagation step */
+#else
+#define PROP3_STEP_STAMP(p_) do { } while (0)
 #endif
-        ROLL_STAMP(7);                               // wave 0's tiles of a propagation step
+#define PROP3_STEP(p_) { \
+        if ((p_) > 0) { \
+            __syncthreads();                         /* step p-1's rows of this workgroup's samples are written */ \
+            ROLL_STAMP(8);                           /* waiting for the other waves at a propagation step's end */ \
+            if (tid == 0) *tile_ctr = PROP_WAVES; \
+            __syncthreads(); \
+        } \
+        A.proj = ((p_) & 1) ? proj_b : proj_a; \
+        A.proj_next = ((p_) & 1) ? proj_a : proj_b; \
+        if (TAPE) { \
+            A.eff_in = eff + (size_t)(p_) * bn64; \
+            A.eff = eff + (size_t)((p_) + 1) * bn64; \
+            A.mask_out = mask_hist + (size_t)(p_) * B * N * DRP_K * 2; \
+            A.agg_out = agg_hist ? agg_hist + (size_t)(p_) * bn64 : nullptr; \
+        } \
+        if (ECACHE && (p_) == 0) { \
+            prop_tiles<false, TAPE, PAIR, CARRY, 1, WORK, ONE>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG); \
+        } else if ((p_) + 1 < DRP_PSTEP) { \
+            prop_tiles<false, TAPE, PAIR, CARRY, ECACHE ? 2 : 0, WORK, ONE>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG); \
+        } else { \
+            L.w_x = reinterpret_cast<const bf16x8*>(w6_f) + 3 * 1536; \
+            prop_tiles<true, TAPE, PAIR, CARRY, ECACHE ? 2 : 0, WORK, ONE>(A, L, first_of, decode, row_of, lane, hc PROP_STAMPS_ARG); \
+        } \
+        PROP3_STEP_STAMP(p_); \
+        ROLL_STAMP(7);                               /* wave 0's tiles of a propagation step */ \
     }
+    // The cached kernels run the three steps as three straight-line blocks: the rows a step hands to the next in registers
+    // (HeadCarry) are then live from one node part to the next step's start and nowhere else -- around the back edge of a
+    // rolled loop they would be live through the first step's chain loop too (900 spilled registers).  The others keep the
+    // rolled loop: its two bodies (not the last step / the last) are 20 KB each.
+    if constexpr (ECACHE) {
+        PROP3_STEP(0) PROP3_STEP(1) PROP3_STEP(2)
+    } else {
+#pragma unroll 1
+        for (int p = 0; p < DRP_PSTEP; ++p) PROP3_STEP(p)
+    }
+#undef PROP3_STEP
+#undef PROP3_STEP_STAMP
 #ifdef ROLLOUT_STAMPS
     if (roll_on) {                                   // shader clock over wall clock for the whole step
         atomicAdd(&g_roll_stamps[9], __builtin_amdgcn_s_memtime() - roll_c0);
@@ -1495,7 +1531,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     const Prop3Lds P = prop3_lds(lds);
     prop3_fill_resident(P, sw, sw6, mw);
     prop3_step<TAPE, PAIR, PAIR && !TAPE /* the tape's kernel has no register to spare for the carried head; the big kernel's
-                                            allocation is not to move (with it: 256 VGPRs) */, ECACHE, WORK>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
+                                            allocation is not to move (with it: 256 VGPRs) */, ECACHE, WORK, PAIR && !TAPE && ECACHE /* paired tiles: at most eight */>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
                      eff, N, B, spw, s_delta, s_out, out_stride, cself, cself_ok, mask_hist, agg_hist, re_scale, re_inv, order_rows,
                      (int)threadIdx.x, ECACHE ? ecache + (size_t)blockIdx.x * ec_stride : nullptr, work PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS

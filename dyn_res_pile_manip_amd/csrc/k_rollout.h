@@ -45,7 +45,7 @@ struct RolloutArgs {
     DrpCam cam;
 };
 
-template <bool PAIR, bool ECACHE, bool WORK>
+template <bool PAIR, bool ECACHE, bool WORK, bool ONE /* no more tiles than waves per workgroup: rows handed from step to step in registers */>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_rollout(const RolloutArgs* __restrict__ args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -119,7 +119,7 @@ km_rollout(const RolloutArgs* __restrict__ args) {
         }
         __syncthreads();                             // the lists are written, the positions no longer needed
         ROLL_STAMP(2);                               // neighbour lists
-        prop3_step<false, PAIR, true, ECACHE, WORK>(P, a->sw, a->sw6, a->mw, s_prev, prev_mod, prev_stride, a->attr, nbat, a->dens, nbat, nbr_idx, nbr_cnt,
+        prop3_step<false, PAIR, true, ECACHE, WORK, ONE>(P, a->sw, a->sw6, a->mw, s_prev, prev_mod, prev_stride, a->attr, nbat, a->dens, nbat, nbr_idx, nbr_cnt,
                           a->proj_a, a->proj_b, a->c_node, a->eff, N, B, spw, s_delta, states + (size_t)t * N * 3, hstride,
                           a->cself, a->cself_ok, nullptr, nullptr, a->re_scale, a->re_inv, a->order_rows, tid,
                           ECACHE ? a->ecache + (size_t)blockIdx.x * a->ec_stride : nullptr, a->work PROP_STAMPS_ARG);
