@@ -720,21 +720,25 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                    a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist, c->re_scale, c->re_inv, (c->prop3_order ? 1 : 0)
             const bool pair = c->prop_pair(spw, N, B);
             note_degrees(c, spw, N, B);
-            // (the cached kernel of paired tiles hands a tile's own rows from step to step in registers: one tile per wave)
-            const bool ec = c->use_ecache(grid.x, (long)spw * N, pair) && (!pair || tape || ((long)spw * N + 15) / 16 <= PROP_WAVES);
+            const bool ec = c->use_ecache(grid.x, (long)spw * N, pair);
             const size_t ec_stride = drp_ctx::ecache_stride((long)spw * N, pair);
             if (ec) CHK(ensure(c, c->ecache, (size_t)grid.x * ec_stride * 16));
             float4* ecp = ec ? ptr<float4>(c->ecache) : nullptr;
             unsigned long long* const wk = c->work_ptr();    // not null: the counting instantiations (drp_probe_begin("prop+work"))
+            // ONE: no more tiles than waves in a workgroup -- the cached kernel then hands a tile's own rows from one propagation
+            // step to the next in registers
+            const bool one = ec && (pair ? ((long)spw * N + 15) / 16 : ((long)spw * N + 31) / 32) <= PROP_WAVES;
+#define PROP3_LAUNCH_W(TAPE_, PAIR_, EC_, ONE_) do { \
+                if (wk) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, EC_, true, ONE_>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); \
+                else hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, EC_, false, ONE_>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); } while (0)
 #define PROP3_LAUNCH(TAPE_, PAIR_) do { \
-                if (ec && wk) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, true, true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); \
-                else if (ec) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, true, false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); \
-                else if (wk) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, false, true>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); \
-                else hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, false, false>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); } while (0)
+                if (one) PROP3_LAUNCH_W(TAPE_, PAIR_, true, true); else if (ec) PROP3_LAUNCH_W(TAPE_, PAIR_, true, false); \
+                else PROP3_LAUNCH_W(TAPE_, PAIR_, false, false); } while (0)
             if (!tape && !pair) PROP3_LAUNCH(false, false);
             else if (!tape) PROP3_LAUNCH(false, true);
             else if (!pair) PROP3_LAUNCH(true, false);
             else PROP3_LAUNCH(true, true);
+#undef PROP3_LAUNCH_W
 #undef PROP3_LAUNCH
 #undef PROP3_ARGS
         }
@@ -1276,22 +1280,30 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_prop<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_prop<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP_LDS(true)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)km_prop3<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<false, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_prop3<true, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_PROP3_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_rollout<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_rollout<false, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_rollout<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||

@@ -738,7 +738,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
     // waves of a SIMD do not advance evenly (tools/prop_stamps.py: with five tiles each the first wave of the
     // chip was done at 0.7 of the last one's time, and a SIMD with one wave left runs at about 0.6 of its
     // two-wave rate); on demand the waves end within 10 us of each other.
-    constexpr bool ROWS = CARRY && EC != 0 && ONE;    // HeadCarry's rows: the cached kernels whose waves keep one tile
+    constexpr bool ROWS = EC != 0 && ONE;             // HeadCarry's rows: the cached kernels whose waves keep one tile
     bool first_tile = true;
     TileId cur = first_of(), nxt = {false, 0, 0};
     TileHead hd_next = {};
@@ -978,6 +978,20 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
             if (EC == 1) ++it;
         }
         }
+        if (ROWS && PAIR) {
+            // a receiver's second column takes the FIRST column's aggregate (its own was summed odd slot first: equal to the last
+            // place only): from here on both columns compute the same bits, so the rows the second column keeps for the next
+            // step are what it would have loaded back -- the first column's stores -- and paired tiles keep giving the
+            // unpaired bits.  The rotation runs with every lane on (under the selection's mask its source lanes would be off
+            // and read as zero): taken first, made opaque, selected afterwards.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float o0 = dpp_ror8(acc.v[0][r]), o1 = dpp_ror8(acc.v[1][r]);
+                asm volatile("" : "+v"(o0), "+v"(o1));
+                acc.v[0][r] = par ? o0 : acc.v[0][r];
+                acc.v[1][r] = par ? o1 : acc.v[1][r];
+            }
+        }
         // ---- node update on the aggregate still in registers
         asm volatile("" ::: "memory");
 #ifdef PROP_STAMPS
@@ -1014,10 +1028,6 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
         frag_relu(e);
         if (live) frag_to_row(eff + row * 64, h, e);
         const bool keep_rows = ROWS && !LAST && first_tile && hc.rows_ok;        // wave-uniform
-        // (PAIR: a receiver's second column keeps its OWN copies -- its aggregate was summed odd slot first, so they equal the
-        // first column's to the last place only, where a reload would have fetched the first column's stores: with the rows
-        // kept, paired and unpaired tiles agree to the last place of a sum, not bit for bit; copying the first column's over
-        // (`row_ror:8` + select, 96 registers) costs more than the kept rows save at 20 - 32 particles)
         if (keep_rows) hc.re = e;
         split_frag6(e, f6);
         __builtin_amdgcn_sched_barrier(0);
@@ -1509,7 +1519,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
 #endif
 }
 
-template <bool TAPE, bool PAIR, bool ECACHE, bool WORK>
+template <bool TAPE, bool PAIR, bool ECACHE, bool WORK, bool ONE /* no more tiles than waves per workgroup (the host's promise; cached kernels) */>
 __global__ void __launch_bounds__(64 * PROP_WAVES)
 km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
          const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1531,7 +1541,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     const Prop3Lds P = prop3_lds(lds);
     prop3_fill_resident(P, sw, sw6, mw);
     prop3_step<TAPE, PAIR, PAIR && !TAPE /* the tape's kernel has no register to spare for the carried head; the big kernel's
-                                            allocation is not to move (with it: 256 VGPRs) */, ECACHE, WORK, PAIR && !TAPE && ECACHE /* paired tiles: at most eight */>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
+                                            allocation is not to move (with it: 256 VGPRs) */, ECACHE, WORK, ONE>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
                      eff, N, B, spw, s_delta, s_out, out_stride, cself, cself_ok, mask_hist, agg_hist, re_scale, re_inv, order_rows,
                      (int)threadIdx.x, ECACHE ? ecache + (size_t)blockIdx.x * ec_stride : nullptr, work PROP_STAMPS_ARG);
 #ifdef PROP_STAMPS

@@ -38,11 +38,6 @@ def _engine(monkeypatch, env):
                                      (1, 40, 1),        # a single particle
                                      (300, 6, 1)])      # a handful of large samples: the per-step kernel, one tile per CU
 def test_paired_tiles_give_the_unpaired_bits(monkeypatch, path, N, ns, nb):
-    # with the edge-chain cache off: its kernels keep a tile's own rows in registers from one propagation step to the next,
-    # and a paired tile's second column then works from its own copy of the receiver's effect (summed odd slot first) where
-    # a reload fetched the first column's -- equal to the last place of a sum, which is what the cached kernels are held to
-    # (test_paired_rollout_against_the_oracle and tests/test_gpu_fullsize.py::test_edge_cache_against_the_oracle run them)
-    monkeypatch.setenv('DRP_ECACHE_MAX_MB', '0')
     H = 3
     s0, dens, attr = syn.make_pile(N, nb, seed=N + 1)
     acts = syn.sample_pushes(ns * nb, H, seed=N)
