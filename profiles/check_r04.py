@@ -6,15 +6,27 @@ usage: python3 profiles/check_r04.py   (reads profiles/r04_bench_default.json an
 import csv
 import json
 import os
+import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def counts_work(name):
+    """True for the WORK instantiations (the calibration iteration's counting kernels): km_prop<LAST, TAPE, PAIR, WORK>,
+    km_prop3<TAPE, PAIR, ECACHE, WORK, ONE>, km_rollout<PAIR, ECACHE, WORK, ONE>."""
+    m = re.match(r'(km_prop3|km_prop|km_rollout)<([^>]*)>', name.strip())
+    if not m:
+        return False
+    a = [x.strip() for x in m.group(2).split(',')]
+    i = {'km_prop': 3, 'km_prop3': 3, 'km_rollout': 2}[m.group(1)]
+    return len(a) > i and a[i] == 'true'
 
 
 def mfmas_from_sq(tag, prefixes):
     best = None
     for r in csv.DictReader(open(os.path.join(HERE, 'r04_%s_pmc_sq_per_kernel.csv' % tag))):
         name = r['Kernel_Name']
-        if not name.startswith(prefixes) or name.rstrip().endswith(', true>') or not r['Counter_Name'].startswith('SQ_INSTS_VALU_MFMA_MOPS'):
+        if not name.startswith(prefixes) or counts_work(name) or not r['Counter_Name'].startswith('SQ_INSTS_VALU_MFMA_MOPS'):
             continue
         best = best or {}
         best.setdefault(name, 0.0)

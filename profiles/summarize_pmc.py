@@ -9,11 +9,13 @@ pattern: km_update reads three [B*N,64] fp32 buffers with float4 loads = 230 400
 launch at 1024 x 300 and FETCH_SIZE reports 115 461 KiB (x0.501).
 
 usage: summarize_pmc.py <engine | gd-demo> <fetch_counter_collection.csv> <write_counter_collection.csv>
+(the per-kernel reductions profiles/r04_<preset>_pmc_{fetch,write}_per_kernel.csv are accepted as well)
 """
 import collections
 import csv
 import json
 import os
+import re
 import sys
 
 CLASS = {'k_graph': 'graph', 'k_graph_strips': 'graph', 'k_graph_sort': 'graph_sort', 'k_node_encode': 'node_encode', 'k_edge_encode': 'edge_encode',
@@ -25,10 +27,20 @@ CLASS = {'k_graph': 'graph', 'k_graph_strips': 'graph', 'k_graph_sort': 'graph_s
          'kmb_step_bwd': 'step_bwd', 'kb_reward': 'bwd_reward', 'kb_reverse_lists': 'bwd_lists', 'kb_sdelta': 'bwd_push'}
 
 
+def counts_work(name):
+    """True for the WORK instantiations (the calibration iteration's counting kernels): km_prop<LAST, TAPE, PAIR, WORK>,
+    km_prop3<TAPE, PAIR, ECACHE, WORK, ONE>, km_rollout<PAIR, ECACHE, WORK, ONE>."""
+    m = re.match(r'(km_prop3|km_prop|km_rollout)<([^>]*)>', name.strip())
+    if not m:
+        return False
+    a = [x.strip() for x in m.group(2).split(',')]
+    i = {'km_prop': 3, 'km_prop3': 3, 'km_rollout': 2}[m.group(1)]
+    return len(a) > i and a[i] == 'true'
+
+
 def norm(name):
-    # the counting instantiations (last template argument WORK = true: one calibration iteration of bench.py) are not the
-    # kernels the timed region runs
-    if name.startswith(('km_prop', 'km_rollout')) and name.rstrip().endswith(', true>'):
+    # the counting instantiations (one calibration iteration of bench.py) are not the kernels the timed region runs
+    if counts_work(name):
         return '(counting instantiation)'
     # km_prop gained a second template argument (tape); both spellings mean the same kernel here
     if name.startswith('km_prop<false'):
@@ -50,7 +62,10 @@ def per_kernel(path, counter):
         if r['Counter_Name'] != counter:
             continue
         name = norm(r['Kernel_Name'].split('(')[0].replace('void ', '').strip())
-        d[name].append(float(r['Counter_Value']))
+        if 'Mean_Counter_Value' in r:         # a per-kernel reduction (profiles/reduce_pmc.py) instead of the raw collection
+            d[name].extend([float(r['Mean_Counter_Value'])] * int(r['Dispatches']))
+        else:
+            d[name].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in d.items()}, {k: len(v) for k, v in d.items()}
 
 

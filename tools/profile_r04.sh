@@ -65,7 +65,7 @@ for l in open('gpurun_out/r04/calib.log'):
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 tools/train_timing.py > $O/train_stats.log 2>&1
 cp $(ls $O/train_stats/*/*_kernel_stats.csv | head -1) $O/summ/r04_train_kernel_stats.csv
-tail -4 $O/train_stats.log > $O/summ/r04_train_timing.txt
+grep "ms per training" $O/train_stats.log > $O/summ/r04_train_timing.txt
 python3 tools/gd_timing.py 5 10 20 30 40 50 100 > $O/summ/r04_gd_timing.txt 2>&1
 python3 tools/planner_timing.py > $O/summ/r04_planner_timing.txt 2>&1
 # the bench lines of this build on this box
