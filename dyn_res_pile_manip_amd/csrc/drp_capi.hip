@@ -176,6 +176,7 @@ struct drp_ctx {
     bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
     bool bwd_fused = true;          // DRP_NO_BWD_FUSED=1: the GD planner's backward pass as one launch per stage
+    bool bwd_rows = true;           // DRP_NO_BWD_ROWS=1: piles of up to 256 particles through kmb_step_bwd (rows through memory) instead of kmb_rows_bwd
     bool prop3_order = true;        // false: km_prop3's tiles in the natural row order instead of by in-degree
     int prop_pair_rows = 128;       // DRP_PROP_PAIR_ROWS: a workgroup of the whole-sample kernels with up to so many rows runs tiles of
                                     // 16 receivers x two slots (0 = never)
@@ -1238,6 +1239,7 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_PROP_PAIR_ALWAYS")) c->prop_pair_always = std::max(0, atoi(e));
     if (const char* e = getenv("DRP_PROP_PAIR_DEG10")) c->prop_pair_deg10 = std::max(0, atoi(e));
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
+    c->bwd_rows = getenv("DRP_NO_BWD_ROWS") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
     if (const char* e = getenv("DRP_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_timeout_s = v; }
     if (const char* e = getenv("DRP_COMM_INIT_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_init_timeout_s = v; }
@@ -1317,6 +1319,7 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_rollout<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_rollout<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kmb_rows_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_ROWS_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kt_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kt_wgrad_mfma_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||
@@ -2309,7 +2312,21 @@ int gd_forward_backward(drp_ctx* c) {
                                    cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
         }
         const int spw_b = (B + c->n_cu - 1) / c->n_cu;
-        if (c->bwd_fused && whole_samples(c, B, N) && ((long)spw_b * N + 31) / 32 >= c->bwd_fused_min_tiles) {
+        if (c->bwd_fused && c->bwd_rows && N <= KMB_ROWS_MAX) {
+            // piles of up to 256 particles: a workgroup takes groups of whole samples with at most 256 rows, a wave keeps
+            // its tile's rows in registers through all phases (kmb_rows_bwd).  Samples per group: the fewest that do not
+            // add a round of groups over the CUs (fewer waves at work per CU, more CUs at work)
+            const int g_max = KMB_ROWS_MAX / N;
+            auto rounds = [&](int g) { return (((long)B + g - 1) / g + c->n_cu - 1) / c->n_cu; };
+            int gps = g_max;
+            while (gps > 1 && rounds(gps - 1) == rounds(g_max)) --gps;
+            const long n_groups = ((long)B + gps - 1) / gps;
+            ProbeScope ps(c, KC_BWD_NODE);
+            hipLaunchKernelGGL(kmb_rows_bwd, dim3((unsigned)(n_groups < (long)c->n_cu ? n_groups : (long)c->n_cu)), dim3(64 * KMB_FUSED_WAVES),
+                               KMB_ROWS_LDS, st, ptr<float>(c->w_mfma), ptr<float>(c->w_mfma_bwd), eht, mht, cnt, ptr<int>(c->rev_off),
+                               ptr<int>(c->rev), g_out, (size_t)N * 3, ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr),
+                               nb, ptr<float>(c->dens), nb, N, B, gps, t > 0 ? gah : (float*)nullptr, ptr<float>(c->g_sdelta));
+        } else if (c->bwd_fused && whole_samples(c, B, N) && ((long)spw_b * N + 31) / 32 >= c->bwd_fused_min_tiles) {
             // chip-filling batches: everything between the reward's gradient and the impulses' in one launch,
             // a workgroup owning whole samples (kmb_step_bwd)
             ProbeScope ps(c, KC_BWD_NODE);

@@ -254,6 +254,69 @@ kmb_node_encode(const float* __restrict__ mw, const float* __restrict__ mb, cons
 #define KMB_MIN_TILES 1          // round 3: the tiles are dealt workgroup-cyclically, so a handful of them (a training batch) runs one per CU
 #define KMB_NODE_ENCODE_LDS ((size_t)(512 + 2 * 4096 + 192) * sizeof(float))
 
+// acc += scale * v where the row's mask word has the element's bit (bit 31 - (16 ob + q)), + 0 elsewhere: one signed
+// bit-field extract (0 / -1), one AND, one add per element -- inline assembly: written in C the optimiser turns the
+// extract back into AND + compare + select and adds a copy per element (330 instructions per list entry instead of 96),
+// and with the temporary inside the statement no 32 of them are alive at once.
+template <int POS>
+__device__ __forceinline__ float add_if_bit(float acc, float v, unsigned w) {
+    float t;
+    asm("v_bfe_i32 %1, %3, %4, 1\n\tv_and_b32 %1, %1, %2\n\tv_add_f32 %0, %0, %1" : "+v"(acc), "=&v"(t) : "v"(v), "v"(w), "n"(POS));
+    return acc;
+}
+template <int POS>
+__device__ __forceinline__ float fma_if_bit(float acc, float v, unsigned w, float scale) {
+    float t;
+    asm("v_bfe_i32 %1, %3, %4, 1\n\tv_and_b32 %1, %1, %2\n\tv_fmac_f32 %0, %1, %5" : "+v"(acc), "=&v"(t) : "v"(v), "v"(w), "n"(POS), "v"(scale));
+    return acc;
+}
+template <int E>
+__device__ __forceinline__ void frag_add_masked_from(Frag& acc, const Frag& v, unsigned w) {
+    if constexpr (E < 32) {
+        acc.v[E >> 4][E & 15] = add_if_bit<31 - E>(acc.v[E >> 4][E & 15], v.v[E >> 4][E & 15], w);
+        frag_add_masked_from<E + 1>(acc, v, w);
+    }
+}
+__device__ __forceinline__ void frag_add_masked(Frag& acc, const Frag& v, unsigned w) { frag_add_masked_from<0>(acc, v, w); }
+template <int E>
+__device__ __forceinline__ void frag_fma_masked_from(Frag& acc, const Frag& v, unsigned w, float scale) {
+    if constexpr (E < 32) {
+        acc.v[E >> 4][E & 15] = fma_if_bit<31 - E>(acc.v[E >> 4][E & 15], v.v[E >> 4][E & 15], w, scale);
+        frag_fma_masked_from<E + 1>(acc, v, w, scale);
+    }
+}
+// The statements above are opaque to the compiler's hazard recognizer: it does not know that their last instruction is
+// a vector write, and an MFMA reading that register needs two wait states after one (seen: the receiver term's element
+// consumed by the very next v_mfma with one s_nop between -- stale operands, wrong gradients).  A fragment built by
+// them goes through one VISIBLE vector instruction per element before the matrix cores read it: times an exact 1.0
+// the optimiser cannot see through.
+__device__ __forceinline__ void frag_settle(Frag& f) {
+    float one = 1.0f;
+    asm volatile("" : "+v"(one));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { f.v[0][r] *= one; f.v[1][r] *= one; }
+}
+// receiver term of a row: sum over its slots of (slot's mask) . g -- the SAME row g under every mask, so per element it is
+// g times the number of slots whose mask has the bit: the ten mask words are added bit-sliced (four planes: counts up
+// to 15), then pr = sum_b 2^b (plane_b . g): four masked terms instead of ten (each term exact, three roundings)
+__device__ __forceinline__ void receiver_term(Frag& pr, const Frag& g, const unsigned (&wk)[DRP_K]) {
+    unsigned c0 = 0u, c1 = 0u, c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int k = 0; k < DRP_K; ++k) {
+        unsigned carry = wk[k], t;
+        t = c0 & carry; c0 ^= carry; carry = t;
+        t = c1 & carry; c1 ^= carry; carry = t;
+        t = c2 & carry; c2 ^= carry; carry = t;
+        c3 ^= carry;
+    }
+    frag_zero(pr);
+    frag_add_masked(pr, g, c0);
+    frag_fma_masked_from<0>(pr, g, c1, 2.0f);
+    frag_fma_masked_from<0>(pr, g, c2, 4.0f);
+    frag_fma_masked_from<0>(pr, g, c3, 8.0f);
+    frag_settle(pr);
+}
+
 // ---- the whole node / edge part of one rollout step's backward pass in ONE launch (the GD planner) ------------
 // The sequence above -- kmb_predict, then per propagation step kb_edge_terms between two kmb_node_step halves,
 // then kmb_node_encode -- is nine launches whose intermediates (g_proj [B,N,128] written and read three times,
@@ -266,7 +329,7 @@ kmb_node_encode(const float* __restrict__ mw, const float* __restrict__ mb, cons
 //             stay in registers and go straight into W_r^T / W_s^T; then the update of step p-1 (-> g_agg[p-1]),
 //             or, for p = 0, the particle encoder's backward (-> g_s_delta)       -> g_proj never exists
 // Tiles are 32 consecutive rows of the workgroup's row list (only its last tile has idle lanes), drawn on demand.
-// Every sum runs in a fixed order (slot order, reversed-list order): gradients are bit-reproducible.
+// Every sum runs in a fixed order (bit planes of the slot count, reversed-list order): gradients are bit-reproducible.
 // fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout, as the launch-per-stage kernels.
 #define KMB_FUSED_WAVES 8
 #define KMB_FUSED_LDS ((size_t)(7 * 4096 + 512 + 256 + 192 + 4) * sizeof(float))
@@ -401,21 +464,11 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
             int e1 = (1 < nrev) ? rv[p0 + 1] : 0;
             {
                 // the row's ten mask words are independent loads: all in flight at once (a loop over k waited for each
-                // in turn -- ten L2 round trips per tile and phase), then the additions in slot order as before
+                // in turn -- ten L2 round trips per tile and phase)
                 unsigned wk[DRP_K];
 #pragma unroll
                 for (int k = 0; k < DRP_K; ++k) wk[k] = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + h] : 0u;
-#pragma unroll
-                for (int k = 0; k < DRP_K; ++k) {
-                    if (k < cmax) {                       // wave-uniform
-                        const unsigned w = wk[k];
-#pragma unroll
-                        for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                            for (int q = 0; q < 16; ++q)
-                                pr.v[ob][q] += ((w >> (31 - (16 * ob + q))) & 1u) ? gi.v[ob][q] : 0.0f;
-                    }
-                }
+                receiver_term(pr, gi, wk);
             }
             // sender term over the reversed list (ascending receiver, then slot), software-pipelined two deep: the
             // mask word and the g_agg row of entry q0 + 1 and the index of entry q0 + 3 are requested before entry q0's
@@ -438,11 +491,7 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                     frag_from_row(g_agg_p + (srow0 + (on_next ? er : i)) * 64, h, v_nxt);
                 }
                 const int e3 = (q0 + 3 < nrev) ? rv[p0 + q0 + 3] : 0;
-#pragma unroll
-                for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        ps.v[ob][q] += ((w_cur >> (31 - (16 * ob + q))) & 1u) ? v_cur.v[ob][q] : 0.0f;
+                frag_add_masked(ps, v_cur, w_cur);
                 w_cur = w_nxt;
                 v_cur = v_nxt;
                 e1 = e2;
@@ -451,6 +500,7 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
             // projection backward: g_eff += W_r^T (receiver term) + W_s^T (sender term)
             Frag ge;
             frag_from_row(g_eff + row * 64, h, ge);
+            frag_settle(ps);
             mfma_layer64<false>(reinterpret_cast<const float4*>(wr), pr, ge, lane);
             mfma_layer64<false>(reinterpret_cast<const float4*>(ws), ps, ge, lane);
             if (p > 0) {
@@ -516,6 +566,257 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                     g_sdelta[row * 3 + 1] = out[1];
                     g_sdelta[row * 3 + 2] = out[2];
                 }
+            }
+        }
+    }
+}
+
+
+// ---- the same pass with a wave keeping its 32 rows from the first phase to the last (piles of up to 256 particles) ------
+// kmb_step_bwd above is latency: per tile and phase it re-reads g_eff, g_cnode and its own g_agg rows from memory, gathers
+// the senders' g_agg rows from L2 (or behind it) and writes all of them back -- 0.9 GB per launch at the GD planner's
+// demo shape, 46 % of the wave cycles waiting, 436 us.  Here a workgroup takes GROUPS of whole samples with at most 256
+// rows together -- one tile of 32 rows per wave, eight waves -- and
+//   * g_eff, g_cnode and the tile's own g_agg rows never leave the wave's registers between the phases;
+//   * the group's g_agg rows of the current propagation step sit in LDS (68 KB: rows padded to 17 float4, so that a gather
+//     of arbitrary rows spreads over the banks): the reversed-list gather is ds_read_b128, its mask words are requested
+//     four entries ahead;
+//   * g_agg goes to memory only when a later stage wants it (kmb_edge_encode of a horizon > 1; `g_agg_hist` may be null).
+// LDS: W_agg^T, W_r^T, W_s^T resident; one 32-KB region holds the predictor's two matrices in phase P and the particle
+// encoder's two (transposed) from then on, refilled per group.  Same sums in the same order as kmb_step_bwd: same bits.
+#define KMB_ROWS_MAX 256
+#define KMB_ROWS_LDS ((size_t)(5 * 4096 + 512 + 256 + 192 + KMB_ROWS_MAX * 68) * sizeof(float))
+#define KMB_ROWS_LD 68            // floats per g_agg row in LDS: 17 float4 -- consecutive rows start four banks apart
+__device__ __forceinline__ void gagg_lds_read(const float* gl, int r, int h, Frag& f) { frag_from_row(gl + r * KMB_ROWS_LD, h, f); }
+__device__ __forceinline__ void gagg_lds_write(float* gl, int r, int h, const Frag& f) { frag_to_row(gl + r * KMB_ROWS_LD, h, f); }
+#ifndef KMB_DBG
+#define KMB_DBG 0
+#endif
+__device__ __forceinline__ void frag_add_masked_c(Frag& acc, const Frag& v, unsigned w) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            acc.v[ob][q] += ((w >> (31 - (16 * ob + q))) & 1u) ? v.v[ob][q] : 0.0f;
+}
+__device__ __forceinline__ void receiver_term_c(Frag& pr, const Frag& g, const unsigned (&wk)[DRP_K]) {
+    frag_zero(pr);
+#pragma unroll
+    for (int k = 0; k < DRP_K; ++k) frag_add_masked_c(pr, g, wk[k]);
+}
+#if KMB_DBG & 1
+#define KMB_DBG_ADD frag_add_masked_c
+#else
+#define KMB_DBG_ADD frag_add_masked
+#endif
+#if KMB_DBG & 2
+#define KMB_DBG_RECV receiver_term_c
+#else
+#define KMB_DBG_RECV receiver_term
+#endif
+__global__ void __launch_bounds__(64 * KMB_FUSED_WAVES)
+kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
+             const float* __restrict__ eff_hist /* [4][B*N,64] */, const unsigned* __restrict__ mask_hist /* [3][B*N*10][2] */,
+             const uint8_t* __restrict__ nbr_cnt, const int* __restrict__ rev_off, const int* __restrict__ rev,
+             const float* __restrict__ g_out, size_t g_stride, const float* __restrict__ s_delta,
+             const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
+             int N, int B, int gps /* samples per group: gps * N <= 256 */,
+             float* __restrict__ g_agg_hist /* [3][B*N,64], or null */, float* __restrict__ g_sdelta) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wagg = lds;               // W_agg^T, W_r^T, W_s^T
+    float* wr = wagg + 4096;
+    float* ws = wr + 4096;
+    float* swp0 = ws + 4096;         // phase P: predictor layer 0 (forward pack), then transposed;
+    float* swp1 = swp0 + 4096;       // afterwards: W_pe^T and the particle encoder's layer 2, transposed
+    float* w1 = swp1 + 4096;         // particle encoder layer 0, forward pack (K = 8)
+    float* rows_pr = w1 + 512;       // b_pr0 [64], w_pr1 [3][64]
+    float* rows_pe = rows_pr + 256;  // encoder layer-0 columns 0..2
+    float* gl = rows_pe + 192;       // the group's g_agg rows of the current propagation step
+    lds_fill(wagg, mb + MB_AGG, 3 * 4096);          // MB_AGG, MB_RPR, MB_RPS are consecutive
+    lds_fill(w1, mw + M_PE0, 512);
+    lds_fill(rows_pr, mw + R_PR0_B, 256);
+    lds_fill(rows_pe, mb + RB_PE0, 192);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const float inv_N = 1.0f / (float)N;
+    const size_t bn64 = (size_t)B * N * 64;
+    const size_t bnk2 = (size_t)B * N * DRP_K * 2;
+    const int n_groups = (B + gps - 1) / gps;
+#pragma unroll 1
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int b0 = grp * gps, nbw = min(gps, B - b0);
+        const int grp_rows = nbw * N;
+        __syncthreads();                                   // the group before is through with the swap region and with gl
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));                      // the fills' per-thread addresses are recomputed per group, not kept (spilled) across it
+        lds_fill(swp0, mw + M_PR0, 4096, tid);
+        lds_fill(swp1, mb + MB_PR0, 4096, tid);
+        __syncthreads();
+        const bool active = wave * 32 < grp_rows;          // wave-uniform
+        const bool live = (wave * 32 + j) < grp_rows;
+        const int r = min(wave * 32 + j, grp_rows - 1);
+        int m, i;
+        divmod_small(r, N, inv_N, m, i);
+        const int b = b0 + m;
+        const size_t row = (size_t)b0 * N + r;
+        const size_t srow0 = (size_t)b * N;                // first row of the lane's sample
+        const int lrow0 = m * N;                           // ... within the group
+        const int cnt = live ? (int)nbr_cnt[row] : 0;
+        const int* ro = rev_off + (size_t)b * (N + 1);
+        const int p0 = ro[i];
+        const int nrev = live ? ro[i + 1] - p0 : 0;
+        const int* rv = rev + srow0 * DRP_K + p0;
+        int cmax = cnt, lmax = nrev;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cmax = max(cmax, __shfl_xor(cmax, o, 64));
+            lmax = max(lmax, __shfl_xor(lmax, o, 64));
+        }
+        Frag ge, gc, ga;
+        // ---- phase P: predictor backward + update of the last propagation step
+        if (active) {
+            Frag x, hh, gh;
+            frag_from_row(eff_hist + 3 * bn64 + row * 64, h, x);
+            frag_from_row(rows_pr, h, hh);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(swp0), x, hh, lane);
+            const float* go = g_out + (size_t)b * g_stride + (size_t)i * 3;
+            const float g0 = go[0], g1 = go[1], g2 = go[2];
+            {
+                Frag wx, wy, wz;
+                frag_from_row(rows_pr + 64, h, wx);
+                frag_from_row(rows_pr + 128, h, wy);
+                frag_from_row(rows_pr + 192, h, wz);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float g = wx.v[ob][q] * g0 + wy.v[ob][q] * g1 + wz.v[ob][q] * g2;
+                        gh.v[ob][q] = hh.v[ob][q] > 0.0f ? g : 0.0f;
+                    }
+            }
+            frag_zero(ge);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(swp1), gh, ge, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                ge.v[0][q] = x.v[0][q] > 0.0f ? ge.v[0][q] : 0.0f;
+                ge.v[1][q] = x.v[1][q] > 0.0f ? ge.v[1][q] : 0.0f;
+            }
+            gc = ge;
+            frag_zero(ga);
+            mfma_layer64<false>(reinterpret_cast<const float4*>(wagg), ge, ga, lane);
+            if (live) {
+                gagg_lds_write(gl, r, h, ga);
+                if (g_agg_hist != nullptr) frag_to_row(g_agg_hist + 2 * bn64 + row * 64, h, ga);
+            }
+        }
+        __syncthreads();                                   // g_agg of step 2 is in LDS; nobody reads the predictor's matrices any more
+        asm volatile("" : "+v"(tid));
+        lds_fill(swp0, mb + MB_PPE, 2 * 4096, tid);        // MB_PPE, MB_PE2 consecutive: read in phase 0, two barriers from here
+        // ---- phases p = 2, 1, 0
+#pragma unroll 1
+        for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+            if (active) {
+                const unsigned* mk = mask_hist + (size_t)p * bnk2 + srow0 * DRP_K * 2;      // the sample's slots of this step
+                // the row of the effects this phase's ReLU mask comes from (eff_hist[p]: after step p - 1, or after the encoder)
+                Frag en;
+                frag_from_row(eff_hist + (size_t)p * bn64 + row * 64, h, en);
+                // sender term's first entries and mask words
+                int e0 = (0 < nrev) ? rv[0] : 0, e1 = (1 < nrev) ? rv[1] : 0, e2 = (2 < nrev) ? rv[2] : 0, e3 = (3 < nrev) ? rv[3] : 0;
+                int e4 = (4 < nrev) ? rv[4] : 0, e5 = (5 < nrev) ? rv[5] : 0;
+                unsigned w0 = (0 < nrev) ? mk[(size_t)e0 * 2 + h] : 0u, w1_ = (1 < nrev) ? mk[(size_t)e1 * 2 + h] : 0u;
+                unsigned w2 = (2 < nrev) ? mk[(size_t)e2 * 2 + h] : 0u, w3 = (3 < nrev) ? mk[(size_t)e3 * 2 + h] : 0u;
+                // receiver term: the tile's own g_agg rows (registers) under the masks of the row's own slots, in slot order
+                Frag pr, ps;
+                frag_zero(ps);
+                {
+                    unsigned wk[DRP_K];
+#pragma unroll
+                    for (int k = 0; k < DRP_K; ++k) wk[k] = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + h] : 0u;
+                    KMB_DBG_RECV(pr, ga, wk);
+                }
+                mfma_layer64<false>(reinterpret_cast<const float4*>(wr), pr, ge, lane);
+                const unsigned en_pos = frag_positive_bits_any(en);      // all this phase wants of that row (requested a projection ago)
+                // sender term over the reversed list (ascending receiver, then slot): rows from LDS one entry ahead, in two
+                // buffers that change roles (no copies), mask words four entries ahead, list entries six
+                Frag va, vb;
+                frag_zero(va);
+                frag_zero(vb);
+                {
+                    int er, ek;
+                    divmod_small(e0, DRP_K, 0.1f, er, ek);
+                    if (0 < nrev) gagg_lds_read(gl, lrow0 + er, h, va);
+                }
+#define KMB_ROWS_ENTRY(cur_, nxt_, q_) { \
+                    { \
+                        int er, ek; \
+                        divmod_small(e1, DRP_K, 0.1f, er, ek); \
+                        if ((q_) + 1 < nrev) gagg_lds_read(gl, lrow0 + er, h, nxt_); \
+                    } \
+                    const unsigned w4 = ((q_) + 4 < nrev) ? mk[(size_t)e4 * 2 + h] : 0u; \
+                    const int e6 = ((q_) + 6 < nrev) ? rv[(q_) + 6] : 0; \
+                    KMB_DBG_ADD(ps, cur_, w0); \
+                    w0 = w1_; w1_ = w2; w2 = w3; w3 = w4; \
+                    e1 = e2; e2 = e3; e3 = e4; e4 = e5; e5 = e6; }
+                for (int q0 = 0; q0 < lmax; q0 += 2) {
+                    KMB_ROWS_ENTRY(va, vb, q0)
+                    KMB_ROWS_ENTRY(vb, va, q0 + 1)        /* past the longest list: no loads, mask words 0 */
+                }
+#undef KMB_ROWS_ENTRY
+                frag_settle(ps);
+                mfma_layer64<false>(reinterpret_cast<const float4*>(ws), ps, ge, lane);
+                if (p > 0) {
+                    // update of step p - 1: g_z = g_eff . [eff_p > 0]; g_cnode += g_z; g_agg[p-1] = W_agg^T g_z
+                    frag_keep_bits(ge, en_pos);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { gc.v[0][q] += ge.v[0][q]; gc.v[1][q] += ge.v[1][q]; }
+                    frag_zero(ga);
+                    mfma_layer64<false>(reinterpret_cast<const float4*>(wagg), ge, ga, lane);
+                    if (live && g_agg_hist != nullptr) frag_to_row(g_agg_hist + (size_t)(p - 1) * bn64 + row * 64, h, ga);
+                } else {
+                    // particle encoder backward: g_pe = g_eff0 + W_pe^T g_cnode, through relu(W2 relu(W1 x + b1) + b2) to the impulse
+                    int q_, bm;
+                    divmod_small(b, attr_mod, 1.0f / (float)attr_mod, q_, bm);
+                    const float d = dens[bm] / DRP_DENS_SCALE;
+                    const float* sd = s_delta + row * 3;
+                    const float at = attr[(size_t)bm * N + i];
+                    float x[4];
+                    if (h == 0) { x[0] = sd[0]; x[1] = sd[2]; x[2] = d; x[3] = 0.0f; }
+                    else { x[0] = sd[1]; x[1] = at; x[2] = 1.0f; x[3] = 0.0f; }
+                    Frag h1, gh;
+                    frag_zero(h1);
+                    mfma_layer8(reinterpret_cast<const float4*>(w1), x, h1, lane);
+                    mfma_layer64<false>(reinterpret_cast<const float4*>(swp0), gc, ge, lane);
+                    frag_keep_bits(ge, en_pos);
+                    frag_zero(gh);
+                    mfma_layer64<false>(reinterpret_cast<const float4*>(swp1), ge, gh, lane);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        gh.v[0][q] = h1.v[0][q] > 0.0f ? gh.v[0][q] : 0.0f;
+                        gh.v[1][q] = h1.v[1][q] > 0.0f ? gh.v[1][q] : 0.0f;
+                    }
+                    float out[3];
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        Frag w;
+                        frag_from_row(rows_pe + 64 * o, h, w);
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) acc = fmaf(gh.v[0][q], w.v[0][q], acc);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) acc = fmaf(gh.v[1][q], w.v[1][q], acc);
+                        out[o] = acc + __shfl_xor(acc, 32, 64);
+                    }
+                    if (live && h == 0) {
+                        g_sdelta[row * 3 + 0] = out[0];
+                        g_sdelta[row * 3 + 1] = out[1];
+                        g_sdelta[row * 3 + 2] = out[2];
+                    }
+                }
+            }
+            if (p > 0) {
+                __syncthreads();                           // every gather of this step's rows is done
+                if (active && live) gagg_lds_write(gl, r, h, ga);
+                __syncthreads();
             }
         }
     }

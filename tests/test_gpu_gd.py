@@ -232,6 +232,38 @@ def test_fused_backward_equals_the_stage_kernels_for_small_piles_and_batches(mon
     assert np.abs(res[False][1] - res[True][1]).max() < 2e-5 * scale
 
 
+@pytest.mark.parametrize('N,B,H', [(12, 1500, 1), (20, 1500, 1), (50, 300, 1), (100, 750, 1), (100, 7, 2), (64, 300, 2),
+                                   (256, 40, 1), (5, 260, 2), (33, 257, 1)])
+def test_rows_kept_in_registers_give_the_bits_of_the_rows_through_memory(monkeypatch, N, B, H):
+    """kmb_rows_bwd (piles of up to 256 particles: a wave keeps g_eff, g_cnode and its own g_agg rows in registers through
+    all phases, the group's g_agg rows in LDS) against kmb_step_bwd (DRP_NO_BWD_ROWS=1: every row through memory per
+    phase): the same sums in the same order -- rewards, push gradients and state gradients bit for bit; horizon 2 also
+    covers the g_agg rows the relation encoder's backward reads from memory."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    from dyn_res_pile_manip_amd import weights
+    from dyn_res_pile_manip_amd.planners import world2cam_affine
+    s0, dens, attr = syn.make_pile(N, 1, seed=N)
+    acts = syn.sample_pushes(B, H, seed=B)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    res = {}
+    for rows in (True, False):
+        if rows:
+            monkeypatch.delenv('DRP_NO_BWD_ROWS', raising=False)
+        else:
+            monkeypatch.setenv('DRP_NO_BWD_ROWS', '1')
+        eng = Engine(0)
+        eng.load_weights(weights.blob_from_state_dict(weights.random_state_dict(seed=0)), 0.08)
+        eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+        eng.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+        eng.gd_begin(s0, attr, dens, acts, 0.05, lo, hi)
+        res[rows] = eng.gd_grad(want_state_grad=True)
+        eng.close()
+    assert np.abs(res[True][1]).max() > 0 and np.isfinite(res[True][1]).all()
+    for a, b in zip(res[True], res[False]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_pipelined_iterations_equal_the_blocking_ones(ctx, golden):
     """drp_gd_step_async / drp_gd_wait (iteration i + 1 enqueued before the host waits for iteration i) against
     drp_gd_step + drp_gd_get: the same rewards and pushes, bit for bit, in every iteration; a slot that has not been
