@@ -227,7 +227,7 @@ struct drp_ctx {
     float re_scale = 1.0f, re_inv = 1.0f;
     bool re_ok = true;
     int re_shift_env = 0x7fffffff;  // a fixed shift k instead of the one derived from the weights (experiments)
-    DevBuf w_raw, w_valu, w_mfma, w_mfma_bwd, w_split, w_split6;
+    DevBuf w_raw, w_valu, w_mfma, w_mfma_bwd, w_split, w_split6, w_split6_bwd;
     DrpCam cam{};
     DevBuf goal_field, goal_coor, cself;
     unsigned cself_tag = 0;         // bumped by every prepare_cself: who filled c->cself last
@@ -1341,7 +1341,7 @@ void drp_destroy(drp_ctx* c) {
     helpers_wait(5.0);                        // no helper thread (an abort, an init) inside RCCL while the stream goes away
     if (c->comm) { RcclApi* R = rccl_api(); if (R) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
     DevBuf* bufs[] = {&c->probe_work, &c->ecache, &c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
-                      &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
+                      &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->w_split6_bwd, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
                       &c->attr, &c->dens, &c->s_delta, &c->nbr_idx, &c->nbr_cnt, &c->eff, &c->c_node,
                       &c->agg, &c->proj, &c->c_edge, &c->states, &c->actions, &c->rewards, &c->s_out,
                       &c->scratch, &c->nominal, &c->noise, &c->partials, &c->gathered, &c->stats, &c->elite, &c->elite_all, &c->xchg, &c->cself,
@@ -1419,6 +1419,9 @@ int drp_load_weights(drp_ctx* c, const float* blob, size_t n_floats, float adj_t
         std::vector<uint16_t> sp6;
         pack_split6(blob, sp6);
         CHK(h2d(c, c->w_split6, sp6.data(), sp6.size() * sizeof(uint16_t)));
+        // the transposed layers of the GD planner's backward pass in the same split: packed on the device from the raw blob
+        CHK(ensure(c, c->w_split6_bwd, (size_t)SB6_TOTAL * 16));
+        hipLaunchKernelGGL(kt_repack_split6_bwd, dim3(6 * 16), dim3(256), 0, c->stream, ptr<float>(c->w_raw), ptr<uint16_t>(c->w_split6_bwd));
         CHK(guarded_wait(c, nullptr));     // sp6 too
         CHK(guarded_wait(c, nullptr));     // m, sp are about to go out of scope
     }
@@ -2323,7 +2326,8 @@ int gd_forward_backward(drp_ctx* c) {
             const long n_groups = ((long)B + gps - 1) / gps;
             ProbeScope ps(c, KC_BWD_NODE);
             hipLaunchKernelGGL(kmb_rows_bwd, dim3((unsigned)(n_groups < (long)c->n_cu ? n_groups : (long)c->n_cu)), dim3(64 * KMB_FUSED_WAVES),
-                               KMB_ROWS_LDS, st, ptr<float>(c->w_mfma), ptr<float>(c->w_mfma_bwd), eht, mht, cnt, ptr<int>(c->rev_off),
+                               KMB_ROWS_LDS, st, ptr<float>(c->w_mfma), ptr<float>(c->w_mfma_bwd), ptr<uint16_t>(c->w_split6),
+                               ptr<uint16_t>(c->w_split6_bwd), eht, mht, cnt, ptr<int>(c->rev_off),
                                ptr<int>(c->rev), g_out, (size_t)N * 3, ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr),
                                nb, ptr<float>(c->dens), nb, N, B, gps, t > 0 ? gah : (float*)nullptr, ptr<float>(c->g_sdelta));
         } else if (c->bwd_fused && whole_samples(c, B, N) && ((long)spw_b * N + 31) / 32 >= c->bwd_fused_min_tiles) {
@@ -2860,6 +2864,7 @@ int repack_on_device(drp_ctx* c) {
     hipLaunchKernelGGL(kt_repack_gather, dim3((M_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_mfma), ptr<float>(c->w_mfma), (int)M_TOTAL);
     hipLaunchKernelGGL(kt_repack_gather, dim3((MB_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_mfma_bwd), ptr<float>(c->w_mfma_bwd), (int)MB_TOTAL);
     hipLaunchKernelGGL(kt_repack_split6, dim3(7 * 16), dim3(256), 0, st, w, ptr<uint16_t>(c->w_split6));
+    hipLaunchKernelGGL(kt_repack_split6_bwd, dim3(6 * 16), dim3(256), 0, st, w, ptr<uint16_t>(c->w_split6_bwd));
     // the relation encoder's range shift depends on the new weights: fetch the blob (it is the host copy
     // drp_get_weights serves anyway), derive the shift, then pack the split-fp16 fragments with it
     HIPCHK(c, hipMemcpyAsync(c->w_pin, c->w_raw.p, (size_t)W_TOTAL * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -3266,6 +3271,7 @@ long drp_debug_fetch(drp_ctx* c, const char* name, void* out, size_t out_bytes) 
     else if (!strcmp(name, "w_mfma_bwd")) { b = &c->w_mfma_bwd; bytes = (size_t)MB_TOTAL * 4; }
     else if (!strcmp(name, "w_split")) { b = &c->w_split; bytes = (size_t)S_ALLOC * 16; }
     else if (!strcmp(name, "w_split6")) { b = &c->w_split6; bytes = (size_t)S6_TOTAL * 16; }
+    else if (!strcmp(name, "w_split6_bwd")) { b = &c->w_split6_bwd; bytes = (size_t)SB6_TOTAL * 16; }
     else return fail(c, DRP_EINVAL, "unknown buffer '%s'", name);
     // a GD session keeps every step's impulses and lists in its tape, not in the step workspace: the last step's
     DevBuf tape{};

@@ -8,6 +8,8 @@
 #pragma once
 #include "k_backward.h"
 #include "k_mlp_mfma.h"
+#include "k_mlp_split.h"
+#include "k_train.h"
 
 // transposed 64x64 blocks, packed like M_* ([ob 2][s4 8][lane 64][c 4])
 enum {
@@ -585,37 +587,19 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
 // LDS: W_agg^T, W_r^T, W_s^T resident; one 32-KB region holds the predictor's two matrices in phase P and the particle
 // encoder's two (transposed) from then on, refilled per group.  Same sums in the same order as kmb_step_bwd: same bits.
 #define KMB_ROWS_MAX 256
-#define KMB_ROWS_LDS ((size_t)(5 * 4096 + 512 + 256 + 192 + KMB_ROWS_MAX * 68) * sizeof(float))
+#define KMB_ROWS_LDS ((size_t)(3 * 1536 * 4 + KMB_ROWS_MAX * KMB_ROWS_LD + 512 + 256 + 192) * sizeof(float))
 #define KMB_ROWS_LD 68            // floats per g_agg row in LDS: 17 float4 -- consecutive rows start four banks apart
 __device__ __forceinline__ void gagg_lds_read(const float* gl, int r, int h, Frag& f) { frag_from_row(gl + r * KMB_ROWS_LD, h, f); }
 __device__ __forceinline__ void gagg_lds_write(float* gl, int r, int h, const Frag& f) { frag_to_row(gl + r * KMB_ROWS_LD, h, f); }
-#ifndef KMB_DBG
-#define KMB_DBG 0
-#endif
-__device__ __forceinline__ void frag_add_masked_c(Frag& acc, const Frag& v, unsigned w) {
-#pragma unroll
-    for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            acc.v[ob][q] += ((w >> (31 - (16 * ob + q))) & 1u) ? v.v[ob][q] : 0.0f;
+// one 64 x 64 layer on the six-product bf16 split: acc += W in, W packed as pack_split6 / kt_repack_split6_bwd
+__device__ __forceinline__ void rows_layer(const bf16x8* __restrict__ wp, const Frag& in, Frag& acc, int lane) {
+    FragB6 b;
+    split_frag6(in, b);
+    mfma_layer64_split6(wp, b, acc, lane);
 }
-__device__ __forceinline__ void receiver_term_c(Frag& pr, const Frag& g, const unsigned (&wk)[DRP_K]) {
-    frag_zero(pr);
-#pragma unroll
-    for (int k = 0; k < DRP_K; ++k) frag_add_masked_c(pr, g, wk[k]);
-}
-#if KMB_DBG & 1
-#define KMB_DBG_ADD frag_add_masked_c
-#else
-#define KMB_DBG_ADD frag_add_masked
-#endif
-#if KMB_DBG & 2
-#define KMB_DBG_RECV receiver_term_c
-#else
-#define KMB_DBG_RECV receiver_term
-#endif
 __global__ void __launch_bounds__(64 * KMB_FUSED_WAVES)
-kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
+kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb, const uint16_t* __restrict__ sw6 /* pack_split6 */,
+             const uint16_t* __restrict__ sb6 /* kt_repack_split6_bwd */,
              const float* __restrict__ eff_hist /* [4][B*N,64] */, const unsigned* __restrict__ mask_hist /* [3][B*N*10][2] */,
              const uint8_t* __restrict__ nbr_cnt, const int* __restrict__ rev_off, const int* __restrict__ rev,
              const float* __restrict__ g_out, size_t g_stride, const float* __restrict__ s_delta,
@@ -623,16 +607,18 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
              int N, int B, int gps /* samples per group: gps * N <= 256 */,
              float* __restrict__ g_agg_hist /* [3][B*N,64], or null */, float* __restrict__ g_sdelta) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wagg = lds;               // W_agg^T, W_r^T, W_s^T
-    float* wr = wagg + 4096;
-    float* ws = wr + 4096;
-    float* swp0 = ws + 4096;         // phase P: predictor layer 0 (forward pack), then transposed;
-    float* swp1 = swp0 + 4096;       // afterwards: W_pe^T and the particle encoder's layer 2, transposed
-    float* w1 = swp1 + 4096;         // particle encoder layer 0, forward pack (K = 8)
-    float* rows_pr = w1 + 512;       // b_pr0 [64], w_pr1 [3][64]
-    float* rows_pe = rows_pr + 256;  // encoder layer-0 columns 0..2
-    float* gl = rows_pe + 192;       // the group's g_agg rows of the current propagation step
-    lds_fill(wagg, mb + MB_AGG, 3 * 4096);          // MB_AGG, MB_RPR, MB_RPS are consecutive
+    float* wres = lds;                               // W_agg^T, W_r^T, W_s^T in the split: 3 x 1536 bf16x8
+    float* gl = wres + 3 * 1536 * 4;                 // the group's g_agg rows of the current propagation step; in phase P and in
+                                                     // the encoder's part of phase 0 (no gathers) two more matrices instead
+    float* w1 = gl + KMB_ROWS_MAX * KMB_ROWS_LD;     // particle encoder layer 0, forward pack (K = 8, fp32)
+    float* rows_pr = w1 + 512;                       // b_pr0 [64], w_pr1 [3][64]
+    float* rows_pe = rows_pr + 256;                  // encoder layer-0 columns 0..2
+    const bf16x8* wagg = reinterpret_cast<const bf16x8*>(wres);
+    const bf16x8* wr = wagg + 1536;
+    const bf16x8* ws = wr + 1536;
+    const bf16x8* wx0 = reinterpret_cast<const bf16x8*>(gl);
+    const bf16x8* wx1 = wx0 + 1536;
+    lds_fill(wres, reinterpret_cast<const float*>(sb6) + (size_t)SB6_AGG * 4, 3 * 1536 * 4);      // SB6_AGG, _RPR, _RPS consecutive
     lds_fill(w1, mw + M_PE0, 512);
     lds_fill(rows_pr, mw + R_PR0_B, 256);
     lds_fill(rows_pe, mb + RB_PE0, 192);
@@ -646,11 +632,11 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * gps, nbw = min(gps, B - b0);
         const int grp_rows = nbw * N;
-        __syncthreads();                                   // the group before is through with the swap region and with gl
+        __syncthreads();                                   // the group before is through with gl (the encoder's matrices)
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));                      // the fills' per-thread addresses are recomputed per group, not kept (spilled) across it
-        lds_fill(swp0, mw + M_PR0, 4096, tid);
-        lds_fill(swp1, mb + MB_PR0, 4096, tid);
+        lds_fill(gl, reinterpret_cast<const float*>(sw6) + (size_t)S6_PR0 * 4, 1536 * 4, tid);                 // predictor layer 0, forward
+        lds_fill(gl + 1536 * 4, reinterpret_cast<const float*>(sb6) + (size_t)SB6_PR0 * 4, 1536 * 4, tid);    // ... transposed
         __syncthreads();
         const bool active = wave * 32 < grp_rows;          // wave-uniform
         const bool live = (wave * 32 + j) < grp_rows;
@@ -666,19 +652,16 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
         const int p0 = ro[i];
         const int nrev = live ? ro[i + 1] - p0 : 0;
         const int* rv = rev + srow0 * DRP_K + p0;
-        int cmax = cnt, lmax = nrev;
+        int lmax = nrev;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            cmax = max(cmax, __shfl_xor(cmax, o, 64));
-            lmax = max(lmax, __shfl_xor(lmax, o, 64));
-        }
+        for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o, 64));
         Frag ge, gc, ga;
         // ---- phase P: predictor backward + update of the last propagation step
         if (active) {
             Frag x, hh, gh;
             frag_from_row(eff_hist + 3 * bn64 + row * 64, h, x);
             frag_from_row(rows_pr, h, hh);
-            mfma_layer64<false>(reinterpret_cast<const float4*>(swp0), x, hh, lane);
+            rows_layer(wx0, x, hh, lane);
             const float* go = g_out + (size_t)b * g_stride + (size_t)i * 3;
             const float g0 = go[0], g1 = go[1], g2 = go[2];
             {
@@ -695,7 +678,7 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                     }
             }
             frag_zero(ge);
-            mfma_layer64<false>(reinterpret_cast<const float4*>(swp1), gh, ge, lane);
+            rows_layer(wx1, gh, ge, lane);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 ge.v[0][q] = x.v[0][q] > 0.0f ? ge.v[0][q] : 0.0f;
@@ -703,16 +686,14 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
             }
             gc = ge;
             frag_zero(ga);
-            mfma_layer64<false>(reinterpret_cast<const float4*>(wagg), ge, ga, lane);
-            if (live) {
-                gagg_lds_write(gl, r, h, ga);
-                if (g_agg_hist != nullptr) frag_to_row(g_agg_hist + 2 * bn64 + row * 64, h, ga);
-            }
+            rows_layer(wagg, ge, ga, lane);
+            if (live && g_agg_hist != nullptr) frag_to_row(g_agg_hist + 2 * bn64 + row * 64, h, ga);
         }
-        __syncthreads();                                   // g_agg of step 2 is in LDS; nobody reads the predictor's matrices any more
-        asm volatile("" : "+v"(tid));
-        lds_fill(swp0, mb + MB_PPE, 2 * 4096, tid);        // MB_PPE, MB_PE2 consecutive: read in phase 0, two barriers from here
+        __syncthreads();                                   // nobody reads the predictor's matrices any more: gl becomes rows
+        if (active && live) gagg_lds_write(gl, r, h, ga);
+        __syncthreads();
         // ---- phases p = 2, 1, 0
+        unsigned en_pos = 0u;                              // [eff_hist[p] > 0] of the lane's row, of the phase that ran last
 #pragma unroll 1
         for (int p = DRP_PSTEP - 1; p >= 0; --p) {
             if (active) {
@@ -725,17 +706,17 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                 int e4 = (4 < nrev) ? rv[4] : 0, e5 = (5 < nrev) ? rv[5] : 0;
                 unsigned w0 = (0 < nrev) ? mk[(size_t)e0 * 2 + h] : 0u, w1_ = (1 < nrev) ? mk[(size_t)e1 * 2 + h] : 0u;
                 unsigned w2 = (2 < nrev) ? mk[(size_t)e2 * 2 + h] : 0u, w3 = (3 < nrev) ? mk[(size_t)e3 * 2 + h] : 0u;
-                // receiver term: the tile's own g_agg rows (registers) under the masks of the row's own slots, in slot order
+                // receiver term: the tile's own g_agg rows (registers) under the masks of the row's own slots
                 Frag pr, ps;
                 frag_zero(ps);
                 {
                     unsigned wk[DRP_K];
 #pragma unroll
                     for (int k = 0; k < DRP_K; ++k) wk[k] = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + h] : 0u;
-                    KMB_DBG_RECV(pr, ga, wk);
+                    receiver_term(pr, ga, wk);
                 }
-                mfma_layer64<false>(reinterpret_cast<const float4*>(wr), pr, ge, lane);
-                const unsigned en_pos = frag_positive_bits_any(en);      // all this phase wants of that row (requested a projection ago)
+                rows_layer(wr, pr, ge, lane);
+                en_pos = frag_positive_bits_any(en);      // all this phase wants of that row (requested a projection ago)
                 // sender term over the reversed list (ascending receiver, then slot): rows from LDS one entry ahead, in two
                 // buffers that change roles (no copies), mask words four entries ahead, list entries six
                 Frag va, vb;
@@ -754,7 +735,7 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                     } \
                     const unsigned w4 = ((q_) + 4 < nrev) ? mk[(size_t)e4 * 2 + h] : 0u; \
                     const int e6 = ((q_) + 6 < nrev) ? rv[(q_) + 6] : 0; \
-                    KMB_DBG_ADD(ps, cur_, w0); \
+                    frag_add_masked(ps, cur_, w0); \
                     w0 = w1_; w1_ = w2; w2 = w3; w3 = w4; \
                     e1 = e2; e2 = e3; e3 = e4; e4 = e5; e5 = e6; }
                 for (int q0 = 0; q0 < lmax; q0 += 2) {
@@ -763,65 +744,68 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                 }
 #undef KMB_ROWS_ENTRY
                 frag_settle(ps);
-                mfma_layer64<false>(reinterpret_cast<const float4*>(ws), ps, ge, lane);
+                rows_layer(ws, ps, ge, lane);
                 if (p > 0) {
                     // update of step p - 1: g_z = g_eff . [eff_p > 0]; g_cnode += g_z; g_agg[p-1] = W_agg^T g_z
                     frag_keep_bits(ge, en_pos);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) { gc.v[0][q] += ge.v[0][q]; gc.v[1][q] += ge.v[1][q]; }
                     frag_zero(ga);
-                    mfma_layer64<false>(reinterpret_cast<const float4*>(wagg), ge, ga, lane);
+                    rows_layer(wagg, ge, ga, lane);
                     if (live && g_agg_hist != nullptr) frag_to_row(g_agg_hist + (size_t)(p - 1) * bn64 + row * 64, h, ga);
-                } else {
-                    // particle encoder backward: g_pe = g_eff0 + W_pe^T g_cnode, through relu(W2 relu(W1 x + b1) + b2) to the impulse
-                    int q_, bm;
-                    divmod_small(b, attr_mod, 1.0f / (float)attr_mod, q_, bm);
-                    const float d = dens[bm] / DRP_DENS_SCALE;
-                    const float* sd = s_delta + row * 3;
-                    const float at = attr[(size_t)bm * N + i];
-                    float x[4];
-                    if (h == 0) { x[0] = sd[0]; x[1] = sd[2]; x[2] = d; x[3] = 0.0f; }
-                    else { x[0] = sd[1]; x[1] = at; x[2] = 1.0f; x[3] = 0.0f; }
-                    Frag h1, gh;
-                    frag_zero(h1);
-                    mfma_layer8(reinterpret_cast<const float4*>(w1), x, h1, lane);
-                    mfma_layer64<false>(reinterpret_cast<const float4*>(swp0), gc, ge, lane);
-                    frag_keep_bits(ge, en_pos);
-                    frag_zero(gh);
-                    mfma_layer64<false>(reinterpret_cast<const float4*>(swp1), ge, gh, lane);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        gh.v[0][q] = h1.v[0][q] > 0.0f ? gh.v[0][q] : 0.0f;
-                        gh.v[1][q] = h1.v[1][q] > 0.0f ? gh.v[1][q] : 0.0f;
-                    }
-                    float out[3];
-#pragma unroll
-                    for (int o = 0; o < 3; ++o) {
-                        Frag w;
-                        frag_from_row(rows_pe + 64 * o, h, w);
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) acc = fmaf(gh.v[0][q], w.v[0][q], acc);
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) acc = fmaf(gh.v[1][q], w.v[1][q], acc);
-                        out[o] = acc + __shfl_xor(acc, 32, 64);
-                    }
-                    if (live && h == 0) {
-                        g_sdelta[row * 3 + 0] = out[0];
-                        g_sdelta[row * 3 + 1] = out[1];
-                        g_sdelta[row * 3 + 2] = out[2];
-                    }
                 }
             }
+            __syncthreads();                               // every gather of this step's rows is done
             if (p > 0) {
-                __syncthreads();                           // every gather of this step's rows is done
                 if (active && live) gagg_lds_write(gl, r, h, ga);
-                __syncthreads();
+            } else {
+                asm volatile("" : "+v"(tid));
+                lds_fill(gl, reinterpret_cast<const float*>(sb6) + (size_t)SB6_PPE * 4, 2 * 1536 * 4, tid);   // SB6_PPE, SB6_PE2 consecutive
+            }
+            __syncthreads();
+        }
+        if (active) {
+            // particle encoder backward: g_pe = g_eff0 + W_pe^T g_cnode, through relu(W2 relu(W1 x + b1) + b2) to the impulse
+            int q_, bm;
+            divmod_small(b, attr_mod, 1.0f / (float)attr_mod, q_, bm);
+            const float d = dens[bm] / DRP_DENS_SCALE;
+            const float* sd = s_delta + row * 3;
+            const float at = attr[(size_t)bm * N + i];
+            float x[4];
+            if (h == 0) { x[0] = sd[0]; x[1] = sd[2]; x[2] = d; x[3] = 0.0f; }
+            else { x[0] = sd[1]; x[1] = at; x[2] = 1.0f; x[3] = 0.0f; }
+            Frag h1, gh;
+            frag_zero(h1);
+            mfma_layer8(reinterpret_cast<const float4*>(w1), x, h1, lane);
+            rows_layer(wx0, gc, ge, lane);
+            frag_keep_bits(ge, en_pos);                    // phase 0 read eff_hist[0]: the effects after the encoder
+            frag_zero(gh);
+            rows_layer(wx1, ge, gh, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                gh.v[0][q] = h1.v[0][q] > 0.0f ? gh.v[0][q] : 0.0f;
+                gh.v[1][q] = h1.v[1][q] > 0.0f ? gh.v[1][q] : 0.0f;
+            }
+            float out[3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                Frag w;
+                frag_from_row(rows_pe + 64 * o, h, w);
+                float acc = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = fmaf(gh.v[0][q], w.v[0][q], acc);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = fmaf(gh.v[1][q], w.v[1][q], acc);
+                out[o] = acc + __shfl_xor(acc, 32, 64);
+            }
+            if (live && h == 0) {
+                g_sdelta[row * 3 + 0] = out[0];
+                g_sdelta[row * 3 + 1] = out[1];
+                g_sdelta[row * 3 + 2] = out[2];
             }
         }
     }
 }
-
 
 // ---- relation encoder backward on the matrix cores (horizons > 1 of the GD planner, training) -------------------
 // What kb_edge_encode (k_backward.h) computes per edge slot, as the forward chain of km_edge_encode run both ways on

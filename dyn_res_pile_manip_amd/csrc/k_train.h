@@ -468,6 +468,37 @@ kt_repack_split(const float* __restrict__ w, int shift, uint16_t* __restrict__ o
     out[(size_t)(dst + ((1 * 2 + ob) * 4 + s) * 64 + lane) * 8 + jj] = dev_f16_rne(v - hi);
 }
 
+// The TRANSPOSED 64 x 64 layers of the backward pass in the six-product bf16 split (kmb_rows_bwd): the layout of
+// pack_split6 with A[i][k] = W[k][col0 + i].  Packed on the device only, from the raw blob, at load time and after every
+// optimiser step: grid.x = 6 jobs (AGG, RPR, RPS, PR0, PPE, PE2) x 16 blocks.
+enum {                        // units of bf16x8, [part 3][ob 2][s 4][lane 64] each
+    SB6_AGG = 0,
+    SB6_RPR = SB6_AGG + 1536,
+    SB6_RPS = SB6_RPR + 1536,
+    SB6_PR0 = SB6_RPS + 1536,
+    SB6_PPE = SB6_PR0 + 1536,
+    SB6_PE2 = SB6_PPE + 1536,
+    SB6_TOTAL = SB6_PE2 + 1536
+};
+__global__ void __launch_bounds__(256)
+kt_repack_split6_bwd(const float* __restrict__ w, uint16_t* __restrict__ out) {
+    const int job = blockIdx.x >> 4, e = (blockIdx.x & 15) * 256 + threadIdx.x;
+    const int dsts[6] = {SB6_AGG, SB6_RPR, SB6_RPS, SB6_PR0, SB6_PPE, SB6_PE2};
+    const int srcs[6] = {W_PP_W, W_RP_W, W_RP_W, W_PR0_W, W_PP_W, W_PE2_W};
+    const int lds_[6] = {129, 193, 193, 64, 129, 64};
+    const int cols[6] = {64, 64, 128, 0, 0, 0};
+    const int dst = dsts[job], src = srcs[job], ld = lds_[job], col0 = cols[job];
+    const int jj = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 3, ob = e >> 11;
+    const int i = lane & 31, h = lane >> 5;
+    float v = w[src + dev_split_feature(s, h, jj) * ld + col0 + 32 * ob + i];
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        const uint16_t q = dev_bf16_rne(v);
+        out[((size_t)dst + ((part * 2 + ob) * 4 + s) * 64 + lane) * 8 + jj] = q;
+        v -= dev_bf16_to_f32(q);
+    }
+}
+
 // pack_split6 on the device: grid.x = 7 jobs (AGG, RPR, RPS, PR0, PE2, PPE, PE0) x 16 blocks
 __global__ void __launch_bounds__(256)
 kt_repack_split6(const float* __restrict__ w, uint16_t* __restrict__ out) {

@@ -234,10 +234,11 @@ def test_fused_backward_equals_the_stage_kernels_for_small_piles_and_batches(mon
 
 @pytest.mark.parametrize('N,B,H', [(12, 1500, 1), (20, 1500, 1), (50, 300, 1), (100, 750, 1), (100, 7, 2), (64, 300, 2),
                                    (256, 40, 1), (5, 260, 2), (33, 257, 1)])
-def test_rows_kept_in_registers_give_the_bits_of_the_rows_through_memory(monkeypatch, N, B, H):
+def test_rows_kept_in_registers_against_the_rows_through_memory(monkeypatch, N, B, H):
     """kmb_rows_bwd (piles of up to 256 particles: a wave keeps g_eff, g_cnode and its own g_agg rows in registers through
-    all phases, the group's g_agg rows in LDS) against kmb_step_bwd (DRP_NO_BWD_ROWS=1: every row through memory per
-    phase): the same sums in the same order -- rewards, push gradients and state gradients bit for bit; horizon 2 also
+    all phases, the group's g_agg rows in LDS, the 64 x 64 layers on the six-product bf16 split) against kmb_step_bwd
+    (DRP_NO_BWD_ROWS=1: every row through memory per phase, fp32 MFMA): the same masked sums in the same order, the
+    layers to fp32 rounding -- rewards bit for bit, push and state gradients to 5e-5 of their scale (seen: 1e-6, 8e-6 at 100 particles); horizon 2 also
     covers the g_agg rows the relation encoder's backward reads from memory."""
     from dyn_res_pile_manip_amd.engine import Engine
     from dyn_res_pile_manip_amd import weights
@@ -259,9 +260,12 @@ def test_rows_kept_in_registers_give_the_bits_of_the_rows_through_memory(monkeyp
         eng.gd_begin(s0, attr, dens, acts, 0.05, lo, hi)
         res[rows] = eng.gd_grad(want_state_grad=True)
         eng.close()
-    assert np.abs(res[True][1]).max() > 0 and np.isfinite(res[True][1]).all()
-    for a, b in zip(res[True], res[False]):
-        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        scale = np.abs(b).max()
+        assert scale > 0 and np.isfinite(a).all()
+        print('N=%d B=%d H=%d: max deviation %.2e of the scale' % (N, B, H, np.abs(a - b).max() / scale))
+        assert np.abs(a - b).max() < 5e-5 * scale
 
 
 def test_pipelined_iterations_equal_the_blocking_ones(ctx, golden):

@@ -1,7 +1,7 @@
 # kernel trace of the GD planner's iteration at small piles: kernel time per iteration against the wall time
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for n in 20 50; do
+for n in ${GD_NS:-20 50}; do
 rm -rf gpurun_out/prof_gd_$n
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_gd_$n -- python3 tools/gd_timing.py $n > gpurun_out/prof_gd_$n.log 2>&1
 tail -1 gpurun_out/prof_gd_$n.log
