@@ -3303,6 +3303,18 @@ extern "C" int drp_debug_roll_stamps(unsigned long long* out16, int reset) {
 }
 #endif
 
+#ifdef ROLLOUT_STAMPS
+extern "C" int drp_debug_bwd_stamps(unsigned long long* out16, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bwd_stamps), 16 * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 #ifdef GC_STATS
 extern "C" int drp_gc_stats(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gc_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;

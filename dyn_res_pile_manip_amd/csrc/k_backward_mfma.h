@@ -591,6 +591,15 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
 #define KMB_ROWS_LD 68            // floats per g_agg row in LDS: 17 float4 -- consecutive rows start four banks apart
 __device__ __forceinline__ void gagg_lds_read(const float* gl, int r, int h, Frag& f) { frag_from_row(gl + r * KMB_ROWS_LD, h, f); }
 __device__ __forceinline__ void gagg_lds_write(float* gl, int r, int h, const Frag& f) { frag_to_row(gl + r * KMB_ROWS_LD, h, f); }
+#ifdef ROLLOUT_STAMPS
+// Diagnostic build only (tools/bwd_stamps.py): 100 MHz wall stamps between the phases of a group, summed by wave 0 of
+// every 32nd workgroup
+__device__ unsigned long long g_bwd_stamps[16];
+#define BWD_STAMP(q) do { if (roll_on) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+                                         atomicAdd(&g_bwd_stamps[q], now_ - roll_t); roll_t = now_; } } while (0)
+#else
+#define BWD_STAMP(q) do { } while (0)
+#endif
 // one 64 x 64 layer on the six-product bf16 split: acc += W in, W packed as pack_split6 / kt_repack_split6_bwd
 __device__ __forceinline__ void rows_layer(const bf16x8* __restrict__ wp, const Frag& in, Frag& acc, int lane) {
     FragB6 b;
@@ -628,6 +637,10 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb, const u
     const size_t bn64 = (size_t)B * N * 64;
     const size_t bnk2 = (size_t)B * N * DRP_K * 2;
     const int n_groups = (B + gps - 1) / gps;
+#ifdef ROLLOUT_STAMPS
+    const bool roll_on = threadIdx.x == 0 && (blockIdx.x & 31) == 0;
+    unsigned long long roll_t = roll_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
 #pragma unroll 1
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * gps, nbw = min(gps, B - b0);
@@ -638,6 +651,7 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb, const u
         lds_fill(gl, reinterpret_cast<const float*>(sw6) + (size_t)S6_PR0 * 4, 1536 * 4, tid);                 // predictor layer 0, forward
         lds_fill(gl + 1536 * 4, reinterpret_cast<const float*>(sb6) + (size_t)SB6_PR0 * 4, 1536 * 4, tid);    // ... transposed
         __syncthreads();
+        BWD_STAMP(0);
         const bool active = wave * 32 < grp_rows;          // wave-uniform
         const bool live = (wave * 32 + j) < grp_rows;
         const int r = min(wave * 32 + j, grp_rows - 1);
@@ -689,9 +703,11 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb, const u
             rows_layer(wagg, ge, ga, lane);
             if (live && g_agg_hist != nullptr) frag_to_row(g_agg_hist + 2 * bn64 + row * 64, h, ga);
         }
+        BWD_STAMP(1);
         __syncthreads();                                   // nobody reads the predictor's matrices any more: gl becomes rows
         if (active && live) gagg_lds_write(gl, r, h, ga);
         __syncthreads();
+        BWD_STAMP(2);
         // ---- phases p = 2, 1, 0
         unsigned en_pos = 0u;                              // [eff_hist[p] > 0] of the lane's row, of the phase that ran last
 #pragma unroll 1
@@ -716,6 +732,7 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb, const u
                     receiver_term(pr, ga, wk);
                 }
                 rows_layer(wr, pr, ge, lane);
+                BWD_STAMP(3);
                 en_pos = frag_positive_bits_any(en);      // all this phase wants of that row (requested a projection ago)
                 // sender term over the reversed list (ascending receiver, then slot): rows from LDS one entry ahead, in two
                 // buffers that change roles (no copies), mask words four entries ahead, list entries six
@@ -744,6 +761,7 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb, const u
                 }
 #undef KMB_ROWS_ENTRY
                 frag_settle(ps);
+                BWD_STAMP(4);
                 rows_layer(ws, ps, ge, lane);
                 if (p > 0) {
                     // update of step p - 1: g_z = g_eff . [eff_p > 0]; g_cnode += g_z; g_agg[p-1] = W_agg^T g_z
@@ -755,6 +773,7 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb, const u
                     if (live && g_agg_hist != nullptr) frag_to_row(g_agg_hist + (size_t)(p - 1) * bn64 + row * 64, h, ga);
                 }
             }
+            BWD_STAMP(5);
             __syncthreads();                               // every gather of this step's rows is done
             if (p > 0) {
                 if (active && live) gagg_lds_write(gl, r, h, ga);
@@ -763,6 +782,7 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb, const u
                 lds_fill(gl, reinterpret_cast<const float*>(sb6) + (size_t)SB6_PPE * 4, 2 * 1536 * 4, tid);   // SB6_PPE, SB6_PE2 consecutive
             }
             __syncthreads();
+            BWD_STAMP(6);
         }
         if (active) {
             // particle encoder backward: g_pe = g_eff0 + W_pe^T g_cnode, through relu(W2 relu(W1 x + b1) + b2) to the impulse
@@ -804,6 +824,10 @@ kmb_rows_bwd(const float* __restrict__ mw, const float* __restrict__ mb, const u
                 g_sdelta[row * 3 + 2] = out[2];
             }
         }
+        BWD_STAMP(7);
+#ifdef ROLLOUT_STAMPS
+        if (roll_on) atomicAdd(&g_bwd_stamps[15], 1ull);
+#endif
     }
 }
 

@@ -518,13 +518,21 @@ k_cself(const float* __restrict__ vw, const float* __restrict__ attr, int attr_m
 // trainer's backward pass want it (k_backward.h): two 32-bit words per edge slot, word h = the
 // half-wave that holds the features, bit 31 - (16*ob + r) <-> accumulator register r of output
 // block ob, i.e. feature 32*ob + (r&3) + 8*(r>>2) + 4*h.
+// m <- (m << 1) | [t > 0] for a relu'd t (> 0 <=> its bits != 0 <=> 0 - bits is negative): a subtraction and one
+// v_alignbit_b32 ({m, s} >> 31).  Written in C (shift, or, compare) the compiler makes a compare, a select through an SGPR
+// pair, a shift and an OR of it -- six issue slots per element with the s_nops between them, a fifth of the tape-writing
+// kernel's slot loop.  (The word only ever goes to a store: no matrix instruction reads what these statements write.)
+__device__ __forceinline__ unsigned push_positive_bit(unsigned m, float t) {
+    unsigned s;
+    asm("v_sub_u32 %1, 0, %2\n\tv_alignbit_b32 %0, %0, %1, 31" : "+v"(m), "=&v"(s) : "v"(t));
+    return m;
+}
 __device__ __forceinline__ unsigned frag_positive_bits(const Frag& f) {
     unsigned m = 0;
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            m = (m << 1) | ((unsigned)(0 - __float_as_int(f.v[ob][r])) >> 31);   // values are relu'd: > 0 <=> bits != 0
+        for (int r = 0; r < 16; ++r) m = push_positive_bit(m, f.v[ob][r]);
     return m;
 }
 
@@ -875,7 +883,7 @@ __device__ __forceinline__ void prop_tiles(const PropArgs& A, const PropLds& L, 
                         const float t = relu1(fmaf(qv[e], inv, bpr.v[ob][r] + sv[e]));
                         acc.v[ob][r] += t;
                         if (PAIR) acc.v[ob][r] += dpp_ror8(t);
-                        if (TAPE) mbits = (mbits << 1) | ((unsigned)(0 - __float_as_int(t)) >> 31);
+                        if (TAPE) mbits = push_positive_bit(mbits, t);
                     }
                 }
                 if (TAPE && ob == 1 && live_row && (!PAIR || k < DRP_K)) mask_out[(row * DRP_K + k) * 2 + h] = mbits;
