@@ -60,7 +60,7 @@ __device__ __forceinline__ KbRange kb_range(int N, int chunks) {
 __global__ void __launch_bounds__(256)
 kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float* __restrict__ G, int Hh, int Ww,
           const float* __restrict__ goal_coor, int M, DrpCam cam, int normalize, float* __restrict__ g_state,
-          size_t g_stride, float* __restrict__ reward_out) {
+          size_t g_stride, float* __restrict__ reward_out, float* __restrict__ reward_copy = nullptr /* pinned host memory */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* px = lds;
     float* py = lds + N;
@@ -144,6 +144,7 @@ kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float
             float r = t1 + t2;
             if (normalize) r = __fdiv_rn(r, (float)N);
             reward_out[blockIdx.x] = -r;
+            if (reward_copy != nullptr) reward_copy[blockIdx.x] = -r;
         }
     }
 }
@@ -746,7 +747,7 @@ kb_gather_pos(const float* __restrict__ gpos_edge, const int* __restrict__ rev_o
 //      planners.py:674, :743-746, :756-764
 __global__ void k_adam(float* __restrict__ act, const float* __restrict__ grad, float* __restrict__ m,
                        float* __restrict__ v, int n, float step_size, float bc2_sqrt, float4 lo, float4 hi,
-                       float b1 = 0.9f) {
+                       float b1 = 0.9f, float* __restrict__ act_copy = nullptr /* pinned host memory: the updated values once more */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float b2 = 0.999f, eps = 1e-8f;
@@ -760,5 +761,7 @@ __global__ void k_adam(float* __restrict__ act, const float* __restrict__ grad, 
     const int c = i & 3;
     const float l = (c == 0) ? lo.x : (c == 1) ? lo.y : (c == 2) ? lo.z : lo.w;
     const float h = (c == 0) ? hi.x : (c == 1) ? hi.y : (c == 2) ? hi.z : hi.w;
-    act[i] = fminf(fmaxf(a, l), h);
+    a = fminf(fmaxf(a, l), h);
+    act[i] = a;
+    if (act_copy != nullptr) act_copy[i] = a;
 }

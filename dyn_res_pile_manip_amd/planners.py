@@ -27,6 +27,10 @@ def particle_num_to_iter_time(particle_num):
     return max(int(t), 1)
 
 
+GD_SLOTS = 8        # include/drp.h DRP_GD_SLOTS: result slots of drp_gd_step_async
+GD_AHEAD = 3        # iterations enqueued ahead of the one the host waits for (< GD_SLOTS)
+
+
 def gd_iteration_count(n_update_iter, time_lim_ms, particle_num):
     """planners.py:590,679-682: the GD loop runs min(n_update_iter, int(time_lim / model)) iterations,
     the budget in ms divided by the fitted per-iteration time -- a function of the arguments only (the
@@ -358,19 +362,20 @@ class PlannerGD(Planner):
             eng.gd_begin(state_cur_np, attr_cur_np, state_param, cand, cfg['gd']['lr'], lo, hi)   # [traj*nb,H,4]
             reward_seqs = np.zeros((cand.shape[0],), np.float32)
             act_seqs_last = cand
-            # Iteration i + 1 is enqueued before the host waits for iteration i (its rewards and updated pushes arrive in
-            # pinned memory behind its kernels): the bookkeeping below runs beside the device.  With the opt-in wall-clock
-            # break the loop may stop after any iteration, so nothing is enqueued ahead there.
+            # Iterations i + 1 .. i + GD_AHEAD are enqueued before the host waits for iteration i (the iteration's own kernels
+            # write its rewards and updated pushes to pinned memory): the bookkeeping below runs beside the device, and a slow
+            # turn of it does not leave the device idle.  With the opt-in wall-clock break the loop may stop after any
+            # iteration, so nothing is enqueued ahead there.
             ahead = not wallclock_limit
             t0 = time.perf_counter()
-            if ahead:
-                eng.gd_step_async(0)
+            enqueued = 0
             for i in range(n_iter):
                 before = act_seqs_last
                 if ahead:
-                    if i + 1 < n_iter:
-                        eng.gd_step_async((i + 1) & 1)
-                    reward_seqs, act_seqs_last = eng.gd_wait(i & 1)
+                    while enqueued < n_iter and enqueued <= i + GD_AHEAD:
+                        eng.gd_step_async(enqueued % GD_SLOTS)
+                        enqueued += 1
+                    reward_seqs, act_seqs_last = eng.gd_wait(i % GD_SLOTS)
                 else:
                     reward_seqs = eng.gd_step()
                     act_seqs_last = eng.gd_actions()

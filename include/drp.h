@@ -285,11 +285,13 @@ int drp_gd_grad(drp_ctx* ctx, float* rewards_out, float* grad_act_out, float* gr
 /* one full iteration (forward, backward, Adam, clip); rewards of the iterate BEFORE the update */
 int drp_gd_step(drp_ctx* ctx, float* rewards_out);
 int drp_gd_get(drp_ctx* ctx, float* actions_out);
-/* The same iteration without a host wait: slot (0 or 1) takes the iteration's rewards (of the iterate before the
- * update) and the updated pushes into pinned memory behind the kernels; drp_gd_wait(slot) blocks until they are there and
- * copies them out (each pointer nullable).  The planner's loop enqueues iteration i + 1 before it waits for iteration i,
- * so the per-iteration bookkeeping of planners.py:721-738 runs beside the device instead of between its iterations.
+/* The same iteration without a host wait: slot (0 .. DRP_GD_SLOTS - 1) takes the iteration's rewards (of the iterate
+ * before the update) and the updated pushes in pinned memory, written by the iteration's own kernels (no copy on the
+ * stream); drp_gd_wait(slot) blocks until they are there and copies them out (each pointer nullable).  The planner's loop
+ * keeps a few iterations enqueued ahead of the one it waits for, so the per-iteration bookkeeping of planners.py:721-738
+ * runs beside the device instead of between its iterations.
  * A slot must be waited for before it is used again; drp_gd_begin and the one-shot calls drop what is in flight. */
+#define DRP_GD_SLOTS 8
 int drp_gd_step_async(drp_ctx* ctx, int slot);
 int drp_gd_wait(drp_ctx* ctx, int slot, float* rewards_out, float* actions_out);
 

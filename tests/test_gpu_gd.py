@@ -295,3 +295,14 @@ def test_pipelined_iterations_equal_the_blocking_ones(ctx, golden):
         np.testing.assert_array_equal(a, want[i][1])
     with pytest.raises(_lib.DrpError):
         ctx.gd_wait(0)
+    # all five enqueued before the first wait (the planner keeps three ahead): the iterations' own kernels write the
+    # eight pinned slots, no copy sits between two iterations on the stream
+    ctx.gd_begin(*args)
+    for i in range(5):
+        ctx.gd_step_async(3 + i)
+    with pytest.raises(_lib.DrpError):
+        ctx.gd_step_async(8)
+    for i in range(5):
+        r, a = ctx.gd_wait(3 + i)
+        np.testing.assert_array_equal(r, want[i][0])
+        np.testing.assert_array_equal(a, want[i][1])
