@@ -176,6 +176,7 @@ struct drp_ctx {
     bool graph_strips = true;       // DRP_NO_GRAPH_STRIPS=1: plain neighbour sweep for every shape
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
     bool bwd_fused = true;          // DRP_NO_BWD_FUSED=1: the GD planner's backward pass as one launch per stage
+    bool graph_rev = true;          // DRP_NO_GRAPH_REV=1: the GD planner's reversed lists always in a launch of their own (kb_reverse_lists)
     bool bwd_rows = true;           // DRP_NO_BWD_ROWS=1: piles of up to 256 particles through kmb_step_bwd (rows through memory) instead of kmb_rows_bwd
     bool prop3_order = true;        // false: km_prop3's tiles in the natural row order instead of by in-degree
     int prop_pair_rows = 128;       // DRP_PROP_PAIR_ROWS: a workgroup of the whole-sample kernels with up to so many rows runs tiles of
@@ -260,6 +261,7 @@ struct drp_ctx {
     hipEvent_t gd_ev[DRP_GD_SLOTS] = {};
     float* gd_host_rewards = nullptr;        // where the iteration being enqueued writes them (null: device buffers only)
     float* gd_host_actions = nullptr;
+    KbAdam gd_adam = KbAdam{};               // gd_iteration: the optimiser step rides on the last kb_sdelta launch (act == null: gradients only)
     bool gd_pending[DRP_GD_SLOTS] = {};
     float* mpc_pin[2] = {nullptr, nullptr};  // drp_mpc_fetch_async: [B*H*4 pushes | B final rewards] of two iterations in flight
     size_t mpc_pin_floats = 0;
@@ -554,6 +556,9 @@ struct StepArgs {
     const float* cself = nullptr;   // [B,64] self-edge constant + per-sample validity (fused engine, k_cself)
     const uint8_t* cself_ok = nullptr;
     bool padded = false;            // training batches: zero-padded (coincident) particles -> plain k_graph
+    int* rev_off = nullptr;         // the GD planner's forward, samples of one graph chunk: the reversed lists in the lists' own launch
+    int* rev = nullptr;             //   (k_graph_rev); run_step says in rev_built whether it did
+    bool* rev_built = nullptr;
 };
 
 // km_prop3 / kmb_step_bwd (a workgroup owns whole samples and runs all propagation steps in one launch) or the
@@ -806,8 +811,16 @@ int run_step(drp_ctx* c, const StepArgs& a) {
     const float* vw = ptr<float>(c->w_valu);
     if (a.build_graph) {
         ProbeScope ps(c, KC_GRAPH);
-        launch_graph(c, st, a.s_prev, a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, B, N, nbr_idx, nbr_cnt,
-                     (c->engine == DRP_ENGINE_FUSED && a.cself != nullptr) ? 1 : 0, a.padded);
+        const int self_first = (c->engine == DRP_ENGINE_FUSED && a.cself != nullptr) ? 1 : 0;
+        if (a.rev_off != nullptr && N <= GRAPH_THREADS && c->graph_rev) {
+            hipLaunchKernelGGL(k_graph_rev, dim3(SPREAD_GRID(B)), dim3(GRAPH_THREADS), (size_t)12 * N * sizeof(int), st, a.s_prev,
+                               a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, N, nbr_idx, nbr_cnt, c->cam, c->thr,
+                               B, self_first, a.rev_off, a.rev);
+            if (a.rev_built) *a.rev_built = true;
+        } else {
+            launch_graph(c, st, a.s_prev, a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, B, N, nbr_idx, nbr_cnt,
+                         self_first, a.padded);
+        }
     }
     if (c->engine != DRP_ENGINE_VALU) {
         int rc = run_step_mfma(c, a);
@@ -1242,6 +1255,7 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_PROP_PAIR_DEG10")) c->prop_pair_deg10 = std::max(0, atoi(e));
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
     c->bwd_rows = getenv("DRP_NO_BWD_ROWS") == nullptr;
+    c->graph_rev = getenv("DRP_NO_GRAPH_REV") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
     if (const char* e = getenv("DRP_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_timeout_s = v; }
     if (const char* e = getenv("DRP_COMM_INIT_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_init_timeout_s = v; }
@@ -2264,6 +2278,7 @@ int gd_forward_backward(drp_ctx* c) {
     }
     const float* cself = c->gd_cself;
     const uint8_t* cself_ok = c->gd_cself_ok;
+    bool rev_built = false;
     for (int t = 0; t < H && rc == DRP_OK; ++t) {
         StepArgs a{};
         if (t == 0) { a.s_prev = ptr<float>(c->s_in); a.prev_mod = nb; a.prev_stride = (size_t)N * 3; }
@@ -2277,6 +2292,7 @@ int gd_forward_backward(drp_ctx* c) {
         a.eff_hist = eh + (size_t)t * 4 * bn * 64;
         a.mask_hist = mh + (size_t)t * DRP_PSTEP * bn * DRP_K * 2;
         a.cself = cself; a.cself_ok = cself_ok;
+        if (H == 1) { a.rev_off = ptr<int>(c->rev_off); a.rev = ptr<int>(c->rev); a.rev_built = &rev_built; }   // one set of reversed lists: the only step's
         // the step's impulses and neighbour lists are part of the tape: the step writes them there (its
         // workspace pointers are lent the tape's slices for the call) instead of being copied afterwards
         void* const save_sd = c->s_delta.p; void* const save_idx = c->nbr_idx.p; void* const save_cnt = c->nbr_cnt.p;
@@ -2309,7 +2325,7 @@ int gd_forward_backward(drp_ctx* c) {
         const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         float* g_out = g_state + (size_t)t * bn * 3;
         float* gah = ptr<float>(c->g_agg_hist);
-        {
+        if (!rev_built) {
             ProbeScope ps(c, KC_BWD_LISTS);
             if (N <= 512)
                 hipLaunchKernelGGL(kb_reverse_lists<256>, dim3(B), dim3(256), KB_REV_LDS(N, rev_lds), st, idx,
@@ -2433,7 +2449,7 @@ int gd_forward_backward(drp_ctx* c) {
         { ProbeScope ps(c, KC_BWD_PUSH);
         hipLaunchKernelGGL(kb_sdelta, dim3(B), dim3(256), 0, st, s_prev, prev_mod, prev_stride,
                            ptr<float>(c->actions) + (size_t)t * 4, (size_t)H * 4, ptr<float>(c->g_sdelta), N, c->cam,
-                           ptr<float>(c->g_act) + (size_t)t * 4, (size_t)H * 4, g_prev, (size_t)N * 3);
+                           ptr<float>(c->g_act) + (size_t)t * 4, (size_t)H * 4, g_prev, (size_t)N * 3, t == 0 ? c->gd_adam : KbAdam{});
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -2514,19 +2530,23 @@ int drp_gd_grad(drp_ctx* c, float* rewards_out, float* grad_act_out, float* grad
 }
 
 namespace {
-// one iteration on the stream: forward, backward, Adam, clip
+// one iteration on the stream: forward, backward, Adam, clip -- the optimiser step of a row in the kb_sdelta launch that
+// completes the row's gradient (rollout step 0's, the last of the backward pass): one launch fewer per iteration
 int gd_iteration(drp_ctx* c) {
-    CHK(gd_forward_backward(c));
-    c->gd_iter += 1;
     // torch.optim.Adam: step_size = lr / (1 - beta1^t), denom = sqrt(v) / sqrt(1 - beta2^t) + eps
-    const double bc1 = 1.0 - pow(0.9, (double)c->gd_iter), bc2 = 1.0 - pow(0.999, (double)c->gd_iter);
-    const int n = c->gd_B * c->gd_H * 4;
-    { ProbeScope ps(c, KC_OPT);
-    hipLaunchKernelGGL(k_adam, dim3((n + 255) / 256), dim3(256), 0, c->stream, ptr<float>(c->actions),
-                       ptr<float>(c->g_act), ptr<float>(c->adam_m), ptr<float>(c->adam_v), n, (float)(c->gd_lr / bc1),
-                       (float)sqrt(bc2), make_float4(c->gd_lo[0], c->gd_lo[1], c->gd_lo[2], c->gd_lo[3]),
-                       make_float4(c->gd_hi[0], c->gd_hi[1], c->gd_hi[2], c->gd_hi[3]), 0.9f, c->gd_host_actions);
-    }
+    const double it = (double)(c->gd_iter + 1);
+    const double bc1 = 1.0 - pow(0.9, it), bc2 = 1.0 - pow(0.999, it);
+    KbAdam a{};
+    a.act = ptr<float>(c->actions); a.m = ptr<float>(c->adam_m); a.v = ptr<float>(c->adam_v); a.act_copy = c->gd_host_actions;
+    a.n_row = c->gd_H * 4;
+    a.step_size = (float)(c->gd_lr / bc1); a.bc2_sqrt = (float)sqrt(bc2); a.b1 = 0.9f;
+    a.lo = make_float4(c->gd_lo[0], c->gd_lo[1], c->gd_lo[2], c->gd_lo[3]);
+    a.hi = make_float4(c->gd_hi[0], c->gd_hi[1], c->gd_hi[2], c->gd_hi[3]);
+    c->gd_adam = a;
+    const int rc = gd_forward_backward(c);
+    c->gd_adam = KbAdam{};
+    CHK(rc);
+    c->gd_iter += 1;
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
@@ -3280,6 +3300,8 @@ long drp_debug_fetch(drp_ctx* c, const char* name, void* out, size_t out_bytes) 
     else if (!strcmp(name, "w_split")) { b = &c->w_split; bytes = (size_t)S_ALLOC * 16; }
     else if (!strcmp(name, "w_split6")) { b = &c->w_split6; bytes = (size_t)S6_TOTAL * 16; }
     else if (!strcmp(name, "w_split6_bwd")) { b = &c->w_split6_bwd; bytes = (size_t)SB6_TOTAL * 16; }
+    else if (!strcmp(name, "rev_off")) { b = &c->rev_off; bytes = (size_t)c->lastB * (c->lastN + 1) * 4; }
+    else if (!strcmp(name, "rev")) { b = &c->rev; bytes = bn * DRP_K * 4; }
     else return fail(c, DRP_EINVAL, "unknown buffer '%s'", name);
     // a GD session keeps every step's impulses and lists in its tape, not in the step workspace: the last step's
     DevBuf tape{};

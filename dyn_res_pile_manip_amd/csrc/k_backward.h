@@ -240,69 +240,10 @@ kb_reverse_lists(const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict_
                                                    gradient is identically zero (training batches) */,
                  int n_real_mod = 0 /* > 0: the grid runs over several rollout steps' lists, sample = block % n_real_mod */) {
     extern __shared__ int s_rev[];
-    __shared__ int s_w[T / 64];
-    int* deg = s_rev;
-    int* off = s_rev + N;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int16_t* nb = nbr_idx + (size_t)b * N * DRP_K;
-    const uint8_t* nc = nbr_cnt + (size_t)b * N;
-    int* ro = rev_off + (size_t)b * (N + 1);
-    int* rv = rev + (size_t)b * N * DRP_K;
-    int* fill = in_lds ? s_rev + 2 * N : rv;
+    const int b = blockIdx.x;
     const int n_recv = n_real ? n_real[n_real_mod > 0 ? b % n_real_mod : b] : N;
-    for (int i = tid; i < N; i += T) deg[i] = 0;
-    __syncthreads();
-    for (int e = tid; e < N * DRP_K; e += T) {
-        const int i = e / DRP_K, k = e - i * DRP_K;
-        if (k < nc[i] && i < n_recv) atomicAdd(&deg[nb[e]], 1);
-    }
-    __syncthreads();
-    // exclusive scan of deg: every thread owns a contiguous segment
-    const int seg = (N + T - 1) / T;
-    const int lo = min(tid * seg, N), hi = min(lo + seg, N);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += deg[i];
-    int inc = sum;
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    int base = inc - sum, total = 0;
-    for (int w = 0; w < T / 64; ++w) {
-        if (w < wave) base += s_w[w];
-        total += s_w[w];
-    }
-    for (int i = lo; i < hi; ++i) { off[i] = base; base += deg[i]; }
-    __syncthreads();
-    for (int i = tid; i < N; i += T) { ro[i] = off[i]; deg[i] = 0; }
-    if (tid == 0) ro[N] = total;
-    __syncthreads();
-    for (int e = tid; e < N * DRP_K; e += T) {
-        const int i = e / DRP_K, k = e - i * DRP_K;
-        if (k < nc[i] && i < n_recv) {
-            const int j = nb[e];
-            fill[off[j] + atomicAdd(&deg[j], 1)] = e;
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j < N; j += T) {  // fixed order inside every sender's list
-        int* seg_j = fill + off[j];
-        const int n = deg[j];
-        for (int a = 1; a < n; ++a) {
-            const int v = seg_j[a];
-            int c = a - 1;
-            while (c >= 0 && seg_j[c] > v) { seg_j[c + 1] = seg_j[c]; --c; }
-            seg_j[c + 1] = v;
-        }
-    }
-    if (in_lds) {
-        __syncthreads();
-        for (int p = tid; p < total; p += T) rv[p] = fill[p];
-    }
+    reverse_lists<T>(nbr_idx + (size_t)b * N * DRP_K, nbr_cnt + (size_t)b * N, N, rev_off + (size_t)b * (N + 1),
+                     rev + (size_t)b * N * DRP_K, in_lds, n_recv, s_rev);
 }
 
 // ---- aggregate backward.  The gradient of an edge's pre-activation is the receiver's g_agg row
@@ -498,12 +439,32 @@ template <int ND> __device__ __forceinline__ Dual<ND> dsqrt(const Dual<ND>& a) {
     return r;
 }
 
+// ---- Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8) + the clip box ------------
+//      planners.py:674, :743-746, :756-764
+struct KbAdam {                 // the optimiser step of a row's pushes at the end of kb_sdelta (act == null: not in this launch)
+    float* act; float* m; float* v; float* act_copy /* nullable: pinned host memory */;
+    int n_row;                  // values per row: H * 4
+    float step_size, bc2_sqrt, b1;
+    float4 lo, hi;
+};
+__device__ __forceinline__ float adam_update(float a0, float g, float& m, float& v, float step_size, float bc2_sqrt, float b1,
+                                             float l, float h) {
+    const float b2 = 0.999f, eps = 1e-8f;
+    const float mi = m + (g - m) * (1.0f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v * b2 + (1.0f - b2) * g * g;
+    m = mi;
+    v = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float a = a0 - step_size * (mi / denom);
+    return fminf(fmaxf(a, l), h);
+}
+
 // directions 0..3: the push (sx, sy, ex, ey); 4..6: the particle's own position (x, y, z).
 // g_action[b, 0:4] = sum_n J_n^T g_s_delta[n];  g_pos[b, n, 0:3] += J_pos^T g_s_delta[n] (nullable)
 __global__ void __launch_bounds__(256)
 kb_sdelta(const float* __restrict__ s_cur, int s_mod, size_t s_stride, const float* __restrict__ actions,
           size_t act_stride, const float* __restrict__ g_sdelta, int N, DrpCam cam, float* __restrict__ g_action,
-          size_t gact_stride, float* __restrict__ g_pos, size_t gpos_stride) {
+          size_t gact_stride, float* __restrict__ g_pos, size_t gpos_stride, KbAdam adam = KbAdam{}) {
     typedef Dual<7> D;
     __shared__ float red[4][4];
     const int b = blockIdx.x;
@@ -567,6 +528,22 @@ kb_sdelta(const float* __restrict__ s_cur, int s_mod, size_t s_stride, const flo
         float t = 0.0f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w][threadIdx.x];
         g_action[(size_t)b * gact_stride + threadIdx.x] = t;
+    }
+    // The row's optimiser step, in the launch that completes its gradient (rollout step 0's: the later steps' launches ran
+    // before it, and with step 0 `g_action + b * gact_stride` is the start of the row's H * 4 gradients): thread x owns
+    // value x of the row -- for this step's four values the sum it has just stored itself.
+    if (adam.act != nullptr && (int)threadIdx.x < adam.n_row) {
+        const size_t i = (size_t)b * adam.n_row + threadIdx.x;
+        const int c = threadIdx.x & 3;
+        const float l = (c == 0) ? adam.lo.x : (c == 1) ? adam.lo.y : (c == 2) ? adam.lo.z : adam.lo.w;
+        const float h = (c == 0) ? adam.hi.x : (c == 1) ? adam.hi.y : (c == 2) ? adam.hi.z : adam.hi.w;
+        float mi = adam.m[i], vi = adam.v[i];
+        const float a = adam_update(adam.act[i], g_action[(size_t)b * gact_stride + threadIdx.x], mi, vi, adam.step_size,
+                                    adam.bc2_sqrt, adam.b1, l, h);
+        adam.m[i] = mi;
+        adam.v[i] = vi;
+        adam.act[i] = a;
+        if (adam.act_copy != nullptr) adam.act_copy[i] = a;
     }
 }
 
@@ -743,25 +720,19 @@ kb_gather_pos(const float* __restrict__ gpos_edge, const int* __restrict__ rev_o
     gp[0] = g0 - ax; gp[1] = g1 - ay; gp[2] = g2 - az;
 }
 
-// ---- Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8) + the clip box ------------
-//      planners.py:674, :743-746, :756-764
+// the same step as a launch of its own (the trainer's weights; a planner row whose gradient needs no kb_sdelta launch)
 __global__ void k_adam(float* __restrict__ act, const float* __restrict__ grad, float* __restrict__ m,
                        float* __restrict__ v, int n, float step_size, float bc2_sqrt, float4 lo, float4 hi,
                        float b1 = 0.9f, float* __restrict__ act_copy = nullptr /* pinned host memory: the updated values once more */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float b2 = 0.999f, eps = 1e-8f;
-    const float g = grad[i];
-    const float mi = m[i] + (g - m[i]) * (1.0f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = v[i] * b2 + (1.0f - b2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    float a = act[i] - step_size * (mi / denom);
     const int c = i & 3;
     const float l = (c == 0) ? lo.x : (c == 1) ? lo.y : (c == 2) ? lo.z : lo.w;
     const float h = (c == 0) ? hi.x : (c == 1) ? hi.y : (c == 2) ? hi.z : hi.w;
-    a = fminf(fmaxf(a, l), h);
+    float mi = m[i], vi = v[i];
+    const float a = adam_update(act[i], grad[i], mi, vi, step_size, bc2_sqrt, b1, l, h);
+    m[i] = mi;
+    v[i] = vi;
     act[i] = a;
     if (act_copy != nullptr) act_copy[i] = a;
 }

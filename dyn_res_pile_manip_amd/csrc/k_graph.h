@@ -174,11 +174,79 @@ __device__ __forceinline__ void graph_receiver(const float4* __restrict__ p4, in
     for (int q = cnt; q < DRP_K; ++q) out[q] = -1;
 }
 
-__global__ void __launch_bounds__(GRAPH_THREADS)
-k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
+// ---- reversed neighbour lists of ONE sample by its workgroup of T threads: for every sender j the edge slots (i*10 + k)
+// it feeds, ascending (kb_reverse_lists, k_backward.h, is the launch of its own; k_graph_rev below runs it behind the
+// lists' construction).  Out-degrees counted and scanned in LDS; the lists are filled and put in order in LDS too when they
+// fit (s_rev: 2*N ints, + 10*N ints with `in_lds`).
+template <int T>
+__device__ __forceinline__ void reverse_lists(const int16_t* nb, const uint8_t* nc /* may have been written by this workgroup just before (k_graph_rev) */, int N,
+                                              int* __restrict__ ro /* [N+1] */, int* __restrict__ rv /* [N*10] */, int in_lds,
+                                              int n_recv, int* s_rev) {
+    __shared__ int s_w[T / 64];
+    int* deg = s_rev;
+    int* off = s_rev + N;
+    const int tid = threadIdx.x;
+    int* fill = in_lds ? s_rev + 2 * N : rv;
+    for (int i = tid; i < N; i += T) deg[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < N * DRP_K; e += T) {
+        const int i = e / DRP_K, k = e - i * DRP_K;
+        if (k < nc[i] && i < n_recv) atomicAdd(&deg[nb[e]], 1);
+    }
+    __syncthreads();
+    // exclusive scan of deg: every thread owns a contiguous segment
+    const int seg = (N + T - 1) / T;
+    const int lo = min(tid * seg, N), hi = min(lo + seg, N);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += deg[i];
+    int inc = sum;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int base = inc - sum, total = 0;
+    for (int w = 0; w < T / 64; ++w) {
+        if (w < wave) base += s_w[w];
+        total += s_w[w];
+    }
+    for (int i = lo; i < hi; ++i) { off[i] = base; base += deg[i]; }
+    __syncthreads();
+    for (int i = tid; i < N; i += T) { ro[i] = off[i]; deg[i] = 0; }
+    if (tid == 0) ro[N] = total;
+    __syncthreads();
+    for (int e = tid; e < N * DRP_K; e += T) {
+        const int i = e / DRP_K, k = e - i * DRP_K;
+        if (k < nc[i] && i < n_recv) {
+            const int j = nb[e];
+            fill[off[j] + atomicAdd(&deg[j], 1)] = e;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += T) {  // fixed order inside every sender's list
+        int* seg_j = fill + off[j];
+        const int n = deg[j];
+        for (int a = 1; a < n; ++a) {
+            const int v = seg_j[a];
+            int c = a - 1;
+            while (c >= 0 && seg_j[c] > v) { seg_j[c + 1] = seg_j[c]; --c; }
+            seg_j[c + 1] = v;
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int p = tid; p < total; p += T) rv[p] = fill[p];
+    }
+}
+
+template <bool REV>
+__device__ __forceinline__ void graph_sample(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
         const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
-        int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks,
-        int n_items /* B * chunks; grid = SPREAD_GRID(n_items) */, int self_first) {
+        int16_t* nbr_idx, uint8_t* nbr_cnt, DrpCam cam, float thr, int chunks,
+        int n_items /* B * chunks; grid = SPREAD_GRID(n_items) */, int self_first, int* rev_off, int* rev) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* p4 = reinterpret_cast<float4*>(lds);                       // [N] displaced positions
     const int item = spread_item();
@@ -208,8 +276,32 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
     __syncthreads();
 
     const int i = chunk * GRAPH_THREADS + threadIdx.x;
-    if (i >= N) return;
-    graph_receiver(p4, N, i, thr, self_first, nbr_idx + ((size_t)b * N + i) * DRP_K, nbr_cnt + (size_t)b * N + i);
+    if (i < N) graph_receiver(p4, N, i, thr, self_first, nbr_idx + ((size_t)b * N + i) * DRP_K, nbr_cnt + (size_t)b * N + i);
+    if (REV) {
+        // the sample's reversed lists behind its lists, by the same workgroup (one chunk: N <= GRAPH_THREADS): the GD
+        // planner's backward pass wants them, and a launch of their own costs more than the work (9.5 us at 20 particles)
+        __threadfence_block();
+        __syncthreads();                                               // the lists are written; the positions in LDS are dead
+        reverse_lists<GRAPH_THREADS>(nbr_idx + (size_t)b * N * DRP_K, nbr_cnt + (size_t)b * N, N, rev_off + (size_t)b * (N + 1),
+                                     rev + (size_t)b * N * DRP_K, 1, N, reinterpret_cast<int*>(lds));
+    }
+}
+__global__ void __launch_bounds__(GRAPH_THREADS)
+k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
+        const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
+        int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks,
+        int n_items /* B * chunks; grid = SPREAD_GRID(n_items) */, int self_first) {
+    graph_sample<false>(s_prev, prev_mod, prev_stride, actions, act_stride, s_delta, N, nbr_idx, nbr_cnt, cam, thr, chunks, n_items,
+                        self_first, nullptr, nullptr);
+}
+// dynamic LDS: 12 * N ints (>= the 4 * N floats of the positions)
+__global__ void __launch_bounds__(GRAPH_THREADS)
+k_graph_rev(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
+            const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
+            int16_t* nbr_idx, uint8_t* nbr_cnt, DrpCam cam, float thr, int n_items /* B: one chunk per sample */, int self_first,
+            int* __restrict__ rev_off /* [B][N+1] */, int* __restrict__ rev /* [B][N*10] */) {
+    graph_sample<true>(s_prev, prev_mod, prev_stride, actions, act_stride, s_delta, N, nbr_idx, nbr_cnt, cam, thr, 1, n_items,
+                       self_first, rev_off, rev);
 }
 
 // ---- the plain sweep for a HANDFUL of samples: four threads per receiver -------------------------------------------

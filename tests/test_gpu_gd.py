@@ -268,6 +268,42 @@ def test_rows_kept_in_registers_against_the_rows_through_memory(monkeypatch, N, 
         assert np.abs(a - b).max() < 5e-5 * scale
 
 
+@pytest.mark.parametrize('N,B', [(20, 1500), (100, 300), (128, 40), (7, 33)])
+def test_reversed_lists_from_the_lists_own_launch(monkeypatch, N, B):
+    """Horizon 1, samples of one graph chunk (up to 128 particles): k_graph_rev builds the reversed lists behind the
+    neighbour lists in the same launch, and the optimiser step rides on the last kb_sdelta launch; with
+    DRP_NO_GRAPH_REV=1 kb_reverse_lists runs as a launch of its own.  Same lists: the same rewards, pushes after three
+    iterations and gradients, bit for bit."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    from dyn_res_pile_manip_amd import weights
+    from dyn_res_pile_manip_amd.planners import world2cam_affine
+    s0, dens, attr = syn.make_pile(N, 1, seed=N)
+    acts = syn.sample_pushes(B, 1, seed=B)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    res = {}
+    for own in (False, True):
+        if own:
+            monkeypatch.setenv('DRP_NO_GRAPH_REV', '1')
+        else:
+            monkeypatch.delenv('DRP_NO_GRAPH_REV', raising=False)
+        eng = Engine(0)
+        eng.load_weights(weights.blob_from_state_dict(weights.random_state_dict(seed=0)), 0.08)
+        eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+        eng.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+        eng.gd_begin(s0, attr, dens, acts, 0.05, lo, hi)
+        out = list(eng.gd_grad(want_state_grad=True))
+        for _ in range(3):
+            out.append(eng.gd_step())
+        out.append(eng.gd_actions())
+        out.append(eng.debug_fetch('rev_off', (B, N + 1), np.int32))
+        res[own] = out
+        eng.close()
+    assert np.abs(res[True][1]).max() > 0 and not np.array_equal(res[True][-2], acts)
+    for a, b in zip(res[False], res[True]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_pipelined_iterations_equal_the_blocking_ones(ctx, golden):
     """drp_gd_step_async / drp_gd_wait (iteration i + 1 enqueued before the host waits for iteration i) against
     drp_gd_step + drp_gd_get: the same rewards and pushes, bit for bit, in every iteration; a slot that has not been
