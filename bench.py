@@ -538,7 +538,7 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
         roof, _ = prop_roofline(dom_work, kbar, True, B, N, avg_s, H)
         tkey = 'prop3_tape'
     elif dominant == 'bwd_node' and per_class['bwd_edge'][1] == 0:
-        # kmb_step_bwd (the whole node / edge backward of a rollout step in one launch): algorithmic
+        # kmb_rows_bwd / kmb_step_bwd (the whole node / edge backward of a rollout step in one launch): algorithmic
         # bytes per node -- phase P: effect row + reward gradient in, g_eff / g_cnode / g_agg rows out; per
         # propagation step: own g_agg and g_eff rows, own masks, one (list entry, mask, g_agg row) per edge the
         # node feeds; steps 2 and 1 also the effect row in, g_eff / g_agg rows out and g_cnode in and out; step 0
@@ -547,8 +547,8 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
         work = B * N * per_node
         roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                 'algorithmic_bytes_per_launch': work,
-                'note': 'kmb_step_bwd: fp32 MFMA for the seven 64x64 products per node; the byte model counts every gathered g_agg row, '
-                        'most of which are served by L2 -- traffic (when present) is the HBM side'}
+                'note': 'the GD backward in one launch (kmb_rows_bwd up to 256 particles: rows in registers, gathers from LDS; kmb_step_bwd above); '
+                        'the byte model counts every row of the launch-per-phase formulation -- traffic (when present) is the HBM side'}
         tkey = 'step_bwd'
     elif dominant == 'bwd_edge':
         # kb_edge_terms per node and propagation step: own g_agg row + own masks read, both g_proj halves written,

@@ -24,7 +24,7 @@ CLASS = {'k_graph': 'graph', 'k_graph_strips': 'graph', 'k_graph_sort': 'graph_s
          'km_update<false>': 'update', 'km_update<true>': 'predict', 'k_reward': 'reward',
          'km_prop<false>': 'prop', 'km_prop<true>': 'prop_last', 'km_prop3': 'prop3',
          'km_rollout': 'rollout', 'k_graph_cells': 'graph', 'k_graph_sort2': 'graph_sort',
-         'kmb_step_bwd': 'step_bwd', 'kb_reward': 'bwd_reward', 'kb_reverse_lists': 'bwd_lists', 'kb_sdelta': 'bwd_push'}
+         'kmb_step_bwd': 'step_bwd', 'kmb_rows_bwd': 'step_bwd', 'k_graph_rev': 'graph', 'kb_reward': 'bwd_reward', 'kb_reverse_lists': 'bwd_lists', 'kb_sdelta': 'bwd_push'}
 
 
 def counts_work(name):
