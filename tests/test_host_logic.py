@@ -115,3 +115,15 @@ def test_visible_gpu_count_follows_the_visibility_variables(monkeypatch):
         pytest.skip('no KFD topology with GPUs here')
     monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0')
     assert bench.visible_gpu_count() == 1
+
+
+def test_the_planners_result_slots_are_the_librarys():
+    """planners.GD_SLOTS mirrors include/drp.h's DRP_GD_SLOTS (drp_gd_step_async refuses slots beyond it), and the planner
+    never has more iterations in flight than there are slots."""
+    import os
+    import re
+    from dyn_res_pile_manip_amd import planners
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'drp.h')).read()
+    m = re.search(r'#define\s+DRP_GD_SLOTS\s+(\d+)', header)
+    assert m and int(m.group(1)) == planners.GD_SLOTS
+    assert 0 < planners.GD_AHEAD < planners.GD_SLOTS
