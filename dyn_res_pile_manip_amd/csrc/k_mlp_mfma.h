@@ -263,14 +263,28 @@ __device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ s
 #pragma unroll
         for (int v = 0; v < 8; ++v) *reinterpret_cast<float4*>(dst + idx[v]) = t[v];
     }
-    for (; u < nfull; ++u) {
-        int c = u + c0;
-        if (c >= nfull) c -= nfull;
-        const int i = c * step + off;
-        *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+    // the rest -- up to seven whole chunks and the partial last one -- in flight together as well (workgroup-uniform tests):
+    // one chunk per trip was a round trip to L2 each, six in a row for the 48 / 52 KB the small-pile kernels swap in twice
+    // per rollout step
+    {
+        float4 t[8];
+        int idx[8];
+#pragma unroll
+        for (int v = 0; v < 7; ++v) {
+            int c = u + v + c0;
+            if (c >= nfull) c -= nfull;
+            idx[v] = c * step + off;
+            t[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (u + v < nfull) t[v] = *reinterpret_cast<const float4*>(src + idx[v]);
+        }
+        idx[7] = nfull * step + off;                 // the partial last chunk
+        t[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (idx[7] < n) t[7] = *reinterpret_cast<const float4*>(src + idx[7]);
+#pragma unroll
+        for (int v = 0; v < 7; ++v)
+            if (u + v < nfull) *reinterpret_cast<float4*>(dst + idx[v]) = t[v];
+        if (idx[7] < n) *reinterpret_cast<float4*>(dst + idx[7]) = t[7];
     }
-    const int i = nfull * step + off;                // the partial last chunk
-    if (i < n) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
 }
 __device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ src, int n) { lds_fill(dst, src, n, (int)threadIdx.x); }
 
