@@ -1261,7 +1261,9 @@ __device__ __forceinline__ void prop3_fill_resident(const Prop3Lds& P, const uin
 // three propagation steps, the last one writing s_out.  On entry the resident part of LDS is filled (or being filled:
 // `entry_sync` = the caller has not synchronised since) and the edge-chain region holds nothing this function relies
 // on; on exit every wave has passed its last tile (no barrier after it).
-template <bool TAPE, bool PAIR, bool CARRY, bool ECACHE, bool WORK, bool ONE /* the workgroup has no more tiles than waves (the host's promise) */>
+template <bool TAPE, bool PAIR, bool CARRY, bool ECACHE, bool WORK, bool ONE /* the workgroup has no more tiles than waves (the host's promise) */,
+          bool ENC_PRE = false /* km_rollout<pair>: the caller has filled the encoder's matrices and reset the tile counter, one barrier ago */,
+          class Aux = int /* ENC_PRE: aux(w, nw) -- work for the waves without an encoder tile (the neighbour lists), w-th of nw */>
 __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6,
                                            const float* __restrict__ mw,
                                            const float* __restrict__ s_cur, int s_mod, size_t s_stride,
@@ -1277,6 +1279,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
 #ifdef PROP_STAMPS
                                            , unsigned long long (&st_sum)[8]
 #endif
+                                           , Aux aux = Aux()
 ) {
     float* wsp_f = P.wsp_f;
     float* w6_f = P.w6_f;
@@ -1290,16 +1293,18 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
     const unsigned long long roll_c0 = __builtin_amdgcn_s_memtime(), roll_r0 = roll_t;
 #endif
     const bool phase_e = s_delta != nullptr;
-    if (phase_e) {
-        // the particle encoder's two 64x64 layers borrow the edge chain's region; W_r and W_s are resident anyway
-        lds_fill(wsp_f, reinterpret_cast<const float*>(sw6) + S6_PE2 * 4, 2 * 1536 * 4, tid);
-        lds_fill(pe0_f, reinterpret_cast<const float*>(sw6) + S6_PE0 * 4, 384 * 4, tid);
-        lds_fill(rows_e, mw + R_PE2_B, 192, tid);
-    } else {
-        lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4, tid);
+    if (!ENC_PRE) {
+        if (phase_e) {
+            // the particle encoder's two 64x64 layers borrow the edge chain's region; W_r and W_s are resident anyway
+            lds_fill(wsp_f, reinterpret_cast<const float*>(sw6) + S6_PE2 * 4, 2 * 1536 * 4, tid);
+            lds_fill(pe0_f, reinterpret_cast<const float*>(sw6) + S6_PE0 * 4, 384 * 4, tid);
+            lds_fill(rows_e, mw + R_PE2_B, 192, tid);
+        } else {
+            lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4, tid);
+        }
+        if (tid == 0) *tile_ctr = PROP_WAVES;
+        __syncthreads();
     }
-    if (tid == 0) *tile_ctr = PROP_WAVES;
-    __syncthreads();
     ROLL_STAMP(3);                                   // encoder weights in LDS
     const int lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * spw, nb = min(spw, B - b0);
@@ -1356,8 +1361,14 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
             li = __builtin_amdgcn_readfirstlane(qn);
             if (WORK && lane == 0) atomicAdd(prop_work_shard(work) + PROP_WORK_ENC_TILES, 1ull);
         }
+        if constexpr (ENC_PRE) {
+            // the waves without an encoder tile build the neighbour lists meanwhile (the encoder reads impulses, attributes
+            // and densities, the lists positions: nothing of one another); with a tile for every wave, all of them afterwards
+            if (enc_tiles < PROP_WAVES) { if (wave >= enc_tiles) aux(wave - enc_tiles, PROP_WAVES - enc_tiles); }
+            else aux(wave, PROP_WAVES);
+        }
         ROLL_STAMP(4);                                   // wave 0's encoder tiles
-        __syncthreads();                                 // the encoder's rows of this workgroup's samples are written
+        __syncthreads();                                 // the encoder's rows of this workgroup's samples are written (ENC_PRE: and the lists)
         ROLL_STAMP(5);                                   // waiting for the other waves' encoder tiles
         lds_fill(wsp_f, reinterpret_cast<const float*>(sw), S_TOTAL * 4, tid);
         if (tid == 0) *tile_ctr = PROP_WAVES;

@@ -7,6 +7,9 @@
 //     per step:  push impulses + displaced positions of its samples -> LDS          (gen_s_delta, planners.py:211-257)
 //                neighbour lists, one thread per receiver, two sweeps over the sample (graph_receiver, k_graph.h)
 //                particle encoder -> row order -> three propagation steps -> prediction (prop3_step, k_mlp_split.h)
+//                (paired tiles, i.e. at most 192 rows: the lists are built by the waves that have no encoder tile, WHILE the
+//                others run the encoder -- one barrier and the shorter of the two phases fewer per step: + 4 % at 10 - 64
+//                particles)
 // with the node matrices resident in LDS for the whole launch (the step-by-step pipeline refills 98 KB per rollout
 // step), no launch gap, no graph launch, and no end-of-launch wait for the slowest workgroup of the chip: a workgroup
 // that finishes a step early starts the next one, so the imbalance between workgroups averages out over the H steps
@@ -86,11 +89,51 @@ km_rollout(const RolloutArgs* __restrict__ args) {
         // the previous step's predictions (this workgroup's own stores) and the last readers of the edge chain's LDS
         __syncthreads();
         ROLL_STAMP(0);                               // waiting for the other waves at the end of a rollout step (+ the entry fill)
+        DrpCam cam;
+        for (int q = 0; q < 12; ++q) cam.m[q] = a->cam.m[q];
+        cam.gs = a->cam.gs; cam.fx = a->cam.fx; cam.fy = a->cam.fy; cam.cx = a->cam.cx; cam.cy = a->cam.cy;
+        const float* actions = a->actions;
+        if constexpr (PAIR) {
+            // Paired tiles = at most 192 rows (the host's rule) = at most six encoder tiles for eight waves: the lists are built
+            // by the waves WITHOUT an encoder tile while the others run the encoder (prop3_step<ENC_PRE>).  For that the
+            // encoder's matrices are filled in here, and the displaced positions go to the slack behind the encoder's first
+            // layer (16 B per row; the row order needs that space only after the encoder) instead of the matrices' region.
+            lds_fill(P.wsp_f, reinterpret_cast<const float*>(a->sw6) + S6_PE2 * 4, 2 * 1536 * 4, tid);
+            lds_fill(P.pe0_f, reinterpret_cast<const float*>(a->sw6) + S6_PE0 * 4, 384 * 4, tid);
+            lds_fill(P.rows_e, a->mw + R_PE2_B, 192, tid);
+            if (tid == 0) *P.tile_ctr = PROP_WAVES;
+            float4* p4x = reinterpret_cast<float4*>(P.rows_e + 192);
+            for (int r = tid; r < wg_rows; r += 64 * PROP_WAVES) {
+                int m, i;
+                divmod_small(r, N, inv_N, m, i);
+                const int b = b0 + m;
+                const PushFrame f = push_frame(cam, actions + ((size_t)b * H + t) * 4);
+                const float* s = s_prev + (size_t)(b % prev_mod) * prev_stride;
+                const float x = s[i * 3 + 0], y = s[i * 3 + 1], z = s[i * 3 + 2];
+                float ox, oy, oz;
+                push_delta(f, x, y, z, ox, oy, oz);
+                float* sd = s_delta + ((size_t)b0 * N + r) * 3;
+                sd[0] = ox; sd[1] = oy; sd[2] = oz;
+                p4x[r] = make_float4(__fadd_rn(x, ox), __fadd_rn(y, oy), __fadd_rn(z, oz), 0.0f);      // gnn_dyn.py:224
+            }
+            __syncthreads();
+            ROLL_STAMP(1);                           // encoder matrices, impulses and displaced positions
+            const float thr = a->thr;
+            const int self_first = a->cself != nullptr ? 1 : 0;
+            auto lists = [&](int w, int nw) {
+                for (int r = w * 64 + (tid & 63); r < wg_rows; r += nw * 64) {
+                    int m, i;
+                    divmod_small(r, N, inv_N, m, i);
+                    const size_t row = (size_t)b0 * N + r;
+                    graph_receiver(p4x + m * N, N, i, thr, self_first, nbr_idx + row * DRP_K, nbr_cnt + row);
+                }
+            };
+            prop3_step<false, PAIR, true, ECACHE, WORK, ONE, true>(P, a->sw, a->sw6, a->mw, s_prev, prev_mod, prev_stride, a->attr, nbat, a->dens, nbat, nbr_idx, nbr_cnt,
+                              a->proj_a, a->proj_b, a->c_node, a->eff, N, B, spw, s_delta, states + (size_t)t * N * 3, hstride,
+                              a->cself, a->cself_ok, nullptr, nullptr, a->re_scale, a->re_inv, a->order_rows, tid,
+                              ECACHE ? a->ecache + (size_t)blockIdx.x * a->ec_stride : nullptr, a->work PROP_STAMPS_ARG, lists);
+        } else {
         {
-            DrpCam cam;
-            for (int q = 0; q < 12; ++q) cam.m[q] = a->cam.m[q];
-            cam.gs = a->cam.gs; cam.fx = a->cam.fx; cam.fy = a->cam.fy; cam.cx = a->cam.cx; cam.cy = a->cam.cy;
-            const float* actions = a->actions;
             for (int r = tid; r < wg_rows; r += 64 * PROP_WAVES) {
                 int m, i;
                 divmod_small(r, N, inv_N, m, i);
@@ -123,6 +166,7 @@ km_rollout(const RolloutArgs* __restrict__ args) {
                           a->proj_a, a->proj_b, a->c_node, a->eff, N, B, spw, s_delta, states + (size_t)t * N * 3, hstride,
                           a->cself, a->cself_ok, nullptr, nullptr, a->re_scale, a->re_inv, a->order_rows, tid,
                           ECACHE ? a->ecache + (size_t)blockIdx.x * a->ec_stride : nullptr, a->work PROP_STAMPS_ARG);
+        }
 #ifdef ROLLOUT_STAMPS
         roll_t = __builtin_amdgcn_s_memrealtime();   // prop3_step keeps its own clock
         if (roll_on) atomicAdd(&g_roll_stamps[15], 1ull);
