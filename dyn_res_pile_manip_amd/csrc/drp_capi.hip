@@ -1250,7 +1250,7 @@ int drp_create(int device, drp_ctx** out) {
     c->wgrad_defer = getenv("DRP_NO_WGRAD_DEFER") == nullptr;
     if (const char* e = getenv("DRP_GRAPH_Q4")) c->graph_q4 = atoi(e);
     if (const char* e = getenv("DRP_ROLLOUT_MAX_N")) { c->rollout_max_n = atoi(e); c->rollout_mid_n = 0; c->rollout_max_rows = KM_ROLLOUT_MAX_ROWS; }
-    if (const char* e = getenv("DRP_PROP_PAIR_ROWS")) c->prop_pair_rows = std::min(192, std::max(0, atoi(e)));   // km_rollout<pair> keeps 16 B per row in 3.2 KB of LDS slack
+    if (const char* e = getenv("DRP_PROP_PAIR_ROWS")) c->prop_pair_rows = std::min(256, std::max(0, atoi(e)));   // km_rollout<pair> keeps 16 B per row in the 4 KB behind the encoder's matrices
     if (const char* e = getenv("DRP_PROP_PAIR_ALWAYS")) c->prop_pair_always = std::max(0, atoi(e));
     if (const char* e = getenv("DRP_PROP_PAIR_DEG10")) c->prop_pair_deg10 = std::max(0, atoi(e));
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;

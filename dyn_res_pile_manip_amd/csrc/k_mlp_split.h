@@ -1364,7 +1364,9 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
         if constexpr (ENC_PRE) {
             // the waves without an encoder tile build the neighbour lists meanwhile (the encoder reads impulses, attributes
             // and densities, the lists positions: nothing of one another); with a tile for every wave, all of them afterwards
-            if (enc_tiles < PROP_WAVES) { if (wave >= enc_tiles) aux(wave - enc_tiles, PROP_WAVES - enc_tiles); }
+            // -- unless the tile-less waves would each have more than one round of rows (seven tiles at 50 particles: one wave,
+            // 200 rows: 14 % slower than everybody taking a share behind its tile)
+            if (enc_tiles < PROP_WAVES && wg_rows <= (PROP_WAVES - enc_tiles) * 64) { if (wave >= enc_tiles) aux(wave - enc_tiles, PROP_WAVES - enc_tiles); }
             else aux(wave, PROP_WAVES);
         }
         ROLL_STAMP(4);                                   // wave 0's encoder tiles

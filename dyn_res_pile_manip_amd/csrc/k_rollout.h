@@ -7,9 +7,9 @@
 //     per step:  push impulses + displaced positions of its samples -> LDS          (gen_s_delta, planners.py:211-257)
 //                neighbour lists, one thread per receiver, two sweeps over the sample (graph_receiver, k_graph.h)
 //                particle encoder -> row order -> three propagation steps -> prediction (prop3_step, k_mlp_split.h)
-//                (paired tiles, i.e. at most 192 rows: the lists are built by the waves that have no encoder tile, WHILE the
-//                others run the encoder -- one barrier and the shorter of the two phases fewer per step: + 4 % at 10 - 64
-//                particles)
+//                (workgroups of at most 256 rows with paired tiles or the kept rows: the lists are built by the waves that have
+//                no encoder tile, WHILE the others run the encoder -- one barrier and the shorter of the two phases fewer per
+//                step)
 // with the node matrices resident in LDS for the whole launch (the step-by-step pipeline refills 98 KB per rollout
 // step), no launch gap, no graph launch, and no end-of-launch wait for the slowest workgroup of the chip: a workgroup
 // that finishes a step early starts the next one, so the imbalance between workgroups averages out over the H steps
@@ -93,16 +93,18 @@ km_rollout(const RolloutArgs* __restrict__ args) {
         for (int q = 0; q < 12; ++q) cam.m[q] = a->cam.m[q];
         cam.gs = a->cam.gs; cam.fx = a->cam.fx; cam.fy = a->cam.fy; cam.cx = a->cam.cx; cam.cy = a->cam.cy;
         const float* actions = a->actions;
-        if constexpr (PAIR) {
-            // Paired tiles = at most 192 rows (the host's rule) = at most six encoder tiles for eight waves: the lists are built
-            // by the waves WITHOUT an encoder tile while the others run the encoder (prop3_step<ENC_PRE>).  For that the
-            // encoder's matrices are filled in here, and the displaced positions go to the slack behind the encoder's first
-            // layer (16 B per row; the row order needs that space only after the encoder) instead of the matrices' region.
+        if constexpr (PAIR || ONE) {
+            // Paired tiles (at most 192 rows, the host's rule) or no more unpaired tiles than waves (at most 256 rows): the
+            // lists are built by the waves WITHOUT an encoder tile while the others run the encoder (prop3_step<ENC_PRE>; with a
+            // tile for every wave, by all of them behind it -- still one barrier fewer).  For that the encoder's matrices are
+            // filled in here, and the displaced positions go behind them: the two matrices leave 4 KB of the edge chain's
+            // region free, 16 B per row.
             lds_fill(P.wsp_f, reinterpret_cast<const float*>(a->sw6) + S6_PE2 * 4, 2 * 1536 * 4, tid);
             lds_fill(P.pe0_f, reinterpret_cast<const float*>(a->sw6) + S6_PE0 * 4, 384 * 4, tid);
             lds_fill(P.rows_e, a->mw + R_PE2_B, 192, tid);
             if (tid == 0) *P.tile_ctr = PROP_WAVES;
-            float4* p4x = reinterpret_cast<float4*>(P.rows_e + 192);
+            float4* p4x = reinterpret_cast<float4*>(P.wsp_f + 2 * 1536 * 4);
+            static_assert((S_TOTAL * 4 - 2 * 1536 * 4) * sizeof(float) >= 256 * sizeof(float4), "positions of 256 rows behind the encoder's matrices");
             for (int r = tid; r < wg_rows; r += 64 * PROP_WAVES) {
                 int m, i;
                 divmod_small(r, N, inv_N, m, i);
