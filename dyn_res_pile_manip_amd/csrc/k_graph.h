@@ -151,24 +151,28 @@ __device__ __forceinline__ void graph_receiver(const float4* __restrict__ p4, in
         out[cnt++] = (int16_t)i;
         if (!(0.0f < kth)) --ties_left;              // the self loop (distance 0) is itself one of the ties
     }
+    // One flat predicate per sender and ONE predicated store: written as nested ifs (in radius and not beyond kth / slots left /
+    // not the self loop / strictly nearer, else a tie with budget left) the sweep compiled to five levels of exec-mask
+    // branches that a wave walks for nearly every sender as soon as a few lanes are active -- 11.5 us of a 106-us rollout
+    // step at 50 particles.  The same decisions, the same lists.
+    auto visit = [&](float d, int js) {
+        const bool in = d <= kth && __fsub_rn(d, thr) < 0.0f && cnt < DRP_K && js != skip;
+        const bool strict = d < kth;
+        const bool take = in && (strict || ties_left > 0);
+        if (take) out[cnt] = (int16_t)js;
+        ties_left -= (take && !strict) ? 1 : 0;
+        cnt += take ? 1 : 0;
+    };
     for (j = 0; j + 4 <= N; j += 4) {
         const float4 q0 = p4[j], q1 = p4[j + 1], q2 = p4[j + 2], q3 = p4[j + 3];
         const float d4[4] = {pair_dis(pi.x, pi.y, pi.z, q0.x, q0.y, q0.z), pair_dis(pi.x, pi.y, pi.z, q1.x, q1.y, q1.z),
                              pair_dis(pi.x, pi.y, pi.z, q2.x, q2.y, q2.z), pair_dis(pi.x, pi.y, pi.z, q3.x, q3.y, q3.z)};
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (d4[u] <= kth && __fsub_rn(d4[u], thr) < 0.0f && cnt < DRP_K && j + u != skip) {
-                if (d4[u] < kth) out[cnt++] = (int16_t)(j + u);
-                else if (ties_left > 0) { out[cnt++] = (int16_t)(j + u); --ties_left; }
-            }
+        for (int u = 0; u < 4; ++u) visit(d4[u], j + u);
     }
     for (; j < N; ++j) {
         const float4 pj = p4[j];
-        const float d = pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
-        if (d <= kth && __fsub_rn(d, thr) < 0.0f && cnt < DRP_K && j != skip) {
-            if (d < kth) out[cnt++] = (int16_t)j;
-            else if (ties_left > 0) { out[cnt++] = (int16_t)j; --ties_left; }
-        }
+        visit(pair_dis(pi.x, pi.y, pi.z, pj.x, pj.y, pj.z), j);
     }
     *cnt_out = (uint8_t)cnt;
     for (int q = cnt; q < DRP_K; ++q) out[q] = -1;

@@ -1362,12 +1362,14 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
             if (WORK && lane == 0) atomicAdd(prop_work_shard(work) + PROP_WORK_ENC_TILES, 1ull);
         }
         if constexpr (ENC_PRE) {
+            ROLL_STAMP(4);                               // (wave 0's encoder tile; its share of the lists goes to stamp 14)
             // the waves without an encoder tile build the neighbour lists meanwhile (the encoder reads impulses, attributes
             // and densities, the lists positions: nothing of one another); with a tile for every wave, all of them afterwards
             // -- unless the tile-less waves would each have more than one round of rows (seven tiles at 50 particles: one wave,
             // 200 rows: 14 % slower than everybody taking a share behind its tile)
             if (enc_tiles < PROP_WAVES && wg_rows <= (PROP_WAVES - enc_tiles) * 64) { if (wave >= enc_tiles) aux(wave - enc_tiles, PROP_WAVES - enc_tiles); }
             else aux(wave, PROP_WAVES);
+            ROLL_STAMP(14);
         }
         ROLL_STAMP(4);                                   // wave 0's encoder tiles
         __syncthreads();                                 // the encoder's rows of this workgroup's samples are written (ENC_PRE: and the lists)

@@ -40,6 +40,7 @@ for q, nm in enumerate(names):
     tot += us
     print('  %-36s %7.2f us per rollout step' % (nm, us))
 print('  %-36s %7.2f us' % ('sum', tot))
+print('  of the encoder tiles: wave 0\'s share of the lists %.2f us' % (float(out[14]) * 0.01 / steps))
 print('  wave 0 tiles by propagation step     %.2f / %.2f / %.2f us' % tuple(float(out[11 + q]) * 0.01 / steps for q in range(3)))
 if out[10]:
     print('  in-kernel shader clock %.3f GHz' % (float(out[9]) / (float(out[10]) * 10.0)))
