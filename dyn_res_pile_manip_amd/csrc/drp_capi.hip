@@ -200,8 +200,10 @@ struct drp_ctx {
     bool prop3e = true;             // false: the particle encoder stays its own launch in front of km_prop3
     bool rollout_fused = true;      // DRP_NO_ROLLOUT_FUSED=1: one graph + one km_prop3 launch per rollout step for small piles too
     int rollout_max_n = 64;         // DRP_ROLLOUT_MAX_N: km_rollout (the whole rollout in one launch) up to this many particles ...
-    int rollout_mid_n = 96, rollout_mid_rows = 256;   // ... up to 96 particles for workgroups of up to 256 rows (small batches:
-                                    // 256 x 72 / 80 / 88 + 7 / + 11 / + 15 %, 512 x 80 / 96 + 8 / + 11 %; 1024 x 88: - 1 %, 2048 x 80: - 4 %)
+    int rollout_mid_n = 256, rollout_mid_rows = 256;  // ... up to 256 particles for workgroups of up to 256 rows (small batches; the
+                                    // kernels with the kept rows and the lists beside the encoder: 256 x 80 / 100 / 128 / 150 / 200 / 256
+                                    // + 23 / + 14 / + 13 / + 13 / + 5 / + 6 %, 512 x 100 / 128 + 13 / + 16 %, 128 x 150 + 7 %, 341 x 96 + 16 %;
+                                    // 64 x 256 - 5 %: above 200 particles only from half a chip of samples; 1024 x 80 / 100 (320 / 400 rows): - 1 %)
     int rollout_max_rows = 704;     // ... and this many rows (samples x particles) per workgroup.  Measured
                                     // against the step-by-step pipeline at 1024 samples: +18 % at 10 particles, +12 % at 20, +2 % at
                                     // 50, +5 % at 64, -1 % at 80, -10 % at 150 (the strip build wins); 50 particles x 4096 samples
@@ -912,7 +914,7 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
     // samples from the first step to the last, builds their neighbour lists itself and keeps the node matrices in LDS
     const int spw_r = (int)((B + c->n_cu - 1) / c->n_cu);
     // up to rollout_max_n particles whatever the batch; up to rollout_mid_n while a workgroup holds no more than rollout_mid_rows
-    const bool roll_size = N <= c->rollout_max_n || (N <= c->rollout_mid_n && (long)spw_r * N <= c->rollout_mid_rows);
+    const bool roll_size = N <= c->rollout_max_n || (N <= c->rollout_mid_n && (long)spw_r * N <= c->rollout_mid_rows && (N <= 200 || B >= c->n_cu / 2));
     const bool one_launch = c->engine == DRP_ENGINE_FUSED && c->rollout_fused && c->prop3 && c->prop3e && roll_size &&
                             whole_samples(c, B, N) && ((long)spw_r * N + 31) / 32 >= c->prop3_min_tiles &&
                             (long)spw_r * N <= KM_ROLLOUT_MAX_ROWS && (long)spw_r * N <= c->rollout_max_rows;

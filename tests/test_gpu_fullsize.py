@@ -248,7 +248,9 @@ def test_edge_cache_against_the_oracle(monkeypatch, N, ns, H, nb):
 
 
 @pytest.mark.parametrize('N,ns,H,nb', [(50, 1024, 10, 1), (20, 1024, 10, 1), (150, 600, 4, 1), (256, 1024, 2, 1),
-                                       (100, 300, 3, 30), (64, 16, 5, 2)])
+                                       (100, 300, 3, 30), (64, 16, 5, 2),
+                                       (150, 200, 3, 1),      # one sample a workgroup, five tiles: the lists beside the encoder, unpaired
+                                       (200, 256, 2, 1)])     # seven tiles: every wave takes a share of the lists behind its tile
 def test_whole_rollout_in_one_launch_equals_the_step_by_step_pipeline(monkeypatch, N, ns, H, nb):
     """km_rollout at the reference's own sizes (the planner re-samples the pile at 10 - 100 particles) and beyond its
     default limit of 64 particles (DRP_ROLLOUT_MAX_N lifts it: the kernel takes any workgroup of up to 3072 rows), with
