@@ -125,6 +125,11 @@ SIGNATURES = {
     'drp_probe_begin': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     'drp_probe_read': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.POINTER(ctypes.c_long)]),
     'drp_probe_work': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
+    'drp_dispatch_reset': (ctypes.c_int, [ctypes.c_void_p]),
+    'drp_last_dispatch': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]),
+    'drp_dispatch_variants': (ctypes.c_long, [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]),
+    'drp_range_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), c_double_p, c_double_p,
+                                      ctypes.POINTER(ctypes.c_int)]),
     'drp_debug_fetch': (ctypes.c_long, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p,
                                         ctypes.c_size_t]),
 }

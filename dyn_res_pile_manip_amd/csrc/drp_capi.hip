@@ -51,6 +51,89 @@ const char* const kclass_names[KC_COUNT] = {"graph", "node_encode", "edge_encode
                                             "aggregate", "update", "predict", "reward", "mppi", "prop",
                                             "tape_copy", "bwd_reward", "bwd_lists", "bwd_node", "bwd_edge", "bwd_push", "opt"};
 
+// ---- which kernel variant served a launch (drp_last_dispatch) ---------------------------------------------------
+// Every place that chooses between kernels or template instantiations marks the variant it launched in the context; the
+// host asks for the names (drp_last_dispatch) and for the whole list (drp_dispatch_variants).  tests/test_gpu_fuzz_oracle.py
+// draws shapes under the default dispatch, checks each against the oracle and fails if a variant in the list was never hit:
+// a threshold change that orphans an instantiation turns the suite red.
+enum DispatchVariant {
+    DV_GRAPH_PLAIN = 0, DV_GRAPH_Q4, DV_GRAPH_STRIPS, DV_GRAPH_STRIPS256, DV_GRAPH_CELLS, DV_GRAPH_REV, DV_GRAPH_IN_ROLLOUT,
+    DV_VALU_STEP, DV_NODE_ENCODE, DV_NODE_ENCODE_SPLIT, DV_EDGE_ENCODE, DV_EDGE_ENCODE_SPLIT, DV_AGGREGATE, DV_AGGREGATE_LDS,
+    DV_AGGREGATE_TAPE, DV_UPDATE,
+    DV_PROP,                        // + 8 LAST + 4 TAPE + 2 PAIR + WORK
+    DV_PROP3 = DV_PROP + 16,        // + 12 TAPE + 6 PAIR + 2 cache (0 off, 1 on, 2 on with the rows kept in registers) + WORK
+    DV_ROLLOUT = DV_PROP3 + 24,     // + 6 PAIR + 2 cache + WORK
+    DV_REWARD = DV_ROLLOUT + 12, DV_BWD_REWARD, DV_REV_256, DV_REV_1024, DV_BWD_ROWS, DV_BWD_STEP, DV_BWD_STAGES_MFMA,
+    DV_BWD_STAGES_VALU, DV_BWD_EDGE_MFMA, DV_BWD_EDGE_VALU, DV_TRAIN_NODE_MFMA, DV_TRAIN_NODE_VALU, DV_WGRAD_MFMA, DV_WGRAD_VALU,
+    DV_WGRAD_DEFERRED, DV_MPPI_SOFTMAX, DV_ELITE_SORT, DV_ELITE_ROUNDS, DV_FPS_REG, DV_FPS_MEM, DV_DT_CV5, DV_DT_EXACT,
+    DV_COUNT
+};
+// name of variant `id`; *by_default = reachable without an environment switch (DRP_NO_* / drp_probe_begin("prop+work"))
+void dv_name(int id, char* buf, size_t n, bool* by_default) {
+    bool dflt = true;
+    static const char* const cache_names[3] = {"", ",cache", ",cache+rows"};
+    if (id >= DV_PROP && id < DV_PROP3) {
+        const int f = id - DV_PROP;
+        snprintf(buf, n, "km_prop<%s%s%s%s>", (f & 8) ? "last" : "mid", (f & 4) ? ",tape" : "", (f & 2) ? ",pair" : "", (f & 1) ? ",work" : "");
+        dflt = !(f & 1);
+    } else if (id >= DV_PROP3 && id < DV_ROLLOUT) {
+        const int f = id - DV_PROP3;
+        snprintf(buf, n, "km_prop3<%s%s%s%s>", (f / 12) ? "tape" : "plain", ((f / 6) & 1) ? ",pair" : "", cache_names[(f % 6) / 2], (f & 1) ? ",work" : "");
+        // paired tiles mean at most 128 rows per workgroup: the cache always fits and the rows stay in registers, unless
+        // DRP_ECACHE_MAX_MB says otherwise
+        dflt = !(f & 1) && !(((f / 6) & 1) && (f % 6) / 2 != 2);
+    } else if (id >= DV_ROLLOUT && id < DV_REWARD) {
+        const int f = id - DV_ROLLOUT;
+        snprintf(buf, n, "km_rollout<%s%s%s>", (f / 6) ? "pair" : "tile32", cache_names[(f % 6) / 2], (f & 1) ? ",work" : "");
+        dflt = !(f & 1) && !((f / 6) && (f % 6) / 2 != 2);
+    } else {
+        const char* s = "?";
+        switch (id) {
+        case DV_GRAPH_PLAIN: s = "graph:k_graph"; break;
+        case DV_GRAPH_Q4: s = "graph:k_graph_q4"; break;
+        case DV_GRAPH_STRIPS: s = "graph:k_graph_strips_q<128>"; break;
+        case DV_GRAPH_STRIPS256: s = "graph:k_graph_strips_q<256>"; dflt = false; break;   // from 800 particles, where the cells have taken over (DRP_NO_GRAPH_CELLS=1)
+        case DV_GRAPH_CELLS: s = "graph:k_graph_cells"; break;
+        case DV_GRAPH_REV: s = "graph:k_graph_rev"; break;
+        case DV_GRAPH_IN_ROLLOUT: s = "graph:in km_rollout"; break;
+        case DV_VALU_STEP: s = "valu:k_node_encode..k_predict"; break;
+        case DV_NODE_ENCODE: s = "km_node_encode"; break;
+        case DV_NODE_ENCODE_SPLIT: s = "km_node_encode_split"; break;
+        case DV_EDGE_ENCODE: s = "km_edge_encode"; break;
+        case DV_EDGE_ENCODE_SPLIT: s = "km_edge_encode_split"; break;
+        case DV_AGGREGATE: s = "k_aggregate"; break;
+        case DV_AGGREGATE_LDS: s = "k_aggregate_lds"; break;
+        case DV_AGGREGATE_TAPE: s = "k_aggregate_tape"; break;
+        case DV_UPDATE: s = "km_update"; break;
+        case DV_REWARD: s = "k_reward"; break;
+        case DV_BWD_REWARD: s = "kb_reward"; break;
+        case DV_REV_256: s = "kb_reverse_lists<256>"; break;
+        case DV_REV_1024: s = "kb_reverse_lists<1024>"; break;
+        case DV_BWD_ROWS: s = "bwd:kmb_rows_bwd"; break;
+        case DV_BWD_STEP: s = "bwd:kmb_step_bwd"; break;
+        case DV_BWD_STAGES_MFMA: s = "bwd:stages kmb_*"; break;
+        case DV_BWD_STAGES_VALU: s = "bwd:stages kb_*"; dflt = false; break;              // DRP_BWD_VALU_STAGES=1 (KMB_MIN_TILES is 1 since round 3)
+        case DV_BWD_EDGE_MFMA: s = "bwd:kmb_edge_encode"; break;
+        case DV_BWD_EDGE_VALU: s = "bwd:kb_edge_encode"; dflt = false; break;
+        case DV_TRAIN_NODE_MFMA: s = "train:stages kmb_*"; break;
+        case DV_TRAIN_NODE_VALU: s = "train:stages kb_*"; dflt = false; break;
+        case DV_WGRAD_MFMA: s = "train:kt_wgrad_mfma"; break;
+        case DV_WGRAD_VALU: s = "train:kt_wgrad"; dflt = false; break;
+        case DV_WGRAD_DEFERRED: s = "train:deferred wgrad lists"; break;
+        case DV_MPPI_SOFTMAX: s = "mppi:k_mppi_partials+update"; break;
+        case DV_ELITE_SORT: s = "mppi:k_elite_local sort"; break;
+        case DV_ELITE_ROUNDS: s = "mppi:k_elite_local rounds"; break;
+        case DV_FPS_REG: s = "k_fps_reg"; break;
+        case DV_FPS_MEM: s = "k_fps"; break;
+        case DV_DT_CV5: s = "k_dt_cv5"; break;
+        case DV_DT_EXACT: s = "k_edt"; break;
+        default: break;
+        }
+        snprintf(buf, n, "%s", s);
+    }
+    if (by_default) *by_default = dflt;
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -177,6 +260,7 @@ struct drp_ctx {
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
     bool bwd_fused = true;          // DRP_NO_BWD_FUSED=1: the GD planner's backward pass as one launch per stage
     bool graph_rev = true;          // DRP_NO_GRAPH_REV=1: the GD planner's reversed lists always in a launch of their own (kb_reverse_lists)
+    bool bwd_valu_stages = false;   // DRP_BWD_VALU_STAGES=1: the reverse-mode node stages on the VALU row kernels (kb_predict ... kb_node_encode; cross-check)
     bool bwd_rows = true;           // DRP_NO_BWD_ROWS=1: piles of up to 256 particles through kmb_step_bwd (rows through memory) instead of kmb_rows_bwd
     bool prop3_order = true;        // false: km_prop3's tiles in the natural row order instead of by in-degree
     int prop_pair_rows = 128;       // DRP_PROP_PAIR_ROWS: a workgroup of the whole-sample kernels with up to so many rows runs tiles of
@@ -256,6 +340,7 @@ struct drp_ctx {
     double comm_init_timeout_s = 300.0;  // DRP_COMM_INIT_TIMEOUT_S: ncclCommInitRank (every rank must arrive)
 
     // gradient-descent planner state
+    int gd_engine = DRP_ENGINE_FUSED, tr_engine = DRP_ENGINE_FUSED;   // which engine writes the tape (pick_tape_engine)
     bool gd_on = false;
     int gd_nb = 0, gd_N = 0, gd_B = 0, gd_H = 0, gd_iter = 0;
     float* gd_pin[DRP_GD_SLOTS] = {};        // drp_gd_step_async: pinned host copies [B rewards | B*H*4 pushes] of the iterations in flight,
@@ -317,6 +402,10 @@ struct drp_ctx {
 
     // last shapes (for debug fetch)
     int lastB = 0, lastN = 0, lastH = 0;
+
+    // kernel variants launched since drp_dispatch_reset (DispatchVariant)
+    unsigned char dv_hit[DV_COUNT] = {};
+    void dv(int id) { dv_hit[id] = 1; }
 
     // probe
     DevBuf probe_work;              // PROP_WORK_* counters of the propagation kernels while their class is probed
@@ -393,11 +482,12 @@ bool comm_live(const drp_ctx* c) { return c->comm != nullptr && (c->n_ranks > 1 
 // Helper threads (ncclCommAbort behind a dead collective, ncclCommInitRank waiting for its peers) are tracked: drp_destroy,
 // drp_comm_destroy and process exit give them a bounded time to finish, so that none is still inside RCCL when the stream,
 // the context or the HIP / RCCL libraries' own statics go away.
-struct HelperState { std::atomic<int> done{0}; };
+struct HelperState { std::atomic<int> done{0}; const void* owner = nullptr; };   // owner: the context the thread works for
 std::mutex g_helpers_mu;
 std::vector<std::shared_ptr<HelperState>> g_helpers;
-std::shared_ptr<HelperState> helper_register() {
+std::shared_ptr<HelperState> helper_register(const void* owner) {
     auto h = std::make_shared<HelperState>();
+    h->owner = owner;
     std::lock_guard<std::mutex> lk(g_helpers_mu);
     static bool at_exit = false;
     if (!at_exit) {
@@ -416,11 +506,12 @@ std::shared_ptr<HelperState> helper_register() {
     g_helpers.push_back(h);
     return h;
 }
-void helpers_wait(double seconds) {
+// the helper threads of ONE context (another context's communicator still waiting for its peers is not this one's business)
+void helpers_wait(double seconds, const void* owner) {
     const double t0 = now_s();
     for (;;) {
         bool busy = false;
-        { std::lock_guard<std::mutex> lk(g_helpers_mu); for (auto& q : g_helpers) busy = busy || !q->done.load(std::memory_order_acquire); }
+        { std::lock_guard<std::mutex> lk(g_helpers_mu); for (auto& q : g_helpers) busy = busy || (q->owner == owner && !q->done.load(std::memory_order_acquire)); }
         if (!busy || now_s() - t0 > seconds) return;
         usleep(500);
     }
@@ -433,7 +524,7 @@ void comm_abort(drp_ctx* c) {
     if (c->comm && R) {
         ncclComm_t comm = c->comm;
         const int dev = c->device;
-        auto h = helper_register();
+        auto h = helper_register(c);
         std::thread([R, comm, dev, h] { (void)hipSetDevice(dev); (void)R->CommAbort(comm); h->done.store(1, std::memory_order_release); }).detach();
     }
     // the failure is STICKY: the ranks' shards are no longer combined, so nothing that would have used the communicator may
@@ -500,7 +591,8 @@ struct ProbeScope {
     }
 };
 
-int ensure_step_ws(drp_ctx* c, int B, int N) {
+int ensure_step_ws(drp_ctx* c, int B, int N, int engine = -1) {
+    if (engine < 0) engine = c->engine;
     const size_t bn = (size_t)B * N;
     CHK(ensure(c, c->s_delta, bn * 3 * sizeof(float)));
     CHK(ensure(c, c->nbr_idx, bn * DRP_K * sizeof(int16_t)));
@@ -513,7 +605,7 @@ int ensure_step_ws(drp_ctx* c, int B, int N) {
     // edge constants [B,N,10,64] for the engines that materialise them; the fused engine only parks the graph build's
     // sorted positions and strip starts there (launch_graph)
     const size_t graph_scratch = (size_t)B * (((size_t)N + 3) & ~(size_t)3) * 16 + (size_t)B * (GC_MAX_BANDS * GC_XS + 1) * sizeof(int);
-    CHK(ensure(c, c->c_edge, c->engine == DRP_ENGINE_FUSED ? graph_scratch : bn * DRP_K * 64 * sizeof(float)));
+    CHK(ensure(c, c->c_edge, engine == DRP_ENGINE_FUSED ? graph_scratch : std::max(graph_scratch, bn * DRP_K * 64 * sizeof(float))));
     c->lastB = B;
     c->lastN = N;
     return DRP_OK;
@@ -598,6 +690,7 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
         if (gy < 1) gy = 1;
         const float inv_hb = (float)gy / 0.64f;
         const int ncell = gy * GC_XS;
+        c->dv(DV_GRAPH_CELLS);
         hipLaunchKernelGGL(k_graph_sort2, dim3(B), dim3(GRAPH_SORT_THREADS), 0, st, s_prev, prev_mod, prev_stride, actions,
                            act_stride, s_delta, N, c->cam, gy, inv_hb, sorted, starts);
         const float halo = c->graph_cells_halo > 0.0f ? c->graph_cells_halo
@@ -616,6 +709,7 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
         int* starts = reinterpret_cast<int*>(sorted + (size_t)B * Np);
         hipLaunchKernelGGL(k_graph_sort, dim3(B), dim3(GRAPH_SORT_THREADS), 0, st, s_prev, prev_mod, prev_stride, actions,
                            act_stride, s_delta, N, c->cam, sorted, starts);
+        c->dv(N >= 800 ? DV_GRAPH_STRIPS256 : DV_GRAPH_STRIPS);
         if (N >= 800) {
             const int chunks = (N + 255) / 256;
             hipLaunchKernelGGL(k_graph_strips_q<256>, dim3(SPREAD_GRID(B * chunks)), dim3(256), GRAPH_STRIPS_LDS(N, 256), st,
@@ -628,13 +722,16 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
     else if (c->graph_q4 != 0 && N >= 64 && (c->graph_q4 == 2 || (long)B * ((N + 127) / 128) * 2 <= c->n_cu)) {
         // a handful of samples (training batches): four threads per receiver, each over a quarter of the senders
         const int chunks = (N + 127) / 128;
+        c->dv(DV_GRAPH_Q4);
         hipLaunchKernelGGL(k_graph_q4, dim3((unsigned)(B * chunks)), dim3(GRAPH_Q4_THREADS), GRAPH_Q4_LDS(N), st, s_prev, prev_mod,
                            prev_stride, actions, act_stride, s_delta, N, nbr_idx, nbr_cnt, c->cam, c->thr, chunks, self_first);
     }
-    else
+    else {
+        c->dv(DV_GRAPH_PLAIN);
         hipLaunchKernelGGL(k_graph, dim3(SPREAD_GRID(B * graph_chunks(N))), dim3(GRAPH_THREADS), graph_lds(N), st, s_prev,
                            prev_mod, prev_stride, actions, act_stride, s_delta, N, nbr_idx, nbr_cnt, c->cam, c->thr,
                            graph_chunks(N), B * graph_chunks(N), self_first);
+    }
 }
 
 void launch_aggregate(drp_ctx* c, int B, int N) {
@@ -646,6 +743,7 @@ void launch_aggregate(drp_ctx* c, int B, int N) {
         if (chunks > 2048 / B) chunks = 2048 / B;
         if (chunks < 1) chunks = 1;
     }
+    c->dv((N <= K_AGG_LDS_MAX_N && !c->agg_global_only && chunks == 1) ? DV_AGGREGATE_LDS : DV_AGGREGATE);
     if (N <= K_AGG_LDS_MAX_N && !c->agg_global_only && chunks == 1)
         hipLaunchKernelGGL(k_aggregate_lds, dim3(B), dim3(512), (size_t)N * 256, c->stream,
                            ptr<float>(c->c_edge), ptr<float>(c->proj), ptr<int16_t>(c->nbr_idx),
@@ -677,8 +775,13 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     const long edge_tiles = (long)B * ((N * DRP_K + 31) / 32);
     const size_t bn64 = (size_t)B * N * 64;
     const bool tape = a.eff_hist != nullptr;
-    if (tape && c->engine != DRP_ENGINE_FUSED) return fail(c, DRP_ESTATE, "the backward tape is written by the fused engine");
-    float* eff0 = tape ? a.eff_hist : ptr<float>(c->eff);
+    // the tape of the reverse-mode kernels: km_prop<., TAPE> on the fused engine; on the fp32 matrix engine (what the
+    // gradient-descent planner and the trainer fall back to when the split-fp16 relation encoder refuses the weights or the
+    // inputs) the stage kernels run as always and the tape is copied / written beside them (tape_mfma below)
+    if (tape && c->engine != DRP_ENGINE_FUSED && c->engine != DRP_ENGINE_MFMA)
+        return fail(c, DRP_ESTATE, "the backward tape is written by the fused or the fp32 matrix engine");
+    const bool tape_mfma = tape && c->engine == DRP_ENGINE_MFMA;
+    float* eff0 = (tape && !tape_mfma) ? a.eff_hist : ptr<float>(c->eff);
     // chip-filling batches on the fused engine: the three propagation steps are one launch (km_prop3), and the
     // particle encoder is its first phase unless switched off
     const int tps3 = (N + 31) / 32;
@@ -687,6 +790,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     const bool phase_e = prop3 && c->prop3e;
     if (!phase_e) {
         ProbeScope ps(c, KC_NODE_ENCODE);
+        c->dv(c->engine == DRP_ENGINE_FUSED ? DV_NODE_ENCODE_SPLIT : DV_NODE_ENCODE);
         if (c->engine == DRP_ENGINE_FUSED)
             hipLaunchKernelGGL(km_node_encode_split, dim3(mfma_grid_spread(c, node_tiles)), blk, KM_NODE_SPLIT_LDS, st,
                                ptr<uint16_t>(c->w_split6), mw, ptr<float>(c->s_delta), a.attr, a.attr_mod, a.dens,
@@ -702,6 +806,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     const bool split = fused || c->engine == DRP_ENGINE_SPLIT || c->engine == DRP_ENGINE_FUSED;
     if (!fused) {
         ProbeScope ps(c, KC_EDGE_ENCODE);
+        c->dv(split ? DV_EDGE_ENCODE_SPLIT : DV_EDGE_ENCODE);
         if (split)
             hipLaunchKernelGGL(km_edge_encode_split, dim3(mfma_grid(c, edge_tiles)), blk, KM_EDGE_SPLIT_LDS, st,
                                ptr<uint16_t>(c->w_split), mw, a.s_prev, a.prev_mod, a.prev_stride, a.attr,
@@ -744,6 +849,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
 #define PROP3_LAUNCH(TAPE_, PAIR_) do { \
                 if (one) PROP3_LAUNCH_W(TAPE_, PAIR_, true, true); else if (ec) PROP3_LAUNCH_W(TAPE_, PAIR_, true, false); \
                 else PROP3_LAUNCH_W(TAPE_, PAIR_, false, false); } while (0)
+            c->dv(DV_PROP3 + 12 * (tape ? 1 : 0) + 6 * (pair ? 1 : 0) + 2 * (one ? 2 : ec ? 1 : 0) + (wk ? 1 : 0));
             if (!tape && !pair) PROP3_LAUNCH(false, false);
             else if (!tape) PROP3_LAUNCH(false, true);
             else if (!pair) PROP3_LAUNCH(true, false);
@@ -779,6 +885,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                     if (!last) hipLaunchKernelGGL((km_prop<false, true, PAIR_, WORK_>), grid, pblk, KM_PROP_LDS(false), st, PROP_ARGS); \
                     else hipLaunchKernelGGL((km_prop<true, true, PAIR_, WORK_>), grid, pblk, KM_PROP_LDS(true), st, PROP_ARGS); \
                 } } while (0)
+            c->dv(DV_PROP + 8 * (last ? 1 : 0) + 4 * (tape ? 1 : 0) + 2 * (pair ? 1 : 0) + (c->work_ptr() ? 1 : 0));
             if (c->work_ptr()) { if (pair) PROP_LAUNCH(true, true); else PROP_LAUNCH(false, true); }
             else if (pair) PROP_LAUNCH(true, false);
             else PROP_LAUNCH(false, false);
@@ -788,9 +895,25 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
         }
         return DRP_OK;
     }
+    if (tape_mfma) HIPCHK(c, hipMemcpyAsync(a.eff_hist, c->eff.p, bn64 * sizeof(float), hipMemcpyDeviceToDevice, st));
     for (int p = 0; p < DRP_PSTEP; ++p) {
-        launch_aggregate(c, B, N);
+        if (tape_mfma) {
+            // the aggregate that also leaves the edges' ReLU bits; the aggregated rows and the effects are copied into the tape
+            ProbeScope pa(c, KC_AGGREGATE);
+            int chunks = 1;
+            if (B < c->n_cu / 2) chunks = std::max(1, std::min((N + 15) / 16, 2048 / B));
+            c->dv(DV_AGGREGATE_TAPE);
+            hipLaunchKernelGGL(k_aggregate_tape, dim3(B * chunks), dim3(256), 0, st, ptr<float>(c->c_edge), ptr<float>(c->proj),
+                               ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), N, ptr<float>(c->agg), chunks,
+                               a.mask_hist + (size_t)p * B * N * DRP_K * 2);
+            if (a.agg_hist)
+                HIPCHK(c, hipMemcpyAsync(a.agg_hist + (size_t)p * bn64, c->agg.p, bn64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        } else {
+            launch_aggregate(c, B, N);
+        }
+        {
         ProbeScope ps(c, p + 1 < DRP_PSTEP ? KC_UPDATE : KC_PREDICT);
+        c->dv(DV_UPDATE);
         if (p + 1 < DRP_PSTEP)
             hipLaunchKernelGGL(km_update<false>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
                                ptr<float>(c->agg), ptr<float>(c->c_node), ptr<float>(c->eff), N, B,
@@ -799,6 +922,10 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             hipLaunchKernelGGL(km_update<true>, dim3(mfma_grid(c, node_tiles)), blk, KM_UPD_LDS, st, mw,
                                ptr<float>(c->agg), ptr<float>(c->c_node), ptr<float>(c->eff), N, B,
                                ptr<float>(c->proj), a.s_prev, a.prev_mod, a.prev_stride, a.s_out, a.out_stride);
+        }
+        // the step's effect is the next tape entry (km_update keeps it in place, the last step's too)
+        if (tape_mfma)
+            HIPCHK(c, hipMemcpyAsync(a.eff_hist + (size_t)(p + 1) * bn64, c->eff.p, bn64 * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     return DRP_OK;
 }
@@ -815,6 +942,7 @@ int run_step(drp_ctx* c, const StepArgs& a) {
         ProbeScope ps(c, KC_GRAPH);
         const int self_first = (c->engine == DRP_ENGINE_FUSED && a.cself != nullptr) ? 1 : 0;
         if (a.rev_off != nullptr && N <= GRAPH_THREADS && c->graph_rev) {
+            c->dv(DV_GRAPH_REV);
             hipLaunchKernelGGL(k_graph_rev, dim3(SPREAD_GRID(B)), dim3(GRAPH_THREADS), (size_t)12 * N * sizeof(int), st, a.s_prev,
                                a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, N, nbr_idx, nbr_cnt, c->cam, c->thr,
                                B, self_first, a.rev_off, a.rev);
@@ -830,6 +958,7 @@ int run_step(drp_ctx* c, const StepArgs& a) {
         HIPCHK(c, hipGetLastError());
         return DRP_OK;
     }
+    c->dv(DV_VALU_STEP);
     {
         ProbeScope ps(c, KC_NODE_ENCODE);
         hipLaunchKernelGGL(k_node_encode<8>, dim3(B), dim3(256), 0, st, vw, s_delta, a.attr,
@@ -866,6 +995,7 @@ int run_step(drp_ctx* c, const StepArgs& a) {
 int run_reward(drp_ctx* c, const float* state, size_t row_stride, int rows, int N, int normalize,
                float* out) {
     ProbeScope ps(c, KC_REWARD);
+    c->dv(DV_REWARD);
     hipLaunchKernelGGL(k_reward, dim3(rows), dim3(256), (2 * ((N + 3) & ~3) + 8) * sizeof(float), c->stream, state,
                        row_stride, N, ptr<float>(c->goal_field), c->goal_h, c->goal_w,
                        ptr<float>(c->goal_coor), c->goal_m, c->cam, normalize, out);
@@ -950,6 +1080,8 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
 #define ROLLOUT_LAUNCH_W(PAIR_, EC_, WORK_, ONE_) hipLaunchKernelGGL((km_rollout<PAIR_, EC_, WORK_, ONE_>), dim3(grid_r), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS, \
                                                                      c->stream, ptr<RolloutArgs>(c->roll_args))
 #define ROLLOUT_LAUNCH(PAIR_, EC_, ONE_) do { if (ra.work) ROLLOUT_LAUNCH_W(PAIR_, EC_, true, ONE_); else ROLLOUT_LAUNCH_W(PAIR_, EC_, false, ONE_); } while (0)
+        c->dv(DV_GRAPH_IN_ROLLOUT);
+        c->dv(DV_ROLLOUT + 6 * (pair_r ? 1 : 0) + 2 * (one ? 2 : ec ? 1 : 0) + (ra.work ? 1 : 0));
         if (pair_r) { if (one) ROLLOUT_LAUNCH(true, true, true); else if (ec) ROLLOUT_LAUNCH(true, true, false); else ROLLOUT_LAUNCH(true, false, false); }
         else { if (one) ROLLOUT_LAUNCH(false, true, true); else if (ec) ROLLOUT_LAUNCH(false, true, false); else ROLLOUT_LAUNCH(false, false, false); }
 #undef ROLLOUT_LAUNCH_W
@@ -1033,6 +1165,7 @@ void flush_wgrad(drp_ctx* c) {
         J.j[q].part = static_cast<float*>(c->tr_part.p) + (size_t)q * KT_WGRAD_MAX_BLOCKS * 66 * 64;
         if (J.j[q].blocks > max_blocks) max_blocks = J.j[q].blocks;
     }
+    c->dv(c->wgrad_mfma ? DV_WGRAD_MFMA : DV_WGRAD_VALU);
     if (c->wgrad_mfma)
         hipLaunchKernelGGL(kt_wgrad_mfma_multi, dim3((unsigned)max_blocks, (unsigned)n), dim3(256), KT_WGRAD_MULTI_LDS, c->stream, J);
     else
@@ -1083,6 +1216,8 @@ int flush_wgrad_all(drp_ctx* c) {
         CHK(h2d(c, c->wg_jobs_dev, c->wg_uploaded.data(), jb));
         CHK(h2d(c, c->wg_idx_dev, c->wg_uploaded.data() + jb, ib));
     }
+    c->dv(DV_WGRAD_DEFERRED);
+    c->dv(c->wgrad_mfma ? DV_WGRAD_MFMA : DV_WGRAD_VALU);
     const WgradJob* jd = static_cast<const WgradJob*>(c->wg_jobs_dev.p);
     const int* od = static_cast<const int*>(c->wg_idx_dev.p);
     for (int a = 0; a < n;) {
@@ -1193,6 +1328,18 @@ int range_check(drp_ctx* c, float max_attr, float max_dens, float max_sdelta, bo
                 A, (double)max_dens, (double)max_sdelta, bound, r.shift);
 }
 
+// Which engine writes the tape of the gradient-descent planner / the trainer: the fused one (km_prop<., TAPE>) unless the
+// caller has selected an fp32 engine (drp_set_engine) or the split-fp16 relation encoder would refuse these weights or
+// inputs -- then the fp32 matrix engine's stage kernels with k_aggregate_tape: several times slower, no range limit.  The
+// live planner of the reference IS the gradient-descent one (env/flex_env.py:973-976): it must not stop on DRP_ERANGE.
+int pick_tape_engine(drp_ctx* c, float max_attr, float max_dens, float max_sdelta, int* engine) {
+    if (c->engine == DRP_ENGINE_MFMA || c->engine == DRP_ENGINE_VALU) { *engine = DRP_ENGINE_MFMA; return DRP_OK; }
+    const int rc = range_check(c, max_attr, max_dens, max_sdelta, true);
+    if (rc == DRP_ERANGE) { *engine = DRP_ENGINE_MFMA; c->err.clear(); return DRP_OK; }
+    *engine = DRP_ENGINE_FUSED;
+    return rc;
+}
+
 // range shift of the split relation encoder: proven for |attr| <= 2 (the reference's are 0), |s_r - s_s| <= 1.5
 // per coordinate (radius 0.08 + two impulses; the default clip box's longest push is 8.5 sqrt(2) / 24 = 0.50
 // camera-frame units, the whole workspace diagonal 0.59: 0.08 + 2 x 0.59 = 1.26), density <= 10 000 (training
@@ -1257,6 +1404,7 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_PROP_PAIR_DEG10")) c->prop_pair_deg10 = std::max(0, atoi(e));
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
     c->bwd_rows = getenv("DRP_NO_BWD_ROWS") == nullptr;
+    c->bwd_valu_stages = getenv("DRP_BWD_VALU_STAGES") != nullptr;
     c->graph_rev = getenv("DRP_NO_GRAPH_REV") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
     if (const char* e = getenv("DRP_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_timeout_s = v; }
@@ -1356,7 +1504,7 @@ void drp_destroy(drp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)guarded_wait(c, nullptr);           // a collective that cannot finish must not keep the destructor
-    helpers_wait(5.0);                        // no helper thread (an abort, an init) inside RCCL while the stream goes away
+    helpers_wait(5.0, c);                     // no helper thread of this context (an abort, an init) inside RCCL while its stream goes away
     if (c->comm) { RcclApi* R = rccl_api(); if (R) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
     DevBuf* bufs[] = {&c->probe_work, &c->ecache, &c->tape_mask, &c->g_agg_hist, &c->rev_off, &c->rev, &c->gpos_edge, &c->tape_sdelta, &c->tape_idx, &c->tape_cnt, &c->eff_hist, &c->g_eff, &c->g_cnode, &c->g_agg, &c->g_proj, &c->g_state,
                       &c->g_sdelta, &c->g_act, &c->adam_m, &c->adam_v, &c->w_raw, &c->w_valu, &c->w_mfma, &c->w_mfma_bwd, &c->w_split, &c->w_split6, &c->w_split6_bwd, &c->proj2, &c->goal_field, &c->goal_coor, &c->s_in,
@@ -1693,6 +1841,7 @@ int drp_mpc_partials(drp_ctx* c, double* out) {
 static int launch_update(drp_ctx* c, const double* dev_partials, int n_ranks, int rank_stride = 0) {
     const drp_mpc_params& p = c->mpc;
     ProbeScope ps(c, KC_MPPI);
+    c->dv(DV_MPPI_SOFTMAX);
     hipLaunchKernelGGL(k_mppi_update, dim3(1), dim3(128), 0, c->stream, dev_partials, n_ranks,
                        rank_stride > 0 ? rank_stride : 6 + 4 * p.n_look_ahead, p.n_look_ahead, (double)p.n_sample * (double)n_ranks, ptr<double>(c->nominal),
                        ptr<double>(c->stats));
@@ -1749,6 +1898,7 @@ static int launch_elite_local(drp_ctx* c, int k, double* out) {
     size_t lds = (size_t)n2 * 20;
     if (lds > 150 * 1024 || k > n2) { n2 = 0; lds = (size_t)p.n_sample * 16 + (size_t)k * 4; }
     ProbeScope ps(c, KC_MPPI);
+    c->dv(n2 ? DV_ELITE_SORT : DV_ELITE_ROUNDS);
     hipLaunchKernelGGL(k_elite_local, dim3(1), dim3(256), lds, c->stream, ptr<float>(c->rewards) + (H - 1), H,
                        ptr<float>(c->actions), p.n_sample, p.n_batch, H, k, p.sample_offset, n2, out);
     HIPCHK(c, hipGetLastError());
@@ -1899,9 +2049,11 @@ int drp_fps(drp_ctx* c, const float* pts, int n, int dim, int k, int init_idx, i
     float* md = reinterpret_cast<float*>(ptr<double>(c->stats) + 7);
     const bool in_regs = n <= 1024 * FPS_REG_PT(dim);
     if (dim == 2) {
+        c->dv(in_regs ? DV_FPS_REG : DV_FPS_MEM);
         if (in_regs) hipLaunchKernelGGL(k_fps_reg<2>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, chosen, md);
         else hipLaunchKernelGGL(k_fps<2>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, dist, chosen, md);
     } else {
+        c->dv(in_regs ? DV_FPS_REG : DV_FPS_MEM);
         if (in_regs) hipLaunchKernelGGL(k_fps_reg<3>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, chosen, md);
         else hipLaunchKernelGGL(k_fps<3>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, dist, chosen, md);
     }
@@ -2156,10 +2308,12 @@ int goal_stage_dt(drp_ctx* c, const uint8_t* d_seg, int h, int w, int mode) {
     if (mode == DRP_DT_CV5) {
         const size_t lds = (size_t)3 * (w + 4) * sizeof(int);
         if (lds > 60000) return fail(c, DRP_EINVAL, "image width %d too large for the chamfer kernel", w);
+        c->dv(DV_DT_CV5);
         hipLaunchKernelGGL(k_dt_cv5, dim3(1), dim3(DT_THREADS), lds, st, d_seg, h, w, ptr<int>(c->gl_tmp),
                            ptr<float>(c->gl_dist));
     } else if (mode == DRP_DT_EXACT) {
         if ((size_t)w * sizeof(int) > 60000) return fail(c, DRP_EINVAL, "image width %d too large", w);
+        c->dv(DV_DT_EXACT);
         hipLaunchKernelGGL(k_edt_cols, dim3((w + 255) / 256), dim3(256), 0, st, d_seg, h, w, ptr<int>(c->gl_tmp));
         hipLaunchKernelGGL(k_edt_rows, dim3(h), dim3(256), (size_t)w * sizeof(int), st, ptr<int>(c->gl_tmp), h, w,
                            ptr<float>(c->gl_dist));
@@ -2217,6 +2371,7 @@ int drp_set_goal_image(drp_ctx* c, const float* obs_goal, int h, int w, int mode
     float* fdist = ptr<float>(c->gl_fps);
     int* chosen = reinterpret_cast<int*>(fdist + count);
     float* md = reinterpret_cast<float*>(chosen + m);
+    c->dv(count <= 1024 * FPS_REG_PT(2) ? DV_FPS_REG : DV_FPS_MEM);
     if (count <= 1024 * FPS_REG_PT(2))
         hipLaunchKernelGGL(k_fps_reg<2>, dim3(1), dim3(1024), 0, st, ptr<float>(c->gl_pix), count, m, fps_init, chosen, md);
     else
@@ -2270,7 +2425,7 @@ int gd_forward_backward(drp_ctx* c) {
     // ---- forward on the fused engine; km_prop<., TAPE> leaves what the backward pass needs: the
     //      effect after the encoder and after every propagation step, and the ReLU masks of the edges
     const int saved_engine = c->engine;
-    c->engine = DRP_ENGINE_FUSED;
+    c->engine = c->gd_engine;
     // the self-edge constants depend on attributes and densities only: computed once per GD problem,
     // again only if a rollout in between has reused the buffer
     int rc = DRP_OK;
@@ -2313,6 +2468,7 @@ int gd_forward_backward(drp_ctx* c) {
     float* g_state = ptr<float>(c->g_state);                 // [H][B,N,3]
     {
         ProbeScope ps(c, KC_BWD_REWARD);
+        c->dv(DV_BWD_REWARD);
         hipLaunchKernelGGL(kb_reward, dim3(B), dim3(256), KB_REWARD_LDS(N), st, states + (size_t)(H - 1) * N * 3, hstride,
                            N, ptr<float>(c->goal_field), c->goal_h, c->goal_w, ptr<float>(c->goal_coor), c->goal_m, c->cam,
                            1, g_state + (size_t)(H - 1) * bn * 3, (size_t)N * 3, ptr<float>(c->rewards), c->gd_host_rewards);
@@ -2329,6 +2485,7 @@ int gd_forward_backward(drp_ctx* c) {
         float* gah = ptr<float>(c->g_agg_hist);
         if (!rev_built) {
             ProbeScope ps(c, KC_BWD_LISTS);
+            c->dv(N <= 512 ? DV_REV_256 : DV_REV_1024);
             if (N <= 512)
                 hipLaunchKernelGGL(kb_reverse_lists<256>, dim3(B), dim3(256), KB_REV_LDS(N, rev_lds), st, idx,
                                    cnt, N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, (const int*)nullptr);
@@ -2347,6 +2504,7 @@ int gd_forward_backward(drp_ctx* c) {
             while (gps > 1 && rounds(gps - 1) == rounds(g_max)) --gps;
             const long n_groups = ((long)B + gps - 1) / gps;
             ProbeScope ps(c, KC_BWD_NODE);
+            c->dv(DV_BWD_ROWS);
             hipLaunchKernelGGL(kmb_rows_bwd, dim3((unsigned)(n_groups < (long)c->n_cu ? n_groups : (long)c->n_cu)), dim3(64 * KMB_FUSED_WAVES),
                                KMB_ROWS_LDS, st, ptr<float>(c->w_mfma), ptr<float>(c->w_mfma_bwd), ptr<uint16_t>(c->w_split6),
                                ptr<uint16_t>(c->w_split6_bwd), eht, mht, cnt, ptr<int>(c->rev_off),
@@ -2356,16 +2514,18 @@ int gd_forward_backward(drp_ctx* c) {
             // chip-filling batches: everything between the reward's gradient and the impulses' in one launch,
             // a workgroup owning whole samples (kmb_step_bwd)
             ProbeScope ps(c, KC_BWD_NODE);
+            c->dv(DV_BWD_STEP);
             hipLaunchKernelGGL(kmb_step_bwd, dim3((unsigned)((B + spw_b - 1) / spw_b)), dim3(64 * KMB_FUSED_WAVES), KMB_FUSED_LDS, st,
                                ptr<float>(c->w_mfma), ptr<float>(c->w_mfma_bwd), eht, mht, cnt, ptr<int>(c->rev_off), ptr<int>(c->rev),
                                g_out, (size_t)N * 3, ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb,
                                ptr<float>(c->dens), nb, N, B, spw_b, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), gah,
                                ptr<float>(c->g_sdelta));
-        } else if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES) {      // node stages on the matrix cores
+        } else if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES && !c->bwd_valu_stages) {      // node stages on the matrix cores
             const float* mw = ptr<float>(c->w_mfma);
             const float* mb = ptr<float>(c->w_mfma_bwd);
             const long node_tiles = (long)B * ((N + 31) / 32);
             const dim3 ngrid(mfma_grid_spread(c, node_tiles)), nblk(64 * MFMA_WAVES);
+            c->dv(DV_BWD_STAGES_MFMA);
             { ProbeScope ps(c, KC_BWD_NODE);
             hipLaunchKernelGGL(kmb_predict, ngrid, nblk, KMB_PREDICT_LDS, st, mw, mb, eht + 3 * bn * 64, g_out, (size_t)N * 3, N, B,
                                ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr);
@@ -2404,6 +2564,7 @@ int gd_forward_backward(drp_ctx* c) {
                                (float*)nullptr, (float*)nullptr, (float*)nullptr);
             }
         } else {
+            c->dv(DV_BWD_STAGES_VALU);
             { ProbeScope ps(c, KC_BWD_NODE);
             hipLaunchKernelGGL(kb_predict, dim3(B), dim3(256), 0, st, vw, wraw, eht + 3 * bn * 64, g_out, (size_t)N * 3, N,
                                ptr<float>(c->g_eff), (float*)nullptr, (float*)nullptr, 1);
@@ -2436,6 +2597,7 @@ int gd_forward_backward(drp_ctx* c) {
             g_prev = g_state + (size_t)(t - 1) * bn * 3;
             CHK(d2d(g_prev, g_out, bn * 3 * sizeof(float)));
             { ProbeScope ps(c, KC_BWD_EDGE);
+            c->dv(c->bwd_edge_mfma ? DV_BWD_EDGE_MFMA : DV_BWD_EDGE_VALU);
             if (c->bwd_edge_mfma)
                 launch_edge_encode_mfma(c, s_prev, prev_mod, prev_stride, nb, idx, cnt, gah, mht, bn, N, B, ptr<float>(c->gpos_edge), KbEdgeDump{});
             else
@@ -2470,15 +2632,15 @@ int drp_gd_begin(drp_ctx* c, const float* s0, const float* attr, const float* de
     {
         // Adam moves the pushes, the clip keeps them in the box: bound by the box's diagonals and by the initial pushes
         const float box[8] = {act_lo[0], act_lo[1], act_hi[2], act_hi[3], act_hi[0], act_hi[1], act_lo[2], act_lo[3]};
-        CHK(range_check(c, max_abs(attr, (size_t)nb * N), max_abs(dens, (size_t)nb),
-                        fmaxf(push_len_bound(c, box, 2), push_len_bound(c, actions, (size_t)B * H)), true));
+        CHK(pick_tape_engine(c, max_abs(attr, (size_t)nb * N), max_abs(dens, (size_t)nb),
+                             fmaxf(push_len_bound(c, box, 2), push_len_bound(c, actions, (size_t)B * H)), &c->gd_engine));
     }
     const size_t bn = (size_t)B * N;
     CHK(h2d(c, c->s_in, s0, (size_t)nb * N * 3 * sizeof(float)));
     CHK(h2d(c, c->attr, attr, (size_t)nb * N * sizeof(float)));
     CHK(h2d(c, c->dens, dens, (size_t)nb * sizeof(float)));
     CHK(h2d(c, c->actions, actions, (size_t)B * H * 4 * sizeof(float)));
-    CHK(ensure_step_ws(c, B, N));
+    CHK(ensure_step_ws(c, B, N, c->gd_engine));
     CHK(ensure(c, c->states, (size_t)H * bn * 3 * sizeof(float)));
     CHK(ensure(c, c->rewards, (size_t)B * sizeof(float)));
     CHK(ensure(c, c->eff_hist, (size_t)H * 4 * bn * 64 * sizeof(float)));
@@ -2634,7 +2796,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     double* loss = ptr<double>(c->tr_loss);
     const float scale = 1.0f / (float)(H * B);
     const int saved_engine = c->engine;
-    c->engine = DRP_ENGINE_FUSED;
+    c->engine = c->tr_engine;
     const float* cself = nullptr;
     const uint8_t* cself_ok = nullptr;
     int rc = prepare_cself(c, B, N, B, &cself, &cself_ok);
@@ -2700,6 +2862,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     HIPCHK(c, hipMemsetAsync(G, 0, (size_t)W_TOTAL * sizeof(float), st));
     // the reversed lists of ALL rollout steps in one launch (the tape holds every step's lists; a training batch is a handful
     // of workgroups per step)
+    c->dv(N <= 512 ? DV_REV_256 : DV_REV_1024);
     if (N <= 512)
         hipLaunchKernelGGL(kb_reverse_lists<256>, dim3(B * H), dim3(256), KB_REV_LDS(N, rev_lds), st, ptr<int16_t>(c->tape_idx),
                            ptr<uint8_t>(c->tape_cnt), N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums), B);
@@ -2738,11 +2901,12 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         int* const rev_t = ptr<int>(c->rev) + (size_t)t * bnk;
         // node-level stages: on the matrix cores when the batch has enough 32-row tiles to fill the chip,
         // otherwise the row kernels chunked over (sample, rows)
-        if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES) {
+        if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES && !c->bwd_valu_stages) {
             const float* mw = ptr<float>(c->w_mfma);
             const float* mb = ptr<float>(c->w_mfma_bwd);
             const long node_tiles = (long)B * ((N + 31) / 32);
             const dim3 ngrid(mfma_grid_spread(c, node_tiles)), nblk(64 * MFMA_WAVES);
+            c->dv(DV_TRAIN_NODE_MFMA);
             // predictor
             hipLaunchKernelGGL(kmb_predict, ngrid, nblk, KMB_PREDICT_LDS, st, mw, mb, eht + 3 * bn64, g_out, (size_t)N * 3, N, B,
                                ge_tmp, tr_hact_t, tr_gh_t);
@@ -2793,6 +2957,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                             nullptr, nullptr, 1, 1);
             flush_wgrad(c);
         } else {
+            c->dv(DV_TRAIN_NODE_VALU);
             // predictor
             hipLaunchKernelGGL(kb_predict, rgrid, dim3(256), 0, st, vw, wraw, eht + 3 * bn64, g_out, (size_t)N * 3, N,
                                ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh), chunks);
@@ -2837,6 +3002,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             g_prev = g_state + (size_t)(t - 1) * bn * 3;
             hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
         }
+        c->dv(c->bwd_edge_mfma ? DV_BWD_EDGE_MFMA : DV_BWD_EDGE_VALU);
         if (c->bwd_edge_mfma)
             launch_edge_encode_mfma(c, s_prev, B, prev_stride, B, idx, cnt, gah, mht, bn, N, B,
                                     g_prev != nullptr ? ptr<float>(c->gpos_edge) : (float*)nullptr, ed);
@@ -2946,7 +3112,7 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     {
         float amax = 0.0f;                                    // a_cur = attrs[:, 0]
         for (int b = 0; b < B; ++b) amax = fmaxf(amax, max_abs(attrs + (size_t)b * (c->tr_nroll + 1) * N, (size_t)N));
-        CHK(range_check(c, amax, max_abs(particle_dens, (size_t)B), max_abs(states_delta, (size_t)B * c->tr_nroll * N * 3), true));
+        CHK(pick_tape_engine(c, amax, max_abs(particle_dens, (size_t)B), max_abs(states_delta, (size_t)B * c->tr_nroll * N * 3), &c->tr_engine));
     }
     const int H = c->tr_nroll;
     const size_t bn = (size_t)B * N, bn64 = bn * 64, bnk = bn * DRP_K;
@@ -2960,7 +3126,7 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     CHK(h2d(c, c->scratch, attrs, (size_t)B * (H + 1) * N * sizeof(float)));
     HIPCHK(c, hipMemcpy2DAsync(c->attr.p, (size_t)N * sizeof(float), c->scratch.p, (size_t)(H + 1) * N * sizeof(float),
                                (size_t)N * sizeof(float), B, hipMemcpyDeviceToDevice, c->stream));
-    CHK(ensure_step_ws(c, B, N));
+    CHK(ensure_step_ws(c, B, N, c->tr_engine));
     CHK(ensure(c, c->states, (size_t)H * bn * 3 * sizeof(float)));
     CHK(ensure(c, c->g_state, (size_t)H * bn * 3 * sizeof(float)));
     c->wg_defer_now = false;
@@ -2969,7 +3135,7 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         // deferred weight gradients keep every job's operands until the end of the backward pass: H copies of the node-level
         // dumps (3 H + 1 of g_eff, 3 H of g_proj) and of the relation encoder's dumps -- 0.24 GB per rollout step at 32 x 300
         const size_t keep_bytes = (size_t)H * (16 * bn64 + 7 * bnk * 64 + bnk * 8 + bn * 8) * sizeof(float);
-        const bool defer = c->wgrad_defer && (long)B * ((N + 31) / 32) >= KMB_MIN_TILES && keep_bytes <= ((size_t)8 << 30);
+        const bool defer = c->wgrad_defer && (long)B * ((N + 31) / 32) >= KMB_MIN_TILES && !c->bwd_valu_stages && keep_bytes <= ((size_t)8 << 30);
         c->wg_defer_now = defer;
         const size_t kt = defer ? (size_t)H : 1;
         CHK(ensure(c, c->eff_hist, (size_t)H * 4 * bn64 * sizeof(float)));
@@ -3096,7 +3262,7 @@ int drp_comm_init(drp_ctx* c, const char* id128, int rank, int n_ranks) {
         std::lock_guard<std::mutex> lk(g_used_ids_mu);
         g_used_ids.push_back(key);
     }
-    auto hs = helper_register();
+    auto hs = helper_register(c);
     std::thread([stt, R, id, rank, n_ranks, dev, hs] {
         (void)hipSetDevice(dev);
         stt->res = R->CommInitRank(&stt->comm, n_ranks, id, rank);
@@ -3165,20 +3331,18 @@ int drp_comm_allgather(drp_ctx* c, const void* send, size_t bytes, void* recv) {
 
 int drp_comm_destroy(drp_ctx* c) {
     if (!c) return DRP_EINVAL;
-    c->comm_failed = false;                           // the caller has seen the failure and goes on alone
-    helpers_wait(5.0);                                // an abort still draining the device
+    helpers_wait(5.0, c);                             // an abort of this context still draining the device
+    int rc = DRP_OK;
     if (c->comm) {
         RcclApi* R = rccl_api();
-        const int rc = guarded_wait(c, nullptr);      // aborts the communicator itself when the wait gives up
+        rc = guarded_wait(c, nullptr);                // aborts the communicator itself when the wait gives up (and reports it)
         if (c->comm && R) (void)R->CommDestroy(c->comm);
-        c->comm = nullptr;
-        c->n_ranks = 1;
-        c->rank = 0;
-        return rc;
     }
+    c->comm = nullptr;
     c->n_ranks = 1;
     c->rank = 0;
-    return DRP_OK;
+    c->comm_failed = false;                           // the caller has seen the failure and goes on alone -- AFTER the wait above,
+    return rc;                                        // whose own give-up would have raised the flag again
 }
 
 // ---- measurement / debugging -----------------------------------------------------------------
@@ -3270,6 +3434,43 @@ int drp_probe_read(drp_ctx* c, double* total_ms, long* launches) {
 __global__ void k_debug_stall(unsigned long long ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+int drp_dispatch_reset(drp_ctx* c) {
+    if (!c) return DRP_EINVAL;
+    memset(c->dv_hit, 0, sizeof(c->dv_hit));
+    return DRP_OK;
+}
+
+static long dv_join(const unsigned char* hit, bool default_only, char* out, size_t out_len) {
+    std::string all;
+    char name[96];
+    for (int id = 0; id < DV_COUNT; ++id) {
+        bool dflt = true;
+        dv_name(id, name, sizeof(name), &dflt);
+        if (hit ? !hit[id] : (default_only && !dflt)) continue;
+        if (!all.empty()) all += ';';
+        all += name;
+    }
+    if (out && out_len) snprintf(out, out_len, "%s", all.c_str());
+    return (long)all.size();
+}
+
+long drp_last_dispatch(drp_ctx* c, char* out, size_t out_len) {
+    if (!c) return DRP_EINVAL;
+    return dv_join(c->dv_hit, false, out, out_len);
+}
+
+long drp_dispatch_variants(int default_only, char* out, size_t out_len) { return dv_join(nullptr, default_only != 0, out, out_len); }
+
+int drp_range_info(drp_ctx* c, int* shift, double* bound, double* wmax, int* ok) {
+    CHK(need(c, true, false, false));
+    const SplitRange& r = c->re_range;
+    if (shift) *shift = r.shift;
+    if (bound) *bound = split_range_bound(r, r.env_attr, r.env_delta, r.env_dens);
+    if (wmax) *wmax = (double)r.wmax;
+    if (ok) *ok = c->re_ok ? 1 : 0;
+    return DRP_OK;
 }
 
 int drp_debug_stall(drp_ctx* c, int ms) {

@@ -462,13 +462,16 @@ __device__ __forceinline__ float adam_update(float a0, float g, float& m, float&
 // directions 0..3: the push (sx, sy, ex, ey); 4..6: the particle's own position (x, y, z).
 // g_action[b, 0:4] = sum_n J_n^T g_s_delta[n];  g_pos[b, n, 0:3] += J_pos^T g_s_delta[n] (nullable)
 __global__ void __launch_bounds__(256)
-kb_sdelta(const float* __restrict__ s_cur, int s_mod, size_t s_stride, const float* __restrict__ actions,
-          size_t act_stride, const float* __restrict__ g_sdelta, int N, DrpCam cam, float* __restrict__ g_action,
+kb_sdelta(const float* __restrict__ s_cur, int s_mod, size_t s_stride, const float* actions /* may be adam.act: no restrict */,
+          size_t act_stride, const float* __restrict__ g_sdelta, int N, DrpCam cam, float* g_action /* read back below */,
           size_t gact_stride, float* __restrict__ g_pos, size_t gpos_stride, KbAdam adam = KbAdam{}) {
     typedef Dual<7> D;
     __shared__ float red[4][4];
     const int b = blockIdx.x;
-    const float* act = actions + (size_t)b * act_stride;
+    // the push of this row and step, by value: with rollout step 0 the optimiser step at the end of this kernel overwrites
+    // the very elements (adam.act is the actions buffer)
+    const float act[4] = {actions[(size_t)b * act_stride + 0], actions[(size_t)b * act_stride + 1],
+                          actions[(size_t)b * act_stride + 2], actions[(size_t)b * act_stride + 3]};
     const float* s = s_cur + (size_t)(b % s_mod) * s_stride;
     const float* gs = g_sdelta + (size_t)b * N * 3;
     // camera-frame start / end as duals of (sx, sy, ex, ey): s3 = (sx, 0, -sy), e3 = (ex, 0, -ey)
@@ -532,18 +535,21 @@ kb_sdelta(const float* __restrict__ s_cur, int s_mod, size_t s_stride, const flo
     // The row's optimiser step, in the launch that completes its gradient (rollout step 0's: the later steps' launches ran
     // before it, and with step 0 `g_action + b * gact_stride` is the start of the row's H * 4 gradients): thread x owns
     // value x of the row -- for this step's four values the sum it has just stored itself.
-    if (adam.act != nullptr && (int)threadIdx.x < adam.n_row) {
-        const size_t i = (size_t)b * adam.n_row + threadIdx.x;
-        const int c = threadIdx.x & 3;
-        const float l = (c == 0) ? adam.lo.x : (c == 1) ? adam.lo.y : (c == 2) ? adam.lo.z : adam.lo.w;
-        const float h = (c == 0) ? adam.hi.x : (c == 1) ? adam.hi.y : (c == 2) ? adam.hi.z : adam.hi.w;
-        float mi = adam.m[i], vi = adam.v[i];
-        const float a = adam_update(adam.act[i], g_action[(size_t)b * gact_stride + threadIdx.x], mi, vi, adam.step_size,
-                                    adam.bc2_sqrt, adam.b1, l, h);
-        adam.m[i] = mi;
-        adam.v[i] = vi;
-        adam.act[i] = a;
-        if (adam.act_copy != nullptr) adam.act_copy[i] = a;
+    if (adam.act != nullptr) {
+        // (value x < 4 is the sum thread x has just stored itself; the others come from the later steps' launches)
+        for (int x = threadIdx.x; x < adam.n_row; x += blockDim.x) {         // any horizon: a row's H * 4 values over the block
+            const size_t i = (size_t)b * adam.n_row + x;
+            const int c = x & 3;
+            const float l = (c == 0) ? adam.lo.x : (c == 1) ? adam.lo.y : (c == 2) ? adam.lo.z : adam.lo.w;
+            const float h = (c == 0) ? adam.hi.x : (c == 1) ? adam.hi.y : (c == 2) ? adam.hi.z : adam.hi.w;
+            float mi = adam.m[i], vi = adam.v[i];
+            const float a = adam_update(adam.act[i], g_action[(size_t)b * gact_stride + x], mi, vi, adam.step_size,
+                                        adam.bc2_sqrt, adam.b1, l, h);
+            adam.m[i] = mi;
+            adam.v[i] = vi;
+            adam.act[i] = a;
+            if (adam.act_copy != nullptr) adam.act_copy[i] = a;
+        }
     }
 }
 

@@ -50,8 +50,8 @@ class Engine(object):
 
     auto_engine: a call the fused (or split) engine refuses with DRP_ERANGE -- weights with an entry beyond fp16, inputs
     whose proven activation bound leaves it: include/drp.h -- is repeated on the fp32 matrix engine (`mfma`), which has no
-    such limit; the engine stays switched and a warning is issued once.  (The gradient-descent planner and the trainer
-    write their tape with the fused engine only: there the error stands.)"""
+    such limit; the engine stays switched until other weights are loaded, and a warning is issued.  (The gradient-descent
+    planner and the trainer choose their tape's engine by themselves -- include/drp.h, drp_gd_begin -- and never raise it.)"""
 
     def __init__(self, device=0, engine=None, auto_engine=False):
         self.lib = L.load()
@@ -96,6 +96,7 @@ class Engine(object):
             warnings.warn('the split-fp16 engine refused the call (%s): continuing on the fp32 matrix engine' % e,
                           RuntimeWarning, stacklevel=3)
             self.set_engine(L.ENGINE_MFMA)
+            self._auto_switched = True                # undone by the next load_weights: the refusal belongs to these weights / inputs
             return self._ck(call())
 
     # ---- constants ----------------------------------------------------------------
@@ -112,7 +113,12 @@ class Engine(object):
 
     def load_weights(self, blob, adj_thresh=0.08):
         blob = _f32(blob).ravel()
+        self._weights_owner = None                    # whoever believed its weights were resident no longer is right
         self._ck(self.lib.drp_load_weights(self.h, _fp(blob), blob.size, float(adj_thresh)))
+        if self.auto_engine and self.engine_id == L.ENGINE_MFMA and getattr(self, '_auto_switched', False):
+            # the fallback was for the OTHER weights: these get the fused engine's chance again
+            self.set_engine(L.ENGINE_FUSED)
+            self._auto_switched = False
 
     def set_camera(self, m34, global_scale, intr):
         m34 = _f32(m34).ravel()
@@ -523,6 +529,27 @@ class Engine(object):
         self._ck(self.lib.drp_probe_work(self.h, out))
         keys = ('chain_slots', 'cached_slots', 'tiles', 'tiles_last', 'encoder_tiles', 'mfmas')
         return {k: int(out[i]) for i, k in enumerate(keys)}
+
+    def dispatch_reset(self):
+        self._ck(self.lib.drp_dispatch_reset(self.h))
+
+    def last_dispatch(self):
+        """Names of the kernel variants launched since dispatch_reset() (include/drp.h drp_last_dispatch)."""
+        buf = ctypes.create_string_buffer(8192)
+        self._ck(self.lib.drp_last_dispatch(self.h, buf, len(buf)))
+        return [s for s in buf.value.decode().split(';') if s]
+
+    def dispatch_variants(self, default_only=True):
+        buf = ctypes.create_string_buffer(8192)
+        self.lib.drp_dispatch_variants(int(bool(default_only)), buf, len(buf))
+        return [s for s in buf.value.decode().split(';') if s]
+
+    def range_info(self):
+        """{'shift', 'bound', 'wmax', 'ok'} of the split-fp16 relation encoder for the loaded weights (drp_range_info)."""
+        k, ok = ctypes.c_int(), ctypes.c_int()
+        bound, wmax = ctypes.c_double(), ctypes.c_double()
+        self._ck(self.lib.drp_range_info(self.h, ctypes.byref(k), ctypes.byref(bound), ctypes.byref(wmax), ctypes.byref(ok)))
+        return {'shift': k.value, 'bound': bound.value, 'wmax': wmax.value, 'ok': bool(ok.value)}
 
     def debug_fetch(self, name, shape, dtype=np.float32):
         out = np.empty(shape, dtype=dtype)

@@ -109,8 +109,13 @@ class PropNetDiffDenModel(object):
         eng = self.engine
         ref = getattr(eng, '_weights_owner', None)
         owner = ref() if ref is not None else None
-        if owner is self or self._blob is None:
+        if owner is self:
             return
+        if self._blob is None:
+            # a model that never loaded weights must not compute with whichever other model's are on the shared context
+            if owner is not None:
+                raise RuntimeError('this model has no weights (load_state_dict), and the shared context holds another model\'s')
+            return                                    # nobody's: the engine itself answers 'weights not loaded'
         if owner is not None and owner._device_ahead:
             owner._blob = eng.get_weights()
             owner._device_ahead = False

@@ -211,3 +211,106 @@ def render_depth(n_granules=1500, seed=0, kind='blob', size=SCREEN, grain=0.006,
     obs[..., 3] = 255.0
     obs[..., 4] = (depth * global_scale).astype(np.float32)
     return obs
+
+
+def _relax_overlaps(xy, r_min, iters=4):
+    """Jacobi passes that push apart pairs closer than r_min (each takes half of the overlap)."""
+    for _ in range(iters):
+        d = xy[:, None, :] - xy[None, :, :]
+        dist = np.sqrt((d * d).sum(-1))
+        np.fill_diagonal(dist, np.inf)
+        over = np.maximum(r_min - dist, 0.0)
+        if not over.any():
+            break
+        unit = d / np.maximum(dist, 1e-9)[..., None]
+        xy = xy + 0.5 * (unit * over[..., None]).sum(1)
+    return xy
+
+
+def push_episode(n_particles, n_rollout, seed, kind=None):
+    """A synthetic episode shaped like `ParticleDataset.__getitem__`'s return (dataset/dataset_gnn_dyn.py:
+    states [T+1,n,3], states_delta [T,n,3], attrs [T+1,n], particle_num, particle_den, None), with an ANALYTIC
+    stand-in for the simulator (which is closed source): the particles inside the pusher's swept band advance to the
+    push end -- `states_delta`, by the reference's own formula (dataset/dataset_gnn_dyn.py:136-194, the numpy twin of
+    planners.py:211-257) on the demo camera -- and then pairs left closer than 0.55 / sqrt(density) are pushed
+    apart (the pile spreads ahead of the pusher), with a small positional jitter.  numpy float64 -> float32, seeded:
+    the generator feeds the reference's training loop in tests/golden/make_golden_trained.py AND the device trainer
+    in the tests with bit-identical batches."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(n_particles)
+    kind = kind or ('blob' if rng.uniform() < 0.5 else 'uniform')
+    s, _, _ = make_pile(n, 1, seed=7000 + seed, kind=kind)
+    cur = s[0].astype(np.float64)
+    area = (np.pi * 0.12 ** 2) if kind == 'blob' else 0.16
+    den = float(np.clip(n / area * rng.uniform(0.7, 1.3), 15.0, 6500.0))
+    r_min = 0.55 / np.sqrt(n / area)
+    states = np.zeros((n_rollout + 1, n, 3))
+    sdelta = np.zeros((n_rollout, n, 3))
+    states[0] = cur
+    w = 0.8 / 24.0
+    for t in range(n_rollout):
+        ang = rng.uniform(0, 2 * np.pi)
+        aim = cur[rng.integers(n), :2] * [GLOBAL_SCALE, -GLOBAL_SCALE] + rng.normal(0, 0.3, 2)   # through the pile, push units
+        start = aim + 3.0 * np.array([np.cos(ang), np.sin(ang)])
+        end = aim - rng.uniform(0.3, 2.0) * np.array([np.cos(ang), np.sin(ang)])
+        start = np.clip(start, -WKSPC_W, WKSPC_W)
+        end = np.clip(end, -0.7 * WKSPC_W, 0.7 * WKSPC_W)
+        # demo camera: push point (x, y) = world (x, 0, -y) -> camera (x / 24, -y / 24, 0.75)  (planners.py:192-209,231-234)
+        sc = np.array([start[0], -start[1], 18.0]) / GLOBAL_SCALE
+        ec = np.array([end[0], -end[1], 18.0]) / GLOBAL_SCALE
+        dv = ec - sc
+        length = np.linalg.norm(dv)
+        dirn = dv / length
+        ortho = np.array([-dirn[1], dirn[0], 0.0])
+        rel = cur - sc[None]
+        u, v = rel @ dirn, rel @ ortho
+        hard = ((u < length) & (u > 0.0)).astype(np.float64)
+        soft = np.exp(-np.maximum(np.maximum(-w - v, 0.0), np.maximum(v - w, 0.0)) / 0.01)
+        to_end = (ec[None] - cur) @ dirn
+        sd = to_end[:, None] * dirn[None] * hard[:, None] * soft[:, None]
+        sdelta[t] = sd
+        nxt = cur + sd
+        nxt[:, :2] = _relax_overlaps(nxt[:, :2], r_min)
+        nxt[:, :2] += rng.normal(0, 0.0005, (n, 2))
+        cur = nxt
+        states[t + 1] = cur
+    return (states.astype(np.float32), sdelta.astype(np.float32), np.zeros((n_rollout + 1, n), np.float32), n,
+            np.float32(den), None)
+
+
+PUSH_BATCH_SIZES = (10, 20, 30, 50, 80, 100, 150, 200, 300)
+
+
+def push_batch(iteration, batch_size=4, n_rollout=5, sizes=PUSH_BATCH_SIZES):
+    """Training batch number `iteration`: `batch_size` episodes of push_episode with particle counts drawn from `sizes`,
+    zero-padded to the largest as train/train_gnn_dyn.py:20-43 (`collate_fn`) pads ->
+    (states [B,T+1,n_max,3], states_delta [B,T,n_max,3], attrs [B,T+1,n_max], particle_nums [B] int32, particle_dens [B])."""
+    eps = []
+    for j in range(batch_size):
+        k = iteration * batch_size + j
+        n = int(sizes[np.random.default_rng(9000 + k).integers(len(sizes))])
+        eps.append(push_episode(n, n_rollout, k))
+    n_max = max(e[3] for e in eps)
+    states = np.zeros((batch_size, n_rollout + 1, n_max, 3), np.float32)
+    sdelta = np.zeros((batch_size, n_rollout, n_max, 3), np.float32)
+    attrs = np.zeros((batch_size, n_rollout + 1, n_max), np.float32)
+    for j, e in enumerate(eps):
+        states[j, :, :e[3]] = e[0]
+        sdelta[j, :, :e[3]] = e[1]
+    return (states, sdelta, attrs, np.array([e[3] for e in eps], np.int32), np.array([e[4] for e in eps], np.float32))
+
+
+def pushes_through(s, seed=0):
+    """[B,4] float32 pushes (sx,sy,ex,ey) that cross the piles s [B,N,3] (camera frame, demo camera): from 3 world units
+    before a random particle to 0.3 ... 2 units past it, clipped to the reference's action box (planners.py:151-167)."""
+    rng = np.random.default_rng(4000 + seed)
+    B, N, _ = s.shape
+    lo, hi = action_limits()
+    acts = np.empty((B, 4), np.float64)
+    for b in range(B):
+        ang = rng.uniform(0, 2 * np.pi)
+        d = np.array([np.cos(ang), np.sin(ang)])
+        aim = s[b, rng.integers(N), :2].astype(np.float64) * [GLOBAL_SCALE, -GLOBAL_SCALE] + rng.normal(0, 0.3, 2)
+        acts[b, :2] = aim + 3.0 * d
+        acts[b, 2:] = aim - rng.uniform(0.3, 2.0) * d
+    return np.clip(acts, lo, hi).astype(np.float32)

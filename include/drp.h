@@ -276,7 +276,11 @@ int drp_obs2ptcl(drp_ctx* ctx, const float* depth_raw, int h, int w, float globa
 /* ---- gradient-descent planner (the reference's live mpc_type 'GD') ----------------------------
  * One iteration of planners.py:682-764: rollout -> final-step reward -> loss = -sum(reward)
  * -> d loss / d pushes by reverse mode (through every step of the horizon) -> Adam(lr) step
- * -> clip box.  actions [B,H,4] with B = traj_num * n_batch rows (row = traj * n_batch + batch). */
+ * -> clip box.  actions [B,H,4] with B = traj_num * n_batch rows (row = traj * n_batch + batch).
+ * The forward pass writes its tape on the fused engine; when drp_set_engine has selected an fp32 engine, or the weights /
+ * inputs are outside the split-fp16 relation encoder's range, on the fp32 matrix engine instead (slower, same gradients
+ * to fp32 rounding): drp_gd_* and drp_train_step never return DRP_ERANGE -- env/flex_env.py:973-976 accepts no other
+ * planner than this one. */
 int drp_gd_begin(drp_ctx* ctx, const float* s0, const float* attr, const float* dens, int nb, int N,
                  const float* actions, int B, int H, double lr, const float act_lo[4], const float act_hi[4]);
 /* forward + backward only: rewards [B], d loss / d actions [B,H,4], d loss / d state_pred
@@ -338,6 +342,23 @@ int drp_probe_read(drp_ctx* ctx, double* total_ms, long* launches);
  * propagation steps that are not / are the last (144 / 96), [4] particle-encoder tiles inside the launch (204),
  * [5] the 16-bit MFMAs (32x32x16, 32 768 FLOP each) those add up to; [6], [7] zero.  bench.py's roofline numerator. */
 int drp_probe_work(drp_ctx* ctx, unsigned long long out[8]);
+/* Which kernel variant served the launches since drp_dispatch_reset (or drp_create): graph build (k_graph, k_graph_q4,
+ * k_graph_strips_q<128|256>, k_graph_cells, k_graph_rev, inside km_rollout), propagation kernel with its template flags
+ * (km_prop<last|mid,tape,pair,work>, km_prop3<tape|plain,pair,cache|cache+rows,work>, km_rollout<pair|tile32,...>), the
+ * stage kernels of the fp32 engines, reverse-mode variant (kmb_rows_bwd, kmb_step_bwd, the stage kernels), training and
+ * pre-processing kernels -- names joined by ';' into out (truncated to out_len), return value = the full length.
+ * drp_dispatch_variants lists every name the library can report (default_only != 0: without those that need an environment
+ * switch or the counting probe).  The shapes and thresholds that select a variant are measured constants
+ * (csrc/drp_capi.hip); tests/test_gpu_fuzz_oracle.py checks every default variant against the oracle through these. */
+int drp_dispatch_reset(drp_ctx* ctx);
+long drp_last_dispatch(drp_ctx* ctx, char* out, size_t out_len);
+long drp_dispatch_variants(int default_only, char* out, size_t out_len);
+/* The split-fp16 relation encoder's range shift for the loaded weights: hidden activations travel as two fp16 pieces
+ * times 2^-shift; bound = the proven largest activation for the envelope |attr| <= 2, |s_r - s_s| <= 1.5, density <= 10 000;
+ * wmax = the largest |weight| packed as fp16; ok = 0 when no shift can carry the weights (every call of the fused / split
+ * engine then returns DRP_ERANGE; the gradient-descent planner and the trainer write their tape on the fp32 engine).
+ * Each pointer nullable. */
+int drp_range_info(drp_ctx* ctx, int* shift, double* bound, double* wmax, int* ok);
 /* hold the context's stream for ms (<= 10 000) milliseconds -- what a collective waiting for a dead peer looks like to
  * the host; the tests of the hang guard use it */
 int drp_debug_stall(drp_ctx* ctx, int ms);

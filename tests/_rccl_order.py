@@ -1,7 +1,10 @@
 """Helper of test_gpu_sharded_planner.py: which HIP / HSA / RCCL libraries a process ends up with, by import order, and
 whether a one-rank communicator comes up.  usage: python tests/_rccl_order.py drp_first|torch_first|no_torch"""
+import faulthandler
 import os
 import sys
+faulthandler.dump_traceback_later(45, exit=False)      # the parent gives up after 60 s: leave it every thread's stack first
+sys.stdout.reconfigure(line_buffering=True)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 order = sys.argv[1]
 

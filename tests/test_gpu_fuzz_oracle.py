@@ -1,0 +1,309 @@
+"""GPU: seeded shapes under the library's DEFAULT dispatch, each compared with the ORACLE (oracle/propnet_sparse for the
+forward path at the flat 1e-4 with edge-set equality, oracle/propnet_dense's autograd for the gradients), and a record of
+which kernel variant served each call (drp_last_dispatch).  The last test fails -- with the missing names -- if any variant
+the library can launch without an environment switch (drp_dispatch_variants) was never hit: ~20 template instantiations are
+selected by a dozen measured thresholds in csrc/drp_capi.hip (64 / 128 / 256 / 704 rows, n_cu - n_cu/5 samples, 192 MB of
+cache ...), and a threshold change that orphans one must turn the suite red.
+
+The tests of this file run in file order and share the module's hit record (no -p xdist)."""
+import numpy as np
+import pytest
+
+from dyn_res_pile_manip_amd import synthetic as syn, weights, _lib
+from oracle import propnet_dense as od
+from oracle import propnet_sparse as osp
+from test_gpu_parity import disp_rel
+
+pytestmark = pytest.mark.gpu
+HIT = {}                 # variant name -> the first shape that hit it
+CHECK_ROWS = 5           # rows of a batch the oracle recomputes (rows are independent problems)
+
+
+@pytest.fixture(scope='module')
+def eng(golden):
+    from dyn_res_pile_manip_amd.engine import Engine
+    e = Engine(0)
+    e.M34 = osp.world2cam_affine(syn.demo_cam_extrinsics(), 24)
+    e.set_camera(e.M34, 24.0, syn.demo_cam_params())
+    e.blobs = {'seed0': weights.blob_from_state_dict(golden.weights_seed0),
+               'trained': weights.blob_from_state_dict(golden.weights_trained)}
+    e.Wn = {'seed0': osp.weights_np(golden.weights_seed0), 'trained': osp.weights_np(golden.weights_trained)}
+    e.Wt = {'seed0': od.load_weights(golden.weights_seed0), 'trained': od.load_weights(golden.weights_trained)}
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    e.G = syn.goal_field(obs_goal)
+    e.obs_goal = obs_goal
+    e.cur = None
+    yield e
+    e.close()
+
+
+def use_weights(eng, which):
+    if eng.cur != which:
+        eng.load_weights(eng.blobs[which], 0.08)
+        eng.cur = which
+
+
+def note(eng, label):
+    for v in eng.last_dispatch():
+        HIT.setdefault(v, label)
+    eng.dispatch_reset()
+
+
+def pile(N, nb, seed, kind, attr_kind):
+    if kind == 'tight':                      # everything inside the radius: in-degrees saturate, near-equal distances
+        s, dens, attr = syn.make_pile(N, nb, seed=seed, kind='blob')
+        c = s[:, :, :2].mean(1, keepdims=True)
+        s[:, :, :2] = c + (s[:, :, :2] - c) * np.float32(0.25)
+    else:
+        s, dens, attr = syn.make_pile(N, nb, seed=seed, kind=kind)
+    rng = np.random.default_rng(seed + 77)
+    dens = (dens * rng.uniform(0.7, 1.3, nb)).astype(np.float32)
+    if attr_kind == 'mixed':
+        attr = (rng.random(attr.shape) < 0.5).astype(np.float32)
+    return s, dens, attr
+
+
+def pick_rows(B, seed):
+    rng = np.random.default_rng(seed)
+    rows = {0, B - 1} | set(int(r) for r in rng.integers(0, B, CHECK_ROWS))
+    return np.array(sorted(rows))[:CHECK_ROWS]
+
+
+def check_rows_rollout(eng, W, s0, dens, attr, acts, states, rows, tol=1e-4):
+    """Free-running rollout of the selected rows against the oracle's: per step the edge sets the two trajectories induce
+    must be equal; while they are, the step stays within the flat tolerance of its displacement."""
+    nb = s0.shape[0]
+    # osp.rollout tiles its n_batch axis: hand it one row at a time
+    ref = np.stack([osp.rollout(W, s0[[r % nb]], dens[[r % nb]], attr[[r % nb]], acts[[r]], eng.M34, 24.0)[0] for r in rows])
+    prev_ref = s0[rows % nb]
+    prev_dev = prev_ref
+    for t in range(acts.shape[1]):
+        idx_r, cnt_r = osp.build_neighbours(prev_ref, osp.gen_s_delta(prev_ref, acts[rows, t], eng.M34, 24.0))
+        idx_d, cnt_d = osp.build_neighbours(prev_dev, osp.gen_s_delta(prev_dev, acts[rows, t], eng.M34, 24.0))
+        np.testing.assert_array_equal(cnt_d, cnt_r, err_msg='in-degrees differ at step %d' % t)
+        np.testing.assert_array_equal(idx_d, idx_r, err_msg='edge sets differ at step %d' % t)
+        assert disp_rel(states[rows, t], ref[:, t], prev_ref) < tol, t
+        prev_ref, prev_dev = ref[:, t], states[rows, t]
+
+
+# (B, N, n_batch, H, pile kind, attributes, weights): the designed shapes sit on both sides of every threshold of
+# run_step_mfma / run_rollout / launch_graph; the drawn ones fill in between
+DESIGNED = [
+    (1, 1, 1, 2, 'uniform', 'zero', 'seed0'), (3, 2, 1, 2, 'blob', 'mixed', 'seed0'), (1024, 10, 1, 3, 'blob', 'zero', 'trained'),
+    (1024, 20, 2, 3, 'blob', 'zero', 'trained'), (1024, 50, 1, 2, 'blob', 'zero', 'trained'), (2048, 40, 2, 2, 'uniform', 'mixed', 'seed0'),
+    (1280, 56, 1, 2, 'uniform', 'zero', 'seed0'), (4096, 30, 30, 1, 'blob', 'zero', 'trained'), (256, 100, 1, 2, 'tight', 'zero', 'seed0'),
+    (256, 200, 2, 2, 'uniform', 'zero', 'trained'), (256, 280, 1, 1, 'uniform', 'zero', 'seed0'), (300, 150, 2, 2, 'uniform', 'mixed', 'seed0'),
+    (512, 150, 1, 2, 'uniform', 'zero', 'trained'), (1024, 300, 1, 2, 'uniform', 'zero', 'trained'), (4, 300, 2, 2, 'uniform', 'zero', 'seed0'),
+    (60, 300, 30, 1, 'uniform', 'mixed', 'trained'), (150, 300, 2, 1, 'blob', 'zero', 'seed0'), (2, 96, 1, 2, 'uniform', 'zero', 'seed0'),
+    (300, 96, 2, 2, 'uniform', 'zero', 'trained'), (64, 256, 2, 1, 'uniform', 'zero', 'seed0'), (8, 450, 2, 2, 'uniform', 'zero', 'seed0'),
+    (256, 600, 1, 1, 'uniform', 'mixed', 'seed0'), (16, 1300, 2, 2, 'uniform', 'zero', 'seed0'), (210, 1200, 30, 1, 'uniform', 'zero', 'seed0'),
+    (2, 130, 1, 2, 'tight', 'zero', 'trained'), (700, 64, 1, 3, 'blob', 'zero', 'trained'),
+]
+
+
+def drawn_shapes(n, seed=2026):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        N = int(np.exp(rng.uniform(0, np.log(1300))))
+        B_cap = max(1, min(4096, (24 << 20) // (N * 3 * 4)))              # states of a step up to 24 MB
+        B = int(np.exp(rng.uniform(0, np.log(B_cap))))
+        nb = int(rng.choice([1, 2, 30]))
+        B = max(nb, B // nb * nb)
+        H = int(rng.integers(1, 6)) if B * N < 200000 else int(rng.integers(1, 3))
+        kind = str(rng.choice(['uniform', 'blob', 'tight']))
+        out.append((B, N, nb, H, kind, str(rng.choice(['zero', 'mixed'])), str(rng.choice(['seed0', 'trained']))))
+    return out
+
+
+SHAPES = DESIGNED + drawn_shapes(36)
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: '%dx%dx%d-nb%d-%s-%s-%s' % (s[0], s[1], s[3], s[2], s[4], s[5], s[6]))
+def test_forward_shape_against_the_oracle(eng, shape):
+    B, N, nb, H, kind, attr_kind, which = shape
+    use_weights(eng, which)
+    eng.set_engine(_lib.ENGINE_FUSED)
+    W = eng.Wn[which]
+    seed = B * 7919 + N * 31 + H
+    s0, dens, attr = pile(N, nb, seed, kind, attr_kind)
+    label = 'forward %dx%dx%d nb%d %s' % (B, N, H, nb, kind)
+    acts = np.stack([syn.pushes_through(np.tile(s0, (B // nb, 1, 1)), seed=seed + t) for t in range(H)], 1)
+    rows = pick_rows(B, seed)
+    # the rollout entry point: km_rollout for small piles, graph + km_prop3 / km_prop per step otherwise
+    eng.set_goal(eng.G, syn.goal_coor_strided(eng.obs_goal, min(5 * N, 400)))
+    eng.dispatch_reset()
+    states, rew = eng.rollout(s0, attr, dens, acts, want_reward=True)
+    note(eng, label + ' rollout')
+    check_rows_rollout(eng, W, s0, dens, attr, acts, states, rows)
+    ref_r = osp.reward(states[rows].reshape(-1, N, 3), eng.G, syn.demo_cam_params(),
+                       syn.goal_coor_strided(eng.obs_goal, min(5 * N, 400))).reshape(len(rows), H)
+    np.testing.assert_allclose(rew[rows], ref_r, rtol=1e-4)
+    # the one-step entry point with B DIFFERENT samples (never the one-launch rollout): graph + km_prop3 / km_prop
+    s1 = states[:, -1] if H > 1 else np.tile(s0, (B // nb, 1, 1))
+    a1, d1 = np.tile(attr, (B // nb, 1)), np.tile(dens, B // nb)
+    sd1 = osp.gen_s_delta(s1[rows], acts[rows, 0], eng.M34, 24.0)
+    sd_all = eng.gen_s_delta(s1, acts[:, 0])
+    np.testing.assert_allclose(sd_all[rows], sd1, rtol=0, atol=3e-7)
+    eng.dispatch_reset()
+    out = eng.step(a1, s1, sd_all, d1)
+    note(eng, label + ' step')
+    idx_d, cnt_d = eng.debug_fetch('nbr_idx', (B, N, 10), np.int16), eng.debug_fetch('nbr_cnt', (B, N), np.uint8)
+    idx_r, cnt_r = osp.build_neighbours(s1[rows], sd_all[rows])
+    # the fused engine's lists carry the self edge FIRST (its constant is precomputed); as sets they are the oracle's
+    np.testing.assert_array_equal(cnt_d[rows], cnt_r)
+    np.testing.assert_array_equal(np.sort(np.where(idx_d[rows] < 0, 32767, idx_d[rows]), -1),
+                                  np.sort(np.where(idx_r < 0, 32767, idx_r), -1))
+    ref = osp.predict_one_step(W, a1[rows], s1[rows], sd_all[rows], d1[rows])
+    assert disp_rel(out[rows], ref, s1[rows]) < 1e-4
+    # the counting instantiations (drp_probe_begin("prop+work")) give the same bits
+    eng.probe_begin('prop+work')
+    eng.dispatch_reset()
+    out_w = eng.step(a1, s1, sd_all, d1)
+    states_w, _ = eng.rollout(s0, attr, dens, acts)
+    note(eng, label + ' counted')
+    eng.probe_begin('')
+    np.testing.assert_array_equal(out_w, out)
+    np.testing.assert_array_equal(states_w, states)
+
+
+@pytest.mark.parametrize('engine', ['valu', 'mfma', 'split'])
+def test_the_other_engines_against_the_oracle(eng, engine):
+    use_weights(eng, 'trained')
+    eng.set_engine(_lib.ENGINES[engine])
+    W = eng.Wn['trained']
+    for B, N, nb, H in ((6, 40, 2, 2), (4, 300, 1, 2), (3, 700, 1, 1), (130, 64, 1, 1)):
+        s0, dens, attr = pile(N, nb, 5 + N, 'uniform', 'mixed')
+        acts = np.stack([syn.pushes_through(np.tile(s0, (B // nb, 1, 1)), seed=N + t) for t in range(H)], 1)
+        eng.dispatch_reset()
+        states, _ = eng.rollout(s0, attr, dens, acts)
+        note(eng, '%s %dx%dx%d' % (engine, B, N, H))
+        check_rows_rollout(eng, W, s0, dens, attr, acts, states, np.arange(min(B, 6)))
+    eng.set_engine(_lib.ENGINE_FUSED)
+
+
+# (traj x nb rows, N, nb, H, weights, engine): kmb_rows_bwd up to 256 particles, kmb_step_bwd for chip-filling batches of
+# larger piles, the stage kernels below that; every taped km_prop3 / km_prop variant; the fp32 engine's tape
+GD_SHAPES = [
+    (60, 20, 30, 1, 'trained', 'fused'), (12, 20, 3, 2, 'seed0', 'fused'), (1500, 80, 30, 1, 'trained', 'fused'),
+    (300, 150, 2, 1, 'seed0', 'fused'), (256, 200, 1, 1, 'trained', 'fused'), (8, 300, 2, 1, 'seed0', 'fused'),
+    (60, 300, 1, 2, 'trained', 'fused'), (208, 260, 1, 1, 'seed0', 'fused'), (4, 600, 1, 1, 'seed0', 'fused'),
+    (160, 300, 1, 1, 'trained', 'fused'), (24, 100, 3, 1, 'trained', 'mfma'), (4, 300, 1, 2, 'seed0', 'mfma'), (6, 96, 2, 2, 'seed0', 'fused'),
+]
+
+
+@pytest.mark.parametrize('shape', GD_SHAPES, ids=lambda s: 'gd-%dx%d-nb%d-h%d-%s-%s' % s)
+def test_gradient_shape_against_the_oracle(eng, shape, exact_goal_transform):
+    B, N, nb, H, which, engine = shape
+    use_weights(eng, which)
+    eng.set_engine(_lib.ENGINES[engine])
+    seed = B * 13 + N
+    s0, dens, attr = pile(N, nb, seed, 'blob' if N <= 100 else 'uniform', 'zero')
+    goal_coor = syn.goal_coor_strided(eng.obs_goal, min(5 * N, 500))
+    eng.set_goal(eng.G, goal_coor)
+    acts = np.stack([syn.pushes_through(np.tile(s0, (B // nb, 1, 1)), seed=seed + t) for t in range(H)], 1)
+    lo, hi = syn.action_limits()
+    eng.dispatch_reset()
+    eng.gd_begin(s0, attr, dens, acts, 0.05, lo, hi)
+    r, ga, _ = eng.gd_grad()
+    note(eng, 'gd %dx%d h%d %s' % (B, N, H, engine))
+    rows = pick_rows(B, seed)[:3]
+    for row in rows:
+        rr, gr, _ = od.gd_loss_and_grads(eng.Wt[which], s0[[row % nb]], dens[[row % nb]], attr[[row % nb]], acts[[row]], eng.G,
+                                         syn.demo_cam_params(), goal_coor, syn.demo_cam_extrinsics(), 24)
+        np.testing.assert_allclose(r[row], np.asarray(rr).reshape(-1)[0], rtol=5e-5)
+        scale = max(np.abs(gr).max(), 1e-6)
+        assert np.abs(ga[row] - np.asarray(gr)[0]).max() < 3e-3 * scale, (row, np.abs(ga[row] - np.asarray(gr)[0]).max(), scale)
+    eng.set_engine(_lib.ENGINE_FUSED)
+
+
+TRAIN_SHAPES = [([40, 64, 25, 64], 3, 'fused'), ([300, 120], 2, 'fused'), ([30, 12], 2, 'mfma'), ([200, 180, 90, 200, 150, 60, 200, 10], 2, 'fused')]
+
+
+@pytest.mark.parametrize('shape', TRAIN_SHAPES, ids=lambda s: 'train-%s-r%d-%s' % ('_'.join(map(str, s[0])), s[1], s[2]))
+def test_training_shape_against_the_oracle(eng, golden, shape):
+    nums, T, engine = shape
+    use_weights(eng, 'trained')
+    eng.set_engine(_lib.ENGINES[engine])
+    eps = [syn.push_episode(n, T, 500 + i) for i, n in enumerate(nums)]
+    B, N = len(nums), max(nums)
+    states = np.zeros((B, T + 1, N, 3), np.float32)
+    sdelta = np.zeros((B, T, N, 3), np.float32)
+    attrs = np.zeros((B, T + 1, N), np.float32)
+    for j, e in enumerate(eps):
+        states[j, :, :e[3]], sdelta[j, :, :e[3]] = e[0], e[1]
+    pn = np.asarray(nums, np.int32)
+    dens = np.array([e[4] for e in eps], np.float32)
+    eng.train_begin(T, 1e-3, 0.9)
+    eng.dispatch_reset()
+    loss, grad = eng.train_step(states, sdelta, attrs, pn, dens, mode='grad', want_grad=True)
+    note(eng, 'train %s r%d %s' % (nums, T, engine))
+    Wd = {k[2:]: golden.weights_trained[k] for k in golden.weights_trained.files if k.startswith('w/')}
+    ref_loss, ref_grads = od.train_loss_and_grads(Wd, states, sdelta, attrs, pn, dens)
+    assert abs(loss - ref_loss) < 2e-4 * abs(ref_loss)
+    got = weights.state_dict_from_blob(grad)
+    for k, _ in weights.STATE_DICT_KEYS:
+        scale = max(np.abs(ref_grads[k]).max(), 1e-8)
+        assert np.abs(np.asarray(got[k]).reshape(ref_grads[k].shape) - ref_grads[k]).max() < 1e-3 * scale + 1e-9, k
+    eng.set_engine(_lib.ENGINE_FUSED)
+
+
+def test_update_and_preprocessing_variants(eng):
+    """The planner's update kernels and the pre-processing kernels have parity tests of their own (test_gpu_planner.py,
+    test_gpu_goal.py); here their variants are driven once each, checked against the host arithmetic, and recorded."""
+    from oracle import goal as ogoal
+    from oracle import particles as opart
+    use_weights(eng, 'seed0')
+    eng.set_goal(eng.G, syn.goal_coor_strided(eng.obs_goal, 200))
+    lo, hi = syn.action_limits()
+    for ns, k in ((64, 8), (4200, 16)):          # elite selection by sort / by k rounds (more than 4 096 samples)
+        N, H = 10, 1
+        s0, dens, attr = pile(N, 1, 3, 'blob', 'zero')
+        nom = syn.nominal_pushes(H, seed=1)
+        eng.mpc_begin(s0, attr, dens, nom, ns, 0.6, 0.7, 0.1, lo, hi, seed=5)
+        eng.dispatch_reset()
+        eng.mpc_sample(1)
+        eng.mpc_rollout(False)
+        got = eng.mpc_get(actions=True, rewards=True)
+        eng.mpc_update_device()
+        nominal = eng.mpc_get(nominal=True)['nominal']
+        m, Z, A = osp.mppi_partials(0.1, got['rewards'], got['actions'])
+        np.testing.assert_allclose(nominal, A / Z, rtol=1e-9, atol=1e-9)
+        eng.mpc_update_elite_device(k)
+        nominal = eng.mpc_get(nominal=True)['nominal']
+        order = np.lexsort((np.arange(ns), -got['rewards'].astype(np.float64)))[:k]
+        np.testing.assert_allclose(nominal, got['actions'][order].astype(np.float64).mean(0), rtol=1e-9, atol=1e-9)
+        note(eng, 'mppi %d samples' % ns)
+    rng = np.random.default_rng(0)
+    for n, dim, k in ((3000, 2, 40), (30000, 2, 25), (20000, 3, 20)):
+        pts = rng.uniform(0, 700, (n, dim)).astype(np.float32)
+        eng.dispatch_reset()
+        sel, md, idx = eng.fps(pts, k, 0)
+        note(eng, 'fps %d x %d' % (n, dim))
+        ref_pts = opart.fps_np(pts, k, 0)
+        ref_pts = ref_pts[0] if isinstance(ref_pts, tuple) else ref_pts
+        np.testing.assert_array_equal(sel, ref_pts)
+    mask = (rng.random((96, 80)) < 0.9).astype(np.uint8)
+    for mode in ('cv5', 'exact'):
+        eng.dispatch_reset()
+        got = eng.distance_transform(mask, mode)
+        note(eng, 'dt ' + mode)
+        ref = ogoal.distance_transform_cv5(mask) if mode == 'cv5' else ogoal.distance_transform_edt(mask)
+        np.testing.assert_array_equal(got, ref.astype(np.float32))
+
+
+def test_every_default_variant_was_hit(eng):
+    """The contract of this file: whatever the thresholds of csrc/drp_capi.hip select by default has been compared with
+    the oracle above.  A variant listed by drp_dispatch_variants(default_only) that no shape reached is a failure."""
+    want = eng.dispatch_variants(default_only=True)
+    everything = eng.dispatch_variants(default_only=False)
+    assert set(want) <= set(everything) and len(set(everything)) == len(everything)
+    missing = [v for v in want if v not in HIT]
+    print('\n[dispatch] %d of %d default variants hit (%d names in all, %d hit)' %
+          (len(want) - len(missing), len(want), len(everything), len(HIT)))
+    for v in everything:
+        print('  %-44s %s' % (v, HIT.get(v, '-- not hit' + ('' if v in want else ' (needs a switch)'))))
+    assert not missing, 'default variants no shape reached: %s' % missing
+    # the counting twins of the forward kernels that were hit
+    twins = [v[:-1] + ',work>' for v in HIT if v.startswith(('km_prop', 'km_rollout')) and 'tape' not in v and not v.endswith(',work>')]
+    assert not [t for t in twins if t in everything and t not in HIT], [t for t in twins if t in everything and t not in HIT]
