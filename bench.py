@@ -296,6 +296,8 @@ def cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam):
     cores = min(legs, key=legs.get)
     dt = legs[cores]
     return {'value': ns * N * H / dt, 'unit': 'particle-steps/s', 'cores': cores, 'kind': 'port',
+            'cores_policy': 'the faster of 32 and 64 threads, NOT all %d hardware threads BASELINE.md asks for: the dense formulation\'s '
+                            'small ops run 20x slower at 256 threads than at 8 (measured); both legs\' seconds are in seconds_by_threads' % avail,
             'cpu_model': host_cpu_model(), 'host_threads_available': avail,
             'seconds_by_threads': {str(k): round(v, 3) for k, v in legs.items()},
             'sample': '%d samples x %d particles x %d steps, oracle/propnet_dense.py (dense '
@@ -314,15 +316,23 @@ def load_traffic():
 TRAFFIC_SOURCE = 'profiles/traffic.json (builder-side rocprofv3 --pmc passes of this command, not measured in this run)'
 
 
-def prop_roofline(work, kbar, self_const, B, N, avg_s, H):
-    """km_prop / km_prop3 / km_rollout.  `work` is what the kernels THEMSELVES counted over one
-    iteration (Engine.probe_work, include/drp.h drp_probe_work: slot iterations that ran the relation encoder's 78-MFMA
-    chain, slot iterations served by the edge-chain cache, node parts of 144 / 96 MFMAs, particle-encoder tiles of 204;
-    `launches` = the launches of that iteration) -- an iteration of its own, right before the timed ones: counting costs
-    time.  `frac` is the roofline on the 16-bit FLOPs actually EXECUTED, 2*32*32*16 per MFMA; nothing here re-derives
-    which kernel or tile shape the library chose.  Beside it `useful_frac`, on a FIXED count: SURVEY.md 8d's factored
-    formulation F_fac(K) = 116 096 + 25 472 K FLOP per particle-step at the measured mean in-degree K, times the
-    particle-steps of a launch -- removing redundant work (the self loop's constant, the cached chain) RAISES it.
+MFMA_CYCLES_16BIT = 32       # v_mfma_f32_32x32x16_{f16,bf16}: 8 passes of 4 cycles
+NOMINAL_CLOCK_HZ = 2.4e9     # MI355X_MICROARCH.md peak engine clock (the kernels hold 2.03 - 2.09 GHz: DESIGN_NOTES 5b)
+
+
+def prop_roofline(work, kbar, self_const, B, N, avg_s, H, n_cu=256):
+    """km_prop / km_prop3 / km_rollout, priced as SURVEY.md 8(d) prescribes:
+      achieved = ALGORITHMIC FLOPs of the formulation the kernels execute -- the factored one, F_fac(K) = 116 096 + 25 472 K
+                 per particle-step at the measured mean in-degree K -- times the particle-steps one launch processes, over the
+                 launch's average duration (HIP events on the context's stream);
+      peak     = the dense fp32 matrix peak 8(d) names, 157.3 TFLOP/s (`peak_basis`).
+    `frac` = achieved / peak rises when redundant work is removed.  Beside it, what the matrix pipe is actually given:
+    `frac_executed_16bit` (the 16-bit MFMAs the kernels COUNTED themselves over the iteration before the timed ones --
+    Engine.probe_work: every fp32 product runs as 3 (fp16 pair) or 6 (bf16 triple) MFMA terms, the chain re-runs per
+    propagation step where it is not cached -- x 32 768 FLOP against the 2.5 PFLOP/s 16-bit peak), `mfma_pipe_busy_est`
+    (those MFMAs x 32 cycles over the chip's SIMDs at the nominal clock), and `hbm_algorithmic_frac`, 8(d)'s OTHER roofline:
+    the gather / segmented sum's algorithmic bytes (2K + 2 rows of 256 B per receiver and propagation step) over the same
+    time against 8 TB/s -- bytes the fused kernel mostly never moves (`traffic` is what the counters saw).
     A launch covers one propagation step (km_prop), the three of a rollout step (km_prop3) or a whole rollout."""
     n = float(max(work['launches'], 1))
     flops = work['mfmas'] / n * 32768.0
@@ -331,21 +341,29 @@ def prop_roofline(work, kbar, self_const, B, N, avg_s, H):
     k_run = kbar - (1.0 if self_const else 0.0)                   # chains an average receiver runs: the self loop's is a constant
     slots = work['chain_slots'] + work['cached_slots']
     node_parts = work['tiles'] + work['tiles_last']
-    return {'bound': 'mfma', 'achieved': flops / avg_s / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+    gather_bytes = particle_steps * 3.0 * (2.0 * kbar + 2.0) * 256.0
+    return {'bound': 'mfma', 'achieved': useful / avg_s / 1e12, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+            'peak_basis': 'SURVEY.md 8d: algorithmic FLOPs of the factored formulation, F_fac(K) = 116096 + 25472 K per particle-step '
+                          '(K = %.2f, %.0f particle-steps per launch), against the dense fp32 matrix peak 8d names (157.3 TFLOP/s)' % (kbar, particle_steps),
+            'work_per_launch_flop': useful,
+            'frac_executed_16bit': flops / avg_s / 1e12 / PEAK_BF16_TFLOPS, 'executed_tflops': flops / avg_s / 1e12,
+            'executed_over_algorithmic': flops / useful,
+            'mfma_pipe_busy_est': work['mfmas'] / n * MFMA_CYCLES_16BIT / (4.0 * n_cu) / (avg_s * NOMINAL_CLOCK_HZ),
+            'mfma_pipe_busy_basis': 'counted 16-bit MFMAs x 32 cycles / (4 SIMDs x %d CUs) / (launch time x 2.4 GHz nominal): a lower bound, '
+                                    'the kernels hold about 2.05 GHz; the SQ_VALU_MFMA_BUSY_CYCLES pass is in profiles/' % n_cu,
+            'hbm_algorithmic_frac': gather_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 'hbm_algorithmic_gbs': gather_bytes / avg_s / 1e9,
+            'hbm_algorithmic_basis': 'SURVEY.md 8d: (2K + 2) x 256 B per receiver and propagation step, x 3 steps x the particle-steps of a launch, against 8 TB/s',
             'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
-            'numerator': 'drp_probe_work: counted by the kernels over the iteration before the timed ones',
+            'numerator_executed': 'drp_probe_work: counted by the kernels over the iteration before the timed ones',
             'executed_per_launch': {k: v / n for k, v in work.items() if k != 'launches'},
-            'useful_frac': useful / avg_s / 1e12 / PEAK_BF16_TFLOPS, 'useful_tflops': useful / avg_s / 1e12,
-            'useful_frac_of_f32_mfma_peak': useful / avg_s / 1e12 / PEAK_F32_TFLOPS,
-            'useful_basis': 'SURVEY 8d: F_fac(K) = 116096 + 25472 K FLOP per particle-step, K = %.2f; %.0f particle-steps per launch' % (kbar, particle_steps),
-            'algorithmic_f32_tflops': particle_steps * (116096.0 + 25472.0 * k_run) / avg_s / 1e12,
+            'algorithmic_f32_tflops_without_self_loop': particle_steps * (116096.0 + 25472.0 * k_run) / avg_s / 1e12,
             'slot_iterations_per_tile': slots / float(max(node_parts, 1)),
             'cached_share_of_slot_iterations': work['cached_slots'] / float(max(slots, 1)),
             'tiles_per_step': node_parts / float(3 * H),
             'mean_in_degree_minus_self': k_run,
             'propagation_steps_per_launch': 3.0 * H / n,
             'particle_encoder_in_launch': bool(work['encoder_tiles'] > 0),
-            'graph_build_in_launch': bool(H / n > 1.5)}, flops
+            'graph_build_in_launch': bool(H / n > 1.5)}, useful
 
 
 class Rig(object):
@@ -444,7 +462,7 @@ def mppi_roofline(rig, m, N, ns, H, steps):
     self_const = engine == 'fused' and os.environ.get('DRP_NO_SELF_CONST') is None
     work = None
     if dominant == 'prop':
-        roof, work = prop_roofline(m['work'], kbar, self_const, ns, N, avg_s, H)
+        roof, work = prop_roofline(m['work'], kbar, self_const, ns, N, avg_s, H, rig.n_cu)
     elif dominant == 'aggregate':
         work = ns * N * (2 * kbar + 2) * 256.0
         roof = {'bound': 'hbm', 'achieved': work / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
@@ -535,7 +553,7 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
     tkey = None
     if dominant == 'prop':
         # the forward kernel of the tape-writing instantiation: the same MFMAs as the MPPI model
-        roof, _ = prop_roofline(dom_work, kbar, True, B, N, avg_s, H)
+        roof, _ = prop_roofline(dom_work, kbar, True, B, N, avg_s, H, rig.n_cu)
         tkey = 'prop3_tape'
     elif dominant == 'bwd_node' and per_class['bwd_edge'][1] == 0:
         # kmb_rows_bwd / kmb_step_bwd (the whole node / edge backward of a rollout step in one launch): algorithmic
@@ -567,12 +585,33 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
         roof['frac'] = roof['achieved'] / roof['peak']
         roof['cache_served'] = bool(roof.get('algorithmic_bytes_per_launch', 0) > tb)
     return {'dt': dt, 'median': med, 'per_class': per_class, 'dominant': dominant, 'roofline': roof, 'kbar': kbar,
-            'B': B, 's0': s0, 'dens': dens, 'attr': attr, 'acts': acts}
+            'B': B, 's0': s0, 'dens': dens, 'attr': attr, 'acts': acts, 'step': step}
+
+
+SWEEP_MIN_GPU_S = 1.0        # every sweep entry keeps the GPU busy at least this long (batches of 20 iterations)
+
+
+def more_batches(step, fence, steps, dt_first, min_gpu_s):
+    """Batches of `steps` iterations, each between two fences, until the entry has kept the GPU busy for min_gpu_s: a
+    20-iteration batch of a sub-millisecond workload is 10 ms of GPU time -- shorter than the clock ramp of a GPU that has
+    just been idle.  -> seconds per batch, the contract-style first batch included."""
+    batches, acc = [dt_first], dt_first
+    while acc < min_gpu_s and len(batches) < 400:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        d = time.perf_counter() - t0
+        batches.append(d)
+        acc += d
+    return batches
 
 
 def run_sweep(rig, fence):
-    """The other BASELINE workloads on this GPU, short: 5 warm-ups, 20 iterations each (no median pass); ~3 s in all.
-    (Five iterations after two warm-ups, the first version, read 5 - 8 % low on the sub-millisecond workloads.)"""
+    """The other BASELINE workloads on this GPU: 5 warm-ups, then batches of 20 iterations until each entry has run for at
+    least SWEEP_MIN_GPU_S of GPU time; `ms_per_step` / `value` are the MEDIAN batch, the fastest and the first batch beside
+    them.  (Round 4 timed ONE batch: 10 - 40 ms of GPU time per entry, read 3 - 7 % low on the small piles.)"""
     out = []
     for name in SWEEP:
         N, ns, H, _, label = CONFIGS[name]
@@ -581,22 +620,30 @@ def run_sweep(rig, fence):
         if name == 'gd-demo':
             g = bench_gd(rig, N, ns // 30, 30, H, steps, warm, fence, want_median=False)
             B, roof, per_class, dt = g['B'], g['roofline'], g['per_class'], g['dt']
-            kbar = g['kbar']
+            kbar, step = g['kbar'], g['step']
         else:
             m = bench_mppi(rig, N, ns, H, 0, steps, warm, lambda e: e.mpc_update_device(), fence,
                            ['graph', 'node_encode', 'prop', 'reward', 'mppi'], want_median=False)
             B, roof, per_class, dt, kbar = ns, mppi_roofline(rig, m, N, ns, H, steps), m['per_class'], m['dt'], m['kbar']
-            # HBM-side bytes per launch of the dominant kernel, where a PMC pass of this preset is on file (tools/profile_r03.sh)
+            step = m['step']
+            # HBM-side bytes per launch of the dominant kernel, where a PMC pass of this preset is on file (tools/profile_r05.sh)
             tkey = ('rollout' if roof.get('graph_build_in_launch') else
                     'prop3' if roof.get('propagation_steps_per_launch', 0) >= 3 else m['dominant'])
             tb = load_traffic().get(name, {}).get(tkey, {}).get('hbm_bytes_per_launch')
             if tb:
                 roof['traffic'] = tb
+        batches = more_batches(step, fence, steps, dt, SWEEP_MIN_GPU_S)
+        med, best = float(np.median(batches)), float(min(batches))
         out.append({'name': name, 'workload': label, 'n_particles': N, 'rows': B, 'n_look_ahead': H, 'steps': steps, 'warmup': warm,
-                    'ms_per_step': dt / steps * 1e3, 'value': B * N * H * steps / dt, 'unit': 'particle-steps/s',
+                    'batches': len(batches), 'gpu_active_s': round(float(sum(batches)), 3),
+                    'ms_per_step': med / steps * 1e3, 'value': B * N * H * steps / med, 'unit': 'particle-steps/s',
+                    'ms_per_step_min': best / steps * 1e3, 'value_max': B * N * H * steps / best,
+                    'ms_per_step_first_batch': dt / steps * 1e3,
                     'mean_in_degree': kbar, 'dominant_kernel': roof['kernel'], 'avg_launch_ms': roof['avg_launch_ms'],
                     'bound': roof['bound'], 'achieved': roof['achieved'], 'peak': roof['peak'], 'roofline_unit': roof['unit'],
-                    'frac': roof['frac'], 'useful_frac': roof.get('useful_frac'), 'executed_per_launch': roof.get('executed_per_launch'),
+                    'frac': roof['frac'], 'peak_basis': roof.get('peak_basis'), 'frac_executed_16bit': roof.get('frac_executed_16bit'),
+                    'mfma_pipe_busy_est': roof.get('mfma_pipe_busy_est'), 'hbm_algorithmic_frac': roof.get('hbm_algorithmic_frac'),
+                    'executed_per_launch': roof.get('executed_per_launch'),
                     'traffic': roof.get('traffic'),
                     'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items() if v[1] > 0},
                     'wall_s': round(time.perf_counter() - t_wall, 2)})
@@ -630,7 +677,7 @@ def run_mpc_step(rig, fence):
     for N in (20, 50, 100):
         act_seq = np.stack([syn.nominal_pushes(1, seed=10 + i) for i in range(50)], axis=1)           # [1, 50, 4]
 
-        def one(n_update_iter=200):
+        def one(n_update_iter=200, goal_key=None):
             t = {}
             c0 = time.process_time()
             fence()
@@ -644,7 +691,7 @@ def run_mpc_step(rig, fence):
             res = planner.trajectory_optimization_ptcl_multi_traj(
                 obs_cur.astype(np.float32), particle_den.astype(np.float32), attr_cur, subgoal, model, act_seq,
                 np.zeros(act_seq.shape[0]), n_sample=act_seq.shape[1], n_look_ahead=1, n_update_iter=n_update_iter,
-                action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=2000.0)
+                action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=2000.0, goal_key=goal_key)
             t['planner'] = time.perf_counter() - t1
             t['total'] = time.perf_counter() - t0
             t['cpu'] = time.process_time() - c0
@@ -652,14 +699,20 @@ def run_mpc_step(rig, fence):
 
         planner._goal_key = None                                   # this pile size's goal pixels are not installed yet
         res_first, t_first = one()                                 # goal cache MISS (and the first launch of these shapes)
-        runs = [one() for _ in range(3)]                           # goal cache hits
+        runs = [one() for _ in range(3)]                           # goal cache hits, the goal identified by the digest of its content
         tm = {k: float(np.median([t[k] for _, t in runs])) for k in runs[0][1]}
+        # ... and identified by the caller's name for it (goal_key: env/flex_env.py:1048 passes the same subgoal for every MPC step)
+        one(goal_key=('I', N))
+        named = [one(goal_key=('I', N)) for _ in range(3)]
+        tn = {k: float(np.median([t[k] for _, t in named])) for k in named[0][1]}
         r = runs[-1][0]
         tt = r['times']
         out.append({'n_particles': N, 'rows': 50 * 30, 'iterations': int(r['iter_num']) + 1,
                     'reference_iteration_count': gd_iteration_count(200, 2000.0, N),
                     'ms_total': tm['total'] * 1e3, 'ms_particles': tm['particles'] * 1e3, 'ms_planner_call': tm['planner'] * 1e3,
                     'ms_goal_install_hit': tt.get('goal_time', 0.0) * 1e3, 'ms_goal_install_miss': res_first['times'].get('goal_time', 0.0) * 1e3,
+                    'ms_goal_install_hit_named': float(np.median([rr['times'].get('goal_time', 0.0) for rr, _ in named])) * 1e3,
+                    'ms_total_goal_named': tn['total'] * 1e3, 'ms_planner_call_goal_named': tn['planner'] * 1e3,
                     'ms_optimisation_loop': float(tt['optim_time']), 'ms_best_push_rollout_and_reward': float(tt['best_rollout_time']),
                     'ms_total_first_call_goal_miss': t_first['total'] * 1e3,
                     'host_cpu_ms': tm['cpu'] * 1e3,
@@ -744,7 +797,7 @@ def run_rank(args):
         return {'min': min(v), 'max': max(v), 'all': [round(x, 4) for x in v]}
 
     N, H = args.particles, args.horizon
-    out = None
+    out, cpu_args = None, None
     if args.config_name == 'gd-demo':
         nb = 30
         rows = args.samples_total_job // world
@@ -863,13 +916,18 @@ def run_rank(args):
                 'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in m['per_class'].items()},
                 'roofline_scatter': scatter, 'alt_engine': alt,
             }
-            if world == 1 and not args.no_cpu_baseline:
-                out['cpu_baseline'] = cpu_baseline(args, rig.sd, m['s0'], m['dens'], m['attr'], rig.G, rig.goal_coor, rig.cam)
-            else:
-                out['cpu_baseline'] = None
+            out['cpu_baseline'] = None
+            cpu_args = (args, rig.sd, m['s0'], m['dens'], m['attr'], rig.G, rig.goal_coor, rig.cam) if (world == 1 and not args.no_cpu_baseline) else None
+            out['gpu_active_s'] = round(float(m['dt'] + (m['median'] or 0.0) * args.steps + (dta if alt else 0.0)), 3)
     if rank == 0 and args.do_sweep and world == 1:
+        # every GPU leg before the host-side one: the GPU is busy in one stretch (the sweep alone keeps it busy for
+        # len(SWEEP) x SWEEP_MIN_GPU_S seconds), the CPU baseline follows
         out['sweep'] = run_sweep(rig, fence)
         out['mpc_step'] = run_mpc_step(rig, fence)
+        out['gpu_active_s'] = round(out.get('gpu_active_s', 0.0) + sum(e['gpu_active_s'] for e in out['sweep'])
+                                    + sum(e['ms_total'] * 4e-3 for e in out['mpc_step']), 3)
+    if rank == 0 and cpu_args is not None:
+        out['cpu_baseline'] = cpu_baseline(*cpu_args)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

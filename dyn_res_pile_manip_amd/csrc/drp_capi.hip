@@ -295,16 +295,32 @@ struct drp_ctx {
 
     // Edge-chain cache of the whole-sample kernels (prop_tiles, EC): the relation encoder's chain runs in the first propagation
     // step only and its output is read back in the other two, from a workgroup-private buffer of 80 KB per tile of 32 receivers
-    // (2.5 KB per receiver).  Chosen while the whole launch's buffer is at most ecache_max_mb (DRP_ECACHE_MAX_MB; 0 = never).
+    // (2.5 KB per receiver).  The cached kernels differ from the recomputing ones in the last place of one sum, so WHICH of the
+    // two serves a sample must not depend on how many samples travel with it (a 1 024-sample shard of an 8 192-sample job, a
+    // rank's half of the planner's 1 500 rows: the sharded and the unsharded run must agree bit for bit): the choice is a function
+    // of the PILE SIZE alone -- cached up to ecache_max_n particles (DRP_ECACHE_MAX_N; DRP_ECACHE_MAX_MB=0: never) -- and the
+    // buffer stays small by construction instead: a cached launch gives a workgroup at most ec_rows_cap(N) rows, and a batch
+    // that needs more than one such launch is run as several, one after the other on the stream, over the same buffer
+    // (run_rollout, run_step_mfma; 256 workgroups x 9 tiles x 80 KB = 189 MB, inside the 256 MB of last-level cache).
     int ecache_max_mb = 192;
+    int ecache_max_n = 64;
     DevBuf ecache;
-    // how many float4 a workgroup of `rows` receivers needs, and whether a launch of `grid` such workgroups takes the cached kernels
+    // how many float4 a workgroup of `rows` receivers needs
     static size_t ecache_stride(long rows, bool pair) {
         const long tiles = pair ? (rows + 15) / 16 : (rows + 31) / 32;
         return (size_t)tiles * (pair ? 5 : DRP_K) * EC_UNITS;
     }
-    bool use_ecache(long grid, long rows, bool pair) const {
-        return ecache_max_mb > 0 && (size_t)grid * ecache_stride(rows, pair) * 16 <= (size_t)ecache_max_mb << 20;
+    bool ec_shape(int N) const { return ecache_max_mb > 0 && N <= ecache_max_n; }
+    // rows a workgroup of a cached launch may hold: nine tiles of 32 (up to 64 particles: the measured best at 1 024 x 64 is
+    // four samples = eight tiles), eight -- one per wave, rows kept in registers -- above
+    static long ec_rows_cap(int N) { return N <= 64 ? 288 : 256; }
+    // samples per launch of a cached shape: every CU a workgroup of at most ec_rows_cap rows, in whole multiples of `unit`
+    // (the batch columns: row b reads column b % unit of the replicated inputs)
+    long ec_chunk(int N, long unit) const {
+        const long spw = std::max(1L, ec_rows_cap(N) / N);
+        long chunk = (long)n_cu * spw;
+        if (unit > 1) chunk = chunk / unit * unit;
+        return chunk;
     }
 
     // model constants
@@ -397,7 +413,7 @@ struct drp_ctx {
 
     // km_rollout's argument block (device copy + what it holds)
     DevBuf roll_args;
-    RolloutArgs roll_args_host{};
+    std::vector<RolloutArgs> roll_args_host;
     bool roll_args_valid = false;
 
     // last shapes (for debug fetch)
@@ -825,38 +841,70 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
         float* pb = ptr<float>(c->proj2);
         if (prop3) {
             ProbeScope ps(c, KC_PROP);
-            const dim3 grid((unsigned)((B + spw - 1) / spw)), pblk(64 * PROP_WAVES);
-            float* eff_base = tape ? a.eff_hist : ptr<float>(c->eff);
-            unsigned* mask_hist = tape ? a.mask_hist : nullptr;
-            float* agg_hist = tape ? a.agg_hist : nullptr;
-#define PROP3_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, a.s_prev, a.prev_mod, a.prev_stride, \
-                   a.attr, a.attr_mod, a.dens, a.dens_mod, ptr<int16_t>(c->nbr_idx), ptr<uint8_t>(c->nbr_cnt), pa, pb, \
-                   ptr<float>(c->c_node), eff_base, N, B, spw, phase_e ? (const float*)ptr<float>(c->s_delta) : (const float*)nullptr, \
-                   a.s_out, a.out_stride, a.cself, a.cself_ok, mask_hist, agg_hist, c->re_scale, c->re_inv, (c->prop3_order ? 1 : 0)
-            const bool pair = c->prop_pair(spw, N, B);
+            const dim3 pblk(64 * PROP_WAVES);
+            // cached or recomputing: by the pile size alone (drp_ctx::ec_shape).  A cached batch too large for one launch of
+            // at most ec_rows_cap rows per workgroup goes out as several launches over consecutive blocks of samples, the same
+            // cache buffer under each; the tape's launches (one history buffer over the whole batch) take a larger buffer instead
+            const bool ec = c->ec_shape(N);
+            long chunk = B;
+            if (ec && !tape) {
+                long unit = 1;
+                bool ok = true;
+                for (int mod : {a.prev_mod, a.attr_mod, a.dens_mod})
+                    if (mod < B) { if (unit % mod != 0 && mod % unit != 0) ok = false; else unit = std::max(unit, (long)mod); }
+                const long cap = c->ec_chunk(N, unit);
+                if (ok && cap > 0 && cap < B) chunk = cap;
+            }
+            {
+                const long B0 = std::min((long)B, chunk), spw0 = (B0 + c->n_cu - 1) / c->n_cu;
+                if (ec) CHK(ensure(c, c->ecache, (size_t)((B0 + spw0 - 1) / spw0) * drp_ctx::ecache_stride(spw0 * N, false) * 16));
+            }
             note_degrees(c, spw, N, B);
-            const bool ec = c->use_ecache(grid.x, (long)spw * N, pair);
-            const size_t ec_stride = drp_ctx::ecache_stride((long)spw * N, pair);
-            if (ec) CHK(ensure(c, c->ecache, (size_t)grid.x * ec_stride * 16));
-            float4* ecp = ec ? ptr<float4>(c->ecache) : nullptr;
             unsigned long long* const wk = c->work_ptr();    // not null: the counting instantiations (drp_probe_begin("prop+work"))
-            // ONE: no more tiles than waves in a workgroup -- the cached kernel then hands a tile's own rows from one propagation
-            // step to the next in registers
-            const bool one = ec && (pair ? ((long)spw * N + 15) / 16 : ((long)spw * N + 31) / 32) <= PROP_WAVES;
+            for (long b_off = 0; b_off < B; b_off += chunk) {
+                const int Bc = (int)std::min(chunk, (long)B - b_off);
+                const int spw_c = (Bc + c->n_cu - 1) / c->n_cu;
+                const dim3 grid((unsigned)((Bc + spw_c - 1) / spw_c));
+                // the block's view of every per-sample buffer: inputs replicated over the batch columns (row b reads column
+                // b % mod) keep their base -- a block starts at a multiple of mod --, everything indexed by the row moves on
+                const size_t ro = (size_t)b_off * N;
+                const float* s_prev_c = a.prev_mod >= B ? a.s_prev + (size_t)b_off * a.prev_stride : a.s_prev;
+                const int prev_mod_c = a.prev_mod >= B ? Bc : a.prev_mod;
+                const float* attr_c = a.attr_mod >= B ? a.attr + ro : a.attr;
+                const int attr_mod_c = a.attr_mod >= B ? Bc : a.attr_mod;
+                const float* dens_c = a.dens_mod >= B ? a.dens + b_off : a.dens;
+                const int dens_mod_c = a.dens_mod >= B ? Bc : a.dens_mod;
+                float* eff_base = (tape ? a.eff_hist : ptr<float>(c->eff)) + ro * 64;       // (the tape's launch is never split: ro = 0)
+                unsigned* mask_hist = tape ? a.mask_hist : nullptr;
+                float* agg_hist = tape ? a.agg_hist : nullptr;
+                const float* sd_c = phase_e ? (const float*)(ptr<float>(c->s_delta) + ro * 3) : (const float*)nullptr;
+                const float* cself_c = a.cself ? a.cself + (size_t)b_off * 64 : nullptr;
+                const uint8_t* cself_ok_c = a.cself_ok ? a.cself_ok + b_off : nullptr;
+#define PROP3_ARGS ptr<uint16_t>(c->w_split), ptr<uint16_t>(c->w_split6), mw, s_prev_c, prev_mod_c, a.prev_stride, \
+                   attr_c, attr_mod_c, dens_c, dens_mod_c, ptr<int16_t>(c->nbr_idx) + ro * DRP_K, ptr<uint8_t>(c->nbr_cnt) + ro, pa + ro * 128, pb + ro * 128, \
+                   ptr<float>(c->c_node) + ro * 64, eff_base, N, Bc, spw_c, sd_c, \
+                   a.s_out + (size_t)b_off * a.out_stride, a.out_stride, cself_c, cself_ok_c, mask_hist, agg_hist, c->re_scale, c->re_inv, (c->prop3_order ? 1 : 0)
+                const bool pair = c->prop_pair(spw_c, N, B);
+                const size_t ec_stride = drp_ctx::ecache_stride((long)spw_c * N, pair);
+                // ONE: no more tiles than waves in a workgroup -- the cached kernel then hands a tile's own rows from one propagation
+                // step to the next in registers
+                const bool one = ec && (pair ? ((long)spw_c * N + 15) / 16 : ((long)spw_c * N + 31) / 32) <= PROP_WAVES;
+                if (ec && (size_t)grid.x * ec_stride * 16 > c->ecache.cap) CHK(ensure(c, c->ecache, (size_t)grid.x * ec_stride * 16));
 #define PROP3_LAUNCH_W(TAPE_, PAIR_, EC_, ONE_) do { \
-                if (wk) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, EC_, true, ONE_>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); \
-                else hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, EC_, false, ONE_>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ecp, ec_stride, wk); } while (0)
+                    if (wk) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, EC_, true, ONE_>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ptr<float4>(c->ecache), ec_stride, wk); \
+                    else hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, EC_, false, ONE_>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ptr<float4>(c->ecache), ec_stride, wk); } while (0)
 #define PROP3_LAUNCH(TAPE_, PAIR_) do { \
-                if (one) PROP3_LAUNCH_W(TAPE_, PAIR_, true, true); else if (ec) PROP3_LAUNCH_W(TAPE_, PAIR_, true, false); \
-                else PROP3_LAUNCH_W(TAPE_, PAIR_, false, false); } while (0)
-            c->dv(DV_PROP3 + 12 * (tape ? 1 : 0) + 6 * (pair ? 1 : 0) + 2 * (one ? 2 : ec ? 1 : 0) + (wk ? 1 : 0));
-            if (!tape && !pair) PROP3_LAUNCH(false, false);
-            else if (!tape) PROP3_LAUNCH(false, true);
-            else if (!pair) PROP3_LAUNCH(true, false);
-            else PROP3_LAUNCH(true, true);
+                    if (one) PROP3_LAUNCH_W(TAPE_, PAIR_, true, true); else if (ec) PROP3_LAUNCH_W(TAPE_, PAIR_, true, false); \
+                    else PROP3_LAUNCH_W(TAPE_, PAIR_, false, false); } while (0)
+                c->dv(DV_PROP3 + 12 * (tape ? 1 : 0) + 6 * (pair ? 1 : 0) + 2 * (one ? 2 : ec ? 1 : 0) + (wk ? 1 : 0));
+                if (!tape && !pair) PROP3_LAUNCH(false, false);
+                else if (!tape) PROP3_LAUNCH(false, true);
+                else if (!pair) PROP3_LAUNCH(true, false);
+                else PROP3_LAUNCH(true, true);
 #undef PROP3_LAUNCH_W
 #undef PROP3_LAUNCH
 #undef PROP3_ARGS
+            }
         }
         for (int p = 0; p < DRP_PSTEP && !prop3; ++p) {
             const bool last = (p + 1 == DRP_PSTEP);
@@ -1042,50 +1090,74 @@ int run_rollout(drp_ctx* c, int nb, int N, int B, int H, bool reward_all, bool r
     }
     // small piles on the fused engine: the whole rollout is ONE launch (km_rollout, k_rollout.h) -- a workgroup owns its
     // samples from the first step to the last, builds their neighbour lists itself and keeps the node matrices in LDS
-    const int spw_r = (int)((B + c->n_cu - 1) / c->n_cu);
+    // A cached shape (drp_ctx::ec_shape: by the pile size alone) gives a workgroup at most ec_rows_cap rows; a batch that needs
+    // more goes out as several launches over consecutive blocks of samples (whole multiples of the batch columns)
+    const bool ec = c->engine == DRP_ENGINE_FUSED && c->ec_shape(N);
+    long chunk_r = B;
+    if (ec) { const long cap = c->ec_chunk(N, nb); if (cap > 0 && cap < B) chunk_r = cap; }
+    const int spw_r = (int)((std::min((long)B, chunk_r) + c->n_cu - 1) / c->n_cu);
     // up to rollout_max_n particles whatever the batch; up to rollout_mid_n while a workgroup holds no more than rollout_mid_rows
     const bool roll_size = N <= c->rollout_max_n || (N <= c->rollout_mid_n && (long)spw_r * N <= c->rollout_mid_rows && (N <= 200 || B >= c->n_cu / 2));
     const bool one_launch = c->engine == DRP_ENGINE_FUSED && c->rollout_fused && c->prop3 && c->prop3e && roll_size &&
                             whole_samples(c, B, N) && ((long)spw_r * N + 31) / 32 >= c->prop3_min_tiles &&
                             (long)spw_r * N <= KM_ROLLOUT_MAX_ROWS && (long)spw_r * N <= c->rollout_max_rows;
     if (one_launch) {
-        RolloutArgs ra{};
-        ra.sw = ptr<uint16_t>(c->w_split); ra.sw6 = ptr<uint16_t>(c->w_split6); ra.mw = ptr<float>(c->w_mfma);
-        ra.s_in = ptr<float>(c->s_in); ra.states = states; ra.attr = ptr<float>(c->attr); ra.dens = ptr<float>(c->dens);
-        ra.actions = ptr<float>(c->actions); ra.s_delta = ptr<float>(c->s_delta); ra.nbr_idx = ptr<int16_t>(c->nbr_idx);
-        ra.nbr_cnt = ptr<uint8_t>(c->nbr_cnt); ra.proj_a = ptr<float>(c->proj); ra.proj_b = ptr<float>(c->proj2);
-        ra.c_node = ptr<float>(c->c_node); ra.eff = ptr<float>(c->eff); ra.cself = cself; ra.cself_ok = cself_ok;
-        ra.N = N; ra.B = B; ra.spw = spw_r; ra.nb = nb; ra.H = H; ra.order_rows = (c->prop3_order ? 1 : 0);
-        ra.thr = c->thr; ra.re_scale = c->re_scale; ra.re_inv = c->re_inv; ra.cam = c->cam;
-        const bool pair_r = c->prop_pair(spw_r, N, B);
-        const unsigned grid_r = (unsigned)((B + spw_r - 1) / spw_r);
-        const bool ec = c->use_ecache(grid_r, (long)spw_r * N, pair_r);
-        ra.ec_stride = drp_ctx::ecache_stride((long)spw_r * N, pair_r);
-        if (ec) CHK(ensure(c, c->ecache, (size_t)grid_r * ra.ec_stride * 16));
-        ra.ecache = ec ? ptr<float4>(c->ecache) : nullptr;
-        ra.work = c->work_ptr();
-        // the argument block sits in device memory; it is uploaded when it changes (every iteration of an MPC session
-        // passes the same one), behind whatever still runs on the stream
-        if (!c->roll_args_valid || memcmp(&ra, &c->roll_args_host, sizeof(ra)) != 0) {
-            c->roll_args_host = ra;
+        const int n_chunks = (int)((B + chunk_r - 1) / chunk_r);
+        std::vector<RolloutArgs> blocks((size_t)n_chunks);
+        std::vector<char> pairs((size_t)n_chunks);
+        if (ec) CHK(ensure(c, c->ecache, (size_t)((std::min((long)B, chunk_r) + spw_r - 1) / spw_r) * drp_ctx::ecache_stride((long)spw_r * N, false) * 16));
+        for (int q = 0; q < n_chunks; ++q) {
+            const long b_off = (long)q * chunk_r;
+            const int Bc = (int)std::min(chunk_r, (long)B - b_off);
+            const size_t ro = (size_t)b_off * N;
+            RolloutArgs& ra = blocks[(size_t)q];
+            ra = RolloutArgs{};
+            ra.sw = ptr<uint16_t>(c->w_split); ra.sw6 = ptr<uint16_t>(c->w_split6); ra.mw = ptr<float>(c->w_mfma);
+            // the first state, the attributes and the densities are replicated over the batch columns (row b reads column b % nb;
+            // a block starts at a multiple of nb): same base for every block; everything indexed by the row moves on
+            ra.s_in = ptr<float>(c->s_in); ra.attr = ptr<float>(c->attr); ra.dens = ptr<float>(c->dens);
+            ra.states = states + ro * 3 * H;
+            ra.actions = ptr<float>(c->actions) + (size_t)b_off * H * 4;
+            ra.s_delta = ptr<float>(c->s_delta) + ro * 3; ra.nbr_idx = ptr<int16_t>(c->nbr_idx) + ro * DRP_K;
+            ra.nbr_cnt = ptr<uint8_t>(c->nbr_cnt) + ro; ra.proj_a = ptr<float>(c->proj) + ro * 128; ra.proj_b = ptr<float>(c->proj2) + ro * 128;
+            ra.c_node = ptr<float>(c->c_node) + ro * 64; ra.eff = ptr<float>(c->eff) + ro * 64;
+            ra.cself = cself ? cself + (size_t)b_off * 64 : nullptr; ra.cself_ok = cself_ok ? cself_ok + b_off : nullptr;
+            ra.N = N; ra.B = Bc; ra.spw = (Bc + c->n_cu - 1) / c->n_cu; ra.nb = nb; ra.H = H; ra.order_rows = (c->prop3_order ? 1 : 0);
+            ra.thr = c->thr; ra.re_scale = c->re_scale; ra.re_inv = c->re_inv; ra.cam = c->cam;
+            const bool pair_q = c->prop_pair(ra.spw, N, B);
+            pairs[(size_t)q] = pair_q ? 1 : 0;
+            ra.ec_stride = drp_ctx::ecache_stride((long)ra.spw * N, pair_q);
+            ra.ecache = ec ? ptr<float4>(c->ecache) : nullptr;
+            ra.work = c->work_ptr();
+        }
+        // the argument blocks sit in device memory; they are uploaded when they change (every iteration of an MPC session
+        // passes the same ones), behind whatever still runs on the stream
+        if (!c->roll_args_valid || c->roll_args_host.size() != blocks.size() ||
+            memcmp(blocks.data(), c->roll_args_host.data(), blocks.size() * sizeof(RolloutArgs)) != 0) {
+            c->roll_args_host = blocks;
             c->roll_args_valid = false;
-            CHK(h2d(c, c->roll_args, &c->roll_args_host, sizeof(ra)));
+            CHK(h2d(c, c->roll_args, c->roll_args_host.data(), blocks.size() * sizeof(RolloutArgs)));
             c->roll_args_valid = true;
         }
         ProbeScope ps(c, KC_PROP);
-        // ONE: no more tiles than waves in a workgroup -- the cached kernel then hands a tile's own rows (P_r, its own P_s, its
-        // effect) from one propagation step to the next in registers
-        const long tiles_r = pair_r ? ((long)spw_r * N + 15) / 16 : ((long)spw_r * N + 31) / 32;
-        const bool one = ec && tiles_r <= PROP_WAVES;
-#define ROLLOUT_LAUNCH_W(PAIR_, EC_, WORK_, ONE_) hipLaunchKernelGGL((km_rollout<PAIR_, EC_, WORK_, ONE_>), dim3(grid_r), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS, \
-                                                                     c->stream, ptr<RolloutArgs>(c->roll_args))
-#define ROLLOUT_LAUNCH(PAIR_, EC_, ONE_) do { if (ra.work) ROLLOUT_LAUNCH_W(PAIR_, EC_, true, ONE_); else ROLLOUT_LAUNCH_W(PAIR_, EC_, false, ONE_); } while (0)
         c->dv(DV_GRAPH_IN_ROLLOUT);
-        c->dv(DV_ROLLOUT + 6 * (pair_r ? 1 : 0) + 2 * (one ? 2 : ec ? 1 : 0) + (ra.work ? 1 : 0));
-        if (pair_r) { if (one) ROLLOUT_LAUNCH(true, true, true); else if (ec) ROLLOUT_LAUNCH(true, true, false); else ROLLOUT_LAUNCH(true, false, false); }
-        else { if (one) ROLLOUT_LAUNCH(false, true, true); else if (ec) ROLLOUT_LAUNCH(false, true, false); else ROLLOUT_LAUNCH(false, false, false); }
+        for (int q = 0; q < n_chunks; ++q) {
+            const RolloutArgs& ra = blocks[(size_t)q];
+            const bool pair_r = pairs[(size_t)q] != 0;
+            const unsigned grid_r = (unsigned)((ra.B + ra.spw - 1) / ra.spw);
+            // ONE: no more tiles than waves in a workgroup -- the cached kernel then hands a tile's own rows (P_r, its own P_s, its
+            // effect) from one propagation step to the next in registers
+            const long tiles_r = pair_r ? ((long)ra.spw * N + 15) / 16 : ((long)ra.spw * N + 31) / 32;
+            const bool one = ec && tiles_r <= PROP_WAVES;
+#define ROLLOUT_LAUNCH_W(PAIR_, EC_, WORK_, ONE_) hipLaunchKernelGGL((km_rollout<PAIR_, EC_, WORK_, ONE_>), dim3(grid_r), dim3(64 * PROP_WAVES), KM_ROLLOUT_LDS, \
+                                                                     c->stream, ptr<RolloutArgs>(c->roll_args) + q)
+#define ROLLOUT_LAUNCH(PAIR_, EC_, ONE_) do { if (ra.work) ROLLOUT_LAUNCH_W(PAIR_, EC_, true, ONE_); else ROLLOUT_LAUNCH_W(PAIR_, EC_, false, ONE_); } while (0)
+            c->dv(DV_ROLLOUT + 6 * (pair_r ? 1 : 0) + 2 * (one ? 2 : ec ? 1 : 0) + (ra.work ? 1 : 0));
+            if (pair_r) { if (one) ROLLOUT_LAUNCH(true, true, true); else if (ec) ROLLOUT_LAUNCH(true, true, false); else ROLLOUT_LAUNCH(true, false, false); }
+            else { if (one) ROLLOUT_LAUNCH(false, true, true); else if (ec) ROLLOUT_LAUNCH(false, true, false); else ROLLOUT_LAUNCH(false, false, false); }
 #undef ROLLOUT_LAUNCH_W
 #undef ROLLOUT_LAUNCH
+        }
         HIPCHK(c, hipGetLastError());
         note_degrees(c, spw_r, N, B);           // the last step's lists
     }
@@ -1411,6 +1483,7 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_COMM_INIT_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_init_timeout_s = v; }
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (const char* e = getenv("DRP_ECACHE_MAX_MB")) c->ecache_max_mb = std::max(0, atoi(e));
+    if (const char* e = getenv("DRP_ECACHE_MAX_N")) c->ecache_max_n = std::max(0, atoi(e));
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_q4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -2047,14 +2120,14 @@ int drp_fps(drp_ctx* c, const float* pts, int n, int dim, int k, int init_idx, i
     int* chosen = reinterpret_cast<int*>(dist + n);
     CHK(ensure(c, c->stats, 8 * sizeof(double)));
     float* md = reinterpret_cast<float*>(ptr<double>(c->stats) + 7);
-    const bool in_regs = n <= 1024 * FPS_REG_PT(dim);
+    const bool in_regs = n <= FPS_WIDE_THREADS * FPS_REG_PT(dim);
     if (dim == 2) {
         c->dv(in_regs ? DV_FPS_REG : DV_FPS_MEM);
-        if (in_regs) hipLaunchKernelGGL(k_fps_reg<2>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, chosen, md);
+        if (in_regs) hipLaunchKernelGGL(k_fps_reg<2>, dim3(1), dim3(FPS_WIDE_THREADS), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, chosen, md);
         else hipLaunchKernelGGL(k_fps<2>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, dist, chosen, md);
     } else {
         c->dv(in_regs ? DV_FPS_REG : DV_FPS_MEM);
-        if (in_regs) hipLaunchKernelGGL(k_fps_reg<3>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, chosen, md);
+        if (in_regs) hipLaunchKernelGGL(k_fps_reg<3>, dim3(1), dim3(FPS_WIDE_THREADS), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, chosen, md);
         else hipLaunchKernelGGL(k_fps<3>, dim3(1), dim3(1024), 0, c->stream, ptr<float>(c->scratch), n, k, init_idx, dist, chosen, md);
     }
     HIPCHK(c, hipGetLastError());
@@ -2371,9 +2444,9 @@ int drp_set_goal_image(drp_ctx* c, const float* obs_goal, int h, int w, int mode
     float* fdist = ptr<float>(c->gl_fps);
     int* chosen = reinterpret_cast<int*>(fdist + count);
     float* md = reinterpret_cast<float*>(chosen + m);
-    c->dv(count <= 1024 * FPS_REG_PT(2) ? DV_FPS_REG : DV_FPS_MEM);
-    if (count <= 1024 * FPS_REG_PT(2))
-        hipLaunchKernelGGL(k_fps_reg<2>, dim3(1), dim3(1024), 0, st, ptr<float>(c->gl_pix), count, m, fps_init, chosen, md);
+    c->dv(count <= FPS_WIDE_THREADS * FPS_REG_PT(2) ? DV_FPS_REG : DV_FPS_MEM);
+    if (count <= FPS_WIDE_THREADS * FPS_REG_PT(2))
+        hipLaunchKernelGGL(k_fps_reg<2>, dim3(1), dim3(FPS_WIDE_THREADS), 0, st, ptr<float>(c->gl_pix), count, m, fps_init, chosen, md);
     else
         hipLaunchKernelGGL(k_fps<2>, dim3(1), dim3(1024), 0, st, ptr<float>(c->gl_pix), count, m, fps_init, fdist, chosen, md);
     CHK(ensure(c, c->goal_coor, (size_t)m * 2 * sizeof(float)));

@@ -67,16 +67,34 @@ def recenter(pcd, sampled_pcd, r=0.02):
     return get_engine().recenter(pcd, s[None], [r])[0]
 
 
+def _channel_extrema(obs):
+    """Per-channel maximum and minimum of an [h, w, c] image in two passes over the CONTIGUOUS array: rows of 64 pixels are
+    reduced along axis 0 (a long contiguous inner dimension: vectorised), the 64 x c remainders on their own -- eight times
+    faster than one reduction per strided channel view."""
+    c = obs.shape[-1]
+    a = np.ascontiguousarray(obs).reshape(-1, c)
+    n = a.shape[0] // 64 * 64
+    mx, mn = a[n:].max(0, initial=-np.inf), a[n:].min(0, initial=np.inf)
+    if n:
+        w = a[:n].reshape(-1, 64 * c)
+        mx = np.maximum(mx, w.max(0).reshape(64, c).max(0))
+        mn = np.minimum(mn, w.min(0).reshape(64, c).min(0))
+    return mx, mn
+
+
 def obs2ptcl_fixed_num_batch(obs, particle_num, batch_size, cam_params, global_scale, init_idx=None):
     """env/flex_env.py:933-951 with `self.get_cam_params()` / `self.global_scale` as arguments
     -> (batch_sampled_ptcl [batch,N,3] float64, batch_particle_r [batch])."""
     assert type(obs) == np.ndarray
     assert obs.shape[-1] == 5
-    assert obs[..., :3].max() <= 255.0
-    assert obs[..., :3].min() >= 0.0
-    assert obs[..., :3].max() >= 1.0
-    assert obs[..., -1].max() >= 0.7 * global_scale
-    assert obs[..., -1].max() <= 0.8 * global_scale
+    # the reference's range checks (env/flex_env.py:903-909), from ONE maximum and ONE minimum pass over the contiguous image
+    # instead of five reductions over strided channel views (tools/particles_timing.py)
+    ch_max, ch_min = _channel_extrema(obs)
+    assert ch_max[:3].max() <= 255.0
+    assert ch_min[:3].min() >= 0.0
+    assert ch_max[:3].max() >= 1.0
+    assert ch_max[4] >= 0.7 * global_scale
+    assert ch_max[4] <= 0.8 * global_scale
     eng = get_engine()
     depth_raw = np.ascontiguousarray(obs[..., -1], dtype=np.float32)
     if init_idx is None:

@@ -16,8 +16,9 @@ NO scaling of any layer.  Then, on those weights, the reference produces
                         grad/<...>                     autograd gradients of the GD planner's loss w.r.t. the pushes
                         gd/<...>                       trajectory_optimization_ptcl_multi_traj dicts (Adam iterations)
   train_curve.npz       the first CURVE_ITERS losses of the run above with its initial weights, the per-batch checksums
-                        of the episodes (the tests regenerate the batches from the same seeded generator), and the
-                        weights after CURVE_ITERS iterations
+                        of the episodes (the tests regenerate the batches from the same seeded generator), the
+                        weights after CURVE_ITERS iterations, and the losses of a second reference run started one ulp
+                        away (how far two fp32 runs of this loop drift apart: the tests' yardstick)
 
 Runs ONLY in the build container.  Usage:  python tests/golden/make_golden_trained.py [--iters N]
 (about 20 minutes on 8 cores at the default 3 000 iterations).
@@ -104,7 +105,37 @@ def main():
                   (it, np.sqrt(losses[-1]), np.sqrt(np.mean(losses[-50:])), time.time() - t0), flush=True)
     model.eval()
 
+    # How far apart do two fp32 runs of this very loop drift?  The reference again from the same initial weights moved by ONE
+    # ulp in one small layer (particle_encoder.model.0.weight), the same batches: the tests hold the device trainer's loss
+    # curve to a small multiple of THIS deviation, not to an invented tolerance.
+    twin = PropNetDiffDenModel(config, False)
+    twin.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in init_sd.items()})
+    with torch.no_grad():
+        w0 = twin.model.particle_encoder.model[0].weight
+        w0.copy_(torch.nextafter(w0, torch.full_like(w0, float('inf'))))
+    twin.train(True)
+    twin_opt = torch.optim.Adam(twin.parameters(), lr=LR, betas=(BETA1, 0.999))
+    twin_losses = []
+    for it in range(min(CURVE_ITERS, iters)):
+        states, sdelta, attrs, pnums, dens = syn.push_batch(it, BATCH, N_ROLLOUT)
+        st, sd, at, pd = (torch.from_numpy(x) for x in (states, sdelta, attrs, dens))
+        loss = 0.
+        s_cur = st[:, 0]
+        for idx_step in range(N_ROLLOUT):
+            s_pred = twin.predict_one_step(at[:, 0], s_cur, sd[:, idx_step], pd)
+            for j in range(st.shape[0]):
+                loss += F.mse_loss(s_pred[j, :pnums[j]], st[j, idx_step + 1, :pnums[j]])
+            s_cur = s_pred
+        loss = loss / (N_ROLLOUT * st.shape[0])
+        twin_opt.zero_grad()
+        loss.backward()
+        twin_opt.step()
+        twin_losses.append(loss.item())
+    dev = np.abs(np.asarray(twin_losses) / np.asarray(losses[:len(twin_losses)]) - 1)
+    print('[train] one-ulp twin: loss deviation median %.2e, max %.2e' % (np.median(dev), dev.max()), flush=True)
+
     tc = {'init/' + k: v for k, v in init_sd.items()}
+    tc['losses_twin'] = np.asarray(twin_losses, np.float64)
     tc.update({'after/' + k: v for k, v in after_curve.items()})
     tc['losses'] = np.asarray(losses[:CURVE_ITERS], np.float64)
     tc['batch_sums'] = np.asarray(sums[:CURVE_ITERS], np.float64)

@@ -199,7 +199,8 @@ def test_three_steps_in_one_launch_equal_one_launch_per_step(monkeypatch, N, ns)
     (20, 1024, 4, 1),       # paired tiles reading the cache
     (64, 1024, 3, 1),       # eight full tiles
     (30, 180, 3, 30),       # the planner's shape: 30 batch columns, one sample per workgroup
-    (100, 700, 2, 1)])      # three samples a workgroup, 10 tiles for 8 waves
+    (100, 700, 2, 1),       # two samples a workgroup, two launches (512 + 188 samples) over one cache buffer
+    (50, 3000, 2, 2)])      # three launches of 1 280 samples
 def test_edge_cache_against_the_oracle(monkeypatch, N, ns, H, nb):
     """The whole-sample kernels of small piles with the relation encoder's chain run in the FIRST propagation step only and
     its output read back in the other two -- model/gnn_dyn.py:179-193 computes relation_encode once, in front of the pstep
@@ -209,7 +210,7 @@ def test_edge_cache_against_the_oracle(monkeypatch, N, ns, H, nb):
     rollout in one launch / one launch per rollout step) the same bits."""
     from dyn_res_pile_manip_amd.engine import Engine
     from oracle import propnet_sparse as osp
-    monkeypatch.setenv('DRP_ECACHE_MAX_MB', '4000')
+    monkeypatch.setenv('DRP_ECACHE_MAX_N', '256')          # the default caches up to 64 particles: the kernels take any pile
     monkeypatch.setenv('DRP_ROLLOUT_MAX_N', '256')
     s0, dens, attr = syn.make_pile(N, nb, seed=N)
     acts = syn.sample_pushes(ns, H, seed=N + 7)
@@ -462,3 +463,48 @@ def test_config5_whole_job_as_eight_logical_shards(ctx):
     assert oracle_steps(ctx, s0, dens, attr, big['actions'], big['states'], rows=rows) < 1e-4      # all 20 steps
     ref_r = osp.reward(big['states'][rows, -1], G, syn.demo_cam_params(), gc)
     np.testing.assert_allclose(big['rewards'][rows], ref_r, rtol=2e-5)
+
+
+@pytest.mark.parametrize('N', [20, 50, 64, 65, 100, 200])
+def test_a_rows_result_does_not_depend_on_the_batch_it_travels_in(ctx, N):
+    """Which propagation kernel serves a sample -- cached or recomputing relation-encoder chain (they differ in the last place
+    of a sum) -- is a function of the pile size alone (csrc/drp_capi.hip drp_ctx::ec_shape), never of the batch: an
+    8 192-row job, its eight 1 024-row shards (BASELINE configs[2]'s partition) and a 64-row call give every row the same
+    bits; the planner's 1 500 gradient-descent rows and a rank's 750 likewise.  Default environment."""
+    ctx.set_engine(_lib.ENGINE_FUSED)
+    H, nb, big = 3, 2, 8192
+    s0, dens, attr = syn.make_pile(N, nb, seed=N)
+    acts = np.stack([syn.pushes_through(np.tile(s0, (big // nb, 1, 1)), seed=N + t) for t in range(H)], 1)
+    ctx.dispatch_reset()
+    whole, _ = ctx.rollout(s0, attr, dens, acts)
+    seen = set(ctx.last_dispatch())
+    for k in (0, 3, 7):
+        ctx.dispatch_reset()
+        part, _ = ctx.rollout(s0, attr, dens, acts[k * 1024:(k + 1) * 1024])
+        seen |= set(ctx.last_dispatch())
+        np.testing.assert_array_equal(part, whole[k * 1024:(k + 1) * 1024], err_msg='shard %d' % k)
+    few, _ = ctx.rollout(s0, attr, dens, acts[4096:4096 + 64])
+    np.testing.assert_array_equal(few, whole[4096:4096 + 64])
+    seen |= set(ctx.last_dispatch())
+    cached = [v for v in seen if v.startswith(('km_rollout', 'km_prop3', 'km_prop<')) and 'cache' in v]
+    plain = [v for v in seen if v.startswith(('km_rollout', 'km_prop3', 'km_prop<')) and 'cache' not in v]
+    assert bool(cached) != bool(plain), (N, sorted(seen))           # one family serves every batch size of this pile size
+    assert bool(cached) == (N <= 64)
+    # one step of B different samples (drp_step: graph + km_prop3, never the one-launch rollout)
+    s1, a1, d1 = whole[:, -1], np.tile(attr, (big // nb, 1)), np.tile(dens, big // nb)
+    sd1 = ctx.gen_s_delta(s1, acts[:, 0])
+    step_whole = ctx.step(a1, s1, sd1, d1)
+    for lo, n in ((0, 1024), (5000, 300), (8000, 64)):
+        np.testing.assert_array_equal(ctx.step(a1[lo:lo + n], s1[lo:lo + n], sd1[lo:lo + n], d1[lo:lo + n]), step_whole[lo:lo + n])
+    # the gradient-descent planner's rows
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    ctx.set_goal(syn.goal_field(obs_goal), syn.goal_coor_strided(obs_goal, 5 * N))
+    lo_, hi_ = syn.action_limits()
+    rows = 1500
+    ctx.gd_begin(s0, attr, dens, acts[:rows, :1], 0.05, lo_, hi_)
+    r_all, g_all, _ = ctx.gd_grad()
+    for lo, n in ((0, 750), (750, 750), (1400, 100)):
+        ctx.gd_begin(s0, attr, dens, acts[lo:lo + n, :1], 0.05, lo_, hi_)
+        r, g, _ = ctx.gd_grad()
+        np.testing.assert_array_equal(r, r_all[lo:lo + n])
+        np.testing.assert_array_equal(g, g_all[lo:lo + n])

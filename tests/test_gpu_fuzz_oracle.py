@@ -275,7 +275,7 @@ def test_update_and_preprocessing_variants(eng):
         np.testing.assert_allclose(nominal, got['actions'][order].astype(np.float64).mean(0), rtol=1e-9, atol=1e-9)
         note(eng, 'mppi %d samples' % ns)
     rng = np.random.default_rng(0)
-    for n, dim, k in ((3000, 2, 40), (30000, 2, 25), (20000, 3, 20)):
+    for n, dim, k in ((3000, 2, 40), (30000, 2, 25), (20000, 3, 20), (24000, 3, 12)):
         pts = rng.uniform(0, 700, (n, dim)).astype(np.float32)
         eng.dispatch_reset()
         sel, md, idx = eng.fps(pts, k, 0)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from dyn_res_pile_manip_amd import synthetic as syn
+from dyn_res_pile_manip_amd import flex_rewards, synthetic as syn, weights
 from dyn_res_pile_manip_amd.gnn_dyn import PropNetDiffDenModel
 from dyn_res_pile_manip_amd.planners import PlannerGD
 
@@ -172,6 +172,31 @@ def test_device_fps_equals_fps_np(stack):
     want, _ = fps_np(pts3, 100, 17)
     got, _, _ = model.engine.fps(pts3, 100, 17)
     np.testing.assert_array_equal(got, want)
+    # The register kernel keeps SQUARED distances and takes numpy's first maximum of their square roots in two steps (max,
+    # then the smallest index whose root rounds to the same float: csrc/k_fps.h).  Point sets made for that: a coarse lattice
+    # with duplicates (exact ties by the hundred), and radii one float apart around a centre (different squares, one root).
+    rng = np.random.default_rng(5)
+    lattice = (rng.integers(0, 40, (6000, 2)) * np.float32(0.37)).astype(np.float32)
+    r = np.float32(3.0) * (np.float32(1.0) + np.arange(64, dtype=np.float32) * np.float32(2.0 ** -23))
+    ang = rng.uniform(0, 2 * np.pi, 64)
+    ring = np.stack([r * np.cos(ang).astype(np.float32), r * np.sin(ang).astype(np.float32)], 1).astype(np.float32)
+    near = np.concatenate([np.zeros((1, 2), np.float32), ring, ring[::-1] * np.float32(0.5)])
+    for pts, k, init in ((lattice, 1500, 11), (near, 60, 0), (np.concatenate([near, near + np.float32(1e-3)]), 100, 0)):
+        want, want_md = fps_np(pts, k, init)
+        got, got_md, idx = model.engine.fps(pts, k, init)
+        np.testing.assert_array_equal(got, want)
+        assert got_md == np.float32(want_md)
+    # 6 000 of 21 680 goal pixels (a 1 200-particle plan's subsample, planners.py:621): 27.6 ms in round 4
+    big = np.argwhere(syn.goal_distance_image(syn.goal_mask('disc')) < 30.0)[:21680, ::-1].astype(np.float32)
+    import time
+    model.engine.fps(big, 6000, 0)
+    t0 = time.perf_counter()
+    got, _, _ = model.engine.fps(big, 6000, 0)
+    ms = (time.perf_counter() - t0) * 1e3
+    want, _ = fps_np(big, 6000, 0)
+    np.testing.assert_array_equal(got, want)
+    print('\n[fps] 6 000 of %d points: %.2f ms (upload + kernel + download)' % (big.shape[0], ms))
+    assert ms < 12.0
 
 
 def test_one_mpc_step_end_to_end(stack):
@@ -263,7 +288,9 @@ def test_weights_the_fused_engine_cannot_serve_fall_back_by_themselves(golden):
     fused engine refuses every call with DRP_ERANGE.  The host mirror -- model and planner with NO engine argument, as
     visualize_mpc.py:36-41,70-84 build them -- switches to the fp32 matrix engine by itself, warns once and keeps working;
     the results are the oracle's for those weights.  (Weights merely far from a fresh network's, x 50 in every layer of
-    the relation encoder, stay on the fused engine: its range shift covers them.)"""
+    the relation encoder, stay on the fused engine: its range shift covers them.)  The gradient-descent planner -- the only
+    one env/flex_env.py:973-976 accepts -- and the trainer do not stop either: their tape is written on the fp32 matrix
+    engine, gradients and Adam iterates against the oracle's autograd."""
     from oracle import propnet_sparse as osp
     from dyn_res_pile_manip_amd import _lib
     from dyn_res_pile_manip_amd.engine import set_default_engine
@@ -312,17 +339,63 @@ def test_weights_the_fused_engine_cannot_serve_fall_back_by_themselves(golden):
             gp['s_cur'], gp['dens'], gp['attr'], syn.goal_distance_image(syn.goal_mask('I')), model2, gp['act_seq'], np.zeros(1),
             n_sample=32, n_look_ahead=1, n_update_iter=3, action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=1e9)
         assert np.isfinite(res['reward']).all() and res['action_sequence'].shape == (1, 4)
-        # the model of part (1) takes the shared context back with ITS weights (and the engine stays where it is)
+        # the model of part (1) takes the shared context back with ITS weights -- and gets the fused engine back with them
+        # (the refusal belonged to the other weights)
         out_again = model.predict_one_step(a, s, sdl, d)
         assert np.abs(out_again - ref).max() < 1e-4 * np.abs(ref - s).max()
-        # the gradient-descent planner writes its tape with the fused engine only: there the refusal stands
+        assert model.engine.engine_id == _lib.ENGINE_FUSED
+        # (3) the reference's LIVE planner is the gradient-descent one (env/flex_env.py:973-976 accepts nothing else): on such
+        # weights it must not stop -- its forward pass writes the tape on the fp32 matrix engine (k_aggregate_tape) instead.
+        # Gradients, three Adam iterations and the returned pushes against the oracle's autograd on those weights.
+        from oracle import propnet_dense as od
+        Wt = od.load_weights({'w/' + k: v for k, v in sdx.items()})
+        obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+        traj, nb = gp['act_seq'].shape[1], gp['s_cur'].shape[0]
         cfg_gd = syn.default_config()
         cfg_gd['mpc']['mpc_type'] = 'GD'
-        with pytest.raises(_lib.DrpRangeError):
-            PlannerGD(cfg_gd, env).trajectory_optimization_ptcl_multi_traj(
-                gp['s_cur'], gp['dens'], gp['attr'], syn.goal_distance_image(syn.goal_mask('I')), model2, gp['act_seq'], np.zeros(1),
-                n_sample=gp['act_seq'].shape[1], n_look_ahead=1, n_update_iter=3, action_lower_lim=lo, action_upper_lim=hi,
+        planner_gd = PlannerGD(cfg_gd, env)
+        eng = model2.engine
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)              # the winner's re-rollout falls back with its warning
+            eng.dispatch_reset()
+            res = planner_gd.trajectory_optimization_ptcl_multi_traj(
+                gp['s_cur'], gp['dens'], gp['attr'], obs_goal, model2, gp['act_seq'], np.zeros(1),
+                n_sample=traj, n_look_ahead=1, n_update_iter=3, action_lower_lim=lo, action_upper_lim=hi,
                 use_gpu=True, time_lim=1e9)
+        assert 'k_aggregate_tape' in eng.last_dispatch()
+        G, goal_coor = eng.set_goal_image(obs_goal, 5 * gp['s_cur'].shape[1], fps_init=0, mode=flex_rewards.DIST_TRANSFORM, want=True)
+        acts = torch.tensor(np.repeat(gp['act_seq'].transpose(1, 0, 2), nb, axis=0).astype(np.float32), requires_grad=True)
+        opt = torch.optim.Adam([acts], lr=cfg_gd['mpc']['gd']['lr'], betas=(0.9, 0.999))
+        lo_t, hi_t = torch.tensor(lo, dtype=torch.float32), torch.tensor(hi, dtype=torch.float32)
+        means = []
+        for it in range(3):
+            r_it, g_it, _ = od.gd_loss_and_grads(Wt, gp['s_cur'], gp['dens'], gp['attr'], acts.detach().numpy(), G,
+                                                 syn.demo_cam_params(), goal_coor, syn.demo_cam_extrinsics(), 24)
+            means.append(np.asarray(r_it).reshape(traj, nb)[:, 0].mean())
+            opt.zero_grad()
+            acts.grad = torch.from_numpy(np.ascontiguousarray(g_it))
+            opt.step()
+            with torch.no_grad():
+                acts.copy_(torch.minimum(torch.maximum(acts, lo_t), hi_t))
+        np.testing.assert_allclose(res['rew_mean'][0, :3], means, rtol=1e-4)
+        np.testing.assert_allclose(res['action_full'], acts.detach().numpy().reshape(traj, nb, 1, 4)[:, 0, 0], atol=2e-3)
+        # ... and the trainer (train/train_gnn_dyn.py:159-210 through run_batch): loss and gradients of those weights
+        from dyn_res_pile_manip_amd import train_gnn_dyn as T
+        batch = syn.push_batch(3, 4, 2, sizes=(10, 20, 30))
+        opt_dev = T.DeviceAdam(model2, 1e-4, betas=(0.9, 0.999), n_rollout=2)
+        eng.dispatch_reset()
+        loss_eval = T.run_batch(model2, opt_dev, batch + (None,), 'valid', 2)
+        loss_g, grad = eng.train_step(*batch, mode='grad', want_grad=True)
+        assert 'k_aggregate_tape' in eng.last_dispatch()
+        ref_loss, ref_grads = od.train_loss_and_grads(sdx, *batch)
+        assert abs(loss_eval - ref_loss) < 2e-4 * abs(ref_loss) and abs(loss_g - ref_loss) < 2e-4 * abs(ref_loss)
+        got = weights.state_dict_from_blob(grad)
+        for k, _ in weights.STATE_DICT_KEYS:
+            scale = max(np.abs(ref_grads[k]).max(), 1e-12)
+            assert np.abs(np.asarray(got[k]).reshape(ref_grads[k].shape) - ref_grads[k]).max() < 2e-3 * scale, k
+        loss_tr = T.run_batch(model2, opt_dev, batch + (None,), 'train', 2)          # one Adam step on the device
+        assert abs(loss_tr - ref_loss) < 2e-4 * abs(ref_loss)
+        assert np.isfinite(model2.engine.get_weights()).all()
     finally:
         from dyn_res_pile_manip_amd.engine import default_engine
         default_engine().close()

@@ -93,9 +93,13 @@ def test_free_running_rollout_in_a_chip_filling_batch(eng, golden):
         assert np.abs(big - np.tile(small, (reps, 1, 1, 1))).max() < 2e-6, case
 
 
+@pytest.mark.parametrize('tape', ['fused', 'mfma'])
 @pytest.mark.parametrize('case', ['n20_h1', 'n20_h2', 'n50_h1', 'n50_h2', 'n100_h1', 'n100_h2', 'n300_h1', 'n300_h2'])
-def test_gradients_match_the_reference(eng, golden, case, exact_goal_transform):
-    eng.set_engine(_lib.ENGINE_FUSED)
+def test_gradients_match_the_reference(eng, golden, case, tape, exact_goal_transform):
+    """Reverse mode through reward, predictor, three propagation steps, encoders and gen_s_delta against the reference's
+    autograd on the trained weights -- with the tape written by the fused engine (km_prop<., TAPE>) and by the fp32 matrix
+    engine (k_aggregate_tape: what the planner falls back to when the split-fp16 encoder refuses weights or inputs)."""
+    eng.set_engine(_lib.ENGINES[tape])
     g = golden.trained
     p = 'grad/' + case + '/'
     obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
@@ -112,6 +116,7 @@ def test_gradients_match_the_reference(eng, golden, case, exact_goal_transform):
         np.testing.assert_allclose(r, np.tile(g[p + 'reward'][:, 0], reps), rtol=2e-5)
         assert np.abs(ga - want).max() < 2e-3 * np.abs(ref_ga).max(), (reps, np.abs(ga - want).max(), np.abs(ref_ga).max())
         np.testing.assert_array_equal(np.abs(ga).sum((1, 2)) == 0, np.abs(want).sum((1, 2)) == 0)
+    eng.set_engine(_lib.ENGINE_FUSED)
 
 
 def _model(golden, w=None):
@@ -152,8 +157,9 @@ def test_the_gd_planner_on_trained_weights_matches_the_reference(golden, case, e
 def test_the_device_trainer_follows_the_reference_loss_curve(golden):
     """Row f4 beyond three iterations: `drp_train_step` started from the reference run's initial weights, fed the same
     240 batches (regenerated: synthetic.push_batch; checksums in the fixture), with the reference's optimiser settings.
-    The first iterations agree to rounding; later ones to what two fp32 Adam runs of a chaotic loss keep in common --
-    a windowed mean within 5 %, the whole curve's shape, and the end point's loss."""
+    The first iterations agree to rounding; later ones to what two fp32 Adam runs of this loss keep in common -- measured,
+    not assumed: the fixture carries the reference's OWN second run started one ulp away (`losses_twin`), and the device
+    run's deviation is held to a small multiple of that one's."""
     g = golden.train_curve
     lr, beta1, B, Tn = g['hyper']
 
@@ -171,16 +177,23 @@ def test_the_device_trainer_follows_the_reference_loss_curve(golden):
         s = float(batch[0].astype(np.float64).sum() + batch[1].astype(np.float64).sum() + batch[4].astype(np.float64).sum())
         assert s == g['batch_sums'][it], it
         losses[it] = T.run_batch(model, opt, batch + (None,), 'train', int(Tn))
-    ref = g['losses']
-    rel = np.abs(losses - ref) / ref
+    ref, twin = g['losses'], g['losses_twin']
     win = 20
-    wl = np.array([losses[i:i + win].mean() for i in range(0, n_it, win)])
-    wr = np.array([ref[i:i + win].mean() for i in range(0, n_it, win)])
-    print('\n[train curve] rel. deviation of the loss: first 10 max %.2e, iterations 10-50 max %.2e, all median %.2e max %.2e; '
-          'windowed means max %.2e; last window %.4e vs %.4e' % (rel[:10].max(), rel[10:50].max(), np.median(rel), rel.max(),
-                                                                 np.abs(wl / wr - 1).max(), wl[-1], wr[-1]))
+
+    def windows(x):
+        return np.array([x[i:i + win].mean() for i in range(0, n_it, win)])
+    rel, rel_twin = np.abs(losses / ref - 1), np.abs(twin / ref - 1)
+    wdev, wdev_twin = np.abs(windows(losses) / windows(ref) - 1), np.abs(windows(twin) / windows(ref) - 1)
+    print('\n[train curve] loss deviation from the reference run -- device: first 10 max %.2e, median %.2e, max %.2e, windowed '
+          'max %.2e | the reference started one ulp away: first 10 max %.2e, median %.2e, max %.2e, windowed max %.2e; last '
+          'window %.4e (device) %.4e (reference)' % (rel[:10].max(), np.median(rel), rel.max(), wdev.max(), rel_twin[:10].max(),
+                                                     np.median(rel_twin), rel_twin.max(), wdev_twin.max(),
+                                                     windows(losses)[-1], windows(ref)[-1]))
+    # the first iterations agree to rounding; then the yardstick is what the reference does to itself: two fp32 runs of this
+    # loop one ulp apart drift by `rel_twin` -- the device run may drift by a small multiple of that, no more
     assert rel[:10].max() < 2e-3
-    assert np.abs(wl / wr - 1).max() < 0.05
+    assert np.median(rel) < 4 * np.median(rel_twin) + 1e-3
+    assert wdev.max() < 4 * wdev_twin.max() + 1e-2
     assert losses[-win:].mean() < 0.1 * losses[:5].mean()
     # the weights after the run: the same network up to that divergence -- its loss on a held-out batch equals the
     # reference's end point's (through the device, eval mode) within 5 %
@@ -196,4 +209,4 @@ def test_the_device_trainer_follows_the_reference_loss_curve(golden):
     ref_model.engine.train_begin(int(Tn), float(lr), float(beta1))
     theirs = ref_model.engine.train_step(*held, mode='eval')[0]
     print('[train curve] held-out loss: device-trained %.5e, reference-trained %.5e' % (mine, theirs))
-    assert abs(mine / theirs - 1) < 0.05
+    assert abs(mine / theirs - 1) < 4 * wdev_twin.max() + 1e-2
