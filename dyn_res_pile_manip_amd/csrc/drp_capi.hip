@@ -298,19 +298,30 @@ struct drp_ctx {
     // (2.5 KB per receiver).  The cached kernels differ from the recomputing ones in the last place of one sum, so WHICH of the
     // two serves a sample must not depend on how many samples travel with it (a 1 024-sample shard of an 8 192-sample job, a
     // rank's half of the planner's 1 500 rows: the sharded and the unsharded run must agree bit for bit): the choice is a function
-    // of the PILE SIZE alone -- cached up to ecache_max_n particles (DRP_ECACHE_MAX_N; DRP_ECACHE_MAX_MB=0: never) -- and the
-    // buffer stays small by construction instead: a cached launch gives a workgroup at most ec_rows_cap(N) rows, and a batch
-    // that needs more than one such launch is run as several, one after the other on the stream, over the same buffer
-    // (run_rollout, run_step_mfma; 256 workgroups x 9 tiles x 80 KB = 189 MB, inside the 256 MB of last-level cache).
+    // of the PILE SIZE alone (ec_shape; DRP_ECACHE_MAX_MB=0: never) -- and the buffer stays small by construction instead: a
+    // cached launch gives a workgroup at most ec_rows_cap(N) rows, and a batch that needs more than one such launch is run as
+    // several, one after the other on the stream, over the same buffer (run_rollout, run_step_mfma; 256 workgroups x 9 tiles
+    // x 80 KB = 189 MB, inside the 256 MB of last-level cache).
+    // Which pile sizes: measured with the blocks in place (tools/ab_env_shapes.sh, DRP_ECACHE_MAX_N=64 against 256, one box):
+    // 256 samples x 80 / 100 / 150 / 200 particles + 15 / + 31 / + 35 / + 19 %, 1 024 x 80 / 100 / 128 / 256 + 8 / + 7 / + 7 /
+    // + 3 %, but 1 024 x 150 - 12 % and x 200 - 5 %: one sample of 129 ... 224 particles leaves three to one of a workgroup's
+    // eight waves without a tile.  So: up to ecache_max_n = 128 particles (two samples of up to 128 fill the eight tiles), and
+    // ecache_full_n = 225 ... 256 (one sample, eight tiles).  The TAPE's launches (gradient-descent planner, trainer) write one
+    // history buffer over the whole batch and are not split: their cache covers the whole batch, which pays up to
+    // ecache_tape_max_n = 40 particles at the planner's 1 500 rows (50 particles: 0.398 ms per iteration recomputing, 0.42 cached).
     int ecache_max_mb = 192;
-    int ecache_max_n = 64;
+    int ecache_max_n = 128, ecache_full_n = 225, ecache_tape_max_n = 40;
     DevBuf ecache;
     // how many float4 a workgroup of `rows` receivers needs
     static size_t ecache_stride(long rows, bool pair) {
         const long tiles = pair ? (rows + 15) / 16 : (rows + 31) / 32;
         return (size_t)tiles * (pair ? 5 : DRP_K) * EC_UNITS;
     }
-    bool ec_shape(int N) const { return ecache_max_mb > 0 && N <= ecache_max_n; }
+    bool ec_shape(int N, bool tape = false) const {
+        if (ecache_max_mb <= 0) return false;
+        if (tape) return N <= ecache_tape_max_n;
+        return N <= ecache_max_n || (N >= ecache_full_n && N <= 256);
+    }
     // rows a workgroup of a cached launch may hold: nine tiles of 32 (up to 64 particles: the measured best at 1 024 x 64 is
     // four samples = eight tiles), eight -- one per wave, rows kept in registers -- above
     static long ec_rows_cap(int N) { return N <= 64 ? 288 : 256; }
@@ -845,7 +856,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             // cached or recomputing: by the pile size alone (drp_ctx::ec_shape).  A cached batch too large for one launch of
             // at most ec_rows_cap rows per workgroup goes out as several launches over consecutive blocks of samples, the same
             // cache buffer under each; the tape's launches (one history buffer over the whole batch) take a larger buffer instead
-            const bool ec = c->ec_shape(N);
+            const bool ec = c->ec_shape(N, tape);
             long chunk = B;
             if (ec && !tape) {
                 long unit = 1;
@@ -1483,7 +1494,8 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_COMM_INIT_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_init_timeout_s = v; }
     c->rev_global_only = getenv("DRP_REV_GLOBAL") != nullptr;
     if (const char* e = getenv("DRP_ECACHE_MAX_MB")) c->ecache_max_mb = std::max(0, atoi(e));
-    if (const char* e = getenv("DRP_ECACHE_MAX_N")) c->ecache_max_n = std::max(0, atoi(e));
+    if (const char* e = getenv("DRP_ECACHE_MAX_N")) { c->ecache_max_n = std::max(0, atoi(e)); c->ecache_full_n = 257; }
+    if (const char* e = getenv("DRP_ECACHE_TAPE_MAX_N")) c->ecache_tape_max_n = std::max(0, atoi(e));
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_q4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||

@@ -10,6 +10,12 @@
 #define DRP_PUSHER_W (0.8f / 24.0f)   // planners.py:228
 #define DRP_SOFT_SCALE 0.01f     // planners.py:251
 
+// The correctly rounded square root torch and numpy compute (IEEE sqrtf).  HIP's `__fsqrt_rn` is NOT that: without
+// OCML_BASIC_ROUNDED_OPERATIONS it is __ocml_native_sqrt_f32, the bare v_sqrt_f32 (1 ulp) -- enough to move a particle across
+// gen_s_delta's hard mask `u < len` (planners.py:248) or to break a near-tie of np.argmax in fps_np.  `__builtin_sqrtf` lowers
+// to the llvm.sqrt intrinsic, which the backend expands with its fix-up steps (no fast-math flags in this build).
+__device__ __forceinline__ float drp_sqrt_rn(float x) { return __builtin_sqrtf(x); }
+
 // camera constants, passed by value to kernels (planners.py:192-209,
 // env/flex_rewards.py:189-193)
 struct DrpCam {

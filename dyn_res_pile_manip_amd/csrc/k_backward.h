@@ -122,7 +122,7 @@ kb_reward(const float* __restrict__ state, size_t row_stride, int N, const float
             const float d2 = dx * dx + dy * dy;
             if (d2 < best) { best = d2; arg = n; }       // first minimum, as torch.min
         }
-        const float dist = __fsqrt_rn(best);
+        const float dist = drp_sqrt_rn(best);
         r2 += dist;
         // d |q - p| / d p = -(q - p) / dist
         atomicAdd(reinterpret_cast<unsigned long long*>(&gx[arg]), (unsigned long long)__float2ll_rn(-scale * (qx - px[arg]) / dist * FIX));

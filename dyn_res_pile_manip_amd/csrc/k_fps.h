@@ -32,7 +32,7 @@ k_fps(const float* __restrict__ pts, int n, int k, int init_idx, float* __restri
                 const float d = pts[(size_t)i * DIM + c] - lp[c];
                 sq = __fadd_rn(sq, __fmul_rn(d, d));
             }
-            float nd = __fsqrt_rn(sq);
+            float nd = drp_sqrt_rn(sq);
             if (it > 0) nd = fminf(dist[i], nd);
             dist[i] = nd;
             if (nd > best) { best = nd; arg = i; }          // ascending i: first maximum wins
@@ -74,57 +74,115 @@ k_fps(const float* __restrict__ pts, int n, int k, int init_idx, float* __restri
 // 4.6 us per iteration -- 27.6 ms for the 6 000 goal pixels of a 1 200-particle plan; this one has two barriers, eight waves
 // and about 500 instructions per wave and iteration.
 #define FPS_WIDE_THREADS 512
-#define FPS_REG_PT(DIM) ((DIM) == 2 ? 48 : 40)      // 512 threads, two waves per SIMD: 256 VGPRs each
+#define FPS_REG_PT(DIM) ((DIM) == 2 ? 48 : 32)      // 512 threads, two waves per SIMD: 256 VGPRs each (3-D: 40 points spill)
+// wave-wide max / min as a SCALAR: four DPP row rotations (an all-reduce over each row of 16 lanes), then one v_readlane per
+// row -- a dozen instructions, against six dependent ds_bpermute round trips of a __shfl_xor ladder (two ladders per
+// iteration were most of its 3 us)
+template <int R>
+__device__ __forceinline__ int fps_ror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + R, 0xf, 0xf, true); }
+__device__ __forceinline__ float fps_wave_max(float x) {
+    int v = __float_as_int(x);
+#define FPS_STEP(R) v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(fps_ror<R>(v))))
+    FPS_STEP(8); FPS_STEP(4); FPS_STEP(2); FPS_STEP(1);
+#undef FPS_STEP
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(v, 0)), __int_as_float(__builtin_amdgcn_readlane(v, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(v, 32)), __int_as_float(__builtin_amdgcn_readlane(v, 48))));
+}
+__device__ __forceinline__ int fps_wave_min(int v) {
+    v = min(v, fps_ror<8>(v)); v = min(v, fps_ror<4>(v)); v = min(v, fps_ror<2>(v)); v = min(v, fps_ror<1>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+typedef float fps_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fps_wave_min_f(float x) { return -fps_wave_max(-x); }
+// One CU's vector units and the latency of two block-wide reductions bound an iteration.  Two things keep it short:
+//  * the points are held as PAIRS -- (x_q, x_q+1), (y_q, y_q+1) -- so that differences, squares and the sum are packed fp32
+//    instructions (v_pk_add_f32 / v_pk_mul_f32: two IEEE results each, nothing fused);
+//  * a thread holds CONSECUTIVE points (goal pixels come in raster order: a wave's 64 x PT points are a band of the image) and a
+//    wave knows its bounding box: when the newly chosen point is at least as far from the box as the wave's largest d2, no d2
+//    of the wave can change (fp32 subtraction, squaring and addition are monotone, so the bound holds for the ROUNDED values:
+//    sq_point >= L >= max d2 gives min(d2, sq) = d2 bit for bit) and the wave skips its update -- after the first few hundred
+//    picks most waves skip most iterations.
 template <int DIM>
 __global__ void __launch_bounds__(FPS_WIDE_THREADS)
 k_fps_reg(const float* __restrict__ pts, int n, int k, int init_idx, int* __restrict__ chosen,
           float* __restrict__ max_dist_out) {
-    constexpr int PT = FPS_REG_PT(DIM), NW = FPS_WIDE_THREADS / 64;
+    constexpr int PT = FPS_REG_PT(DIM), NP = PT / 2, NW = FPS_WIDE_THREADS / 64;
+    static_assert(PT % 2 == 0, "points are held in pairs");
     __shared__ float s_m[NW];
     __shared__ int s_i[NW];
     __shared__ float s_c[NW][DIM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float p[PT][DIM], d2[PT];
+    const int per = (n + FPS_WIDE_THREADS - 1) / FPS_WIDE_THREADS;         // consecutive points per thread (<= PT: the host's promise)
+    const int base = tid * per;
+    fps_v2 p[NP][DIM], d2[NP];            // pair h = slots 2h, 2h + 1; slot q is point base + q
+    float lo[DIM], hi[DIM];
 #pragma unroll
-    for (int q = 0; q < PT; ++q) {
-        const int i = tid + q * FPS_WIDE_THREADS;     // ascending in q: a thread's first candidate is its smallest index
+    for (int c = 0; c < DIM; ++c) { lo[c] = __builtin_inff(); hi[c] = -__builtin_inff(); }
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) p[q][c] = i < n ? pts[(size_t)i * DIM + c] : 0.0f;
-        d2[q] = i < n ? __builtin_inff() : -1.0f;     // beyond the set: below every real distance, for ever
+    for (int h = 0; h < NP; ++h) {
+        const int i0 = base + 2 * h, i1 = i0 + 1;
+        const bool v0 = 2 * h < per && i0 < n, v1 = 2 * h + 1 < per && i1 < n;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            p[h][c].x = v0 ? pts[(size_t)i0 * DIM + c] : 0.0f;
+            p[h][c].y = v1 ? pts[(size_t)i1 * DIM + c] : 0.0f;
+            if (v0) { lo[c] = fminf(lo[c], p[h][c].x); hi[c] = fmaxf(hi[c], p[h][c].x); }
+            if (v1) { lo[c] = fminf(lo[c], p[h][c].y); hi[c] = fmaxf(hi[c], p[h][c].y); }
+        }
+        d2[h].x = v0 ? __builtin_inff() : -1.0f;      // beyond the set: below every real distance, for ever
+        d2[h].y = v1 ? __builtin_inff() : -1.0f;
     }
+    // the wave's bounding box, as scalars (an empty wave: lo = +inf, hi = -inf -- infinitely far from everything)
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) { lo[c] = fps_wave_min_f(lo[c]); hi[c] = fps_wave_max(hi[c]); }
     float lp[DIM];
 #pragma unroll
     for (int c = 0; c < DIM; ++c) lp[c] = pts[(size_t)init_idx * DIM + c];
     if (tid == 0) chosen[0] = init_idx;
+    float m = -2.0f, wm = __builtin_inff();           // the thread's and the wave's largest d2
     for (int it = 0; it < k; ++it) {
-        // ---- distances to the last chosen point, the thread's largest
-        float m = -2.0f;
+        // ---- can any d2 of this wave change?  L = the rounded squared distance of the chosen point to the wave's box
+        float L = 0.0f;
 #pragma unroll
-        for (int q = 0; q < PT; ++q) {
-            float sq = 0.0f;
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) {
-                const float d = p[q][c] - lp[c];
-                sq = __fadd_rn(sq, __fmul_rn(d, d));
-            }
-            const float nd = fminf(d2[q], sq);
-            d2[q] = nd;
-            m = fmaxf(m, nd);
+        for (int c = 0; c < DIM; ++c) {
+            const float d = lp[c] < lo[c] ? lo[c] - lp[c] : (lp[c] > hi[c] ? hi[c] - lp[c] : 0.0f);
+            L = c == 0 ? d * d : L + d * d;
         }
-        float wm = m;
+        if (it == 0 || !(L >= wm)) {                  // (the first pass sets every d2, an empty wave's largest to -1)
+            // ---- squared distances to the chosen point (np.linalg.norm's sum of squares, left to right), the thread's largest
+            m = -2.0f;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+            for (int h = 0; h < NP; ++h) {
+                fps_v2 sq;
+                {
+                    const fps_v2 d = p[h][0] - fps_v2{lp[0], lp[0]};
+                    sq = d * d;
+                }
+#pragma unroll
+                for (int c = 1; c < DIM; ++c) {
+                    const fps_v2 d = p[h][c] - fps_v2{lp[c], lp[c]};
+                    sq = sq + d * d;
+                }
+                fps_v2 nd;
+                nd.x = fminf(d2[h].x, sq.x);
+                nd.y = fminf(d2[h].y, sq.y);
+                d2[h] = nd;
+                m = fmaxf(fmaxf(m, nd.x), nd.y);
+            }
+            wm = fps_wave_max(m);
+        }
         if (lane == 0) s_m[wave] = wm;
         __syncthreads();
         float M2 = s_m[0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) M2 = fmaxf(M2, s_m[w]);
-        const float S = __fsqrt_rn(M2);
+        const float S = drp_sqrt_rn(M2);
         // the smallest float whose square root rounds to S
         float T = M2;
         for (int step = 0; step < 8 && T > 0.0f; ++step) {
             const float below = __uint_as_float(__float_as_uint(T) - 1u);
-            if (__fsqrt_rn(below) != S) break;
+            if (drp_sqrt_rn(below) != S) break;
             T = below;
         }
         // ---- the smallest index at that distance, with its coordinates
@@ -132,31 +190,31 @@ k_fps_reg(const float* __restrict__ pts, int n, int k, int init_idx, int* __rest
         float ac[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) ac[c] = 0.0f;
-        if (m >= T) {
+        if (wm >= T) {
+            if (m >= T) {
 #pragma unroll
-            for (int q = PT - 1; q >= 0; --q)
-                if (d2[q] >= T) {
-                    arg = tid + q * FPS_WIDE_THREADS;
+                for (int h = NP - 1; h >= 0; --h) {
+                    if (d2[h].y >= T) {
+                        arg = base + 2 * h + 1;
 #pragma unroll
-                    for (int c = 0; c < DIM; ++c) ac[c] = p[q][c];
+                        for (int c = 0; c < DIM; ++c) ac[c] = p[h][c].y;
+                    }
+                    if (d2[h].x >= T) {
+                        arg = base + 2 * h;
+#pragma unroll
+                        for (int c = 0; c < DIM; ++c) ac[c] = p[h][c].x;
+                    }
                 }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const int oi = __shfl_xor(arg, off, 64);
-            float oc[DIM];
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) oc[c] = __shfl_xor(ac[c], off, 64);
-            if (oi < arg) {
-                arg = oi;
-#pragma unroll
-                for (int c = 0; c < DIM; ++c) ac[c] = oc[c];
             }
-        }
-        if (lane == 0) {
-            s_i[wave] = arg;
+            // the wave's smallest candidate as a scalar; its owner (one lane: indices are unique) publishes it with its coordinates
+            const int wmin = fps_wave_min(arg);
+            if (arg == wmin) {
+                s_i[wave] = wmin;
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) s_c[wave][c] = ac[c];
+                for (int c = 0; c < DIM; ++c) s_c[wave][c] = ac[c];
+            }
+        } else if (lane == 0) {
+            s_i[wave] = 0x7fffffff;
         }
         __syncthreads();
         int best = s_i[0], bw = 0;

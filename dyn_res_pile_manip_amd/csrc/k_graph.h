@@ -36,7 +36,7 @@ __device__ __forceinline__ PushFrame push_frame(const DrpCam& c, const float* ac
     cam_point(c, act[0], 0.0f, -act[1], f.sx, f.sy, f.sz);
     cam_point(c, act[2], 0.0f, -act[3], f.ex, f.ey, f.ez);
     float vx = f.ex - f.sx, vy = f.ey - f.sy, vz = f.ez - f.sz;
-    f.len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)));
+    f.len = drp_sqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)));
     // zero-length push: 0/0 = NaN, exactly as the reference (planners.py:240)
     f.dx = __fdiv_rn(vx, f.len);
     f.dy = __fdiv_rn(vy, f.len);

@@ -75,7 +75,7 @@ k_reward(const float* __restrict__ state, size_t row_stride, int N, const float*
             const float dx = gx - px[n], dy = gy - py[n];
             best = fminf(best, __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
         }
-        r2 += __fsqrt_rn(best);       // min of sqrt == sqrt of min (sqrt is monotone)
+        r2 += drp_sqrt_rn(best);       // min of sqrt == sqrt of min (sqrt is monotone)
     }
     const float t1 = block_sum_256(r1, red);
     const float t2 = block_sum_256(r2, red);

