@@ -1,5 +1,6 @@
 // C ABI of the engine (include/drp.h): context, device workspaces, kernel pipelines.
-// Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -c (this file and csrc/inst_*.hip, in parallel), then -shared
+// (__graft_entry__.build)
 #include "../../include/drp.h"
 
 #include <hip/hip_runtime.h>
@@ -39,6 +40,7 @@
 #include "k_mlp_split.h"
 #include "k_backward_mfma.h"
 #include "k_rollout.h"
+#include "k_prop_inst.h"       // km_prop / km_prop3 / km_rollout: declared here, instantiated in inst_*.hip
 
 namespace {
 

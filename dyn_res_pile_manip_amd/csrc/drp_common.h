@@ -10,6 +10,14 @@
 #define DRP_PUSHER_W (0.8f / 24.0f)   // planners.py:228
 #define DRP_SOFT_SCALE 0.01f     // planners.py:251
 
+// Non-template kernels are DEFINED in these headers.  The translation units that only hold explicit instantiations of the
+// propagation kernels (inst_*.hip, k_prop_inst.h) include the same headers: there they get internal linkage (and are dropped).
+#ifdef DRP_PROP_INSTANTIATE
+#define DRP_GLOBAL static __global__
+#else
+#define DRP_GLOBAL __global__
+#endif
+
 // The correctly rounded square root torch and numpy compute (IEEE sqrtf).  HIP's `__fsqrt_rn` is NOT that: without
 // OCML_BASIC_ROUNDED_OPERATIONS it is __ocml_native_sqrt_f32, the bare v_sqrt_f32 (1 ulp) -- enough to move a particle across
 // gen_s_delta's hard mask `u < len` (planners.py:248) or to break a near-tie of np.argmax in fps_np.  `__builtin_sqrtf` lowers

@@ -1,0 +1,4 @@
+// Explicit instantiations (k_prop_inst.h): this translation unit holds the device code of these kernels; csrc/drp_capi.hip launches them.
+#define DRP_PROP_INSTANTIATE
+#include "k_prop_inst.h"
+KM_PROP_LIST_TAPE(KM_INST_PROP, false) KM_PROP_LIST_TAPE(KM_INST_PROP, true)

@@ -61,7 +61,7 @@ __device__ __forceinline__ void push_delta(const PushFrame& f, float px, float p
 }
 
 // s_delta only (drp_gen_s_delta): grid B, any block size
-__global__ void k_sdelta(const float* __restrict__ s_cur, const float* __restrict__ action, int N,
+DRP_GLOBAL void k_sdelta(const float* __restrict__ s_cur, const float* __restrict__ action, int N,
                          float* __restrict__ s_delta, DrpCam cam) {
     const int b = blockIdx.x;
     const PushFrame f = push_frame(cam, action + (size_t)b * 4);
@@ -290,7 +290,7 @@ __device__ __forceinline__ void graph_sample(const float* __restrict__ s_prev, i
                                      rev + (size_t)b * N * DRP_K, 1, N, reinterpret_cast<int*>(lds));
     }
 }
-__global__ void __launch_bounds__(GRAPH_THREADS)
+DRP_GLOBAL void __launch_bounds__(GRAPH_THREADS)
 k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
         const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
         int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks,
@@ -299,7 +299,7 @@ k_graph(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
                         self_first, nullptr, nullptr);
 }
 // dynamic LDS: 12 * N ints (>= the 4 * N floats of the positions)
-__global__ void __launch_bounds__(GRAPH_THREADS)
+DRP_GLOBAL void __launch_bounds__(GRAPH_THREADS)
 k_graph_rev(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
             const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
             int16_t* nbr_idx, uint8_t* nbr_cnt, DrpCam cam, float thr, int n_items /* B: one chunk per sample */, int self_first,
@@ -323,7 +323,7 @@ k_graph_rev(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
 // The same lists as k_graph for every input, coincident particles and lattices included (tests/test_gpu_graph_strips.py).
 #define GRAPH_Q4_THREADS 512
 #define GRAPH_Q4_LDS(N) ((size_t)4 * ((N) + 3) * sizeof(float) + (size_t)128 * 4 * 10 * sizeof(float) + (size_t)128 * 4 * 22 * sizeof(int16_t))
-__global__ void __launch_bounds__(GRAPH_Q4_THREADS)
+DRP_GLOBAL void __launch_bounds__(GRAPH_Q4_THREADS)
 k_graph_q4(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
            const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
            int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks, int self_first) {
@@ -477,7 +477,7 @@ __device__ __forceinline__ void sort2(int& a, int& b) {
 
 // sorted[b][Np] = (x, y, z, index) in strip order (Np = N rounded up to 4, the padding 1e18 away),
 // starts[b][GRAPH_STRIPS + 1] = first slot of every strip; also writes s_delta when the push is given.
-__global__ void __launch_bounds__(GRAPH_SORT_THREADS)
+DRP_GLOBAL void __launch_bounds__(GRAPH_SORT_THREADS)
 k_graph_sort(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
              const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
              DrpCam cam, float4* __restrict__ sorted, int* __restrict__ starts) {
@@ -745,7 +745,7 @@ __device__ __forceinline__ int graph_band(float y, float inv_hb, int gy) {
 }
 
 // sorted[b][Np] = (x, y, z, index) in cell order (band-major, strip-minor), starts[b][gy * 64 + 1]
-__global__ void __launch_bounds__(GRAPH_SORT_THREADS)
+DRP_GLOBAL void __launch_bounds__(GRAPH_SORT_THREADS)
 k_graph_sort2(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
               const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
               DrpCam cam, int gy, float inv_hb, float4* __restrict__ sorted, int* __restrict__ starts) {
@@ -871,7 +871,7 @@ __device__ unsigned long long gc_stats[16];
 #define GC_STAT(k, v)
 #define GC_STATQ(k, v)
 #endif
-__global__ void __launch_bounds__(GC_THREADS)
+DRP_GLOBAL void __launch_bounds__(GC_THREADS)
 k_graph_cells(const float4* __restrict__ sorted, const int* __restrict__ starts, int N, int gy, float inv_hb,
                int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, float thr, int chunks, int n_items /* B * chunks */,
                int self_first, float halo_first) {
@@ -1099,7 +1099,7 @@ k_graph_cells(const float4* __restrict__ sorted, const int* __restrict__ starts,
 // ---- mean in-degree of a batch's lists, for the host's choice between paired and unpaired tiles (prop_pair, drp_capi.hip)
 // one workgroup; out (host memory the device can write) = sum | rows << 24 | N << 48 in ONE 64-bit store
 #define DEG_STAT_MAX_ROWS 65536
-__global__ void __launch_bounds__(1024)
+DRP_GLOBAL void __launch_bounds__(1024)
 k_deg_stat(const uint8_t* __restrict__ nbr_cnt, int rows, int N, unsigned long long* __restrict__ out) {
     __shared__ int part[16];
     int s = 0;

@@ -312,7 +312,7 @@ __device__ __forceinline__ void frag_bias_dens(const float* b_row, const float* 
 //      :186-187):  c_edge[slot] = W_e relu(L3 relu(L2 relu(L1 x))) + w_d d + b
 // items = edge slots (receiver i, k) in [b][i][k] order, 32 consecutive slots per tile.
 // grid-stride over all B * ceil(10N/32) tiles, 8 waves per workgroup.
-__global__ void __launch_bounds__(64 * MFMA_WAVES)
+DRP_GLOBAL void __launch_bounds__(64 * MFMA_WAVES)
 km_edge_encode(const float* __restrict__ mw, const float* __restrict__ s_cur, int s_mod, size_t s_stride,
                const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
                const int16_t* __restrict__ nbr_idx, const uint8_t* __restrict__ nbr_cnt, int N, int B,
@@ -376,7 +376,7 @@ km_edge_encode(const float* __restrict__ mw, const float* __restrict__ s_cur, in
 //   pe = relu(L2 relu(L1 [s_delta, a, d]))   eff0 = pe                 gnn_dyn.py:174-176
 //   c_node = W_pe pe + w_d d + b             (constant part of :191-193)
 //   proj = [W_r pe | W_s pe]                 (first propagation step's node terms)
-__global__ void __launch_bounds__(64 * MFMA_WAVES)
+DRP_GLOBAL void __launch_bounds__(64 * MFMA_WAVES)
 km_node_encode(const float* __restrict__ mw, const float* __restrict__ s_delta,
                const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
                int N, int B, float* __restrict__ eff, float* __restrict__ c_node, float* __restrict__ proj) {

@@ -306,7 +306,7 @@ __device__ __forceinline__ void edge_chain_split(const f16x8* __restrict__ wsp /
 }
 
 // same contract as km_edge_encode (k_mlp_mfma.h)
-__global__ void __launch_bounds__(64 * MFMA_WAVES)
+DRP_GLOBAL void __launch_bounds__(64 * MFMA_WAVES)
 km_edge_encode_split(const uint16_t* __restrict__ sw, const float* __restrict__ mw,
                      const float* __restrict__ s_cur, int s_mod, size_t s_stride,
                      const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
@@ -487,7 +487,7 @@ __device__ __forceinline__ void mfma_layer8_split6(const bf16x8* __restrict__ wp
 // evaluates it once per rollout in plain fp32 (lane = feature) and flags the samples where it
 // holds; km_prop then starts a receiver's aggregate from relu(c_self + bias + P_r + P_s[i])
 // and skips the self slot: one relation-encoder chain in ten never runs.
-__global__ void __launch_bounds__(64)
+DRP_GLOBAL void __launch_bounds__(64)
 k_cself(const float* __restrict__ vw, const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens,
         int dens_mod, int N, float* __restrict__ cself, uint8_t* __restrict__ ok) {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -1586,7 +1586,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
 // ---- particle encoder, node constant and first projections on the 6-term split --------------
 // Same contract as km_node_encode (k_mlp_mfma.h); outputs go straight from the accumulator
 // layout to their rows (no LDS transposition tiles: LDS holds the 126 KB of packed weights).
-__global__ void __launch_bounds__(64 * MFMA_WAVES)
+DRP_GLOBAL void __launch_bounds__(64 * MFMA_WAVES)
 km_node_encode_split(const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
                      const float* __restrict__ s_delta, const float* __restrict__ attr, int attr_mod,
                      const float* __restrict__ dens, int dens_mod, int N, int B,
