@@ -199,6 +199,52 @@ def test_device_fps_equals_fps_np(stack):
     assert ms < 16.0                      # measured 11.8 ms (1.96 us per pick on ONE workgroup, the chip otherwise idle); round 4: 27.6
 
 
+def test_a_named_goal_is_installed_once_and_gives_the_same_plan(stack, golden):
+    """goal_key (not in the reference): env/flex_env.py:1048 hands the planner the SAME subgoal image on each of its 20 MPC
+    steps; with the caller's name for it the installed field and goal pixels are re-used without copying or hashing the
+    2 MB image, a new name installs again, and the plan is the one the content digest gives."""
+    config, env, model, _ = stack
+    config = dict(config)
+    config['mpc'] = dict(config['mpc'], mpc_type='GD')
+    g = golden.gd_planner
+    goal_i = syn.goal_distance_image(syn.goal_mask('I'))
+    goal_d = syn.goal_distance_image(syn.goal_mask('disc'))
+    lo, hi = syn.action_limits()
+
+    def call(planner, goal, **kw):
+        return planner.trajectory_optimization_ptcl_multi_traj(
+            g['s_cur'], g['dens'], g['attr'], goal, model, g['act_seq'], np.zeros(1), n_sample=10, n_look_ahead=1,
+            n_update_iter=3, action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=1e9, **kw)
+    ref_i, ref_d = call(PlannerGD(config, env), goal_i), call(PlannerGD(config, env), goal_d)
+    assert not np.array_equal(ref_i['action_full'], ref_d['action_full'])
+    planner = PlannerGD(config, env)
+    first = call(planner, goal_i, goal_key='I')
+    assert first['times']['goal_cached'] is False
+    again = call(planner, goal_i, goal_key='I')
+    assert again['times']['goal_cached'] is True and again['times']['goal_time'] < 2e-4
+    other = call(planner, goal_d, goal_key='disc')                  # a new name: installed again
+    assert other['times']['goal_cached'] is False
+    for got, want in ((first, ref_i), (again, ref_i), (other, ref_d)):
+        np.testing.assert_array_equal(got['action_full'], want['action_full'])
+        np.testing.assert_array_equal(got['reward_full'], want['reward_full'])
+    # the name is trusted: the same name with another image keeps the installed goal (the caller's contract)
+    stale = call(planner, goal_i, goal_key='disc')
+    np.testing.assert_array_equal(stale['action_full'], ref_d['action_full'])
+
+
+def test_a_model_without_weights_does_not_compute_with_anothers(stack, golden):
+    """Models share the process's context (engine.default_engine): one that never loaded a state_dict must fail loudly, not
+    answer with whichever other model's weights are resident."""
+    config, _, model, _ = stack
+    g = golden.one_step
+    args = [g['n64/' + k] for k in ('attr', 's_cur', 's_delta', 'dens')]
+    model.predict_one_step(*args)                                   # the fixture's model owns the shared context now
+    empty = PropNetDiffDenModel(config, True, engine=model.engine)
+    with pytest.raises(RuntimeError, match='no weights'):
+        empty.predict_one_step(*args)
+    np.testing.assert_array_equal(model.predict_one_step(*args), model.predict_one_step(*args))
+
+
 def test_one_mpc_step_end_to_end(stack):
     """Observation -> particles -> planner -> push, chained as env/flex_env.py:1016-1065 chains them
     (tools/mpc_step_demo.py), every piece on the device."""
