@@ -1,0 +1,434 @@
+// capi_train.h -- a section of the C ABI's translation unit (textually included by drp_capi.hip, in this order: capi_ctx.h,
+// capi_pipeline.h, then inside extern "C": capi_core.h, capi_mpc.h, capi_prep.h, capi_gd.h, capi_train.h, capi_comm.h, capi_debug.h).
+// Here: training on the same kernels (row f4): forward with tape, reverse mode with weight gradients, Adam, re-packing.
+
+// ---- training on the same kernels (row f4) ------------------------------------------------------
+namespace {
+// forward over n_rollout steps (+ loss), optionally the backward pass with weight gradients
+int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
+    const int H = c->tr_nroll;
+    const size_t bn = (size_t)B * N, bn64 = bn * 64, bnk = bn * DRP_K;
+    const size_t hstride = (size_t)H * N * 3;                 // predicted states [B][H][N][3]
+    const size_t in_stride = (size_t)(H + 1) * N * 3;         // given states     [B][H+1][N][3]
+    hipStream_t st = c->stream;
+    const bool rev_lds = N <= KB_REV_LDS_MAX_N && !c->rev_global_only;
+    float* states = ptr<float>(c->states);
+    const float* given = ptr<float>(c->tr_states);
+    float* eh = ptr<float>(c->eff_hist);
+    unsigned* mh = ptr<unsigned>(c->tape_mask);
+    float* ah = ptr<float>(c->agg_hist);
+    float* g_state = ptr<float>(c->g_state);
+    double* loss = ptr<double>(c->tr_loss);
+    const float scale = 1.0f / (float)(H * B);
+    const int saved_engine = c->engine;
+    c->engine = c->tr_engine;
+    const float* cself = nullptr;
+    const uint8_t* cself_ok = nullptr;
+    int rc = prepare_cself(c, B, N, B, &cself, &cself_ok);
+    for (int t = 0; t < H && rc == DRP_OK; ++t) {
+        // with a backward pass to follow, the step's impulses and neighbour lists are part of the tape: its workspace
+        // pointers are lent the tape's slices for the call (as the GD planner does) instead of three copies afterwards
+        void* const save_sd = c->s_delta.p; void* const save_idx = c->nbr_idx.p; void* const save_cnt = c->nbr_cnt.p;
+        struct Lend {
+            drp_ctx* c; void* sd; void* idx; void* cnt;
+            ~Lend() { c->s_delta.p = sd; c->nbr_idx.p = idx; c->nbr_cnt.p = cnt; }
+        } lend{c, save_sd, save_idx, save_cnt};
+        if (backward) {
+            c->s_delta.p = ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3;
+            c->nbr_idx.p = ptr<int16_t>(c->tape_idx) + (size_t)t * bnk;
+            c->nbr_cnt.p = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
+        }
+        // this step's impulses are data (train/train_gnn_dyn.py:181)
+        hipError_t e = hipMemcpy2DAsync(c->s_delta.p, (size_t)N * 3 * sizeof(float),
+                                        ptr<float>(c->tr_sdelta) + (size_t)t * N * 3, hstride * sizeof(float),
+                                        (size_t)N * 3 * sizeof(float), B, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { rc = fail(c, DRP_EHIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e)); break; }
+        StepArgs a{};
+        if (t == 0) { a.s_prev = given; a.prev_mod = B; a.prev_stride = in_stride; }
+        else { a.s_prev = states + (size_t)(t - 1) * N * 3; a.prev_mod = B; a.prev_stride = hstride; }
+        a.attr = ptr<float>(c->attr); a.attr_mod = B;
+        a.dens = ptr<float>(c->dens); a.dens_mod = B;
+        a.actions = nullptr; a.act_stride = 0;
+        a.build_graph = true;
+        a.s_out = states + (size_t)t * N * 3; a.out_stride = hstride;
+        a.B = B; a.N = N;
+        a.cself = cself; a.cself_ok = cself_ok;
+        a.padded = true;                // collate_fn pads with zero rows: coincident particles
+        if (backward) {
+            a.eff_hist = eh + (size_t)t * 4 * bn64;
+            a.mask_hist = mh + (size_t)t * DRP_PSTEP * bnk * 2;
+            a.agg_hist = ah + (size_t)t * 3 * bn64;
+        }
+        rc = run_step(c, a);
+        if (rc != DRP_OK) break;
+        // loss of this step and d loss / d s_pred_t (train/train_gnn_dyn.py:184-186, :203)
+        hipLaunchKernelGGL(kt_mse_grad, dim3(B), dim3(256), 0, st, states + (size_t)t * N * 3, hstride,
+                           given + (size_t)(t + 1) * N * 3, in_stride, ptr<int>(c->tr_nums), N, scale,
+                           g_state + (size_t)t * bn * 3, loss + (size_t)t * B);
+    }
+    c->engine = saved_engine;
+    CHK(rc);
+    HIPCHK(c, hipGetLastError());
+    if (!backward) return DRP_OK;
+
+    const float* vw = ptr<float>(c->w_valu);
+    const float* wraw = ptr<float>(c->w_raw);
+    float* G = ptr<float>(c->tr_grad);
+    // a training batch is a handful of samples: split each sample's rows over workgroups
+    // (row kernels: one receiver per wave and pass; edge kernels: one receiver per 16 lanes)
+    auto pick = [&](int rows_per_block) {
+        int ch = (N + rows_per_block - 1) / rows_per_block;
+        if (ch > 4096 / B) ch = 4096 / B;
+        return ch < 1 ? 1 : ch;
+    };
+    const int chunks = pick(4), chunks16 = pick(16);
+    const dim3 rgrid((unsigned)(B * chunks)), egrid((unsigned)(B * chunks16));
+    const float* dens = ptr<float>(c->dens);
+    HIPCHK(c, hipMemsetAsync(G, 0, (size_t)W_TOTAL * sizeof(float), st));
+    // the reversed lists of ALL rollout steps in one launch (the tape holds every step's lists; a training batch is a handful
+    // of workgroups per step)
+    c->dv(N <= 512 ? DV_REV_256 : DV_REV_1024);
+    if (N <= 512)
+        hipLaunchKernelGGL(kb_reverse_lists<256>, dim3(B * H), dim3(256), KB_REV_LDS(N, rev_lds), st, ptr<int16_t>(c->tape_idx),
+                           ptr<uint8_t>(c->tape_cnt), N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums), B);
+    else
+        hipLaunchKernelGGL(kb_reverse_lists<1024>, dim3(B * H), dim3(1024), KB_REV_LDS(N, rev_lds), st, ptr<int16_t>(c->tape_idx),
+                           ptr<uint8_t>(c->tape_cnt), N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums), B);
+    // deferred weight gradients: what a job reads keeps a buffer per rollout step t (g_eff and g_proj: per propagation step
+    // too; slot 0 of g_eff is the transient copy the predictor writes and the particle encoder reads)
+    const bool defer = c->wg_defer_now;
+    const size_t per_t = defer ? 1 : 0;
+    for (int t = H - 1; t >= 0; --t) {
+        const size_t tt = per_t * (size_t)t;
+        float* const ge_tmp = ptr<float>(c->g_eff);
+        auto ge_v = [&](int v) { return ptr<float>(c->g_eff) + per_t * ((size_t)(t * 3 + v) + 1) * bn64; };   // v = 0, 1, 2: steps 2, 1, 0
+        auto gp_v = [&](int p) { return ptr<float>(c->g_proj) + per_t * (size_t)(t * 3 + p) * bn64 * 2; };
+        float* const g_cnode_t = ptr<float>(c->g_cnode) + tt * bn64;
+        float* const tr_hact_t = ptr<float>(c->tr_hact) + tt * bn64;
+        float* const tr_gh_t = ptr<float>(c->tr_gh) + tt * bn64;
+        float* const tr_gpe_t = ptr<float>(c->tr_gpe) + tt * bn64;
+        float* const tr_a1n_t = ptr<float>(c->tr_a1n) + tt * bn64;
+        float* const tr_gh1_t = ptr<float>(c->tr_gh1) + tt * bn64;
+        float* const tr_xn_t = ptr<float>(c->tr_xn) + tt * bn * 8;
+        KbEdgeDump ed{ptr<float>(c->ed_re) + tt * bnk * 64, ptr<float>(c->ed_a2) + tt * bnk * 64, ptr<float>(c->ed_a1) + tt * bnk * 64,
+                      ptr<float>(c->ed_x0) + tt * bnk * 8, ptr<float>(c->ed_gce) + tt * bnk * 64, ptr<float>(c->ed_g3) + tt * bnk * 64,
+                      ptr<float>(c->ed_g2) + tt * bnk * 64, ptr<float>(c->ed_g1) + tt * bnk * 64};
+        const float* s_prev = (t == 0) ? given : states + (size_t)(t - 1) * N * 3;
+        const size_t prev_stride = (t == 0) ? in_stride : hstride;
+        float* eht = eh + (size_t)t * 4 * bn64;
+        const unsigned* mht = mh + (size_t)t * DRP_PSTEP * bnk * 2;
+        float* aht = ah + (size_t)t * 3 * bn64;
+        const int16_t* idx = ptr<int16_t>(c->tape_idx) + (size_t)t * bnk;
+        const uint8_t* cnt = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
+        float* g_out = g_state + (size_t)t * bn * 3;
+        float* gah = ptr<float>(c->g_agg_hist);
+        int* const rev_off_t = ptr<int>(c->rev_off) + (size_t)t * B * (N + 1);
+        int* const rev_t = ptr<int>(c->rev) + (size_t)t * bnk;
+        // node-level stages: on the matrix cores when the batch has enough 32-row tiles to fill the chip,
+        // otherwise the row kernels chunked over (sample, rows)
+        if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES && !c->bwd_valu_stages) {
+            const float* mw = ptr<float>(c->w_mfma);
+            const float* mb = ptr<float>(c->w_mfma_bwd);
+            const long node_tiles = (long)B * ((N + 31) / 32);
+            const dim3 ngrid(mfma_grid_spread(c, node_tiles)), nblk(64 * MFMA_WAVES);
+            c->dv(DV_TRAIN_NODE_MFMA);
+            // predictor
+            hipLaunchKernelGGL(kmb_predict, ngrid, nblk, KMB_PREDICT_LDS, st, mw, mb, eht + 3 * bn64, g_out, (size_t)N * 3, N, B,
+                               ge_tmp, tr_hact_t, tr_gh_t);
+            launch_wgrad<64>(c, tr_gh_t, 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
+                             nullptr, 1, 1);
+            launch_wgrad<3>(c, tr_hact_t, 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
+            hipLaunchKernelGGL(kt_colsum3, dim3(1), dim3(1024), 0, st, g_out, (long)bn, G + W_PR1_B);
+            // update of the last propagation step; then per step the edge terms and, in one launch, the
+            // projection of this step with the update of the one before (k_backward_mfma.h)
+            hipLaunchKernelGGL((kmb_node_step<false, true>), ngrid, nblk, KMB_STEP_LDS(false, true), st, mb, ge_tmp, ge_v(0),
+                               (const float*)nullptr, eht + (size_t)DRP_PSTEP * bn64, g_cnode_t, 1,
+                               gah + (size_t)(DRP_PSTEP - 1) * bn64, N, B);
+            for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+                float* g_agg_p = gah + (size_t)p * bn64;
+                const unsigned* mask_p = mht + (size_t)p * bnk * 2;
+                float* const ge_p = ge_v(DRP_PSTEP - 1 - p);     // the pre-activation gradient of step p
+                float* const gp_p = gp_v(p);
+                // particle propagator, aggregate columns
+                launch_wgrad<64>(c, ge_p, 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
+                                 nullptr, nullptr, nullptr, 1, 1);
+                hipLaunchKernelGGL(kb_edge_terms, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, rev_off_t,
+                                   rev_t, N, gp_p, chunks16);
+                // relation propagator, receiver and sender columns
+                launch_wgrad<64>(c, gp_p, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
+                                 nullptr, nullptr, nullptr, 1, 1);
+                launch_wgrad<64>(c, gp_p + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
+                                 1, nullptr, nullptr, nullptr, 1, 1);
+                flush_wgrad(c);                          // (not deferred:) before the next kernel overwrites g_eff (and, next step, g_proj)
+                if (p > 0)
+                    hipLaunchKernelGGL((kmb_node_step<true, true>), ngrid, nblk, KMB_STEP_LDS(true, true), st, mb,
+                                       ge_p, ge_v(DRP_PSTEP - p), gp_p, eht + (size_t)p * bn64,
+                                       g_cnode_t, 0, gah + (size_t)(p - 1) * bn64, N, B);
+                else
+                    hipLaunchKernelGGL((kmb_node_step<true, false>), ngrid, nblk, KMB_STEP_LDS(true, false), st, mb,
+                                       ge_p, ge_tmp, gp_p, (const float*)nullptr, (float*)nullptr, 0,
+                                       (float*)nullptr, N, B);
+            }
+            // particle propagator, encoder columns + density column + bias; particle encoder
+            launch_wgrad<64>(c, g_cnode_t, 64, eht, 64, (long)bn, G + W_PP_W, 129, 1, G + W_PP_B, G + W_PP_W + 128,
+                             dens, B, (long)N);
+            hipLaunchKernelGGL(kmb_node_encode, ngrid, nblk, KMB_NODE_ENCODE_LDS, st, mw, mb,
+                               ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), B, dens, B, eht,
+                               ge_tmp, g_cnode_t, N, B, ptr<float>(c->g_sdelta), tr_gpe_t,
+                               tr_a1n_t, tr_gh1_t, tr_xn_t);
+            launch_wgrad<64>(c, tr_gpe_t, 64, tr_a1n_t, 64, (long)bn, G + W_PE2_W, 64, 1, G + W_PE2_B,
+                             nullptr, nullptr, 1, 1);
+            launch_wgrad<5>(c, tr_gh1_t, 64, tr_xn_t, 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
+                            nullptr, nullptr, 1, 1);
+            flush_wgrad(c);
+        } else {
+            c->dv(DV_TRAIN_NODE_VALU);
+            // predictor
+            hipLaunchKernelGGL(kb_predict, rgrid, dim3(256), 0, st, vw, wraw, eht + 3 * bn64, g_out, (size_t)N * 3, N,
+                               ptr<float>(c->g_eff), ptr<float>(c->tr_hact), ptr<float>(c->tr_gh), chunks);
+            launch_wgrad<64>(c, ptr<float>(c->tr_gh), 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
+                             nullptr, 1, 1);
+            launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
+            hipLaunchKernelGGL(kt_colsum3, dim3(1), dim3(1024), 0, st, g_out, (long)bn, G + W_PR1_B);
+            for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+                float* g_agg_p = gah + (size_t)p * bn64;
+                const unsigned* mask_p = mht + (size_t)p * bnk * 2;
+                hipLaunchKernelGGL(kb_update, rgrid, dim3(256), 0, st, wraw, eht + (size_t)(p + 1) * bn64,
+                                   ptr<float>(c->g_eff), ptr<float>(c->g_cnode), p == DRP_PSTEP - 1 ? 1 : 0, N, g_agg_p, chunks);
+                // particle propagator, aggregate columns: g_eff now holds the pre-activation gradient
+                launch_wgrad<64>(c, ptr<float>(c->g_eff), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
+                                 nullptr, nullptr, nullptr, 1, 1);
+                hipLaunchKernelGGL(kb_edge_terms, egrid, dim3(256), 0, st, g_agg_p, mask_p, cnt, rev_off_t,
+                                   rev_t, N, ptr<float>(c->g_proj), chunks16);
+                // relation propagator, receiver and sender columns
+                launch_wgrad<64>(c, ptr<float>(c->g_proj), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
+                                 nullptr, nullptr, nullptr, 1, 1);
+                launch_wgrad<64>(c, ptr<float>(c->g_proj) + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
+                                 1, nullptr, nullptr, nullptr, 1, 1);
+                flush_wgrad(c);                          // before kb_project overwrites g_eff
+                hipLaunchKernelGGL(kb_project, rgrid, dim3(256), 0, st, wraw, ptr<float>(c->g_proj), N, ptr<float>(c->g_eff), chunks);
+            }
+            // particle propagator, encoder columns + density column + bias; particle encoder
+            launch_wgrad<64>(c, ptr<float>(c->g_cnode), 64, eht, 64, (long)bn, G + W_PP_W, 129, 1, G + W_PP_B, G + W_PP_W + 128,
+                             dens, B, (long)N);
+            hipLaunchKernelGGL(kb_node_encode, rgrid, dim3(256), 0, st, vw, wraw,
+                               ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), B, dens, B, eht,
+                               ptr<float>(c->g_eff), ptr<float>(c->g_cnode), N, ptr<float>(c->g_sdelta), ptr<float>(c->tr_gpe),
+                               ptr<float>(c->tr_a1n), ptr<float>(c->tr_gh1), ptr<float>(c->tr_xn), chunks);
+            launch_wgrad<64>(c, ptr<float>(c->tr_gpe), 64, ptr<float>(c->tr_a1n), 64, (long)bn, G + W_PE2_W, 64, 1, G + W_PE2_B,
+                             nullptr, nullptr, 1, 1);
+            launch_wgrad<5>(c, ptr<float>(c->tr_gh1), 64, ptr<float>(c->tr_xn), 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
+                            nullptr, nullptr, 1, 1);
+            flush_wgrad(c);
+        }
+        // the previous step's output feeds this step as s_cur: residual + relation encoder
+        float* g_prev = nullptr;
+        if (t > 0) {
+            g_prev = g_state + (size_t)(t - 1) * bn * 3;
+            hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
+        }
+        c->dv(c->bwd_edge_mfma ? DV_BWD_EDGE_MFMA : DV_BWD_EDGE_VALU);
+        if (c->bwd_edge_mfma)
+            launch_edge_encode_mfma(c, s_prev, B, prev_stride, B, idx, cnt, gah, mht, bn, N, B,
+                                    g_prev != nullptr ? ptr<float>(c->gpos_edge) : (float*)nullptr, ed);
+        else
+            hipLaunchKernelGGL(kb_edge_encode, rgrid, dim3(256), KB_EDGE_ENCODE_LDS, st, vw, wraw, s_prev, B,
+                               prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, gah, mht, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), ed, chunks);
+        if (g_prev != nullptr)
+            hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
+                               rev_off_t, rev_t, N, g_prev, (size_t)N * 3, c->bwd_edge_mfma ? 1 : 0, cnt);
+        launch_wgrad<64>(c, ed.gce, 64, ed.re, 64, (long)bnk, G + W_RP_W, 193, 1, G + W_RP_B, G + W_RP_W + 192, dens, B,
+                         (long)N * DRP_K);
+        launch_wgrad<64>(c, ed.g3, 64, ed.a2, 64, (long)bnk, G + W_RE4_W, 64, 1, G + W_RE4_B, nullptr, nullptr, 1, 1);
+        launch_wgrad<64>(c, ed.g2, 64, ed.a1, 64, (long)bnk, G + W_RE2_W, 64, 1, G + W_RE2_B, nullptr, nullptr, 1, 1);
+        launch_wgrad<6>(c, ed.g1, 64, ed.x0, 8, (long)bnk, G + W_RE0_W, 6, 1, G + W_RE0_B, nullptr, nullptr, 1, 1);
+        flush_wgrad(c);                                  // the next rollout step rewrites the dumps these jobs read
+    }
+    flush_wgrad(c);
+    if (defer) CHK(flush_wgrad_all(c));
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+// The packed copies of the weights follow an optimiser step without a round trip of the packers through the host
+// (k_train.h): only the blob itself comes back -- the split relation encoder's range shift is a function of the
+// weights (set_split_range), and drp_get_weights serves the host copy.
+int ensure_repack_maps(drp_ctx* c) {
+    if (c->repack_maps_ready) return DRP_OK;
+    std::vector<float> probe((size_t)W_TOTAL);
+    for (int i = 0; i < (int)W_TOTAL; ++i) probe[i] = (float)(i + 1);          // exact in fp32 (38 403 < 2^24)
+    auto to_map = [](const std::vector<float>& packed) {
+        std::vector<int> m(packed.size());
+        for (size_t i = 0; i < packed.size(); ++i)
+            m[i] = packed[i] == 0.0f ? 0 : (packed[i] < 0.0f ? -1 : (int)packed[i]);
+        return m;
+    };
+    std::vector<float> v, m, mb;
+    pack_valu(probe.data(), v);
+    pack_mfma(probe.data(), m);
+    pack_mfma_bwd(probe.data(), mb);
+    const std::vector<int> mv = to_map(v), mm = to_map(m), mmb = to_map(mb);
+    CHK(h2d(c, c->map_valu, mv.data(), mv.size() * sizeof(int)));
+    CHK(h2d(c, c->map_mfma, mm.data(), mm.size() * sizeof(int)));
+    CHK(h2d(c, c->map_mfma_bwd, mmb.data(), mmb.size() * sizeof(int)));
+    CHK(guarded_wait(c, nullptr));                   // the vectors go out of scope
+    if (!c->w_pin) HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->w_pin), (size_t)W_TOTAL * sizeof(float), hipHostMallocDefault));
+    c->repack_maps_ready = true;
+    return DRP_OK;
+}
+
+int repack_on_device(drp_ctx* c) {
+    CHK(ensure_repack_maps(c));
+    hipStream_t st = c->stream;
+    const float* w = ptr<float>(c->w_raw);
+    hipLaunchKernelGGL(kt_repack_gather, dim3((V_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_valu), ptr<float>(c->w_valu), (int)V_TOTAL);
+    hipLaunchKernelGGL(kt_repack_gather, dim3((M_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_mfma), ptr<float>(c->w_mfma), (int)M_TOTAL);
+    hipLaunchKernelGGL(kt_repack_gather, dim3((MB_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_mfma_bwd), ptr<float>(c->w_mfma_bwd), (int)MB_TOTAL);
+    hipLaunchKernelGGL(kt_repack_split6, dim3(7 * 16), dim3(256), 0, st, w, ptr<uint16_t>(c->w_split6));
+    hipLaunchKernelGGL(kt_repack_split6_bwd, dim3(6 * 16), dim3(256), 0, st, w, ptr<uint16_t>(c->w_split6_bwd));
+    // the relation encoder's range shift depends on the new weights: fetch the blob (it is the host copy
+    // drp_get_weights serves anyway), derive the shift, then pack the split-fp16 fragments with it
+    HIPCHK(c, hipMemcpyAsync(c->w_pin, c->w_raw.p, (size_t)W_TOTAL * sizeof(float), hipMemcpyDeviceToHost, st));
+    CHK(guarded_wait(c, nullptr));
+    c->w_host.assign(c->w_pin, c->w_pin + W_TOTAL);
+    set_split_range(c, c->w_host.data());
+    hipLaunchKernelGGL(kt_repack_split, dim3(4 * 16), dim3(256), 0, st, w, c->re_range.shift, ptr<uint16_t>(c->w_split));
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+
+int install_weights(drp_ctx* c, const std::vector<float>& blob) {
+    std::vector<float> tmp(blob);
+    return drp_load_weights(c, tmp.data(), tmp.size(), c->adj_thresh);
+}
+}  // namespace
+
+int drp_train_begin(drp_ctx* c, int n_rollout, double lr, double beta1) {
+    CHK(need(c, true, false, false));
+    if (n_rollout < 1 || n_rollout > 64 || !(lr > 0.0) || !(beta1 >= 0.0 && beta1 < 1.0))
+        return fail(c, DRP_EINVAL, "bad training arguments n_rollout=%d lr=%g beta1=%g", n_rollout, lr, beta1);
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure(c, c->tr_grad, (size_t)W_TOTAL * sizeof(float)));
+    CHK(ensure(c, c->tr_m, (size_t)W_TOTAL * sizeof(float)));
+    CHK(ensure(c, c->tr_v, (size_t)W_TOTAL * sizeof(float)));
+    CHK(ensure(c, c->tr_part, (size_t)KT_WGRAD_MAX_JOBS * KT_WGRAD_MAX_BLOCKS * 66 * 64 * sizeof(float)));
+    HIPCHK(c, hipMemsetAsync(c->tr_m.p, 0, (size_t)W_TOTAL * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->tr_v.p, 0, (size_t)W_TOTAL * sizeof(float), c->stream));
+    CHK(guarded_wait(c, nullptr));
+    c->tr_nroll = n_rollout; c->tr_lr = lr; c->tr_beta1 = beta1; c->tr_iter = 0;
+    c->tr_on = true;
+    c->gd_on = false;
+    c->mpc_on = false;
+    return DRP_OK;
+}
+
+int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, const float* attrs,
+                   const int32_t* particle_nums, const float* particle_dens, int B, int N, int mode, double* loss_out,
+                   float* grad_out) {
+    if (!c || !c->tr_on) return fail(c, DRP_ESTATE, "drp_train_begin not called");
+    CHK(check_bn(c, B, N));
+    if (!states || !states_delta || !attrs || !particle_nums || !particle_dens) return fail(c, DRP_EINVAL, "null argument");
+    if (mode < DRP_TRAIN_EVAL || mode > DRP_TRAIN_UPDATE) return fail(c, DRP_EINVAL, "bad mode %d", mode);
+    for (int b = 0; b < B; ++b)
+        if (particle_nums[b] <= 0 || particle_nums[b] > N)
+            return fail(c, DRP_EINVAL, "particle_nums[%d]=%d outside 1..%d", b, particle_nums[b], N);
+    HIPCHK(c, hipSetDevice(c->device));
+    end_sessions(c);
+    {
+        float amax = 0.0f;                                    // a_cur = attrs[:, 0]
+        for (int b = 0; b < B; ++b) amax = fmaxf(amax, max_abs(attrs + (size_t)b * (c->tr_nroll + 1) * N, (size_t)N));
+        CHK(pick_tape_engine(c, amax, max_abs(particle_dens, (size_t)B), max_abs(states_delta, (size_t)B * c->tr_nroll * N * 3), &c->tr_engine));
+    }
+    const int H = c->tr_nroll;
+    const size_t bn = (size_t)B * N, bn64 = bn * 64, bnk = bn * DRP_K;
+    const bool backward = mode != DRP_TRAIN_EVAL;
+    CHK(h2d(c, c->tr_states, states, (size_t)B * (H + 1) * N * 3 * sizeof(float)));
+    CHK(h2d(c, c->tr_sdelta, states_delta, (size_t)B * H * N * 3 * sizeof(float)));
+    CHK(h2d(c, c->tr_nums, particle_nums, (size_t)B * sizeof(int)));
+    CHK(h2d(c, c->dens, particle_dens, (size_t)B * sizeof(float)));
+    // a_cur = attrs[:, 0] for every step (train/train_gnn_dyn.py:173)
+    CHK(ensure(c, c->attr, bn * sizeof(float)));
+    CHK(h2d(c, c->scratch, attrs, (size_t)B * (H + 1) * N * sizeof(float)));
+    HIPCHK(c, hipMemcpy2DAsync(c->attr.p, (size_t)N * sizeof(float), c->scratch.p, (size_t)(H + 1) * N * sizeof(float),
+                               (size_t)N * sizeof(float), B, hipMemcpyDeviceToDevice, c->stream));
+    CHK(ensure_step_ws(c, B, N, c->tr_engine));
+    CHK(ensure(c, c->states, (size_t)H * bn * 3 * sizeof(float)));
+    CHK(ensure(c, c->g_state, (size_t)H * bn * 3 * sizeof(float)));
+    c->wg_defer_now = false;
+    c->wg_jobs.clear();
+    if (backward) {
+        // deferred weight gradients keep every job's operands until the end of the backward pass: H copies of the node-level
+        // dumps (3 H + 1 of g_eff, 3 H of g_proj) and of the relation encoder's dumps -- 0.24 GB per rollout step at 32 x 300
+        const size_t keep_bytes = (size_t)H * (16 * bn64 + 7 * bnk * 64 + bnk * 8 + bn * 8) * sizeof(float);
+        const bool defer = c->wgrad_defer && (long)B * ((N + 31) / 32) >= KMB_MIN_TILES && !c->bwd_valu_stages && keep_bytes <= ((size_t)8 << 30);
+        c->wg_defer_now = defer;
+        const size_t kt = defer ? (size_t)H : 1;
+        CHK(ensure(c, c->eff_hist, (size_t)H * 4 * bn64 * sizeof(float)));
+        CHK(ensure(c, c->agg_hist, (size_t)H * 3 * bn64 * sizeof(float)));
+        CHK(ensure(c, c->tape_sdelta, (size_t)H * bn * 3 * sizeof(float)));
+        CHK(ensure(c, c->tape_idx, (size_t)H * bnk * sizeof(int16_t)));
+        CHK(ensure(c, c->tape_cnt, (size_t)H * bn));
+        CHK(ensure(c, c->tape_mask, (size_t)H * DRP_PSTEP * bnk * 2 * sizeof(unsigned)));
+        CHK(ensure(c, c->g_agg_hist, (size_t)DRP_PSTEP * bn64 * sizeof(float)));
+        CHK(ensure(c, c->rev_off, (size_t)H * B * (N + 1) * sizeof(int)));
+        CHK(ensure(c, c->rev, (size_t)H * bnk * sizeof(int)));
+        CHK(ensure(c, c->gpos_edge, bnk * 4 * sizeof(float)));
+        CHK(ensure(c, c->g_eff, (defer ? 3 * kt + 1 : 1) * bn64 * sizeof(float)));
+        CHK(ensure(c, c->g_cnode, kt * bn64 * sizeof(float)));
+        CHK(ensure(c, c->g_agg, bn64 * sizeof(float)));
+        CHK(ensure(c, c->g_proj, (defer ? 3 * kt : 1) * bn64 * 2 * sizeof(float)));
+        CHK(ensure(c, c->g_sdelta, bn * 3 * sizeof(float)));
+        DevBuf* node64[] = {&c->tr_hact, &c->tr_gh, &c->tr_gpe, &c->tr_a1n, &c->tr_gh1};
+        for (DevBuf* b : node64) CHK(ensure(c, *b, kt * bn64 * sizeof(float)));
+        CHK(ensure(c, c->tr_xn, kt * bn * 8 * sizeof(float)));
+        DevBuf* edge64[] = {&c->ed_re, &c->ed_a2, &c->ed_a1, &c->ed_gce, &c->ed_g3, &c->ed_g2, &c->ed_g1};
+        for (DevBuf* b : edge64) CHK(ensure(c, *b, kt * bnk * 64 * sizeof(float)));
+        CHK(ensure(c, c->ed_x0, kt * bnk * 8 * sizeof(float)));
+    }
+    CHK(ensure(c, c->tr_loss, (size_t)H * B * sizeof(double)));
+    c->lastH = H;
+    CHK(train_forward_backward(c, B, N, backward));
+    std::vector<double> parts((size_t)H * B);
+    if (loss_out) CHK(d2h(c, parts.data(), c->tr_loss.p, parts.size() * sizeof(double)));
+    if (grad_out && backward) CHK(d2h(c, grad_out, c->tr_grad.p, (size_t)W_TOTAL * sizeof(float)));
+    if (mode == DRP_TRAIN_UPDATE) {
+        c->tr_iter += 1;
+        const double bc1 = 1.0 - pow(c->tr_beta1, (double)c->tr_iter), bc2 = 1.0 - pow(0.999, (double)c->tr_iter);
+        const float inf = __builtin_inff();
+        hipLaunchKernelGGL(k_adam, dim3((W_TOTAL + 255) / 256), dim3(256), 0, c->stream, ptr<float>(c->w_raw),
+                           ptr<float>(c->tr_grad), ptr<float>(c->tr_m), ptr<float>(c->tr_v), (int)W_TOTAL,
+                           (float)(c->tr_lr / bc1), (float)sqrt(bc2), make_float4(-inf, -inf, -inf, -inf),
+                           make_float4(inf, inf, inf, inf), (float)c->tr_beta1);
+        HIPCHK(c, hipGetLastError());
+        // the engines read packed copies of the weights: rebuild them from the updated blob
+        if (c->repack_device) {
+            CHK(repack_on_device(c));
+        } else {
+            std::vector<float> blob((size_t)W_TOTAL);
+            CHK(d2h(c, blob.data(), c->w_raw.p, (size_t)W_TOTAL * sizeof(float)));
+            CHK(guarded_wait(c, nullptr));
+            CHK(install_weights(c, blob));
+        }
+    }
+    CHK(drp_sync(c));
+    if (loss_out) {
+        double total = 0.0;                     // fixed order: step-major, then sample
+        for (double v : parts) total += v;
+        *loss_out = total;
+    }
+    return DRP_OK;
+}
+
+int drp_train_set_lr(drp_ctx* c, double lr) {
+    if (!c || !c->tr_on) return fail(c, DRP_ESTATE, "drp_train_begin not called");
+    if (!(lr > 0.0)) return fail(c, DRP_EINVAL, "bad lr %g", lr);
+    c->tr_lr = lr;
+    return DRP_OK;
+}
+
+int drp_get_weights(drp_ctx* c, float* blob_out, size_t n_floats) {
+    CHK(need(c, true, false, false));
+    if (!blob_out || n_floats != (size_t)W_TOTAL) return fail(c, DRP_EINVAL, "blob_out must hold %d floats", (int)W_TOTAL);
+    memcpy(blob_out, c->w_host.data(), n_floats * sizeof(float));
+    return DRP_OK;
+}

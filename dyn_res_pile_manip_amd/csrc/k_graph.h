@@ -1096,7 +1096,7 @@ k_graph_cells(const float4* __restrict__ sorted, const int* __restrict__ starts,
     for (int q = w; q < DRP_K; ++q) out[q] = -1;
 }
 
-// ---- mean in-degree of a batch's lists, for the host's choice between paired and unpaired tiles (prop_pair, drp_capi.hip)
+// ---- mean in-degree of a batch's lists, for the host's choice between paired and unpaired tiles (prop_pair, capi_ctx.h)
 // one workgroup; out (host memory the device can write) = sum | rows << 24 | N << 48 in ONE 64-bit store
 #define DEG_STAT_MAX_ROWS 65536
 DRP_GLOBAL void __launch_bounds__(1024)

@@ -22,7 +22,7 @@
 // ReLU is positively homogeneous and scaling by 2^k commutes with every fp32 rounding, so the result is the
 // unscaled chain's bit for bit wherever that one neither saturates nor touches subnormals, and correct
 // beyond: weights 1e7 times larger than a trained network's still give the fp32 engines' answer.  A call
-// whose inputs exceed the envelope the bound was proven for is refused with DRP_ERANGE (drp_capi.hip).
+// whose inputs exceed the envelope the bound was proven for is refused with DRP_ERANGE (range_check, capi_pipeline.h).
 // (The first version split into bf16 pairs: same MFMA count, but v_cvt_pk_bf16_f32 issues at about a
 // third of the rate of v_cvt_pkrtz_f16_f32 -- tools/mfma_bench.hip -- and carries 3 bits less.)
 // The node layers (6-term split further down) stay on three bf16 pieces.
@@ -1311,7 +1311,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
     const int wg_rows = (nb > 0 ? nb : 0) * N;       // this workgroup's receivers: rows b0*N .. b0*N + wg_rows
     const int enc_tiles = (wg_rows + 31) >> 5;
     // PAIR (the host's choice for a launch whose workgroups hold up to four tiles of 32 rows for their eight waves, see
-    // prop_pair() in drp_capi.hip): the propagation steps run tiles of 16 receivers x two slots (prop_tiles) -- twice
+    // prop_pair() in capi_ctx.h): the propagation steps run tiles of 16 receivers x two slots (prop_tiles) -- twice
     // the waves at work, half the slot iterations each.  A kernel of its own: the register allocation of the other one
     // is not to move, and both tile loops in one kernel with a per-workgroup choice run 15 % slower, either of them.
     constexpr int tile_rows = PAIR ? 16 : 32;

@@ -349,7 +349,7 @@ int drp_probe_work(drp_ctx* ctx, unsigned long long out[8]);
  * pre-processing kernels -- names joined by ';' into out (truncated to out_len), return value = the full length.
  * drp_dispatch_variants lists every name the library can report (default_only != 0: without those that need an environment
  * switch or the counting probe).  The shapes and thresholds that select a variant are measured constants
- * (csrc/drp_capi.hip); tests/test_gpu_fuzz_oracle.py checks every default variant against the oracle through these. */
+ * (csrc/capi_ctx.h, capi_pipeline.h); tests/test_gpu_fuzz_oracle.py checks every default variant against the oracle through these. */
 int drp_dispatch_reset(drp_ctx* ctx);
 long drp_last_dispatch(drp_ctx* ctx, char* out, size_t out_len);
 long drp_dispatch_variants(int default_only, char* out, size_t out_len);

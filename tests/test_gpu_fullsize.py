@@ -473,7 +473,7 @@ def test_config5_whole_job_as_eight_logical_shards(ctx):
 @pytest.mark.parametrize('N', [20, 50, 64, 65, 100, 128, 150, 200, 240])
 def test_a_rows_result_does_not_depend_on_the_batch_it_travels_in(ctx, N):
     """Which propagation kernel serves a sample -- cached or recomputing relation-encoder chain (they differ in the last place
-    of a sum) -- is a function of the pile size alone (csrc/drp_capi.hip drp_ctx::ec_shape), never of the batch: an
+    of a sum) -- is a function of the pile size alone (csrc/capi_ctx.h drp_ctx::ec_shape), never of the batch: an
     8 192-row job, its eight 1 024-row shards (BASELINE configs[2]'s partition) and a 64-row call give every row the same
     bits; the planner's 1 500 gradient-descent rows and a rank's 750 likewise.  Default environment."""
     ctx.set_engine(_lib.ENGINE_FUSED)

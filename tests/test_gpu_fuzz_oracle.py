@@ -2,7 +2,7 @@
 forward path at the flat 1e-4 with edge-set equality, oracle/propnet_dense's autograd for the gradients), and a record of
 which kernel variant served each call (drp_last_dispatch).  The last test fails -- with the missing names -- if any variant
 the library can launch without an environment switch (drp_dispatch_variants) was never hit: ~20 template instantiations are
-selected by a dozen measured thresholds in csrc/drp_capi.hip (64 / 128 / 256 / 704 rows, n_cu - n_cu/5 samples, 192 MB of
+selected by a dozen measured thresholds in csrc/capi_ctx.h / capi_pipeline.h (64 / 128 / 256 / 704 rows, n_cu - n_cu/5 samples, 192 MB of
 cache ...), and a threshold change that orphans one must turn the suite red.
 
 The tests of this file run in file order and share the module's hit record (no -p xdist)."""
@@ -294,7 +294,7 @@ def test_update_and_preprocessing_variants(eng):
 
 
 def test_every_default_variant_was_hit(eng):
-    """The contract of this file: whatever the thresholds of csrc/drp_capi.hip select by default has been compared with
+    """The contract of this file: whatever the thresholds of csrc/capi_ctx.h / capi_pipeline.h select by default has been compared with
     the oracle above.  A variant listed by drp_dispatch_variants(default_only) that no shape reached is a failure."""
     want = eng.dispatch_variants(default_only=True)
     everything = eng.dispatch_variants(default_only=False)

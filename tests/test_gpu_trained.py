@@ -210,3 +210,30 @@ def test_the_device_trainer_follows_the_reference_loss_curve(golden):
     theirs = ref_model.engine.train_step(*held, mode='eval')[0]
     print('[train curve] held-out loss: device-trained %.5e, reference-trained %.5e' % (mine, theirs))
     assert abs(mine / theirs - 1) < 4 * wdev_twin.max() + 1e-2
+
+
+@pytest.mark.parametrize('N,ns,H', [(300, 1024, 10), (1200, 128, 6), (50, 1024, 10), (20, 4096, 5)])
+def test_baseline_sizes_on_the_trained_weights(eng, N, ns, H):
+    """BASELINE configs[1] (1024 x 300 x 10), a slice of configs[4]'s pile (1 200 particles) and the small-pile shapes at full
+    batch, on the TRAINED network: pushed particles move by a push's length every step (the seed-0 fixtures: 2 %).  Teacher-
+    forced against the oracle on 24 rows spread over the batch -- every step starts from the device's previous state with the
+    device's impulses, so one flipped near-tie cannot cascade --, at the flat 1e-4 of the step's displacement."""
+    eng.set_engine(_lib.ENGINE_FUSED)
+    s0, dens, attr = syn.make_pile(N, 1, seed=N + 1, kind='blob' if N <= 50 else 'uniform')
+    acts = np.stack([syn.pushes_through(np.tile(s0, (ns, 1, 1)), seed=7 * t + N) for t in range(H)], 1)
+    states, _ = eng.rollout(s0, attr, dens, acts)
+    assert np.isfinite(states).all()
+    rows = np.unique(np.linspace(0, ns - 1, 24).astype(int))
+    prev = np.repeat(s0[:1], len(rows), 0)
+    at, de = np.repeat(attr[:1], len(rows), 0), np.repeat(dens[:1], len(rows))
+    worst, moved = 0.0, 0.0
+    for t in range(H):
+        sd = eng.gen_s_delta(prev, acts[rows, t])
+        ref = osp.predict_one_step(eng.W, at, prev, sd, de)
+        out = states[rows, t]
+        disp = np.abs(ref - prev).reshape(len(rows), -1).max(1)
+        worst = max(worst, float((np.abs(out - ref).reshape(len(rows), -1).max(1) / np.maximum(disp, 1e-12)).max()))
+        moved = max(moved, float(disp.max()))
+        prev = out
+    print('\n[trained, %d x %d x %d] worst step error %.2e of the displacement; largest displacement %.3f' % (ns, N, H, worst, moved))
+    assert worst < 1e-4 and moved > 0.02

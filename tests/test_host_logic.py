@@ -127,3 +127,83 @@ def test_the_planners_result_slots_are_the_librarys():
     m = re.search(r'#define\s+DRP_GD_SLOTS\s+(\d+)', header)
     assert m and int(m.group(1)) == planners.GD_SLOTS
     assert 0 < planners.GD_AHEAD < planners.GD_SLOTS
+
+
+def test_channel_extrema_of_the_observation_checks():
+    """utils.obs2ptcl_fixed_num_batch keeps the reference's range asserts (env/flex_env.py:903-909) but takes every channel's
+    extrema in two passes over the contiguous image: same numbers as one reduction per strided channel view."""
+    import numpy as np
+    from dyn_res_pile_manip_amd.utils import _channel_extrema
+    rng = np.random.default_rng(0)
+    for shape in ((720, 720, 5), (7, 9, 5), (64, 1, 5), (65, 1, 5), (1, 1, 5)):
+        x = rng.normal(size=shape).astype(np.float32)
+        mx, mn = _channel_extrema(x)
+        np.testing.assert_array_equal(mx, x.reshape(-1, 5).max(0))
+        np.testing.assert_array_equal(mn, x.reshape(-1, 5).min(0))
+    view = rng.normal(size=(40, 40, 10)).astype(np.float32)[..., ::2]           # not contiguous: copied, same answer
+    mx, mn = _channel_extrema(view)
+    np.testing.assert_array_equal(mx, view.reshape(-1, 5).max(0))
+
+
+def test_a_named_goal_skips_the_image_on_a_hit():
+    """PlannerGD._set_goal with goal_key: the second call of the same name neither copies nor hashes the image nor calls the
+    engine; another name, another pile size or another transform installs again (no GPU: a recording stand-in engine)."""
+    import numpy as np
+    from dyn_res_pile_manip_amd import flex_rewards, synthetic as syn
+    from dyn_res_pile_manip_amd.planners import PlannerGD
+
+    class Eng(object):
+        calls = 0
+
+        def set_goal_image(self, g, max_goal_pts, fps_init, mode):
+            Eng.calls += 1
+    config = syn.default_config()
+    planner = PlannerGD(config, syn.SyntheticEnv(config))
+    eng = Eng()
+
+    class Boom(object):
+        """an 'image' that fails on any access: a hit must not touch it"""
+        def __array__(self, *a, **k):
+            raise AssertionError('the image was read on a cache hit')
+    img = np.zeros((8, 8), np.float32)
+    planner._set_goal(eng, img, None, max_goal_pts=100, goal_key='A')
+    assert Eng.calls == 1
+    planner._set_goal(eng, Boom(), None, max_goal_pts=100, goal_key='A')
+    assert Eng.calls == 1
+    planner._set_goal(eng, img, None, max_goal_pts=100, goal_key='B')
+    planner._set_goal(eng, img, None, max_goal_pts=250, goal_key='B')
+    assert Eng.calls == 3
+    old = flex_rewards.DIST_TRANSFORM
+    try:
+        flex_rewards.DIST_TRANSFORM = 'exact' if old != 'exact' else 'cv5'
+        planner._set_goal(eng, img, None, max_goal_pts=250, goal_key='B')
+    finally:
+        flex_rewards.DIST_TRANSFORM = old
+    assert Eng.calls == 4
+    planner._set_goal(Eng(), img, None, max_goal_pts=250, goal_key='B')          # another engine object
+    assert Eng.calls == 5
+    # without a name: the content digest, as before
+    planner._set_goal(eng, img, None, max_goal_pts=100)
+    planner._set_goal(eng, img.copy(), None, max_goal_pts=100)
+    assert Eng.calls == 6
+    planner._set_goal(eng, img + 1, None, max_goal_pts=100)
+    assert Eng.calls == 7
+
+
+def test_the_episode_generator_is_a_function_of_its_seed():
+    """synthetic.push_episode / push_batch feed the reference's training loop (tests/golden/make_golden_trained.py) and the
+    device trainer's test with the SAME floats: seeded, shaped like ParticleDataset.__getitem__ / collate_fn."""
+    import numpy as np
+    from dyn_res_pile_manip_amd import synthetic as syn
+    a, b = syn.push_episode(37, 5, 11), syn.push_episode(37, 5, 11)
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_array_equal(x, y)
+    assert a[0].shape == (6, 37, 3) and a[1].shape == (5, 37, 3) and a[2].shape == (6, 37) and a[3] == 37 and 15.0 <= a[4] <= 6500.0
+    assert not np.array_equal(a[0], syn.push_episode(37, 5, 12)[0])
+    moved = np.abs(a[1]).sum(-1) > 0
+    assert moved.any() and not moved.all()                       # a push moves the particles in its band, not the pile
+    np.testing.assert_allclose(a[0][1:][moved] - a[0][:-1][moved], a[1][moved], atol=0.08)   # ... to the push's end, then they spread
+    st, sd, at, pn, de = syn.push_batch(3, 4, 5)
+    assert st.shape[0] == 4 and st.shape[1] == 6 and st.shape[2] == pn.max() and sd.shape == (4, 5, pn.max(), 3)
+    for j in range(4):
+        assert (st[j, :, pn[j]:] == 0).all() and (sd[j, :, pn[j]:] == 0).all()
