@@ -348,3 +348,30 @@ def test_pipelined_iterations_equal_the_blocking_ones(ctx, golden):
         r, a = ctx.gd_wait(3 + i)
         np.testing.assert_array_equal(r, want[i][0])
         np.testing.assert_array_equal(a, want[i][1])
+
+
+@pytest.mark.parametrize('case', ['h1', 'h2'])
+def test_the_valu_stage_kernels_against_the_reference(monkeypatch, golden, case):
+    """kb_predict / kb_update / kb_project / kb_node_encode (one row per wave, fp32 VALU) are the reverse-mode stages no default
+    shape reaches any more (KMB_MIN_TILES = 1 since round 3: every batch has a tile for the matrix-core stages) --
+    tests/test_gpu_fuzz_oracle.py lists them as needing a switch.  DRP_BWD_VALU_STAGES=1 (with the one-launch kernels off) runs
+    them: the reference's autograd gradients, and the dispatch says it was them."""
+    from dyn_res_pile_manip_amd.engine import Engine
+    for k in ('DRP_BWD_VALU_STAGES', 'DRP_NO_BWD_ROWS', 'DRP_NO_BWD_FUSED'):
+        monkeypatch.setenv(k, '1')
+    g = golden.grad
+    eng = Engine(0)
+    eng.load_weights(weights.blob_from_state_dict(golden.weights_seed0), 0.08)
+    eng.set_camera(world2cam_affine(syn.demo_cam_extrinsics()), 24.0, syn.demo_cam_params())
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    eng.set_goal(syn.goal_field(obs_goal), g[case + '/goal_coor'])
+    lo, hi = syn.action_limits()
+    eng.gd_begin(g[case + '/s_cur'], g[case + '/attr'], g[case + '/dens'], g[case + '/act_seqs'], 0.05, lo, hi)
+    eng.dispatch_reset()
+    r, ga, _ = eng.gd_grad()
+    ran = eng.last_dispatch()
+    eng.close()
+    assert 'bwd:stages kb_*' in ran and 'bwd:kmb_rows_bwd' not in ran and 'bwd:kmb_step_bwd' not in ran, ran
+    np.testing.assert_allclose(r, g[case + '/reward'][:, 0], rtol=2e-5)
+    ref_ga = g[case + '/grad_act']
+    assert np.abs(ga - ref_ga).max() < 2e-3 * np.abs(ref_ga).max()

@@ -237,3 +237,27 @@ def test_deferred_weight_gradients_equal_the_flushed_ones(golden, monkeypatch, c
         assert runs[0][0] == runs[1][0] and runs[0][2] == runs[1][2]
         np.testing.assert_array_equal(runs[0][1], runs[1][1])
         np.testing.assert_array_equal(runs[0][3], runs[1][3])
+
+
+def test_training_through_the_valu_stage_kernels(golden, monkeypatch):
+    """DRP_BWD_VALU_STAGES=1: the trainer's node stages on the VALU row kernels (the path batches below KMB_MIN_TILES tiles took
+    until round 3; no default batch reaches it now) -- the reference's loss and every parameter's gradient."""
+    monkeypatch.setenv('DRP_BWD_VALU_STAGES', '1')
+    from dyn_res_pile_manip_amd.engine import Engine
+    g = golden.train
+    case = 'b2_r5'
+    eng = Engine(0)
+    eng.load_weights(weights.blob_from_state_dict(golden.weights_seed0), 0.08)
+    batch = _batch(g, case)
+    eng.train_begin(batch[0].shape[1] - 1, 1e-3, 0.9)
+    eng.dispatch_reset()
+    loss, grad = eng.train_step(*batch, mode='grad', want_grad=True)
+    ran = eng.last_dispatch()
+    eng.close()
+    assert 'train:stages kb_*' in ran and 'train:stages kmb_*' not in ran, ran
+    assert abs(loss - g[case + '/losses'][0]) < 1e-4 * g[case + '/losses'][0]
+    got = weights.state_dict_from_blob(grad)
+    for k, _ in weights.STATE_DICT_KEYS:
+        ref = g[case + '/grad/' + k]
+        scale = max(np.abs(ref).max(), 1e-8)
+        assert np.abs(np.asarray(got[k]).reshape(ref.shape) - ref).max() < 2e-4 * scale + 1e-9, k
