@@ -43,6 +43,9 @@ int drp_create(int device, drp_ctx** out) {
     c->bwd_fused = getenv("DRP_NO_BWD_FUSED") == nullptr;
     c->bwd_rows = getenv("DRP_NO_BWD_ROWS") == nullptr;
     c->bwd_valu_stages = getenv("DRP_BWD_VALU_STAGES") != nullptr;
+    if (const char* e = getenv("DRP_TRAIN_PARTS")) c->train_parts = atoi(e);
+    if (const char* e = getenv("DRP_TRAIN_COOP")) c->train_coop = atoi(e);
+    if (const char* e = getenv("DRP_TRAIN_FUSED")) c->train_fused = atoi(e);
     c->graph_rev = getenv("DRP_NO_GRAPH_REV") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
     if (const char* e = getenv("DRP_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->comm_timeout_s = v; }
@@ -124,7 +127,9 @@ int drp_create(int device, drp_ctx** out) {
         hipFuncSetAttribute((const void*)km_rollout<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_rollout<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)km_rollout<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KM_ROLLOUT_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)kmb_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kmb_step_bwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kmb_step_bwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_FUSED_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)kmb_step_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_COOP_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_rows_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_ROWS_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kmb_edge_encode, hipFuncAttributeMaxDynamicSharedMemorySize, KMB_EDGE_ENCODE_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)kt_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, KT_WGRAD_MULTI_LDS) != hipSuccess ||
@@ -155,7 +160,7 @@ void drp_destroy(drp_ctx* c) {
                       &c->px_cellcnt, &c->px_cellfill, &c->px_celloff, &c->px_list, &c->px_down, &c->px_down32, &c->px_init,
                       &c->px_dist, &c->px_chosen, &c->px_pts, &c->px_r, &c->px_rr, &c->px_out,
                       &c->gl_goal, &c->gl_seg, &c->gl_tmp, &c->gl_dist, &c->gl_blk, &c->gl_pix, &c->gl_fps,
-                      &c->tr_part, &c->tr_states, &c->tr_sdelta, &c->tr_nums, &c->tr_grad, &c->tr_m, &c->tr_v, &c->tr_loss, &c->agg_hist,
+                      &c->tr_part, &c->tr_states, &c->tr_sdelta, &c->tr_nums, &c->tr_arena, &c->re_shift_dev, &c->tr_grad, &c->tr_m, &c->tr_v, &c->tr_loss, &c->agg_hist,
                       &c->tr_hact, &c->tr_gh, &c->tr_gpe, &c->tr_a1n, &c->tr_gh1, &c->tr_xn, &c->ed_re, &c->ed_a2, &c->ed_a1,
                       &c->ed_x0, &c->ed_gce, &c->ed_g3, &c->ed_g2, &c->ed_g1, &c->roll_args, &c->map_valu, &c->map_mfma, &c->map_mfma_bwd,
                       &c->wg_jobs_dev, &c->wg_idx_dev};
@@ -171,6 +176,7 @@ void drp_destroy(drp_ctx* c) {
         if (c->mpc_ev[q]) (void)hipEventDestroy(c->mpc_ev[q]);
     }
     if (c->w_pin) (void)hipHostFree(c->w_pin);
+    if (c->tr_pin) (void)hipHostFree(c->tr_pin);
     if (c->deg_stat) (void)hipHostFree(c->deg_stat);
     (void)hipStreamDestroy(c->stream);
     delete c;

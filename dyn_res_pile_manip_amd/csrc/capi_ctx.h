@@ -26,7 +26,7 @@ enum DispatchVariant {
     DV_PROP3 = DV_PROP + 16,        // + 12 TAPE + 6 PAIR + 2 cache (0 off, 1 on, 2 on with the rows kept in registers) + WORK
     DV_ROLLOUT = DV_PROP3 + 24,     // + 6 PAIR + 2 cache + WORK
     DV_REWARD = DV_ROLLOUT + 12, DV_BWD_REWARD, DV_REV_256, DV_REV_1024, DV_BWD_ROWS, DV_BWD_STEP, DV_BWD_STAGES_MFMA,
-    DV_BWD_STAGES_VALU, DV_BWD_EDGE_MFMA, DV_BWD_EDGE_VALU, DV_TRAIN_NODE_MFMA, DV_TRAIN_NODE_VALU, DV_WGRAD_MFMA, DV_WGRAD_VALU,
+    DV_BWD_STAGES_VALU, DV_BWD_EDGE_MFMA, DV_BWD_EDGE_VALU, DV_TRAIN_NODE_FUSED, DV_TRAIN_NODE_FUSED_COOP, DV_TRAIN_NODE_MFMA, DV_TRAIN_NODE_VALU, DV_WGRAD_MFMA, DV_WGRAD_VALU,
     DV_WGRAD_DEFERRED, DV_MPPI_SOFTMAX, DV_ELITE_SORT, DV_ELITE_ROUNDS, DV_FPS_REG, DV_FPS_MEM, DV_DT_CV5, DV_DT_EXACT,
     DV_COUNT
 };
@@ -77,7 +77,9 @@ void dv_name(int id, char* buf, size_t n, bool* by_default) {
         case DV_BWD_STAGES_VALU: s = "bwd:stages kb_*"; dflt = false; break;              // DRP_BWD_VALU_STAGES=1 (KMB_MIN_TILES is 1 since round 3)
         case DV_BWD_EDGE_MFMA: s = "bwd:kmb_edge_encode"; break;
         case DV_BWD_EDGE_VALU: s = "bwd:kb_edge_encode"; dflt = false; break;
-        case DV_TRAIN_NODE_MFMA: s = "train:stages kmb_*"; break;
+        case DV_TRAIN_NODE_FUSED: s = "train:kmb_step_bwd<dump>"; break;
+        case DV_TRAIN_NODE_FUSED_COOP: s = "train:kmb_step_bwd<dump,coop>"; break;
+        case DV_TRAIN_NODE_MFMA: s = "train:stages kmb_*"; dflt = false; break;          // DRP_NO_BWD_FUSED=1 / DRP_NO_WGRAD_DEFER=1
         case DV_TRAIN_NODE_VALU: s = "train:stages kb_*"; dflt = false; break;
         case DV_WGRAD_MFMA: s = "train:kt_wgrad_mfma"; break;
         case DV_WGRAD_VALU: s = "train:kt_wgrad"; dflt = false; break;
@@ -222,6 +224,9 @@ struct drp_ctx {
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
     bool bwd_fused = true;          // DRP_NO_BWD_FUSED=1: the GD planner's backward pass as one launch per stage
     bool graph_rev = true;          // DRP_NO_GRAPH_REV=1: the GD planner's reversed lists always in a launch of their own (kb_reverse_lists)
+    int train_fused = -1;           // DRP_TRAIN_FUSED=0/1: the trainer's node stages as one launch per rollout step (kmb_step_bwd<dump>) never / for any batch (-1: up to n_cu / 4 tiles)
+    int train_coop = -1;            // DRP_TRAIN_COOP=0/1: the workgroup-wide gather of the edge terms off / on whatever the tile count (-1: by tiles per workgroup)
+    int train_parts = 0;            // DRP_TRAIN_PARTS=n: workgroups per group of samples in the trainer's kmb_step_bwd (0: as many as there are CUs for)
     bool bwd_valu_stages = false;   // DRP_BWD_VALU_STAGES=1: the reverse-mode node stages on the VALU row kernels (kb_predict ... kb_node_encode; cross-check)
     bool bwd_rows = true;           // DRP_NO_BWD_ROWS=1: piles of up to 256 particles through kmb_step_bwd (rows through memory) instead of kmb_rows_bwd
     bool prop3_order = true;        // false: km_prop3's tiles in the natural row order instead of by in-degree
@@ -376,7 +381,10 @@ struct drp_ctx {
     // re-packing after an optimiser step on the device (k_train.h): gather maps of the plain packers, pinned copy of the blob
     DevBuf map_valu, map_mfma, map_mfma_bwd;
     bool repack_maps_ready = false;
-    float* w_pin = nullptr;
+    float* w_pin = nullptr;         // pinned: the blob after an optimiser step [W_TOTAL], then the device's range shift (one int)
+    void* tr_pin = nullptr;         // pinned staging of a training batch (drp_train_step: one upload)
+    size_t tr_pin_cap = 0;
+    DevBuf tr_arena, re_shift_dev;  // the batch as uploaded; the shift kt_repack_all derived
     int graph_q4 = 1;               // DRP_GRAPH_Q4=0 / 1 / 2: four threads per receiver in the plain neighbour sweep -- never / for a handful
                                     // of samples (fewer workgroups than half the CUs) / whenever the plain sweep is chosen
     bool wgrad_mfma = true;         // DRP_NO_WGRAD_MFMA=1: the weight gradients' outer-product sums on the VALU kernel (kt_wgrad_multi)

@@ -121,11 +121,11 @@ int gd_forward_backward(drp_ctx* c) {
             // a workgroup owning whole samples (kmb_step_bwd)
             ProbeScope ps(c, KC_BWD_NODE);
             c->dv(DV_BWD_STEP);
-            hipLaunchKernelGGL(kmb_step_bwd, dim3((unsigned)((B + spw_b - 1) / spw_b)), dim3(64 * KMB_FUSED_WAVES), KMB_FUSED_LDS, st,
+            hipLaunchKernelGGL((kmb_step_bwd<false, false>), dim3((unsigned)((B + spw_b - 1) / spw_b)), dim3(64 * KMB_FUSED_WAVES), KMB_FUSED_LDS, st,
                                ptr<float>(c->w_mfma), ptr<float>(c->w_mfma_bwd), eht, mht, cnt, ptr<int>(c->rev_off), ptr<int>(c->rev),
                                g_out, (size_t)N * 3, ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), nb,
                                ptr<float>(c->dens), nb, N, B, spw_b, ptr<float>(c->g_eff), ptr<float>(c->g_cnode), gah,
-                               ptr<float>(c->g_sdelta));
+                               ptr<float>(c->g_sdelta), KmbDump{}, 1, (unsigned*)nullptr, (unsigned*)nullptr);
         } else if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES && !c->bwd_valu_stages) {      // node stages on the matrix cores
             const float* mw = ptr<float>(c->w_mfma);
             const float* mb = ptr<float>(c->w_mfma_bwd);

@@ -986,7 +986,7 @@ int pick_tape_engine(drp_ctx* c, float max_attr, float max_dens, float max_sdelt
 // camera-frame units, the whole workspace diagonal 0.59: 0.08 + 2 x 0.59 = 1.26), density <= 10 000 (training
 // range: 15 .. 6 500); calls beyond are re-checked one by one (range_check)
 void set_split_range(drp_ctx* c, const float* blob) {
-    split_range_init(blob, c->re_range, 2.0, 1.5, 2.0);
+    split_range_init(blob, c->re_range, SPLIT_ENV_ATTR, SPLIT_ENV_DELTA, SPLIT_ENV_DENS);
     if (c->re_shift_env != 0x7fffffff) c->re_range.shift = c->re_shift_env;
     // weights no shift can carry (a matrix entry beyond fp16, NaN): the split engines refuse every call
     // (range_check); the fp32 engines are unaffected

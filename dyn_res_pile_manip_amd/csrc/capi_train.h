@@ -4,6 +4,25 @@
 
 // ---- training on the same kernels (row f4) ------------------------------------------------------
 namespace {
+#define TR_GRAD_PAD ((W_TOTAL + 63) & ~63)      // tr_grad: the gradient blob, then (from here) kmb_step_bwd's barrier counters
+// the batch as uploaded (drp_train_step): states [B][H+1][N][3] | impulses [B][H][N][3] | attributes [B][H+1][N] | densities [B]
+// | particle counts [B] (ints), every block 16-byte aligned
+struct TrArena { size_t states, sdelta, attrs, dens, nums, bytes; };
+TrArena tr_layout(int B, int H, int N) {
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    TrArena a{};
+    a.states = 0;
+    a.sdelta = up(a.states + (size_t)B * (H + 1) * N * 3 * sizeof(float));
+    a.attrs = up(a.sdelta + (size_t)B * H * N * 3 * sizeof(float));
+    a.dens = up(a.attrs + (size_t)B * (H + 1) * N * sizeof(float));
+    a.nums = up(a.dens + (size_t)B * sizeof(float));
+    a.bytes = up(a.nums + (size_t)B * sizeof(int));
+    return a;
+}
+const float* tr_given(const drp_ctx* c) { return static_cast<const float*>(c->tr_arena.p); }
+const int* tr_nums(const drp_ctx* c, int B, int N) {
+    return reinterpret_cast<const int*>(static_cast<const char*>(c->tr_arena.p) + tr_layout(B, c->tr_nroll, N).nums);
+}
 // forward over n_rollout steps (+ loss), optionally the backward pass with weight gradients
 int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     const int H = c->tr_nroll;
@@ -13,7 +32,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     hipStream_t st = c->stream;
     const bool rev_lds = N <= KB_REV_LDS_MAX_N && !c->rev_global_only;
     float* states = ptr<float>(c->states);
-    const float* given = ptr<float>(c->tr_states);
+    const float* given = tr_given(c);
+    const int* nums = tr_nums(c, B, N);
     float* eh = ptr<float>(c->eff_hist);
     unsigned* mh = ptr<unsigned>(c->tape_mask);
     float* ah = ptr<float>(c->agg_hist);
@@ -33,16 +53,12 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             drp_ctx* c; void* sd; void* idx; void* cnt;
             ~Lend() { c->s_delta.p = sd; c->nbr_idx.p = idx; c->nbr_cnt.p = cnt; }
         } lend{c, save_sd, save_idx, save_cnt};
+        // this step's impulses are data (train/train_gnn_dyn.py:181): the step-major copy kt_unpack_inputs left (the tape's)
+        c->s_delta.p = ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3;
         if (backward) {
-            c->s_delta.p = ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3;
             c->nbr_idx.p = ptr<int16_t>(c->tape_idx) + (size_t)t * bnk;
             c->nbr_cnt.p = ptr<uint8_t>(c->tape_cnt) + (size_t)t * bn;
         }
-        // this step's impulses are data (train/train_gnn_dyn.py:181)
-        hipError_t e = hipMemcpy2DAsync(c->s_delta.p, (size_t)N * 3 * sizeof(float),
-                                        ptr<float>(c->tr_sdelta) + (size_t)t * N * 3, hstride * sizeof(float),
-                                        (size_t)N * 3 * sizeof(float), B, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) { rc = fail(c, DRP_EHIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e)); break; }
         StepArgs a{};
         if (t == 0) { a.s_prev = given; a.prev_mod = B; a.prev_stride = in_stride; }
         else { a.s_prev = states + (size_t)(t - 1) * N * 3; a.prev_mod = B; a.prev_stride = hstride; }
@@ -61,13 +77,12 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         }
         rc = run_step(c, a);
         if (rc != DRP_OK) break;
-        // loss of this step and d loss / d s_pred_t (train/train_gnn_dyn.py:184-186, :203)
-        hipLaunchKernelGGL(kt_mse_grad, dim3(B), dim3(256), 0, st, states + (size_t)t * N * 3, hstride,
-                           given + (size_t)(t + 1) * N * 3, in_stride, ptr<int>(c->tr_nums), N, scale,
-                           g_state + (size_t)t * bn * 3, loss + (size_t)t * B);
     }
     c->engine = saved_engine;
     CHK(rc);
+    // the loss of every step and d loss / d s_pred_t (train/train_gnn_dyn.py:184-186, :203) in one launch
+    hipLaunchKernelGGL(kt_mse_grad, dim3(B, H), dim3(256), 0, st, states, hstride, given + (size_t)N * 3, in_stride,
+                       nums, N, scale, g_state, loss);
     HIPCHK(c, hipGetLastError());
     if (!backward) return DRP_OK;
 
@@ -84,20 +99,41 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     const int chunks = pick(4), chunks16 = pick(16);
     const dim3 rgrid((unsigned)(B * chunks)), egrid((unsigned)(B * chunks16));
     const float* dens = ptr<float>(c->dens);
-    HIPCHK(c, hipMemsetAsync(G, 0, (size_t)W_TOTAL * sizeof(float), st));
+    HIPCHK(c, hipMemsetAsync(G, 0, ((size_t)TR_GRAD_PAD + (size_t)H * c->n_cu + 1) * sizeof(float), st));    // with kmb_step_bwd's counters behind it
     // the reversed lists of ALL rollout steps in one launch (the tape holds every step's lists; a training batch is a handful
     // of workgroups per step)
     c->dv(N <= 512 ? DV_REV_256 : DV_REV_1024);
     if (N <= 512)
         hipLaunchKernelGGL(kb_reverse_lists<256>, dim3(B * H), dim3(256), KB_REV_LDS(N, rev_lds), st, ptr<int16_t>(c->tape_idx),
-                           ptr<uint8_t>(c->tape_cnt), N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums), B);
+                           ptr<uint8_t>(c->tape_cnt), N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, nums, B);
     else
         hipLaunchKernelGGL(kb_reverse_lists<1024>, dim3(B * H), dim3(1024), KB_REV_LDS(N, rev_lds), st, ptr<int16_t>(c->tape_idx),
-                           ptr<uint8_t>(c->tape_cnt), N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, ptr<int>(c->tr_nums), B);
+                           ptr<uint8_t>(c->tape_cnt), N, ptr<int>(c->rev_off), ptr<int>(c->rev), rev_lds ? 1 : 0, nums, B);
     // deferred weight gradients: what a job reads keeps a buffer per rollout step t (g_eff and g_proj: per propagation step
     // too; slot 0 of g_eff is the transient copy the predictor writes and the particle encoder reads)
     const bool defer = c->wg_defer_now;
     const size_t per_t = defer ? 1 : 0;
+    // the fused node / edge-term pass needs every dump in a buffer of its own (the deferred weight gradients' layout).  A
+    // group of `f_spw` samples is shared by `f_parts` workgroups, the grid at most one workgroup per CU (kmb_step_bwd's barrier)
+    // It pays for a handful of tiles only (the reference's batch of 4 x <= 300 particles: 40): every tile is a chain of L2 round
+    // trips, and the stage kernels spread the same gathers over more threads (32 x 300: 3.3 ms staged, 4.3 ms in one launch)
+    const long f_tiles = (long)B * ((N + 31) / 32);
+    const bool fused = defer && c->bwd_fused && !c->bwd_valu_stages &&
+                       (c->train_fused >= 0 ? c->train_fused != 0 : f_tiles <= c->n_cu / 4);
+    const int f_spw = (B + c->n_cu - 1) / c->n_cu, f_groups = (B + f_spw - 1) / f_spw;
+    int f_parts = 1;
+    bool f_coop = false;
+    if (fused) {
+        const int group_tiles = (int)(((long)f_spw * N + 31) / 32);
+        f_parts = c->train_parts > 0 ? c->train_parts : c->n_cu / f_groups;
+        if (f_parts > c->n_cu / f_groups) f_parts = c->n_cu / f_groups;
+        if (f_parts > group_tiles) f_parts = group_tiles;
+        if (f_parts < 1) f_parts = 1;
+        // a handful of tiles per workgroup: all eight waves gather a tile's edge terms (a wave on its own is one long chain of
+        // L2 round trips per tile and phase: 27 us against 6); many: a tile per wave, the waves hide each other's latency
+        f_coop = c->train_coop >= 0 ? c->train_coop != 0 : (group_tiles + f_parts - 1) / f_parts <= 2 * KMB_COOP_SLOTS;
+    }
+    unsigned* const f_bar = reinterpret_cast<unsigned*>(G + TR_GRAD_PAD);        // [H][f_groups] arrival counters, then the give-up flag
     for (int t = H - 1; t >= 0; --t) {
         const size_t tt = per_t * (size_t)t;
         float* const ge_tmp = ptr<float>(c->g_eff);
@@ -126,7 +162,39 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         int* const rev_t = ptr<int>(c->rev) + (size_t)t * bnk;
         // node-level stages: on the matrix cores when the batch has enough 32-row tiles to fill the chip,
         // otherwise the row kernels chunked over (sample, rows)
-        if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES && !c->bwd_valu_stages) {
+        if (fused) {
+            // everything between the loss gradient and the relation encoder's backward in ONE launch (kmb_step_bwd<DUMP>): the
+            // operands of the weight gradients are its dumps; same queue order as the stage kernels below
+            c->dv(f_coop ? DV_TRAIN_NODE_FUSED_COOP : DV_TRAIN_NODE_FUSED);
+            KmbDump dump{};
+            dump.hact = tr_hact_t; dump.gh = tr_gh_t;
+            for (int v = 0; v < 3; ++v) { dump.ge[v] = ge_v(v); dump.gp[v] = gp_v(v); }
+            dump.gpe = tr_gpe_t; dump.a1n = tr_a1n_t; dump.gh1 = tr_gh1_t; dump.xn = tr_xn_t;
+#define STEP_BWD_ARGS ptr<float>(c->w_mfma), ptr<float>(c->w_mfma_bwd), eht, mht, cnt, rev_off_t, rev_t, g_out, (size_t)N * 3, \
+                      ptr<float>(c->tape_sdelta) + (size_t)t * bn * 3, ptr<float>(c->attr), B, dens, B, N, B, f_spw, ge_tmp, \
+                      g_cnode_t, gah, ptr<float>(c->g_sdelta), dump, f_parts, f_bar + (size_t)t * f_groups, f_bar + (size_t)H * f_groups
+            if (f_coop)
+                hipLaunchKernelGGL((kmb_step_bwd<true, true>), dim3((unsigned)(f_groups * f_parts)), dim3(64 * KMB_FUSED_WAVES), KMB_COOP_LDS, st, STEP_BWD_ARGS);
+            else
+                hipLaunchKernelGGL((kmb_step_bwd<true, false>), dim3((unsigned)(f_groups * f_parts)), dim3(64 * KMB_FUSED_WAVES), KMB_FUSED_LDS, st, STEP_BWD_ARGS);
+#undef STEP_BWD_ARGS
+            launch_wgrad<64>(c, tr_gh_t, 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr, nullptr, 1, 1);
+            launch_wgrad<3>(c, tr_hact_t, 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
+            for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+                launch_wgrad<64>(c, ge_v(DRP_PSTEP - 1 - p), 64, aht + (size_t)p * bn64, 64, (long)bn, G + W_PP_W + 64, 129, 1,
+                                 nullptr, nullptr, nullptr, 1, 1);
+                launch_wgrad<64>(c, gp_v(p), 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 64, 193, 1,
+                                 nullptr, nullptr, nullptr, 1, 1);
+                launch_wgrad<64>(c, gp_v(p) + 64, 128, eht + (size_t)p * bn64, 64, (long)bn, G + W_RP_W + 128, 193,
+                                 1, nullptr, nullptr, nullptr, 1, 1);
+            }
+            launch_wgrad<64>(c, g_cnode_t, 64, eht, 64, (long)bn, G + W_PP_W, 129, 1, G + W_PP_B, G + W_PP_W + 128,
+                             dens, B, (long)N);
+            launch_wgrad<64>(c, tr_gpe_t, 64, tr_a1n_t, 64, (long)bn, G + W_PE2_W, 64, 1, G + W_PE2_B,
+                             nullptr, nullptr, 1, 1);
+            launch_wgrad<5>(c, tr_gh1_t, 64, tr_xn_t, 8, (long)bn, G + W_PE0_W, 5, 1, G + W_PE0_B,
+                            nullptr, nullptr, 1, 1);
+        } else if ((long)B * ((N + 31) / 32) >= KMB_MIN_TILES && !c->bwd_valu_stages) {
             const float* mw = ptr<float>(c->w_mfma);
             const float* mb = ptr<float>(c->w_mfma_bwd);
             const long node_tiles = (long)B * ((N + 31) / 32);
@@ -138,7 +206,6 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             launch_wgrad<64>(c, tr_gh_t, 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
                              nullptr, 1, 1);
             launch_wgrad<3>(c, tr_hact_t, 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
-            hipLaunchKernelGGL(kt_colsum3, dim3(1), dim3(1024), 0, st, g_out, (long)bn, G + W_PR1_B);
             // update of the last propagation step; then per step the edge terms and, in one launch, the
             // projection of this step with the update of the one before (k_backward_mfma.h)
             hipLaunchKernelGGL((kmb_node_step<false, true>), ngrid, nblk, KMB_STEP_LDS(false, true), st, mb, ge_tmp, ge_v(0),
@@ -189,7 +256,6 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
             launch_wgrad<64>(c, ptr<float>(c->tr_gh), 64, eht + 3 * bn64, 64, (long)bn, G + W_PR0_W, 64, 1, G + W_PR0_B, nullptr,
                              nullptr, 1, 1);
             launch_wgrad<3>(c, ptr<float>(c->tr_hact), 64, g_out, 3, (long)bn, G + W_PR1_W, 1, 64, nullptr, nullptr, nullptr, 1, 1);
-            hipLaunchKernelGGL(kt_colsum3, dim3(1), dim3(1024), 0, st, g_out, (long)bn, G + W_PR1_B);
             for (int p = DRP_PSTEP - 1; p >= 0; --p) {
                 float* g_agg_p = gah + (size_t)p * bn64;
                 const unsigned* mask_p = mht + (size_t)p * bnk * 2;
@@ -225,7 +291,9 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         float* g_prev = nullptr;
         if (t > 0) {
             g_prev = g_state + (size_t)(t - 1) * bn * 3;
-            hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
+            // the residual's share: with the matrix-core edge kernel nothing touches g_prev before kb_gather_pos, which adds it first
+            if (!c->bwd_edge_mfma)
+                hipLaunchKernelGGL(kt_add, dim3((unsigned)((bn * 3 + 255) / 256)), dim3(256), 0, st, g_prev, g_out, bn * 3);
         }
         c->dv(c->bwd_edge_mfma ? DV_BWD_EDGE_MFMA : DV_BWD_EDGE_VALU);
         if (c->bwd_edge_mfma)
@@ -236,7 +304,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
                                prev_stride, ptr<float>(c->attr), B, dens, B, idx, cnt, gah, mht, bn, N, g_prev, (size_t)N * 3, ptr<float>(c->gpos_edge), ed, chunks);
         if (g_prev != nullptr)
             hipLaunchKernelGGL(kb_gather_pos, dim3((N + 255) / 256, B), dim3(256), 0, st, ptr<float>(c->gpos_edge),
-                               rev_off_t, rev_t, N, g_prev, (size_t)N * 3, c->bwd_edge_mfma ? 1 : 0, cnt);
+                               rev_off_t, rev_t, N, g_prev, (size_t)N * 3, c->bwd_edge_mfma ? 1 : 0, cnt,
+                               c->bwd_edge_mfma ? (const float*)g_out : (const float*)nullptr);
         launch_wgrad<64>(c, ed.gce, 64, ed.re, 64, (long)bnk, G + W_RP_W, 193, 1, G + W_RP_B, G + W_RP_W + 192, dens, B,
                          (long)N * DRP_K);
         launch_wgrad<64>(c, ed.g3, 64, ed.a2, 64, (long)bnk, G + W_RE4_W, 64, 1, G + W_RE4_B, nullptr, nullptr, 1, 1);
@@ -245,6 +314,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
         flush_wgrad(c);                                  // the next rollout step rewrites the dumps these jobs read
     }
     flush_wgrad(c);
+    // bias of the predictor's last layer: the column sums of every step's d loss / d s_pred (all final by now), one launch
+    hipLaunchKernelGGL(kt_colsum3, dim3(1), dim3(1024), 0, st, g_state, (long)(H * bn), G + W_PR1_B);
     if (defer) CHK(flush_wgrad_all(c));
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
@@ -272,28 +343,45 @@ int ensure_repack_maps(drp_ctx* c) {
     CHK(h2d(c, c->map_mfma, mm.data(), mm.size() * sizeof(int)));
     CHK(h2d(c, c->map_mfma_bwd, mmb.data(), mmb.size() * sizeof(int)));
     CHK(guarded_wait(c, nullptr));                   // the vectors go out of scope
-    if (!c->w_pin) HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->w_pin), (size_t)W_TOTAL * sizeof(float), hipHostMallocDefault));
+    if (!c->w_pin) HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->w_pin), ((size_t)W_TOTAL + 4) * sizeof(float), hipHostMallocDefault));
     c->repack_maps_ready = true;
     return DRP_OK;
 }
 
+// launches only: the caller's final wait brings the blob and the device's shift back (finish_repack)
 int repack_on_device(drp_ctx* c) {
     CHK(ensure_repack_maps(c));
+    CHK(ensure(c, c->re_shift_dev, sizeof(int)));
     hipStream_t st = c->stream;
     const float* w = ptr<float>(c->w_raw);
-    hipLaunchKernelGGL(kt_repack_gather, dim3((V_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_valu), ptr<float>(c->w_valu), (int)V_TOTAL);
-    hipLaunchKernelGGL(kt_repack_gather, dim3((M_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_mfma), ptr<float>(c->w_mfma), (int)M_TOTAL);
-    hipLaunchKernelGGL(kt_repack_gather, dim3((MB_TOTAL + 255) / 256), dim3(256), 0, st, w, ptr<int>(c->map_mfma_bwd), ptr<float>(c->w_mfma_bwd), (int)MB_TOTAL);
-    hipLaunchKernelGGL(kt_repack_split6, dim3(7 * 16), dim3(256), 0, st, w, ptr<uint16_t>(c->w_split6));
-    hipLaunchKernelGGL(kt_repack_split6_bwd, dim3(6 * 16), dim3(256), 0, st, w, ptr<uint16_t>(c->w_split6_bwd));
-    // the relation encoder's range shift depends on the new weights: fetch the blob (it is the host copy
-    // drp_get_weights serves anyway), derive the shift, then pack the split-fp16 fragments with it
+    RepackAll a{};
+    a.map_v = ptr<int>(c->map_valu); a.dst_v = ptr<float>(c->w_valu); a.n_v = (int)V_TOTAL;
+    a.map_m = ptr<int>(c->map_mfma); a.dst_m = ptr<float>(c->w_mfma); a.n_m = (int)M_TOTAL;
+    a.map_mb = ptr<int>(c->map_mfma_bwd); a.dst_mb = ptr<float>(c->w_mfma_bwd); a.n_mb = (int)MB_TOTAL;
+    a.out6 = ptr<uint16_t>(c->w_split6); a.out6b = ptr<uint16_t>(c->w_split6_bwd);
+    a.forced_shift = c->re_shift_env; a.shift_out = ptr<int>(c->re_shift_dev);
+    hipLaunchKernelGGL(kt_repack_all, dim3(KT_REPACK_ALL_BLOCKS((int)V_TOTAL, (int)M_TOTAL, (int)MB_TOTAL)), dim3(256), 0, st, w, a);
+    // the relation encoder's range shift depends on the new weights: the launch above derived it; the blob itself comes
+    // back too (it is the host copy drp_get_weights serves, and the host's own range for the calls to come)
+    hipLaunchKernelGGL(kt_repack_split, dim3(4 * 16), dim3(256), 0, st, w, 0, ptr<uint16_t>(c->w_split), ptr<int>(c->re_shift_dev));
     HIPCHK(c, hipMemcpyAsync(c->w_pin, c->w_raw.p, (size_t)W_TOTAL * sizeof(float), hipMemcpyDeviceToHost, st));
-    CHK(guarded_wait(c, nullptr));
+    HIPCHK(c, hipMemcpyAsync(c->w_pin + W_TOTAL, c->re_shift_dev.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipGetLastError());
+    return DRP_OK;
+}
+// after the wait: the host's copy of the blob and its range; host and device derive the shift by the same operations --
+// should they ever disagree, the fragments are packed again with the host's
+int finish_repack(drp_ctx* c) {
     c->w_host.assign(c->w_pin, c->w_pin + W_TOTAL);
     set_split_range(c, c->w_host.data());
-    hipLaunchKernelGGL(kt_repack_split, dim3(4 * 16), dim3(256), 0, st, w, c->re_range.shift, ptr<uint16_t>(c->w_split));
-    HIPCHK(c, hipGetLastError());
+    int dev_shift;
+    memcpy(&dev_shift, c->w_pin + W_TOTAL, sizeof(int));
+    if (dev_shift != c->re_range.shift) {
+        hipLaunchKernelGGL(kt_repack_split, dim3(4 * 16), dim3(256), 0, c->stream, ptr<float>(c->w_raw), c->re_range.shift,
+                           ptr<uint16_t>(c->w_split), (const int*)nullptr);
+        HIPCHK(c, hipGetLastError());
+        CHK(guarded_wait(c, nullptr));
+    }
     return DRP_OK;
 }
 
@@ -308,7 +396,7 @@ int drp_train_begin(drp_ctx* c, int n_rollout, double lr, double beta1) {
     if (n_rollout < 1 || n_rollout > 64 || !(lr > 0.0) || !(beta1 >= 0.0 && beta1 < 1.0))
         return fail(c, DRP_EINVAL, "bad training arguments n_rollout=%d lr=%g beta1=%g", n_rollout, lr, beta1);
     HIPCHK(c, hipSetDevice(c->device));
-    CHK(ensure(c, c->tr_grad, (size_t)W_TOTAL * sizeof(float)));
+    CHK(ensure(c, c->tr_grad, ((size_t)TR_GRAD_PAD + (size_t)n_rollout * c->n_cu + 1) * sizeof(float)));
     CHK(ensure(c, c->tr_m, (size_t)W_TOTAL * sizeof(float)));
     CHK(ensure(c, c->tr_v, (size_t)W_TOTAL * sizeof(float)));
     CHK(ensure(c, c->tr_part, (size_t)KT_WGRAD_MAX_JOBS * KT_WGRAD_MAX_BLOCKS * 66 * 64 * sizeof(float)));
@@ -342,15 +430,33 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     const int H = c->tr_nroll;
     const size_t bn = (size_t)B * N, bn64 = bn * 64, bnk = bn * DRP_K;
     const bool backward = mode != DRP_TRAIN_EVAL;
-    CHK(h2d(c, c->tr_states, states, (size_t)B * (H + 1) * N * 3 * sizeof(float)));
-    CHK(h2d(c, c->tr_sdelta, states_delta, (size_t)B * H * N * 3 * sizeof(float)));
-    CHK(h2d(c, c->tr_nums, particle_nums, (size_t)B * sizeof(int)));
-    CHK(h2d(c, c->dens, particle_dens, (size_t)B * sizeof(float)));
-    // a_cur = attrs[:, 0] for every step (train/train_gnn_dyn.py:173)
+    // the batch in one copy: packed into pinned staging in the caller's layouts, unpacked by one launch (kt_unpack_inputs)
+    const TrArena lay = tr_layout(B, H, N);
+    if (c->tr_pin_cap < lay.bytes) {
+        if (c->tr_pin) { (void)hipHostFree(c->tr_pin); c->tr_pin = nullptr; c->tr_pin_cap = 0; }
+        HIPCHK(c, hipHostMalloc(&c->tr_pin, lay.bytes, hipHostMallocDefault));
+        c->tr_pin_cap = lay.bytes;
+    }
+    {
+        char* pin = static_cast<char*>(c->tr_pin);
+        memcpy(pin + lay.states, states, (size_t)B * (H + 1) * N * 3 * sizeof(float));
+        memcpy(pin + lay.sdelta, states_delta, (size_t)B * H * N * 3 * sizeof(float));
+        memcpy(pin + lay.attrs, attrs, (size_t)B * (H + 1) * N * sizeof(float));
+        memcpy(pin + lay.dens, particle_dens, (size_t)B * sizeof(float));
+        memcpy(pin + lay.nums, particle_nums, (size_t)B * sizeof(int));
+    }
+    CHK(h2d(c, c->tr_arena, c->tr_pin, lay.bytes));
     CHK(ensure(c, c->attr, bn * sizeof(float)));
-    CHK(h2d(c, c->scratch, attrs, (size_t)B * (H + 1) * N * sizeof(float)));
-    HIPCHK(c, hipMemcpy2DAsync(c->attr.p, (size_t)N * sizeof(float), c->scratch.p, (size_t)(H + 1) * N * sizeof(float),
-                               (size_t)N * sizeof(float), B, hipMemcpyDeviceToDevice, c->stream));
+    CHK(ensure(c, c->dens, (size_t)B * sizeof(float)));
+    CHK(ensure(c, c->tape_sdelta, (size_t)H * bn * 3 * sizeof(float)));
+    {
+        const char* ar = static_cast<const char*>(c->tr_arena.p);
+        const size_t total = (size_t)H * bn * 3;
+        hipLaunchKernelGGL(kt_unpack_inputs, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1024)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const float*>(ar + lay.sdelta), reinterpret_cast<const float*>(ar + lay.attrs),
+                           reinterpret_cast<const float*>(ar + lay.dens), B, H, N, ptr<float>(c->tape_sdelta), ptr<float>(c->attr),
+                           ptr<float>(c->dens));
+    }
     CHK(ensure_step_ws(c, B, N, c->tr_engine));
     CHK(ensure(c, c->states, (size_t)H * bn * 3 * sizeof(float)));
     CHK(ensure(c, c->g_state, (size_t)H * bn * 3 * sizeof(float)));
@@ -391,6 +497,12 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     std::vector<double> parts((size_t)H * B);
     if (loss_out) CHK(d2h(c, parts.data(), c->tr_loss.p, parts.size() * sizeof(double)));
     if (grad_out && backward) CHK(d2h(c, grad_out, c->tr_grad.p, (size_t)W_TOTAL * sizeof(float)));
+    bool repacked = false;
+    unsigned gave_up = 0;                       // kmb_step_bwd's barrier among workgroups (the flag sits behind its counters)
+    if (backward) {
+        const int f_spw = (B + c->n_cu - 1) / c->n_cu, f_groups = (B + f_spw - 1) / f_spw;
+        CHK(d2h(c, &gave_up, ptr<float>(c->tr_grad) + TR_GRAD_PAD + (size_t)H * f_groups, sizeof(unsigned)));
+    }
     if (mode == DRP_TRAIN_UPDATE) {
         c->tr_iter += 1;
         const double bc1 = 1.0 - pow(c->tr_beta1, (double)c->tr_iter), bc2 = 1.0 - pow(0.999, (double)c->tr_iter);
@@ -403,6 +515,7 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         // the engines read packed copies of the weights: rebuild them from the updated blob
         if (c->repack_device) {
             CHK(repack_on_device(c));
+            repacked = true;
         } else {
             std::vector<float> blob((size_t)W_TOTAL);
             CHK(d2h(c, blob.data(), c->w_raw.p, (size_t)W_TOTAL * sizeof(float)));
@@ -411,6 +524,8 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         }
     }
     CHK(drp_sync(c));
+    if (repacked) CHK(finish_repack(c));
+    if (gave_up) return fail(c, DRP_EHIP, "kmb_step_bwd: a workgroup waited two seconds for the others of its group (DRP_TRAIN_PARTS=1 runs a group on one workgroup)");
     if (loss_out) {
         double total = 0.0;                     // fixed order: step-major, then sample
         for (double v : parts) total += v;

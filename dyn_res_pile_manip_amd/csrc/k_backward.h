@@ -699,7 +699,9 @@ kb_edge_encode(const float* __restrict__ vw, const float* __restrict__ wraw, con
 // in the order of the reversed lists (no atomics)
 __global__ void __launch_bounds__(256)
 kb_gather_pos(const float* __restrict__ gpos_edge, const int* __restrict__ rev_off, const int* __restrict__ rev, int N,
-              float* __restrict__ g_pos, size_t gpos_stride, int add_recv = 0, const uint8_t* __restrict__ nbr_cnt = nullptr) {
+              float* __restrict__ g_pos, size_t gpos_stride, int add_recv = 0, const uint8_t* __restrict__ nbr_cnt = nullptr,
+              const float* __restrict__ g_add = nullptr /* nullable, laid out as g_pos: added first (the residual's share of the
+                                                           next step's gradient -- the trainer's kt_add folded in) */) {
     const int b = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
@@ -708,6 +710,10 @@ kb_gather_pos(const float* __restrict__ gpos_edge, const int* __restrict__ rev_o
     const float4* ge = reinterpret_cast<const float4*>(gpos_edge) + (size_t)b * N * DRP_K;
     float* gp = g_pos + (size_t)b * gpos_stride + (size_t)j * 3;
     float g0 = gp[0], g1 = gp[1], g2 = gp[2];
+    if (g_add != nullptr) {
+        const float* ga = g_add + (size_t)b * gpos_stride + (size_t)j * 3;
+        g0 += ga[0]; g1 += ga[1]; g2 += ga[2];
+    }
     if (add_recv) {
         // receiver part (kmb_edge_encode leaves it here): the sum over the node's own slots, in slot order
         const int cnt = nbr_cnt[(size_t)b * N + j];

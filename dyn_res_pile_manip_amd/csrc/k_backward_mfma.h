@@ -333,16 +333,97 @@ __device__ __forceinline__ void receiver_term(Frag& pr, const Frag& g, const uns
 // Tiles are 32 consecutive rows of the workgroup's row list (only its last tile has idle lanes), drawn on demand.
 // Every sum runs in a fixed order (bit planes of the slot count, reversed-list order): gradients are bit-reproducible.
 // fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout, as the launch-per-stage kernels.
+#ifdef ROLLOUT_STAMPS
+// Diagnostic build only (tools/bwd_stamps.py): 100 MHz wall stamps between the phases of a group, summed by wave 0 of
+// every 32nd workgroup
+__device__ unsigned long long g_bwd_stamps[16];
+#define BWD_STAMP(q) do { if (roll_on) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+                                         atomicAdd(&g_bwd_stamps[q], now_ - roll_t); roll_t = now_; } } while (0)
+#else
+#define BWD_STAMP(q) do { } while (0)
+#endif
 #define KMB_FUSED_WAVES 8
+#define KMB_ROWS_LD 68            // floats per 64-float row in LDS: 17 float4 -- consecutive rows start four banks apart
+__device__ __forceinline__ void gagg_lds_read(const float* gl, int r, int h, Frag& f) { frag_from_row(gl + r * KMB_ROWS_LD, h, f); }
+__device__ __forceinline__ void gagg_lds_write(float* gl, int r, int h, const Frag& f) { frag_to_row(gl + r * KMB_ROWS_LD, h, f); }
 #define KMB_FUSED_LDS ((size_t)(7 * 4096 + 512 + 256 + 192 + 4) * sizeof(float))
+// DUMP (the trainer): what the weight gradients read leaves the launch as well -- per propagation step the pre-activation
+// gradient (ge[0..2]: steps 2, 1, 0; the chain reads ge[k] and writes ge[k + 1] instead of overwriting g_eff) and both edge
+// terms (gp[p]: [rows][128] = receiver | sender), the predictor's hidden activation and its gradient, the particle encoder's
+// (kmb_predict's / kmb_node_encode's dumps).  A training batch is a handful of samples: with `parts` > 1 a group of samples
+// is shared by `parts` workgroups (tiles dealt statically: part + wave * parts, stride parts * waves) and the phases are
+// separated by a barrier among those workgroups -- a counter in memory per group (`bar`, zeroed by the host; every wave's
+// stores are performed at device scope before its workgroup arrives, every wave invalidates its L1 after the wait).  The
+// host keeps the grid at or below the number of CUs (all workgroups resident); a wait that lasts two seconds gives up and
+// sets bar_err instead of hanging the device.
+struct KmbDump {
+    float* hact; float* gh;          // predictor: relu(hidden), hidden pre-activation gradient        [rows][64]
+    float* ge[3];                    // pre-activation gradient of propagation steps 2, 1, 0           [rows][64]
+    float* gp[3];                    // edge terms of propagation step p                                [rows][128]
+    float* gpe; float* a1n; float* gh1; float* xn;   // particle encoder (kmb_node_encode's dumps)
+};
+// both edge terms of one row by 16 lanes (lane q: features 4q .. 4q + 3), kb_edge_terms' layout with kmb_step_bwd's own
+// arithmetic (the receiver term by the bit planes of the slot count, the sender term entry by entry in list order): the same
+// bits as the wave-wide gather below, with 32 rows of a tile in flight over the workgroup's 512 threads instead of one wave's
+// two-deep pipeline
+__device__ __forceinline__ float plane_sum(int n, float g) {
+    float acc = 0.0f + ((n & 1) ? g : 0.0f);
+    acc = fmaf((n & 2) ? g : 0.0f, 2.0f, acc);
+    acc = fmaf((n & 4) ? g : 0.0f, 4.0f, acc);
+    return fmaf((n & 8) ? g : 0.0f, 8.0f, acc);
+}
+__device__ __forceinline__ void coop_edge_terms(const float* g_agg_p, const unsigned* __restrict__ mk /* the sample's slots */,
+                                                const int* __restrict__ rv, int p0, int p1, int i, int cnt, size_t srow0, int q,
+                                                float4& pr, float4& ps) {
+    const float4* ga = reinterpret_cast<const float4*>(g_agg_p);
+    const float4 gi = ga[(srow0 + i) * 16 + q];
+    unsigned wk[DRP_K];
+#pragma unroll
+    for (int k = 0; k < DRP_K; ++k) wk[k] = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + (q & 1)] : 0u;
+    const int sh = 28 - 16 * (q >> 3) - 4 * ((q >> 1) & 3);
+    int nx = 0, ny = 0, nz = 0, nw = 0;
+#pragma unroll
+    for (int k = 0; k < DRP_K; ++k) {
+        const unsigned nib = (wk[k] >> sh) & 0xfu;
+        nx += (nib >> 3) & 1; ny += (nib >> 2) & 1; nz += (nib >> 1) & 1; nw += nib & 1;
+    }
+    pr = make_float4(plane_sum(nx, gi.x), plane_sum(ny, gi.y), plane_sum(nz, gi.z), plane_sum(nw, gi.w));
+    ps = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pp = p0; pp < p1; pp += 4) {
+        int e[4];
+        unsigned w[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = (pp + u < p1) ? rv[pp + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ee = e[u] < 0 ? 0 : e[u];
+            w[u] = e[u] < 0 ? 0u : (mk[(size_t)ee * 2 + (q & 1)] >> sh) & 0xfu;
+            v[u] = ga[(srow0 + ee / DRP_K) * 16 + q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ps.x += (w[u] & 8u) ? v[u].x : 0.0f;
+            ps.y += (w[u] & 4u) ? v[u].y : 0.0f;
+            ps.z += (w[u] & 2u) ? v[u].z : 0.0f;
+            ps.w += (w[u] & 1u) ? v[u].w : 0.0f;
+        }
+    }
+}
+#define KMB_COOP_SLOTS 2
+#define KMB_COOP_LDS (KMB_FUSED_LDS + (size_t)KMB_COOP_SLOTS * 2 * 32 * KMB_ROWS_LD * sizeof(float))
+// COOP (with DUMP, a handful of tiles per workgroup): the workgroup's tiles go round by round, KMB_COOP_SLOTS at a time -- all
+// eight waves gather a tile's edge terms into LDS (coop_edge_terms), then one wave per tile runs the matrix chain on them
+template <bool DUMP, bool COOP>
 __global__ void __launch_bounds__(64 * KMB_FUSED_WAVES)
 kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
              const float* __restrict__ eff_hist /* [4][B*N,64] */, const unsigned* __restrict__ mask_hist /* [3][B*N*10][2] */,
              const uint8_t* __restrict__ nbr_cnt, const int* __restrict__ rev_off, const int* __restrict__ rev,
              const float* __restrict__ g_out, size_t g_stride, const float* __restrict__ s_delta,
              const float* __restrict__ attr, int attr_mod, const float* __restrict__ dens, int dens_mod,
-             int N, int B, int spw, float* __restrict__ g_eff, float* __restrict__ g_cnode,
-             float* __restrict__ g_agg_hist /* [3][B*N,64] */, float* __restrict__ g_sdelta) {
+             int N, int B, int spw, float* g_eff, float* g_cnode,
+             float* g_agg_hist /* [3][B*N,64] */, float* __restrict__ g_sdelta,
+             KmbDump dump, int parts, unsigned* bar /* [groups], zero */, unsigned* bar_err) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w0 = lds;                 // predictor layer 0, forward pack
     float* w0t = w0 + 4096;          // transposed
@@ -355,6 +436,7 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
     float* rows_pr = w1 + 512;       // b_pr0 [64], w_pr1 [3][64]
     float* rows_pe = rows_pr + 256;  // encoder layer-0 columns 0..2
     int* ctr = reinterpret_cast<int*>(rows_pe + 192);
+    float* et = rows_pe + 192 + 4;   // COOP: [slot][receiver | sender][32][KMB_ROWS_LD]
     lds_fill(w0, mw + M_PR0, 4096);
     lds_fill(w0t, mb + MB_PR0, 4096);
     lds_fill(wagg, mb + MB_AGG, 3 * 4096);          // MB_AGG, MB_RPR, MB_RPS are consecutive
@@ -363,21 +445,50 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
     lds_fill(rows_pr, mw + R_PR0_B, 256);
     lds_fill(rows_pe, mb + RB_PE0, 192);
     if (threadIdx.x == 0) *ctr = KMB_FUSED_WAVES;
+#ifdef ROLLOUT_STAMPS
+    const bool roll_on = DUMP && threadIdx.x == 0;             // tools/train_stamps.py: wave 0 of every workgroup
+    unsigned long long roll_t = roll_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
     __syncthreads();
+    BWD_STAMP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int b0 = blockIdx.x * spw, nbw = min(spw, B - b0);
+    const int group = (int)blockIdx.x / parts, part = (int)blockIdx.x - group * parts;
+    const int b0 = group * spw, nbw = min(spw, B - b0);
     const int wg_rows = (nbw > 0 ? nbw : 0) * N;
     const int wg_tiles = (wg_rows + 31) >> 5;
     const float inv_N = 1.0f / (float)N;
     const size_t bn64 = (size_t)B * N * 64;
     const size_t bnk2 = (size_t)B * N * DRP_K * 2;
-    auto next_tile = [&]() {
+    // one workgroup per group: tiles on demand (a counter in LDS); several: dealt statically, workgroup-cyclic first (a
+    // handful of tiles: one per CU)
+    const int first_tile = parts > 1 ? part + wave * parts : wave;
+    auto next_tile = [&](int li) {
+        if (parts > 1) return li + parts * KMB_FUSED_WAVES;
         int q = 0;
         if (lane == 0) q = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return __builtin_amdgcn_readfirstlane(q);
     };
+    unsigned arrivals = 0;
     auto phase_end = [&]() {
+        if (parts > 1) {
+            __threadfence();                               // this wave's rows are in memory, device-wide
+            __syncthreads();
+            BWD_STAMP(5);
+            arrivals += (unsigned)parts;
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(bar + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(bar + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { *bar_err = 1u; break; }      // 2 s at 100 MHz
+                }
+            }
+            BWD_STAMP(6);
+            __syncthreads();
+            __threadfence();                               // nothing of the other workgroups' rows from this CU's L1
+            return;
+        }
         __syncthreads();                                   // this phase's rows of the workgroup's samples are written
         if (threadIdx.x == 0) *ctr = KMB_FUSED_WAVES;
         __syncthreads();
@@ -386,7 +497,7 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
     {
         const float* eff3 = eff_hist + 3 * bn64;
         float* g_agg2 = g_agg_hist + 2 * bn64;
-        for (int li = wave; li < wg_tiles; li = next_tile()) {
+        for (int li = first_tile; li < wg_tiles; li = next_tile(li)) {
             const bool live = (li * 32 + j) < wg_rows;
             const int r = min(li * 32 + j, wg_rows - 1);
             int m, i;
@@ -421,8 +532,13 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                 ge.v[1][q] = x.v[1][q] > 0.0f ? ge.v[1][q] : 0.0f;
             }
             if (live) {
-                frag_to_row(g_eff + row * 64, h, ge);
+                frag_to_row((DUMP ? dump.ge[0] : g_eff) + row * 64, h, ge);
                 frag_to_row(g_cnode + row * 64, h, ge);
+                if (DUMP) {
+                    frag_to_row(dump.gh + row * 64, h, gh);
+                    frag_relu(hh);
+                    frag_to_row(dump.hact + row * 64, h, hh);
+                }
             }
             Frag ga;
             frag_zero(ga);
@@ -433,76 +549,126 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
     // ---- phases p = 2, 1, 0
 #pragma unroll 1
     for (int p = DRP_PSTEP - 1; p >= 0; --p) {
+        BWD_STAMP(p == DRP_PSTEP - 1 ? 1 : 4);
         phase_end();
+        BWD_STAMP(2);
         const float* g_agg_p = g_agg_hist + (size_t)p * bn64;
         const unsigned* mask_p = mask_hist + (size_t)p * bnk2;
-        for (int li = wave; li < wg_tiles; li = next_tile()) {
+        const float* ge_rd = DUMP ? dump.ge[DRP_PSTEP - 1 - p] : g_eff;
+        float* ge_wr = DUMP ? dump.ge[p > 0 ? DRP_PSTEP - p : 0] : g_eff;
+        for (int k0 = 0, li = first_tile;; k0 += KMB_COOP_SLOTS) {
+            if (COOP) {
+                // a round: the edge terms of up to KMB_COOP_SLOTS of the workgroup's tiles (part, part + parts, ...) into LDS
+                if (part + k0 * parts >= wg_tiles) break;
+                if (k0 > 0) __syncthreads();                          // the last round's chains have read their slots
+#pragma unroll 1
+                for (int sl = 0; sl < KMB_COOP_SLOTS; ++sl) {
+                    const int lt = part + (k0 + sl) * parts;
+                    if (lt >= wg_tiles) break;
+                    const int rl = (int)threadIdx.x >> 4, q = (int)threadIdx.x & 15;
+                    const bool live_g = (lt * 32 + rl) < wg_rows;
+                    const int rr = min(lt * 32 + rl, wg_rows - 1);
+                    int m, i;
+                    divmod_small(rr, N, inv_N, m, i);
+                    const int b = b0 + m;
+                    const size_t srow0 = (size_t)b * N;
+                    const int* ro = rev_off + (size_t)b * (N + 1);
+                    float4 pr4, ps4;
+                    coop_edge_terms(g_agg_p, mask_p + srow0 * DRP_K * 2, rev + srow0 * DRP_K, ro[i], ro[i + 1], i, nbr_cnt[srow0 + i],
+                                    srow0, q, pr4, ps4);
+                    float* e_r = et + (size_t)(sl * 2) * 32 * KMB_ROWS_LD + rl * KMB_ROWS_LD + q * 4;
+                    *reinterpret_cast<float4*>(e_r) = pr4;
+                    *reinterpret_cast<float4*>(e_r + 32 * KMB_ROWS_LD) = ps4;
+                    if (DUMP && live_g) {
+                        float* gp = dump.gp[p] + (srow0 + i) * 128 + q * 4;
+                        *reinterpret_cast<float4*>(gp) = pr4;
+                        *reinterpret_cast<float4*>(gp + 64) = ps4;
+                    }
+                }
+                __syncthreads();
+                BWD_STAMP(3);
+                li = part + (k0 + wave) * parts;
+                if (wave >= KMB_COOP_SLOTS || li >= wg_tiles) continue;
+            } else {
+                if (k0 > 0) li = next_tile(li);
+                if (li >= wg_tiles) break;
+            }
             const bool live = (li * 32 + j) < wg_rows;
             const int r = min(li * 32 + j, wg_rows - 1);
             int m, i;
             divmod_small(r, N, inv_N, m, i);
             const int b = b0 + m;
             const size_t row = (size_t)b0 * N + r;
-            const size_t srow0 = (size_t)b * N;                       // first row of the lane's sample
-            // receiver term: g_agg[p][row] under the masks of the row's own slots, one addition per slot
-            Frag gi, pr, ps;
-            frag_from_row(g_agg_p + row * 64, h, gi);
-            frag_zero(pr);
-            frag_zero(ps);
-            const int cnt = nbr_cnt[row];
-            const int* ro = rev_off + (size_t)b * (N + 1);
-            const int p0 = ro[i], p1 = ro[i + 1];
-            const int* rv = rev + srow0 * DRP_K;
-            const unsigned* mk = mask_p + srow0 * DRP_K * 2;          // the sample's slots, word h of a slot at [slot * 2 + h]
-            int cmax = cnt, lmax = p1 - p0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                cmax = max(cmax, __shfl_xor(cmax, o, 64));
-                lmax = max(lmax, __shfl_xor(lmax, o, 64));
-            }
-            // the sender term's first entries are requested before the receiver term runs
-            const int nrev = p1 - p0;
-            int e0 = (0 < nrev) ? rv[p0] : 0;
-            int e1 = (1 < nrev) ? rv[p0 + 1] : 0;
-            {
-                // the row's ten mask words are independent loads: all in flight at once (a loop over k waited for each
-                // in turn -- ten L2 round trips per tile and phase)
-                unsigned wk[DRP_K];
-#pragma unroll
-                for (int k = 0; k < DRP_K; ++k) wk[k] = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + h] : 0u;
-                receiver_term(pr, gi, wk);
-            }
-            // sender term over the reversed list (ascending receiver, then slot), software-pipelined two deep: the
-            // mask word and the g_agg row of entry q0 + 1 and the index of entry q0 + 3 are requested before entry q0's
-            // row is added (the additions keep the list's order)
-            unsigned w_cur = (0 < nrev) ? mk[(size_t)e0 * 2 + h] : 0u;
-            Frag v_cur;
-            {
-                int er, ek;
-                divmod_small(e0, DRP_K, 0.1f, er, ek);
-                frag_from_row(g_agg_p + (srow0 + ((0 < nrev) ? er : i)) * 64, h, v_cur);
-            }
-            int e2 = (2 < nrev) ? rv[p0 + 2] : 0;
-            for (int q0 = 0; q0 < lmax; ++q0) {
-                const bool on_next = q0 + 1 < nrev;
-                const unsigned w_nxt = on_next ? mk[(size_t)e1 * 2 + h] : 0u;
-                Frag v_nxt;
+            Frag pr, ps;
+            if (COOP) {
+                gagg_lds_read(et + (size_t)(wave * 2) * 32 * KMB_ROWS_LD, j, h, pr);
+                gagg_lds_read(et + (size_t)(wave * 2 + 1) * 32 * KMB_ROWS_LD, j, h, ps);
+            } else {
+                const size_t srow0 = (size_t)b * N;                       // first row of the lane's sample
+                // receiver term: g_agg[p][row] under the masks of the row's own slots, one addition per slot
+                Frag gi;
+                frag_from_row(g_agg_p + row * 64, h, gi);
+                frag_zero(pr);
+                frag_zero(ps);
+                const int cnt = nbr_cnt[row];
+                const int* ro = rev_off + (size_t)b * (N + 1);
+                const int p0 = ro[i], p1 = ro[i + 1];
+                const int* rv = rev + srow0 * DRP_K;
+                const unsigned* mk = mask_p + srow0 * DRP_K * 2;          // the sample's slots, word h of a slot at [slot * 2 + h]
+                int cmax = cnt, lmax = p1 - p0;
+    #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    cmax = max(cmax, __shfl_xor(cmax, o, 64));
+                    lmax = max(lmax, __shfl_xor(lmax, o, 64));
+                }
+                // the sender term's first entries are requested before the receiver term runs
+                const int nrev = p1 - p0;
+                int e0 = (0 < nrev) ? rv[p0] : 0;
+                int e1 = (1 < nrev) ? rv[p0 + 1] : 0;
+                {
+                    // the row's ten mask words are independent loads: all in flight at once (a loop over k waited for each
+                    // in turn -- ten L2 round trips per tile and phase)
+                    unsigned wk[DRP_K];
+    #pragma unroll
+                    for (int k = 0; k < DRP_K; ++k) wk[k] = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + h] : 0u;
+                    receiver_term(pr, gi, wk);
+                }
+                // sender term over the reversed list (ascending receiver, then slot), software-pipelined two deep: the
+                // mask word and the g_agg row of entry q0 + 1 and the index of entry q0 + 3 are requested before entry q0's
+                // row is added (the additions keep the list's order)
+                unsigned w_cur = (0 < nrev) ? mk[(size_t)e0 * 2 + h] : 0u;
+                Frag v_cur;
                 {
                     int er, ek;
-                    divmod_small(e1, DRP_K, 0.1f, er, ek);
-                    frag_from_row(g_agg_p + (srow0 + (on_next ? er : i)) * 64, h, v_nxt);
+                    divmod_small(e0, DRP_K, 0.1f, er, ek);
+                    frag_from_row(g_agg_p + (srow0 + ((0 < nrev) ? er : i)) * 64, h, v_cur);
                 }
-                const int e3 = (q0 + 3 < nrev) ? rv[p0 + q0 + 3] : 0;
-                frag_add_masked(ps, v_cur, w_cur);
-                w_cur = w_nxt;
-                v_cur = v_nxt;
-                e1 = e2;
-                e2 = e3;
+                int e2 = (2 < nrev) ? rv[p0 + 2] : 0;
+                for (int q0 = 0; q0 < lmax; ++q0) {
+                    const bool on_next = q0 + 1 < nrev;
+                    const unsigned w_nxt = on_next ? mk[(size_t)e1 * 2 + h] : 0u;
+                    Frag v_nxt;
+                    {
+                        int er, ek;
+                        divmod_small(e1, DRP_K, 0.1f, er, ek);
+                        frag_from_row(g_agg_p + (srow0 + (on_next ? er : i)) * 64, h, v_nxt);
+                    }
+                    const int e3 = (q0 + 3 < nrev) ? rv[p0 + q0 + 3] : 0;
+                    frag_add_masked(ps, v_cur, w_cur);
+                    w_cur = w_nxt;
+                    v_cur = v_nxt;
+                    e1 = e2;
+                    e2 = e3;
+                }
+                frag_settle(ps);
+                if (DUMP && live) {
+                    frag_to_row(dump.gp[p] + row * 128, h, pr);
+                    frag_to_row(dump.gp[p] + row * 128 + 64, h, ps);
+                }
             }
             // projection backward: g_eff += W_r^T (receiver term) + W_s^T (sender term)
             Frag ge;
-            frag_from_row(g_eff + row * 64, h, ge);
-            frag_settle(ps);
+            frag_from_row(ge_rd + row * 64, h, ge);
             mfma_layer64<false>(reinterpret_cast<const float4*>(wr), pr, ge, lane);
             mfma_layer64<false>(reinterpret_cast<const float4*>(ws), ps, ge, lane);
             if (p > 0) {
@@ -514,7 +680,7 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                     ge.v[0][q] = en.v[0][q] > 0.0f ? ge.v[0][q] : 0.0f;
                     ge.v[1][q] = en.v[1][q] > 0.0f ? ge.v[1][q] : 0.0f;
                 }
-                if (live) frag_to_row(g_eff + row * 64, h, ge);
+                if (live) frag_to_row(ge_wr + row * 64, h, ge);
                 frag_from_row(g_cnode + row * 64, h, en);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { en.v[0][q] += ge.v[0][q]; en.v[1][q] += ge.v[1][q]; }
@@ -568,9 +734,23 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                     g_sdelta[row * 3 + 1] = out[1];
                     g_sdelta[row * 3 + 2] = out[2];
                 }
+                if (DUMP && live) {
+                    frag_to_row(dump.gpe + row * 64, h, ge);
+                    frag_to_row(dump.gh1 + row * 64, h, gh);
+                    frag_relu(h1);
+                    frag_to_row(dump.a1n + row * 64, h, h1);
+                    if (h == 0) {
+                        float* dx = dump.xn + row * 8;
+                        dx[0] = sd[0]; dx[1] = sd[1]; dx[2] = sd[2]; dx[3] = at; dx[4] = d; dx[5] = 0.0f; dx[6] = 0.0f; dx[7] = 0.0f;
+                    }
+                }
             }
         }
     }
+#ifdef ROLLOUT_STAMPS
+    BWD_STAMP(4);
+    if (roll_on) atomicAdd(&g_bwd_stamps[15], 1ull);
+#endif
 }
 
 
@@ -588,18 +768,6 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
 // encoder's two (transposed) from then on, refilled per group.  Same sums in the same order as kmb_step_bwd: same bits.
 #define KMB_ROWS_MAX 256
 #define KMB_ROWS_LDS ((size_t)(3 * 1536 * 4 + KMB_ROWS_MAX * KMB_ROWS_LD + 512 + 256 + 192) * sizeof(float))
-#define KMB_ROWS_LD 68            // floats per g_agg row in LDS: 17 float4 -- consecutive rows start four banks apart
-__device__ __forceinline__ void gagg_lds_read(const float* gl, int r, int h, Frag& f) { frag_from_row(gl + r * KMB_ROWS_LD, h, f); }
-__device__ __forceinline__ void gagg_lds_write(float* gl, int r, int h, const Frag& f) { frag_to_row(gl + r * KMB_ROWS_LD, h, f); }
-#ifdef ROLLOUT_STAMPS
-// Diagnostic build only (tools/bwd_stamps.py): 100 MHz wall stamps between the phases of a group, summed by wave 0 of
-// every 32nd workgroup
-__device__ unsigned long long g_bwd_stamps[16];
-#define BWD_STAMP(q) do { if (roll_on) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
-                                         atomicAdd(&g_bwd_stamps[q], now_ - roll_t); roll_t = now_; } } while (0)
-#else
-#define BWD_STAMP(q) do { } while (0)
-#endif
 // one 64 x 64 layer on the six-product bf16 split: acc += W in, W packed as pack_split6 / kt_repack_split6_bwd
 __device__ __forceinline__ void rows_layer(const bf16x8* __restrict__ wp, const Frag& in, Frag& acc, int lane) {
     FragB6 b;

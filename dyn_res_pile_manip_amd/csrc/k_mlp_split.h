@@ -72,6 +72,23 @@ inline double split_range_bound(const SplitRange& r, double A, double D, double 
     for (int o = 0; o < 64; ++o) h3 = fmax(h3, r.rs4[o] * h2 + r.b4[o]);
     return fmax(fmax(h1, h2), fmax(h3, 1.0));      // 1.0: the constant input column of the first layer
 }
+// k: 2^k bound <= 2^15, a factor two under fp16's end.  floor(log2(32768 / bound)) read off the quotient's exponent field
+// (exact, and the same instruction sequence on host and device: kt_repack_all derives the shift after an optimiser step)
+#define SPLIT_ENV_ATTR 2.0
+#define SPLIT_ENV_DELTA 1.5
+#define SPLIT_ENV_DENS 2.0
+__host__ __device__ inline int range_shift_of(double bound) {
+    const double x = 32768.0 / bound;
+    if (!(x > 0.0)) return -60;                       // bound = inf or NaN
+    unsigned long long u;
+    memcpy(&u, &x, sizeof(u));
+    const int e = (int)((u >> 52) & 0x7ffu);
+    if (e == 0x7ff) return 14;                        // bound = 0 cannot happen (>= 1.0), kept total
+    int k = e - 1023;                                 // subnormal quotients read -1023: clamped below
+    if (k > 14) k = 14;
+    if (k < -60) k = -60;
+    return k;
+}
 inline void split_range_init(const float* w, SplitRange& r, double A, double D, double dm) {
     r.wmax = 0.0f;
     // fmaxf / fmax drop a NaN operand, so the sums and maxima below would let NaN weights through as a finite bound:
@@ -99,10 +116,7 @@ inline void split_range_init(const float* w, SplitRange& r, double A, double D, 
     }
     r.env_attr = (float)A; r.env_delta = (float)D; r.env_dens = (float)dm;
     const double bound = split_range_bound(r, A, D, dm);
-    int k = (int)floor(log2(32768.0 / bound));       // 2^k bound <= 2^15: a factor two under fp16's end
-    if (k > 14) k = 14;
-    if (k < -60) k = -60;
-    r.shift = k;
+    r.shift = range_shift_of(bound);
 }
 
 inline uint16_t host_bf16_rne(float f) {

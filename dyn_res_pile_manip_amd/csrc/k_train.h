@@ -11,18 +11,19 @@
 #include "drp_common.h"
 #include "k_mlp_split.h"
 
-// d loss / d s_pred_t and the loss itself.  particle_nums[b] real particles per sample, the rest of
-// the N rows are padding (zero rows at the origin, never connected to a real particle).
+// d loss / d s_pred_t and the loss itself, every rollout step in one launch (grid B x H; blockIdx.y = t: the states of
+// step t sit t * N * 3 floats into a sample's block, on both sides).  particle_nums[b] real particles per sample, the rest
+// of the N rows are padding (zero rows at the origin, never connected to a real particle).
 __global__ void __launch_bounds__(256)
 kt_mse_grad(const float* __restrict__ s_pred, size_t pred_stride, const float* __restrict__ s_nxt, size_t nxt_stride,
-            const int* __restrict__ particle_nums, int N, float scale, float* __restrict__ g_out,
-            double* __restrict__ loss) {
+            const int* __restrict__ particle_nums, int N, float scale, float* __restrict__ g_out /* [H][B][N][3] */,
+            double* __restrict__ loss /* [H][B] */) {
     __shared__ double s_w[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, t = blockIdx.y, B = gridDim.x;
     const int nb = particle_nums[b];
-    const float* p = s_pred + (size_t)b * pred_stride;
-    const float* q = s_nxt + (size_t)b * nxt_stride;
-    float* g = g_out + (size_t)b * N * 3;
+    const float* p = s_pred + (size_t)b * pred_stride + (size_t)t * N * 3;
+    const float* q = s_nxt + (size_t)b * nxt_stride + (size_t)t * N * 3;
+    float* g = g_out + ((size_t)t * B + b) * N * 3;
     const float inv = scale / (float)(3 * nb);
     double acc = 0.0;
     for (int i = threadIdx.x; i < N * 3; i += 256) {
@@ -38,7 +39,28 @@ kt_mse_grad(const float* __restrict__ s_pred, size_t pred_stride, const float* _
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss[b] = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) * (double)inv;   // one slot per (step, sample)
+    if (threadIdx.x == 0) loss[(size_t)t * B + b] = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) * (double)inv;   // one slot per (step, sample)
+}
+
+// A training batch arrives as ONE copy (pinned staging -> arena: states | impulses | attributes | densities | particle counts,
+// the caller's layouts).  The states and the counts are read where they land; this launch puts the rest where the step
+// kernels expect it: the impulses step-major ([H][B][N][3]: a step's slice is the s_delta of that step, and the tape's),
+// a_cur = attrs[:, 0] (train/train_gnn_dyn.py:173), the densities.
+__global__ void __launch_bounds__(256)
+kt_unpack_inputs(const float* __restrict__ sdelta_in /* [B][H][N][3] */, const float* __restrict__ attrs_in /* [B][H+1][N] */,
+                 const float* __restrict__ dens_in, int B, int H, int N, float* __restrict__ sdelta_out /* [H][B][N][3] */,
+                 float* __restrict__ attr_out /* [B][N] */, float* __restrict__ dens_out) {
+    const size_t n3 = (size_t)N * 3, total = (size_t)B * H * n3;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t bt = e / n3, r = e - bt * n3;
+        const int b = (int)(bt / H), t = (int)(bt - (size_t)b * H);
+        sdelta_out[((size_t)t * B + b) * n3 + r] = sdelta_in[e];
+        if (e < (size_t)B * N) {
+            const int ab = (int)(e / N), ai = (int)(e - (size_t)ab * N);
+            attr_out[e] = attrs_in[(size_t)ab * (H + 1) * N + ai];
+        }
+        if (e < (size_t)B) dens_out[e] = dens_in[e];
+    }
 }
 
 __global__ void kt_add(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
@@ -404,11 +426,14 @@ __global__ void __launch_bounds__(1024) kt_colsum3(const float* __restrict__ g, 
 // repeat pack_split / pack_split6 element by element (same rounding: RNE to fp16 by the conversion instruction, RNE to
 // bf16 by the integer rule of host_bf16_rne; residuals in fp32); tests/test_gpu_train.py compares all five with the
 // host packers byte by byte.
-__global__ void kt_repack_gather(const float* __restrict__ w, const int* __restrict__ map, float* __restrict__ dst, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void repack_gather_block(const float* __restrict__ w, const int* __restrict__ map, float* __restrict__ dst, int n, int blk) {
+    const int i = blk * 256 + threadIdx.x;
     if (i >= n) return;
     const int m = map[i];
     dst[i] = m > 0 ? w[m - 1] : (m == 0 ? 0.0f : -1e30f);
+}
+__global__ void kt_repack_gather(const float* __restrict__ w, const int* __restrict__ map, float* __restrict__ dst, int n) {
+    repack_gather_block(w, map, dst, n, (int)blockIdx.x);
 }
 
 __device__ __forceinline__ uint16_t dev_f16_rne(float f) {
@@ -431,7 +456,9 @@ __device__ __forceinline__ int dev_split_feature(int s, int h, int jj) {
 // pack_split (k_mlp_split.h) on the device: grid.x = 4 jobs (RE0, RE2, RE4, RPE) x 16 blocks of 256 threads;
 // one thread per (ob, s, lane, jj) of a 64x64 matrix (4096), per (ob, lane, jj) of the first layer (1024)
 __global__ void __launch_bounds__(256)
-kt_repack_split(const float* __restrict__ w, int shift, uint16_t* __restrict__ out) {
+kt_repack_split(const float* __restrict__ w, int shift, uint16_t* __restrict__ out,
+                const int* __restrict__ shift_dev = nullptr /* nullable: the shift kt_repack_all derived from these weights */) {
+    if (shift_dev != nullptr) shift = *shift_dev;
     const int job = blockIdx.x >> 4, e = (blockIdx.x & 15) * 256 + threadIdx.x;
     if (job == 0) {
         if (e < 1024) {
@@ -480,9 +507,8 @@ enum {                        // units of bf16x8, [part 3][ob 2][s 4][lane 64] e
     SB6_PE2 = SB6_PPE + 1536,
     SB6_TOTAL = SB6_PE2 + 1536
 };
-__global__ void __launch_bounds__(256)
-kt_repack_split6_bwd(const float* __restrict__ w, uint16_t* __restrict__ out) {
-    const int job = blockIdx.x >> 4, e = (blockIdx.x & 15) * 256 + threadIdx.x;
+__device__ __forceinline__ void repack_split6_bwd_block(const float* __restrict__ w, uint16_t* __restrict__ out, int blk) {
+    const int job = blk >> 4, e = (blk & 15) * 256 + threadIdx.x;
     const int dsts[6] = {SB6_AGG, SB6_RPR, SB6_RPS, SB6_PR0, SB6_PPE, SB6_PE2};
     const int srcs[6] = {W_PP_W, W_RP_W, W_RP_W, W_PR0_W, W_PP_W, W_PE2_W};
     const int lds_[6] = {129, 193, 193, 64, 129, 64};
@@ -499,10 +525,12 @@ kt_repack_split6_bwd(const float* __restrict__ w, uint16_t* __restrict__ out) {
     }
 }
 
-// pack_split6 on the device: grid.x = 7 jobs (AGG, RPR, RPS, PR0, PE2, PPE, PE0) x 16 blocks
 __global__ void __launch_bounds__(256)
-kt_repack_split6(const float* __restrict__ w, uint16_t* __restrict__ out) {
-    const int job = blockIdx.x >> 4, e = (blockIdx.x & 15) * 256 + threadIdx.x;
+kt_repack_split6_bwd(const float* __restrict__ w, uint16_t* __restrict__ out) { repack_split6_bwd_block(w, out, (int)blockIdx.x); }
+
+// pack_split6 on the device: grid.x = 7 jobs (AGG, RPR, RPS, PR0, PE2, PPE, PE0) x 16 blocks
+__device__ __forceinline__ void repack_split6_block(const float* __restrict__ w, uint16_t* __restrict__ out, int blk) {
+    const int job = blk >> 4, e = (blk & 15) * 256 + threadIdx.x;
     if (job == 6) {
         if (e >= 1024) return;
         const int jj = e & 7, lane = (e >> 3) & 63, ob = e >> 9;
@@ -532,4 +560,66 @@ kt_repack_split6(const float* __restrict__ w, uint16_t* __restrict__ out) {
         out[((size_t)dst + ((part * 2 + ob) * 4 + s) * 64 + lane) * 8 + jj] = q;
         v -= dev_bf16_to_f32(q);
     }
+}
+__global__ void __launch_bounds__(256)
+kt_repack_split6(const float* __restrict__ w, uint16_t* __restrict__ out) { repack_split6_block(w, out, (int)blockIdx.x); }
+
+// The range shift of the split relation encoder from the weights, on the device: split_range_init + split_range_bound
+// (k_mlp_split.h) operation by operation -- the same float sums in the same order, the same double products and maxima,
+// range_shift_of's exponent read -- so that host and device agree on k (the host still compares, capi_train.h).
+// One workgroup of 256 threads; thread o < 64 owns row o.
+__device__ __forceinline__ void split_range_shift_block(const float* __restrict__ w, int forced, int* __restrict__ shift_out) {
+    __shared__ double s_h[64];
+    __shared__ float s_rs2[64], s_b2[64], s_rs4[64], s_b4[64];
+    const int o = threadIdx.x;
+    if (o < 64) {
+        const float* w1 = w + W_RE0_W + o * 6;
+        const float a1 = fabsf(w1[0]) + fabsf(w1[1]);
+        const float d1 = fabsf(w1[2]) + fabsf(w1[3]) + fabsf(w1[4]);
+        const float m1 = fabsf(w1[5]);
+        const float b1 = fabsf(w[W_RE0_B + o]);
+        float s2 = 0, s4 = 0;
+        for (int k = 0; k < 64; ++k) {
+            s2 += fabsf(w[W_RE2_W + o * 64 + k]);
+            s4 += fabsf(w[W_RE4_W + o * 64 + k]);
+        }
+        s_rs2[o] = s2; s_b2[o] = fabsf(w[W_RE2_B + o]);
+        s_rs4[o] = s4; s_b4[o] = fabsf(w[W_RE4_B + o]);
+        s_h[o] = a1 * SPLIT_ENV_ATTR + d1 * SPLIT_ENV_DELTA + m1 * SPLIT_ENV_DENS + b1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double h1 = 0, h2 = 0, h3 = 0;
+        for (int q = 0; q < 64; ++q) h1 = fmax(h1, s_h[q]);
+        for (int q = 0; q < 64; ++q) h2 = fmax(h2, s_rs2[q] * h1 + s_b2[q]);
+        for (int q = 0; q < 64; ++q) h3 = fmax(h3, s_rs4[q] * h2 + s_b4[q]);
+        const double bound = fmax(fmax(h1, h2), fmax(h3, 1.0));
+        *shift_out = forced != 0x7fffffff ? forced : range_shift_of(bound);
+    }
+}
+
+// Everything that follows an optimiser step except the shifted fp16 fragments, in ONE launch: the three gathered copies,
+// the two bf16 splits, the range shift (the last block).  kt_repack_split then reads the shift from memory.
+struct RepackAll {
+    const int* map_v; float* dst_v; int n_v;
+    const int* map_m; float* dst_m; int n_m;
+    const int* map_mb; float* dst_mb; int n_mb;
+    uint16_t* out6; uint16_t* out6b;
+    int forced_shift; int* shift_out;
+};
+#define KT_REPACK_ALL_BLOCKS(nv, nm, nmb) (((nv) + 255) / 256 + ((nm) + 255) / 256 + ((nmb) + 255) / 256 + 7 * 16 + 6 * 16 + 1)
+__global__ void __launch_bounds__(256)
+kt_repack_all(const float* __restrict__ w, RepackAll a) {
+    int blk = (int)blockIdx.x;
+    const int bv = (a.n_v + 255) / 256, bm = (a.n_m + 255) / 256, bmb = (a.n_mb + 255) / 256;
+    if (blk < bv) { repack_gather_block(w, a.map_v, a.dst_v, a.n_v, blk); return; }
+    blk -= bv;
+    if (blk < bm) { repack_gather_block(w, a.map_m, a.dst_m, a.n_m, blk); return; }
+    blk -= bm;
+    if (blk < bmb) { repack_gather_block(w, a.map_mb, a.dst_mb, a.n_mb, blk); return; }
+    blk -= bmb;
+    if (blk < 7 * 16) { repack_split6_block(w, a.out6, blk); return; }
+    blk -= 7 * 16;
+    if (blk < 6 * 16) { repack_split6_bwd_block(w, a.out6b, blk); return; }
+    split_range_shift_block(w, a.forced_shift, a.shift_out);
 }

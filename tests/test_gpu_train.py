@@ -218,6 +218,9 @@ def test_deferred_weight_gradients_equal_the_flushed_ones(golden, monkeypatch, c
     g = golden.train
     batch = _batch(g, case)
     lr, beta1 = g[case + '/lr_beta1']
+    # the stage kernels on both sides (the deferred jobs' default producer, kmb_step_bwd<dump>, adds the receiver term by bit
+    # planes: last-bit differences from kb_edge_terms; test_the_one_launch_backward_pass_of_the_trainer compares the two)
+    monkeypatch.setenv('DRP_NO_BWD_FUSED', '1')
     for valu in (False, True):
         runs = []
         for flushed in (False, True):
@@ -261,3 +264,48 @@ def test_training_through_the_valu_stage_kernels(golden, monkeypatch):
         ref = g[case + '/grad/' + k]
         scale = max(np.abs(ref).max(), 1e-8)
         assert np.abs(np.asarray(got[k]).reshape(ref.shape) - ref).max() < 2e-4 * scale + 1e-9, k
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_the_one_launch_backward_pass_of_the_trainer(golden, monkeypatch, case):
+    """Default: one launch per rollout step for everything between the loss gradient and the relation encoder's backward
+    (kmb_step_bwd<dump, coop>: a group of samples shared by as many workgroups as there are CUs for, a barrier in memory
+    between the phases; the edge terms of a tile gathered by the whole workgroup).  Against the stage kernels
+    (DRP_NO_BWD_FUSED=1): the same loss bit for bit (the forward pass is the same), the gradients to rounding.  And the SAME
+    BITS however the tiles are dealt and the edge terms gathered: one workgroup per group (DRP_TRAIN_PARTS=1: tiles on demand,
+    __syncthreads between the phases) or three, a wave's own gather (DRP_TRAIN_COOP=0) or the workgroup's."""
+    g = golden.train
+    batch = _batch(g, case)
+    lr, beta1 = g[case + '/lr_beta1']
+    runs = {}
+    variants = (('default', {}), ('one', {'DRP_TRAIN_PARTS': '1'}), ('three', {'DRP_TRAIN_PARTS': '3'}),
+                ('wave', {'DRP_TRAIN_COOP': '0'}), ('wave-one', {'DRP_TRAIN_COOP': '0', 'DRP_TRAIN_PARTS': '1'}),
+                ('coop-one', {'DRP_TRAIN_COOP': '1', 'DRP_TRAIN_PARTS': '1'}), ('stages', {'DRP_NO_BWD_FUSED': '1'}))
+    for name, env in variants:
+        for k in ('DRP_TRAIN_PARTS', 'DRP_TRAIN_COOP', 'DRP_NO_BWD_FUSED'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model = _model(golden)
+        eng = model.engine
+        eng.train_begin(batch[0].shape[1] - 1, float(lr), float(beta1))
+        eng.dispatch_reset()
+        loss, grad = eng.train_step(*batch, mode='grad', want_grad=True)
+        ran = eng.last_dispatch()
+        losses = [eng.train_step(*batch, mode='update')[0] for _ in range(3)]
+        runs[name] = (loss, grad, losses, eng.get_weights(), ran)
+        eng.close()
+    assert 'train:kmb_step_bwd<dump,coop>' in runs['default'][4] and 'train:stages kmb_*' not in runs['default'][4], runs['default'][4]
+    assert "train:kmb_step_bwd<dump>" in list(runs["wave"][4]), runs["wave"][4]
+    assert 'train:stages kmb_*' in runs['stages'][4] and 'train:kmb_step_bwd' not in runs['stages'][4], runs['stages'][4]
+    for other in ('one', 'three', 'wave', 'wave-one', 'coop-one'):
+        assert runs[other][0] == runs['default'][0] and runs[other][2] == runs['default'][2], other
+        np.testing.assert_array_equal(runs[other][1], runs['default'][1], err_msg=other)
+        np.testing.assert_array_equal(runs[other][3], runs['default'][3], err_msg=other)
+    assert runs['stages'][0] == runs['default'][0]
+    a = weights.state_dict_from_blob(runs['stages'][1])
+    b = weights.state_dict_from_blob(runs['default'][1])
+    for k, _ in weights.STATE_DICT_KEYS:
+        scale = max(np.abs(np.asarray(a[k])).max(), 1e-8)
+        assert np.abs(np.asarray(a[k]) - np.asarray(b[k])).max() < 2e-5 * scale, k
+    np.testing.assert_allclose(runs['default'][2], runs['stages'][2], rtol=1e-4)
