@@ -77,9 +77,9 @@ void dv_name(int id, char* buf, size_t n, bool* by_default) {
         case DV_BWD_STAGES_VALU: s = "bwd:stages kb_*"; dflt = false; break;              // DRP_BWD_VALU_STAGES=1 (KMB_MIN_TILES is 1 since round 3)
         case DV_BWD_EDGE_MFMA: s = "bwd:kmb_edge_encode"; break;
         case DV_BWD_EDGE_VALU: s = "bwd:kb_edge_encode"; dflt = false; break;
-        case DV_TRAIN_NODE_FUSED: s = "train:kmb_step_bwd<dump>"; break;
+        case DV_TRAIN_NODE_FUSED: s = "train:kmb_step_bwd<dump>"; dflt = false; break;    // DRP_TRAIN_COOP=0 (by default a workgroup of the one-launch pass has one tile)
         case DV_TRAIN_NODE_FUSED_COOP: s = "train:kmb_step_bwd<dump,coop>"; break;
-        case DV_TRAIN_NODE_MFMA: s = "train:stages kmb_*"; dflt = false; break;          // DRP_NO_BWD_FUSED=1 / DRP_NO_WGRAD_DEFER=1
+        case DV_TRAIN_NODE_MFMA: s = "train:stages kmb_*"; break;
         case DV_TRAIN_NODE_VALU: s = "train:stages kb_*"; dflt = false; break;
         case DV_WGRAD_MFMA: s = "train:kt_wgrad_mfma"; break;
         case DV_WGRAD_VALU: s = "train:kt_wgrad"; dflt = false; break;

@@ -82,7 +82,8 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     CHK(rc);
     // the loss of every step and d loss / d s_pred_t (train/train_gnn_dyn.py:184-186, :203) in one launch
     hipLaunchKernelGGL(kt_mse_grad, dim3(B, H), dim3(256), 0, st, states, hstride, given + (size_t)N * 3, in_stride,
-                       nums, N, scale, g_state, loss);
+                       nums, N, scale, g_state, loss, backward ? ptr<float>(c->tr_grad) : (float*)nullptr,
+                       (size_t)TR_GRAD_PAD + (size_t)H * c->n_cu + 1);      // the gradient blob with kmb_step_bwd's counters behind it
     HIPCHK(c, hipGetLastError());
     if (!backward) return DRP_OK;
 
@@ -99,7 +100,6 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     const int chunks = pick(4), chunks16 = pick(16);
     const dim3 rgrid((unsigned)(B * chunks)), egrid((unsigned)(B * chunks16));
     const float* dens = ptr<float>(c->dens);
-    HIPCHK(c, hipMemsetAsync(G, 0, ((size_t)TR_GRAD_PAD + (size_t)H * c->n_cu + 1) * sizeof(float), st));    // with kmb_step_bwd's counters behind it
     // the reversed lists of ALL rollout steps in one launch (the tape holds every step's lists; a training batch is a handful
     // of workgroups per step)
     c->dv(N <= 512 ? DV_REV_256 : DV_REV_1024);

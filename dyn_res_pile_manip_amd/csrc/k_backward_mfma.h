@@ -375,12 +375,41 @@ __device__ __forceinline__ float plane_sum(int n, float g) {
 __device__ __forceinline__ void coop_edge_terms(const float* g_agg_p, const unsigned* __restrict__ mk /* the sample's slots */,
                                                 const int* __restrict__ rv, int p0, int p1, int i, int cnt, size_t srow0, int q,
                                                 float4& pr, float4& ps) {
+    // Every load that does not depend on another is requested before the first wait: the list's first eight entries, the
+    // row's own mask words and g_agg row; then per batch of eight entries their mask words and rows TOGETHER with the next
+    // batch's entries -- one L2 round trip per eight entries instead of two per four
+    constexpr int W = 8;
     const float4* ga = reinterpret_cast<const float4*>(g_agg_p);
+    int e[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) e[u] = (p0 + u < p1) ? rv[p0 + u] : -1;
     const float4 gi = ga[(srow0 + i) * 16 + q];
     unsigned wk[DRP_K];
 #pragma unroll
     for (int k = 0; k < DRP_K; ++k) wk[k] = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + (q & 1)] : 0u;
     const int sh = 28 - 16 * (q >> 3) - 4 * ((q >> 1) & 3);
+    ps = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pp = p0; pp < p1; pp += W) {
+        unsigned w[W];
+        float4 v[W];
+        int en[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const int ee = e[u] < 0 ? 0 : e[u];
+            w[u] = e[u] < 0 ? 0u : (mk[(size_t)ee * 2 + (q & 1)] >> sh) & 0xfu;
+            v[u] = ga[(srow0 + ee / DRP_K) * 16 + q];
+        }
+#pragma unroll
+        for (int u = 0; u < W; ++u) en[u] = (pp + W + u < p1) ? rv[pp + W + u] : -1;
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            ps.x += (w[u] & 8u) ? v[u].x : 0.0f;
+            ps.y += (w[u] & 4u) ? v[u].y : 0.0f;
+            ps.z += (w[u] & 2u) ? v[u].z : 0.0f;
+            ps.w += (w[u] & 1u) ? v[u].w : 0.0f;
+            e[u] = en[u];
+        }
+    }
     int nx = 0, ny = 0, nz = 0, nw = 0;
 #pragma unroll
     for (int k = 0; k < DRP_K; ++k) {
@@ -388,27 +417,6 @@ __device__ __forceinline__ void coop_edge_terms(const float* g_agg_p, const unsi
         nx += (nib >> 3) & 1; ny += (nib >> 2) & 1; nz += (nib >> 1) & 1; nw += nib & 1;
     }
     pr = make_float4(plane_sum(nx, gi.x), plane_sum(ny, gi.y), plane_sum(nz, gi.z), plane_sum(nw, gi.w));
-    ps = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int pp = p0; pp < p1; pp += 4) {
-        int e[4];
-        unsigned w[4];
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = (pp + u < p1) ? rv[pp + u] : -1;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int ee = e[u] < 0 ? 0 : e[u];
-            w[u] = e[u] < 0 ? 0u : (mk[(size_t)ee * 2 + (q & 1)] >> sh) & 0xfu;
-            v[u] = ga[(srow0 + ee / DRP_K) * 16 + q];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            ps.x += (w[u] & 8u) ? v[u].x : 0.0f;
-            ps.y += (w[u] & 4u) ? v[u].y : 0.0f;
-            ps.z += (w[u] & 2u) ? v[u].z : 0.0f;
-            ps.w += (w[u] & 1u) ? v[u].w : 0.0f;
-        }
-    }
 }
 #define KMB_COOP_SLOTS 2
 #define KMB_COOP_LDS (KMB_FUSED_LDS + (size_t)KMB_COOP_SLOTS * 2 * 32 * KMB_ROWS_LD * sizeof(float))

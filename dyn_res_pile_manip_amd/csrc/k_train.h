@@ -17,9 +17,13 @@
 __global__ void __launch_bounds__(256)
 kt_mse_grad(const float* __restrict__ s_pred, size_t pred_stride, const float* __restrict__ s_nxt, size_t nxt_stride,
             const int* __restrict__ particle_nums, int N, float scale, float* __restrict__ g_out /* [H][B][N][3] */,
-            double* __restrict__ loss /* [H][B] */) {
+            double* __restrict__ loss /* [H][B] */, float* __restrict__ zero /* nullable */, size_t n_zero) {
     __shared__ double s_w[4];
     const int b = blockIdx.x, t = blockIdx.y, B = gridDim.x;
+    // with a backward pass to follow: the gradient blob (and the counters behind it) start at zero -- here instead of a
+    // memset of their own (two fill launches)
+    if (zero != nullptr)
+        for (size_t e = ((size_t)t * B + b) * 256 + threadIdx.x; e < n_zero; e += (size_t)gridDim.x * gridDim.y * 256) zero[e] = 0.0f;
     const int nb = particle_nums[b];
     const float* p = s_pred + (size_t)b * pred_stride + (size_t)t * N * 3;
     const float* q = s_nxt + (size_t)b * nxt_stride + (size_t)t * N * 3;

@@ -218,7 +218,9 @@ def test_gradient_shape_against_the_oracle(eng, shape, exact_goal_transform):
     eng.set_engine(_lib.ENGINE_FUSED)
 
 
-TRAIN_SHAPES = [([40, 64, 25, 64], 3, 'fused'), ([300, 120], 2, 'fused'), ([30, 12], 2, 'mfma'), ([200, 180, 90, 200, 150, 60, 200, 10], 2, 'fused')]
+# up to n_cu / 4 tiles of 32 rows the node stages of a rollout step are one launch (kmb_step_bwd<dump, coop>), beyond the stage kernels
+TRAIN_SHAPES = [([40, 64, 25, 64], 3, 'fused'), ([300, 120], 2, 'fused'), ([30, 12], 2, 'mfma'), ([200, 180, 90, 200, 150, 60, 200, 10], 2, 'fused'),
+                ([300, 280, 150, 290, 300, 40, 260, 300], 1, 'fused')]
 
 
 @pytest.mark.parametrize('shape', TRAIN_SHAPES, ids=lambda s: 'train-%s-r%d-%s' % ('_'.join(map(str, s[0])), s[1], s[2]))
@@ -238,6 +240,10 @@ def test_training_shape_against_the_oracle(eng, golden, shape):
     eng.train_begin(T, 1e-3, 0.9)
     eng.dispatch_reset()
     loss, grad = eng.train_step(states, sdelta, attrs, pn, dens, mode='grad', want_grad=True)
+    # the same batch again (the weight-gradient jobs' table is the cached one now): the same bits
+    loss2, grad2 = eng.train_step(states, sdelta, attrs, pn, dens, mode='grad', want_grad=True)
+    assert loss2 == loss
+    np.testing.assert_array_equal(grad2, grad)
     note(eng, 'train %s r%d %s' % (nums, T, engine))
     Wd = {k[2:]: golden.weights_trained[k] for k in golden.weights_trained.files if k.startswith('w/')}
     ref_loss, ref_grads = od.train_loss_and_grads(Wd, states, sdelta, attrs, pn, dens)
