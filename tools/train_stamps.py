@@ -1,5 +1,5 @@
 """Where the trainer's one-launch backward pass (kmb_step_bwd<dump, coop>) spends its time, from a diagnostic build:
-  python __graft_entry__.py --lib tools/bin/libdrp_rstamps.so -DROLLOUT_STAMPS ;  DRP_LIB=tools/bin/libdrp_rstamps.so python tools/train_stamps.py [shape]
+  python __graft_entry__.py --lib tools/bin/libdrp_ts.so -DROLLOUT_STAMPS ;  DRP_LIB=tools/bin/libdrp_ts.so python tools/train_stamps.py [shape]   (tools/bin/ is git-ignored; this name travels to the GPU box)
 100 MHz wall stamps of thread 0 of every workgroup, per launch."""
 import ctypes
 import sys
