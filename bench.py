@@ -721,6 +721,49 @@ def run_mpc_step(rig, fence):
     return out
 
 
+def run_train_step(rig, fence):
+    """One iteration of train/train_gnn_dyn.py:159-210 on the device (row f4): the reference's batch (config/train/gnn_dyn.yaml:
+    batch_size 4, n_rollout 5) of synthetic push episodes, zero-padded as collate_fn pads; upload, five steps forward with the
+    tape, loss, backward through time, every weight gradient, Adam, the packed copies of the weights rebuilt.  Timed over >= 0.5 s
+    in batches of 20 iterations: the same batch every iteration (the shape every per-iteration table is cached for) and eight
+    batches of different sizes in turn (what a training run does).  The engine gets its weights back afterwards."""
+    from dyn_res_pile_manip_amd import synthetic as syn, weights
+    eng = rig.eng
+    H = 5
+    fixed = syn.push_batch(0, 4, H, sizes=(300, 240, 150, 280))
+    varying = [syn.push_batch(1 + i, 4, H) for i in range(8)]
+    eng.train_begin(H, 1e-3, 0.9)
+    out = {'batch_size': 4, 'n_rollout': H, 'source': 'config/train/gnn_dyn.yaml; train/train_gnn_dyn.py:159-210',
+           'n_max_fixed': int(fixed[0].shape[2]), 'n_max_varying': [int(b[0].shape[2]) for b in varying]}
+
+    def timed(batches, mode, min_s):
+        for b in batches[:2]:
+            eng.train_step(*b, mode=mode)
+        fence()
+        per, tot, k = [], 0.0, 0
+        while tot < min_s:
+            t0 = time.perf_counter()
+            for _ in range(20):
+                eng.train_step(*batches[k % len(batches)], mode=mode)
+                k += 1
+            fence()
+            dt = time.perf_counter() - t0
+            per.append(dt / 20 * 1e3)
+            tot += dt
+        return float(np.median(per)), float(np.min(per)), tot
+
+    md, mn, t1 = timed([fixed], 'update', 0.5)
+    out['ms_per_iteration'] = round(md, 4)
+    out['ms_per_iteration_min'] = round(mn, 4)
+    md, mn, t2 = timed([fixed], 'eval', 0.25)
+    out['ms_forward_only'] = round(md, 4)
+    md, mn, t3 = timed(varying, 'update', 0.5)
+    out['ms_per_iteration_varying_batches'] = round(md, 4)
+    out['gpu_active_s'] = round(t1 + t2 + t3, 3)
+    eng.load_weights(weights.blob_from_state_dict(rig.sd), 0.08)
+    return out
+
+
 def run_rank(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -924,8 +967,9 @@ def run_rank(args):
         # len(SWEEP) x SWEEP_MIN_GPU_S seconds), the CPU baseline follows
         out['sweep'] = run_sweep(rig, fence)
         out['mpc_step'] = run_mpc_step(rig, fence)
+        out['train_step'] = run_train_step(rig, fence)
         out['gpu_active_s'] = round(out.get('gpu_active_s', 0.0) + sum(e['gpu_active_s'] for e in out['sweep'])
-                                    + sum(e['ms_total'] * 4e-3 for e in out['mpc_step']), 3)
+                                    + sum(e['ms_total'] * 4e-3 for e in out['mpc_step']) + out['train_step']['gpu_active_s'], 3)
     if rank == 0 and cpu_args is not None:
         out['cpu_baseline'] = cpu_baseline(*cpu_args)
     if rank == 0:

@@ -123,6 +123,12 @@ def test_the_sweep_block_carries_the_other_baseline_workloads():
         assert 0 < e['ms_particles'] < e['ms_total'] and 0 < e['ms_optimisation_loop'] <= e['ms_planner_call'] < e['reference_budget_ms']
         assert e['ms_goal_install_hit'] < e['ms_goal_install_miss']
         assert all(s.syn_lo <= v <= s.syn_hi for v, s in zip(e['push'], [type('b', (), {'syn_lo': -5.01, 'syn_hi': 5.01})] * 4))
+    # one training iteration (train/train_gnn_dyn.py:159-210) at the reference's batch: the same batch every iteration, and
+    # eight batches of different sizes in turn
+    t = d['train_step']
+    assert t['batch_size'] == 4 and t['n_rollout'] == 5 and len(t['n_max_varying']) == 8
+    assert 0 < t['ms_forward_only'] < t['ms_per_iteration_min'] <= t['ms_per_iteration'] < 10.0, t
+    assert 0 < t['ms_per_iteration_varying_batches'] < 10.0 and t['gpu_active_s'] >= 1.2, t
 
 
 @pytest.mark.parametrize('mode', ['weak', 'strong', 'elite'])
