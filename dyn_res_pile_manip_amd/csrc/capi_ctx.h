@@ -372,7 +372,7 @@ struct drp_ctx {
     bool wgrad_defer = true, wg_defer_now = false;
     DevBuf wg_jobs_dev, wg_idx_dev;
     std::vector<unsigned char> wg_uploaded;     // what wg_jobs_dev / wg_idx_dev hold (re-uploaded when the iteration's jobs change)
-    DevBuf tr_part, tr_states, tr_sdelta, tr_nums, tr_grad, tr_m, tr_v, tr_loss, agg_hist, tr_hact, tr_gh, tr_gpe, tr_a1n,
+    DevBuf tr_part, tr_grad, tr_m, tr_v, tr_loss, agg_hist, tr_hact, tr_gh, tr_gpe, tr_a1n,
         tr_gh1, tr_xn, ed_re, ed_a2, ed_a1, ed_x0, ed_gce, ed_g3, ed_g2, ed_g1;
 
     // goal pre-processing (row f3)

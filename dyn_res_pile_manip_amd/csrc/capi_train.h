@@ -113,10 +113,11 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     // too; slot 0 of g_eff is the transient copy the predictor writes and the particle encoder reads)
     const bool defer = c->wg_defer_now;
     const size_t per_t = defer ? 1 : 0;
-    // the fused node / edge-term pass needs every dump in a buffer of its own (the deferred weight gradients' layout).  A
-    // group of `f_spw` samples is shared by `f_parts` workgroups, the grid at most one workgroup per CU (kmb_step_bwd's barrier)
-    // It pays for a handful of tiles only (the reference's batch of 4 x <= 300 particles: 40): every tile is a chain of L2 round
-    // trips, and the stage kernels spread the same gathers over more threads (32 x 300: 3.3 ms staged, 4.3 ms in one launch)
+    // The node stages of a rollout step in ONE launch (kmb_step_bwd<dump>): it needs every dump in a buffer of its own (the
+    // deferred weight gradients' layout).  A group of `f_spw` samples is shared by `f_parts` workgroups, the grid at most one
+    // workgroup per CU (the kernel's barrier in memory).  It pays for a handful of tiles only (the reference's batch of
+    // 4 x <= 300 particles: 40): every tile is a chain of memory round trips, and the stage kernels spread the same gathers
+    // over more threads (32 x 300: 2.6 ms per iteration staged, 4.3 in one launch)
     const long f_tiles = (long)B * ((N + 31) / 32);
     const bool fused = defer && c->bwd_fused && !c->bwd_valu_stages &&
                        (c->train_fused >= 0 ? c->train_fused != 0 : f_tiles <= c->n_cu / 4);
