@@ -63,9 +63,20 @@ for l in open('gpurun_out/r05/calib.log'):
     if l.startswith('k_'):
         print('  ' + l.strip())
 PY
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 tools/train_timing.py > $O/train_stats.log 2>&1
+# training: the reference's batch alone (shape 0 of tools/train_timing.py: 2 + 30 update and 2 + 10 forward-only iterations -- the
+# launches of an iteration can be counted off the stats), its iterations in order (tools/train_trace.py), then all three shapes unprofiled
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 tools/train_timing.py 0 30 > $O/train_stats.log 2>&1
 cp $(ls $O/train_stats/*/*_kernel_stats.csv | head -1) $O/summ/r05_train_kernel_stats.csv
-grep "ms per training" $O/train_stats.log > $O/summ/r05_train_timing.txt
+python3 tools/train_trace.py $O/train_stats > $O/summ/r05_train_trace.txt 2>&1
+python3 tools/train_timing.py 2>/dev/null | grep "ms per training" > $O/summ/r05_train_timing.txt
+python3 tools/particles_timing.py > $O/summ/r05_particles_timing.txt 2>&1
+# from the -DROLLOUT_STAMPS build of the same tree (python __graft_entry__.py --lib tools/bin/libdrp_ts.so -DROLLOUT_STAMPS), when it is there
+if [ -f tools/bin/libdrp_ts.so ]; then
+  DRP_LIB=tools/bin/libdrp_ts.so python3 tools/train_stamps.py 0 > $O/summ/r05_train_stamps.txt 2>&1
+  DRP_LIB=tools/bin/libdrp_ts.so python3 tools/rollout_stamps.py 20 > $O/summ/r05_rollout_stamps_20.txt 2>&1
+  DRP_LIB=tools/bin/libdrp_ts.so python3 tools/rollout_stamps.py 50 > $O/summ/r05_rollout_stamps_50.txt 2>&1
+fi
+python3 tools/prep_timing.py > $O/summ/r05_prep_timing.txt 2>&1
 python3 tools/gd_timing.py 5 10 20 30 40 50 100 > $O/summ/r05_gd_timing.txt 2>&1
 python3 tools/planner_timing.py > $O/summ/r05_planner_timing.txt 2>&1
 # the bench lines of this build on this box
