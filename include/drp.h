@@ -213,7 +213,9 @@ int drp_fps(drp_ctx* ctx, const float* pts, int n, int dim, int k, int init_idx,
  *   s_cur = s_pred;  loss /= n_rollout * B;  loss.backward();  Adam(lr, betas=(beta1, .999)).step()
  * states [B, n_rollout+1, N, 3], states_delta [B, n_rollout, N, 3], attrs [B, n_rollout+1, N],
  * particle_nums [B], particle_dens [B].  loss_out receives the loss (before the update),
- * grad_out (nullable, 38 403 floats in state_dict order) the gradient of every parameter. */
+ * grad_out (nullable, 38 403 floats in state_dict order) the gradient of every parameter.
+ * The arrays are copied before the call returns (one upload), and the call returns when the iteration is complete on
+ * the device (its only host wait): the caller's buffers are free at once, drp_get_weights serves the updated weights. */
 #define DRP_TRAIN_EVAL 0     /* loss only ('valid' phase, torch.set_grad_enabled(False)) */
 #define DRP_TRAIN_GRAD 1     /* loss + gradients, weights untouched */
 #define DRP_TRAIN_UPDATE 2   /* loss + gradients + one Adam step on the context's weights */
