@@ -39,7 +39,13 @@
 #define KM_INST_PROP3(T, P, E, W, O) template KM_PROP3_SIG(T, P, E, W, O);
 #define KM_INST_ROLLOUT(P, E, W, O) template KM_ROLLOUT_SIG(P, E, W, O);
 
-#ifndef DRP_PROP_INSTANTIATE
+// The diagnostic builds (-DROLLOUT_STAMPS, -DPROP_STAMPS, -DGC_STATS) keep their counters in __device__ variables, and a
+// __device__ variable is one per translation unit: there everything is instantiated where it is launched (csrc/drp_capi.hip,
+// implicitly) and the inst_*.hip units are empty.
+#if defined(ROLLOUT_STAMPS) || defined(PROP_STAMPS) || defined(GC_STATS)
+#define DRP_UNITY 1
+#endif
+#if !defined(DRP_PROP_INSTANTIATE) && !defined(DRP_UNITY)
 KM_PROP_LIST_TAPE(KM_DECL_PROP, false)
 KM_PROP_LIST_TAPE(KM_DECL_PROP, true)
 KM_PROP3_LIST_TAPE(KM_DECL_PROP3, false)
