@@ -45,6 +45,7 @@ int drp_create(int device, drp_ctx** out) {
     c->bwd_valu_stages = getenv("DRP_BWD_VALU_STAGES") != nullptr;
     if (const char* e = getenv("DRP_TRAIN_PARTS")) c->train_parts = atoi(e);
     if (const char* e = getenv("DRP_TRAIN_COOP")) c->train_coop = atoi(e);
+    c->graph_encode = getenv("DRP_NO_GRAPH_ENCODE") == nullptr;
     if (const char* e = getenv("DRP_TRAIN_FUSED")) c->train_fused = atoi(e);
     c->graph_rev = getenv("DRP_NO_GRAPH_REV") == nullptr;
     c->comm_always = getenv("DRP_COMM_ALWAYS") != nullptr;
@@ -56,6 +57,7 @@ int drp_create(int device, drp_ctx** out) {
     if (const char* e = getenv("DRP_ECACHE_TAPE_MAX_N")) c->ecache_tape_max_n = std::max(0, atoi(e));
     if (hipFuncSetAttribute((const void*)k_graph, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_q4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)km_graph_q4_encode, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_local, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_elite_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_graph_strips_q<GRAPH_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||

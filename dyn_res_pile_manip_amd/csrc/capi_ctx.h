@@ -19,7 +19,7 @@ const char* const kclass_names[KC_COUNT] = {"graph", "node_encode", "edge_encode
 // draws shapes under the default dispatch, checks each against the oracle and fails if a variant in the list was never hit:
 // a threshold change that orphans an instantiation turns the suite red.
 enum DispatchVariant {
-    DV_GRAPH_PLAIN = 0, DV_GRAPH_Q4, DV_GRAPH_STRIPS, DV_GRAPH_STRIPS256, DV_GRAPH_CELLS, DV_GRAPH_REV, DV_GRAPH_IN_ROLLOUT,
+    DV_GRAPH_PLAIN = 0, DV_GRAPH_Q4, DV_GRAPH_Q4_ENCODE, DV_GRAPH_STRIPS, DV_GRAPH_STRIPS256, DV_GRAPH_CELLS, DV_GRAPH_REV, DV_GRAPH_IN_ROLLOUT,
     DV_VALU_STEP, DV_NODE_ENCODE, DV_NODE_ENCODE_SPLIT, DV_EDGE_ENCODE, DV_EDGE_ENCODE_SPLIT, DV_AGGREGATE, DV_AGGREGATE_LDS,
     DV_AGGREGATE_TAPE, DV_UPDATE,
     DV_PROP,                        // + 8 LAST + 4 TAPE + 2 PAIR + WORK
@@ -53,6 +53,7 @@ void dv_name(int id, char* buf, size_t n, bool* by_default) {
         switch (id) {
         case DV_GRAPH_PLAIN: s = "graph:k_graph"; break;
         case DV_GRAPH_Q4: s = "graph:k_graph_q4"; break;
+        case DV_GRAPH_Q4_ENCODE: s = "graph:km_graph_q4_encode (+ particle encoder)"; break;
         case DV_GRAPH_STRIPS: s = "graph:k_graph_strips_q<128>"; break;
         case DV_GRAPH_STRIPS256: s = "graph:k_graph_strips_q<256>"; dflt = false; break;   // from 800 particles, where the cells have taken over (DRP_NO_GRAPH_CELLS=1)
         case DV_GRAPH_CELLS: s = "graph:k_graph_cells"; break;
@@ -224,6 +225,7 @@ struct drp_ctx {
     bool comm_always = false;       // DRP_COMM_ALWAYS=1: a one-rank communicator still goes through ncclAllGather (bench.py --force-comm)
     bool bwd_fused = true;          // DRP_NO_BWD_FUSED=1: the GD planner's backward pass as one launch per stage
     bool graph_rev = true;          // DRP_NO_GRAPH_REV=1: the GD planner's reversed lists always in a launch of their own (kb_reverse_lists)
+    bool graph_encode = true;       // DRP_NO_GRAPH_ENCODE=1: k_graph_q4 and km_node_encode_split as two launches where they could be one (km_graph_q4_encode)
     int train_fused = -1;           // DRP_TRAIN_FUSED=0/1: the trainer's node stages as one launch per rollout step (kmb_step_bwd<dump>) never / for any batch (-1: up to n_cu / 4 tiles)
     int train_coop = -1;            // DRP_TRAIN_COOP=0/1: the workgroup-wide gather of the edge terms off / on whatever the tile count (-1: by tiles per workgroup)
     int train_parts = 0;            // DRP_TRAIN_PARTS=n: workgroups per group of samples in the trainer's kmb_step_bwd (0: as many as there are CUs for)

@@ -235,6 +235,7 @@ struct StepArgs {
     const float* cself = nullptr;   // [B,64] self-edge constant + per-sample validity (fused engine, k_cself)
     const uint8_t* cself_ok = nullptr;
     bool padded = false;            // training batches: zero-padded (coincident) particles -> plain k_graph
+    mutable bool encoded = false;   // run_step: the particle encoder already ran, in the neighbour lists' launch (km_graph_q4_encode)
     int* rev_off = nullptr;         // the GD planner's forward, samples of one graph chunk: the reversed lists in the lists' own launch
     int* rev = nullptr;             //   (k_graph_rev); run_step says in rev_built whether it did
     bool* rev_built = nullptr;
@@ -258,6 +259,18 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
                   bool padded);
 size_t graph_lds(int N) { return (size_t)4 * N * sizeof(float); }
 
+// which build launch_graph picks, in its order: cells, x strips, then k_graph_q4 for a handful of samples
+bool graph_takes_q4(const drp_ctx* c, int B, int N, bool padded) {
+    if (c->graph_cells && c->graph_strips && !padded && N >= c->graph_cells_min_n) return false;
+    if (c->graph_strips && !padded && N > GRAPH_THREADS) return false;
+    return c->graph_q4 != 0 && N >= 64 && (c->graph_q4 == 2 || (long)B * ((N + 127) / 128) * 2 <= c->n_cu);
+}
+// km_prop3 with the particle encoder as its first phase (run_step_mfma): no encoder launch to share
+bool step_has_phase_e(const drp_ctx* c, int B, int N) {
+    const int spw = (int)((B + c->n_cu - 1) / c->n_cu);
+    const bool prop3 = c->engine == DRP_ENGINE_FUSED && c->prop3 && whole_samples(c, B, N) && ((long)spw * N + 31) / 32 >= c->prop3_min_tiles;
+    return prop3 && c->prop3e;
+}
 void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod, size_t prev_stride, const float* actions,
                   size_t act_stride, float* s_delta, int B, int N, int16_t* nbr_idx, uint8_t* nbr_cnt, int self_first,
                   bool padded) {
@@ -304,7 +317,7 @@ void launch_graph(drp_ctx* c, hipStream_t st, const float* s_prev, int prev_mod,
                                (const float4*)sorted, (const int*)starts, N, nbr_idx, nbr_cnt, c->thr, graph_chunks(N), B * graph_chunks(N), self_first);
         }
     }
-    else if (c->graph_q4 != 0 && N >= 64 && (c->graph_q4 == 2 || (long)B * ((N + 127) / 128) * 2 <= c->n_cu)) {
+    else if (graph_takes_q4(c, B, N, padded)) {
         // a handful of samples (training batches): four threads per receiver, each over a quarter of the senders
         const int chunks = (N + 127) / 128;
         c->dv(DV_GRAPH_Q4);
@@ -373,7 +386,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
     const int spw = (int)((B + c->n_cu - 1) / c->n_cu);
     const bool prop3 = c->engine == DRP_ENGINE_FUSED && c->prop3 && whole_samples(c, B, N) && ((long)spw * N + 31) / 32 >= c->prop3_min_tiles;
     const bool phase_e = prop3 && c->prop3e;
-    if (!phase_e) {
+    if (!phase_e && !a.encoded) {
         ProbeScope ps(c, KC_NODE_ENCODE);
         c->dv(c->engine == DRP_ENGINE_FUSED ? DV_NODE_ENCODE_SPLIT : DV_NODE_ENCODE);
         if (c->engine == DRP_ENGINE_FUSED)
@@ -555,6 +568,7 @@ int run_step(drp_ctx* c, const StepArgs& a) {
     int16_t* nbr_idx = ptr<int16_t>(c->nbr_idx);
     uint8_t* nbr_cnt = ptr<uint8_t>(c->nbr_cnt);
     const float* vw = ptr<float>(c->w_valu);
+    a.encoded = false;
     if (a.build_graph) {
         ProbeScope ps(c, KC_GRAPH);
         const int self_first = (c->engine == DRP_ENGINE_FUSED && a.cself != nullptr) ? 1 : 0;
@@ -564,6 +578,19 @@ int run_step(drp_ctx* c, const StepArgs& a) {
                                a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, N, nbr_idx, nbr_cnt, c->cam, c->thr,
                                B, self_first, a.rev_off, a.rev);
             if (a.rev_built) *a.rev_built = true;
+        } else if (graph_takes_q4(c, B, N, a.padded) && a.actions == nullptr && c->engine == DRP_ENGINE_FUSED && c->graph_encode &&
+                   !step_has_phase_e(c, B, N)) {
+            // a handful of samples whose impulses are data (the trainer's forward pass): the lists and the particle encoder
+            // read nothing of one another -- one launch (k_rollout.h)
+            const int chunks = (N + 127) / 128, n_graph = B * chunks;
+            const long node_tiles = (long)B * ((N + 31) / 32);
+            const bool tape = a.eff_hist != nullptr;
+            c->dv(DV_GRAPH_Q4_ENCODE);
+            hipLaunchKernelGGL(km_graph_q4_encode, dim3((unsigned)(n_graph + mfma_grid_spread(c, node_tiles))), dim3(GRAPH_Q4_THREADS),
+                               KM_GRAPH_Q4_ENCODE_LDS(N), st, a.s_prev, a.prev_mod, a.prev_stride, s_delta, N, B, nbr_idx, nbr_cnt, c->cam,
+                               c->thr, chunks, self_first, n_graph, ptr<uint16_t>(c->w_split6), ptr<float>(c->w_mfma), a.attr, a.attr_mod,
+                               a.dens, a.dens_mod, tape ? a.eff_hist : ptr<float>(c->eff), ptr<float>(c->c_node), ptr<float>(c->proj));
+            a.encoded = true;
         } else {
             launch_graph(c, st, a.s_prev, a.prev_mod, a.prev_stride, a.actions, a.act_stride, s_delta, B, N, nbr_idx, nbr_cnt,
                          self_first, a.padded);

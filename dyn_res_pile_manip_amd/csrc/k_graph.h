@@ -323,15 +323,17 @@ k_graph_rev(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
 // The same lists as k_graph for every input, coincident particles and lattices included (tests/test_gpu_graph_strips.py).
 #define GRAPH_Q4_THREADS 512
 #define GRAPH_Q4_LDS(N) ((size_t)4 * ((N) + 3) * sizeof(float) + (size_t)128 * 4 * 10 * sizeof(float) + (size_t)128 * 4 * 22 * sizeof(int16_t))
-DRP_GLOBAL void __launch_bounds__(GRAPH_Q4_THREADS)
-k_graph_q4(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
-           const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
-           int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks, int self_first) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// (the body of workgroup `blk`: k_graph_q4 below, and km_graph_q4_encode of k_rollout.h, where the particle encoder's tiles
+// share the launch)
+__device__ __forceinline__ void
+graph_q4_block(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
+               const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
+               int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, const DrpCam& cam, float thr, int chunks, int self_first,
+               int blk, float* lds) {
     float4* p4 = reinterpret_cast<float4*>(lds);                       // [N] displaced positions
     float* bestq = lds + 4 * ((N + 3) & ~3);                           // [128][4][10]
     int16_t* listq = reinterpret_cast<int16_t*>(bestq + 128 * 4 * 10); // [128][4][22]: 10 strict, 10 ties, 2 counts
-    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const int b = blk / chunks, chunk = blk - b * chunks;
     const float* s = s_prev + (size_t)(b % prev_mod) * prev_stride;
     float* sd = s_delta + (size_t)b * N * 3;
     if (actions != nullptr) {
@@ -437,6 +439,14 @@ k_graph_q4(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
     }
     nbr_cnt[(size_t)b * N + i] = (uint8_t)cnt;
     for (int t = cnt; t < DRP_K; ++t) out[t] = -1;
+}
+DRP_GLOBAL void __launch_bounds__(GRAPH_Q4_THREADS)
+k_graph_q4(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride,
+           const float* __restrict__ actions, size_t act_stride, float* __restrict__ s_delta, int N,
+           int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks, int self_first) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    graph_q4_block(s_prev, prev_mod, prev_stride, actions, act_stride, s_delta, N, nbr_idx, nbr_cnt, cam, thr, chunks, self_first,
+                   (int)blockIdx.x, lds);
 }
 
 // ---- the same lists with the senders bucketed into x strips --------------------------------------------

@@ -1600,12 +1600,12 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
 // ---- particle encoder, node constant and first projections on the 6-term split --------------
 // Same contract as km_node_encode (k_mlp_mfma.h); outputs go straight from the accumulator
 // layout to their rows (no LDS transposition tiles: LDS holds the 126 KB of packed weights).
-DRP_GLOBAL void __launch_bounds__(64 * MFMA_WAVES)
-km_node_encode_split(const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
-                     const float* __restrict__ s_delta, const float* __restrict__ attr, int attr_mod,
-                     const float* __restrict__ dens, int dens_mod, int N, int B,
-                     float* __restrict__ eff, float* __restrict__ c_node, float* __restrict__ proj) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// (the body of workgroup `blk` of `nblk`, 64 * MFMA_WAVES threads: km_node_encode_split below, and km_graph_q4_encode of k_rollout.h)
+__device__ __forceinline__ void
+node_encode_split_block(const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
+                        const float* __restrict__ s_delta, const float* __restrict__ attr, int attr_mod,
+                        const float* __restrict__ dens, int dens_mod, int N, int B,
+                        float* __restrict__ eff, float* __restrict__ c_node, float* __restrict__ proj, int blk, int nblk, float* lds) {
     float* w6_f = lds;                         // PE2 | PPE | RPR | RPS (4 x 1536 units) | PE0 (384)
     float* rows = w6_f + (4 * 1536 + 384) * 4; // b_pe2, b_pp, wd_pp
     lds_fill(w6_f, reinterpret_cast<const float*>(sw6) + S6_PE2 * 4, 2 * 1536 * 4);
@@ -1618,7 +1618,7 @@ km_node_encode_split(const uint16_t* __restrict__ sw6, const float* __restrict__
     const int j = lane & 31, h = lane >> 5;
     const int tps = (N + 31) >> 5;
     const long ntiles = (long)B * tps;
-    for (long gt = (long)blockIdx.x + (long)gridDim.x * wave; gt < ntiles; gt += (long)gridDim.x * MFMA_WAVES) {   // workgroup-cyclic first: few tiles spread one per CU
+    for (long gt = (long)blk + (long)nblk * wave; gt < ntiles; gt += (long)nblk * MFMA_WAVES) {   // workgroup-cyclic first: few tiles spread one per CU
         asm volatile("" ::: "memory");      // keep the packed-weight reads inside the loop (see km_prop)
         const int b = (int)(gt / tps), t = (int)(gt - (long)b * tps);
         const int i = min(t * 32 + j, N - 1);
@@ -1648,5 +1648,13 @@ km_node_encode_split(const uint16_t* __restrict__ sw6, const float* __restrict__
         mfma_layer64_split6(w6 + 3 * 1536, f6, c, lane);
         if (live) frag_to_row(proj + row * 128 + 64, h, c);
     }
+}
+DRP_GLOBAL void __launch_bounds__(64 * MFMA_WAVES)
+km_node_encode_split(const uint16_t* __restrict__ sw6, const float* __restrict__ mw,
+                     const float* __restrict__ s_delta, const float* __restrict__ attr, int attr_mod,
+                     const float* __restrict__ dens, int dens_mod, int N, int B,
+                     float* __restrict__ eff, float* __restrict__ c_node, float* __restrict__ proj) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    node_encode_split_block(sw6, mw, s_delta, attr, attr_mod, dens, dens_mod, N, B, eff, c_node, proj, (int)blockIdx.x, (int)gridDim.x, lds);
 }
 #define KM_NODE_SPLIT_LDS ((size_t)((4 * 1536 + 384) * 4 + 192) * sizeof(float))

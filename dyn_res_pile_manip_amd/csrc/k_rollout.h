@@ -176,3 +176,27 @@ km_rollout(const RolloutArgs* __restrict__ args) {
     }
 }
 #define KM_ROLLOUT_LDS KM_PROP3_LDS
+
+// ---- a handful of samples with impulses that are DATA (the trainer's forward pass, predict_one_step): the neighbour lists
+// (k_graph_q4: positions + impulses -> lists) and the particle encoder (km_node_encode_split: impulses, attributes, densities ->
+// effects, node constants, first projections) read nothing of one another -- one launch, the first `n_graph` workgroups build the
+// lists, the others run the encoder's tiles on their first 64 * MFMA_WAVES threads (the other waves leave at once: a
+// workgroup's barrier counts the waves that are still there).  Either body is the kernel's it comes from: the same bits.
+DRP_GLOBAL void __launch_bounds__(GRAPH_Q4_THREADS)
+km_graph_q4_encode(const float* __restrict__ s_prev, int prev_mod, size_t prev_stride, const float* __restrict__ s_delta, int N, int B,
+                   int16_t* __restrict__ nbr_idx, uint8_t* __restrict__ nbr_cnt, DrpCam cam, float thr, int chunks, int self_first,
+                   int n_graph, const uint16_t* __restrict__ sw6, const float* __restrict__ mw, const float* __restrict__ attr,
+                   int attr_mod, const float* __restrict__ dens, int dens_mod, float* __restrict__ eff, float* __restrict__ c_node,
+                   float* __restrict__ proj) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    static_assert(GRAPH_Q4_THREADS >= 64 * MFMA_WAVES, "the encoder's waves are the first of the workgroup");
+    if ((int)blockIdx.x < n_graph) {
+        graph_q4_block(s_prev, prev_mod, prev_stride, nullptr, 0, const_cast<float*>(s_delta), N, nbr_idx, nbr_cnt, cam, thr, chunks,
+                       self_first, (int)blockIdx.x, lds);
+        return;
+    }
+    if (threadIdx.x >= 64 * MFMA_WAVES) return;
+    node_encode_split_block(sw6, mw, s_delta, attr, attr_mod, dens, dens_mod, N, B, eff, c_node, proj, (int)blockIdx.x - n_graph,
+                            (int)gridDim.x - n_graph, lds);
+}
+#define KM_GRAPH_Q4_ENCODE_LDS(N) (GRAPH_Q4_LDS(N) > KM_NODE_SPLIT_LDS ? GRAPH_Q4_LDS(N) : KM_NODE_SPLIT_LDS)

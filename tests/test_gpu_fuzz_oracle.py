@@ -219,7 +219,7 @@ def test_gradient_shape_against_the_oracle(eng, shape, exact_goal_transform):
 
 
 # up to n_cu / 4 tiles of 32 rows the node stages of a rollout step are one launch (kmb_step_bwd<dump, coop>), beyond the stage kernels
-TRAIN_SHAPES = [([40, 64, 25, 64], 3, 'fused'), ([300, 120], 2, 'fused'), ([30, 12], 2, 'mfma'), ([200, 180, 90, 200, 150, 60, 200, 10], 2, 'fused'),
+TRAIN_SHAPES = [([40, 64, 25, 64], 3, 'fused'), ([300, 120], 2, 'fused'), ([30, 12], 2, 'mfma'), ([70, 64, 20], 1, 'mfma'), ([200, 180, 90, 200, 150, 60, 200, 10], 2, 'fused'),
                 ([300, 280, 150, 290, 300, 40, 260, 300], 1, 'fused')]
 
 
