@@ -624,7 +624,7 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                 const int* rv = rev + srow0 * DRP_K;
                 const unsigned* mk = mask_p + srow0 * DRP_K * 2;          // the sample's slots, word h of a slot at [slot * 2 + h]
                 int cmax = cnt, lmax = p1 - p0;
-    #pragma unroll
+#pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     cmax = max(cmax, __shfl_xor(cmax, o, 64));
                     lmax = max(lmax, __shfl_xor(lmax, o, 64));
@@ -637,7 +637,7 @@ kmb_step_bwd(const float* __restrict__ mw, const float* __restrict__ mb,
                     // the row's ten mask words are independent loads: all in flight at once (a loop over k waited for each
                     // in turn -- ten L2 round trips per tile and phase)
                     unsigned wk[DRP_K];
-    #pragma unroll
+#pragma unroll
                     for (int k = 0; k < DRP_K; ++k) wk[k] = (k < cnt) ? mk[((size_t)i * DRP_K + k) * 2 + h] : 0u;
                     receiver_term(pr, gi, wk);
                 }
