@@ -283,23 +283,30 @@ def cpu_baseline(args, sd, s0, dens, attr, G, goal_coor, cam):
     # leg is timed at both (at min(avail, .) threads) and the faster one is the baseline, both times in the line
     ns, H, N = args.cpu_samples, args.horizon, args.particles
     acts = syn.sample_pushes(ns, H, seed=1)
-    legs = {}
-    for th in sorted(set(min(avail, t) for t in (32, 64))):
+    legs, leg_samples = {}, {}
+    for th in sorted(set(min(avail, t) for t in (32, 64, 128))):
+        # the 128-thread leg (all physical cores of a 2 x 64-core host, what BASELINE.md asks for) runs a quarter of the
+        # sample and is scaled: it is the slow one, and the default run has to end within minutes
+        a = acts if th <= 64 else acts[:max(8, ns // 4)]
         torch.set_num_threads(th)
         with torch.no_grad():
             od.rollout(W, s0, dens, attr, acts[:4, :1], ext, 24)          # warm-up
             t0 = time.perf_counter()
-            st = od.rollout(W, s0, dens, attr, acts, ext, 24)
+            st = od.rollout(W, s0, dens, attr, a, ext, 24)
             r = od.config_reward_ptcl(st[:, -1], G, cam, goal_coor)
-            od.optimize_action(acts, r.numpy(), 0.1)
-            legs[th] = time.perf_counter() - t0
+            od.optimize_action(a, r.numpy(), 0.1)
+            legs[th] = (time.perf_counter() - t0) * ns / a.shape[0]
+            leg_samples[th] = int(a.shape[0])
     cores = min(legs, key=legs.get)
     dt = legs[cores]
     return {'value': ns * N * H / dt, 'unit': 'particle-steps/s', 'cores': cores, 'kind': 'port',
-            'cores_policy': 'the faster of 32 and 64 threads, NOT all %d hardware threads BASELINE.md asks for: the dense formulation\'s '
-                            'small ops run 20x slower at 256 threads than at 8 (measured); both legs\' seconds are in seconds_by_threads' % avail,
-            'cpu_model': host_cpu_model(), 'host_threads_available': avail,
             'seconds_by_threads': {str(k): round(v, 3) for k, v in legs.items()},
+            'value_by_threads': {str(k): round(ns * N * H / v, 1) for k, v in legs.items()},
+            'samples_by_threads': {str(k): v for k, v in leg_samples.items()},
+            'cpu_model': host_cpu_model(), 'host_threads_available': avail,
+            'cores_policy': 'the fastest of the 32-, 64- and 128-thread legs (128 = all physical cores of a 2 x 64-core host, BASELINE.md 3; '
+                            'that leg runs a quarter of the sample, its seconds scaled to the whole): the dense formulation\'s small ops do not '
+                            'scale with threads, every leg is in seconds_by_threads / value_by_threads',
             'sample': '%d samples x %d particles x %d steps, oracle/propnet_dense.py (dense '
                       'Rr/Rs PyTorch fp32, %d of %d host threads of %s; the same leg at %s threads: %s s), %.1f s' % (
                           ns, N, H, cores, avail, host_cpu_model(), ' / '.join(str(k) for k in legs),
@@ -318,6 +325,23 @@ TRAFFIC_SOURCE = 'profiles/traffic.json (builder-side rocprofv3 --pmc passes of 
 
 MFMA_CYCLES_16BIT = 32       # v_mfma_f32_32x32x16_{f16,bf16}: 8 passes of 4 cycles
 NOMINAL_CLOCK_HZ = 2.4e9     # MI355X_MICROARCH.md peak engine clock (the kernels hold 2.03 - 2.09 GHz: DESIGN_NOTES 5b)
+
+
+ROOF_FIRST = ('frac', 'kernel', 'avg_launch_ms', 'launches', 'traffic', 'frac_executed_16bit', 'mfma_pipe_busy_est',
+              'hbm_algorithmic_frac', 'sclk_mhz_under_load', 'frac_at_measured_clock', 'bound', 'achieved', 'peak', 'unit',
+              'frac_basis', 'algorithmic_frac', 'executed_over_algorithmic', 'executed_tflops', 'hbm_algorithmic_gbs',
+              'mfma_pipe_busy_at_measured_clock', 'work_per_launch', 'work_per_launch_flop', 'cache_served')
+
+
+def ordered(d, first=ROOF_FIRST):
+    """The record a reader (or a driver that keeps the first N keys of a block) needs first: the fraction, the kernel, its
+    launch time, the counter traffic, the executed-work pair and the clock -- then the rest, explanatory strings last."""
+    if not isinstance(d, dict):
+        return d
+    head = [k for k in first if k in d]
+    tail = [k for k in d if k not in head]
+    tail.sort(key=lambda k: (isinstance(d[k], (str, dict)) or d[k] is None))
+    return {k: d[k] for k in head + tail}
 
 
 def prop_roofline(work, kbar, self_const, B, N, avg_s, H, n_cu=256):
@@ -342,7 +366,16 @@ def prop_roofline(work, kbar, self_const, B, N, avg_s, H, n_cu=256):
     slots = work['chain_slots'] + work['cached_slots']
     node_parts = work['tiles'] + work['tiles_last']
     gather_bytes = particle_steps * 3.0 * (2.0 * kbar + 2.0) * 256.0
-    return {'bound': 'mfma', 'achieved': useful / avg_s / 1e12, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+    # the shader clock the counted launches ran at: s_memtime over s_memrealtime (100 MHz) between entry and exit, summed over
+    # their workgroups (drp_probe_work [6] / [7]); the peaks above are quoted at the 2.4 GHz engine clock
+    sclk = 100.0 * work['clk_cycles'] / work['clk_ticks'] if work.get('clk_ticks') else None
+    at_clk = (NOMINAL_CLOCK_HZ / 1e6 / sclk) if sclk else None
+    return {'sclk_mhz_under_load': sclk,
+            'frac_at_measured_clock': (useful / avg_s / 1e12 / PEAK_F32_TFLOPS * at_clk) if sclk else None,
+            'mfma_pipe_busy_at_measured_clock': (work['mfmas'] / n * MFMA_CYCLES_16BIT / (4.0 * n_cu) / (avg_s * sclk * 1e6)) if sclk else None,
+            'sclk_basis': 'sum of s_memtime deltas / sum of s_memrealtime deltas (100 MHz) over the workgroups of the counting launches of '
+                          'this kernel, in the iteration before the timed ones; frac_at_measured_clock = frac x 2400 / sclk',
+            'bound': 'mfma', 'achieved': useful / avg_s / 1e12, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
             'peak_basis': 'SURVEY.md 8d: algorithmic FLOPs of the factored formulation, F_fac(K) = 116096 + 25472 K per particle-step '
                           '(K = %.2f, %.0f particle-steps per launch), against the dense fp32 matrix peak 8d names (157.3 TFLOP/s)' % (kbar, particle_steps),
             'work_per_launch_flop': useful,
@@ -355,7 +388,7 @@ def prop_roofline(work, kbar, self_const, B, N, avg_s, H, n_cu=256):
             'hbm_algorithmic_basis': 'SURVEY.md 8d: (2K + 2) x 256 B per receiver and propagation step, x 3 steps x the particle-steps of a launch, against 8 TB/s',
             'mfma_dtype': 'fp16 operands for the relation encoder (fp32 values split in 2 fp16 terms), bf16 for the node layers (3 terms), fp32 accumulate',
             'numerator_executed': 'drp_probe_work: counted by the kernels over the iteration before the timed ones',
-            'executed_per_launch': {k: v / n for k, v in work.items() if k != 'launches'},
+            'executed_per_launch': {k: v / n for k, v in work.items() if k not in ('launches', 'clk_cycles', 'clk_ticks')},
             'algorithmic_f32_tflops_without_self_loop': particle_steps * (116096.0 + 25472.0 * k_run) / avg_s / 1e12,
             'slot_iterations_per_tile': slots / float(max(node_parts, 1)),
             'cached_share_of_slot_iterations': work['cached_slots'] / float(max(slots, 1)),
@@ -479,7 +512,7 @@ def mppi_roofline(rig, m, N, ns, H, steps):
     roof['avg_launch_ms'] = avg_s * 1e3
     roof['launches'] = m['dom_n']
     roof['work_per_launch'] = work
-    return roof
+    return ordered(roof)
 
 
 def scatter_roofline(ns, N, kbar, agg_ms, agg_n, traffic_bytes):
@@ -494,12 +527,12 @@ def scatter_roofline(ns, N, kbar, agg_ms, agg_n, traffic_bytes):
     alg = ns * N * (2 * kbar + 2) * 256.0
     compulsory = ns * N * (kbar * 256.0 + 512.0 + 256.0)
     hbm, basis = (traffic_bytes, 'pmc traffic') if traffic_bytes else (compulsory, 'compulsory bytes (each row once)')
-    return {'kernel': 'k_aggregate (engine mfma: segmented sum over the receiver-major lists)', 'bound': 'hbm',
+    return ordered({'kernel': 'k_aggregate (engine mfma: segmented sum over the receiver-major lists)', 'bound': 'hbm',
             'achieved': hbm / agg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm / agg_s / 1e9 / PEAK_HBM_GBS,
             'frac_basis': basis, 'avg_launch_ms': agg_s * 1e3, 'launches': agg_n,
             'algorithmic_bytes_per_launch': alg, 'algorithmic_gbs': alg / agg_s / 1e9,
             'compulsory_bytes_per_launch': compulsory, 'cache_served': bool(alg > hbm), 'mean_in_degree': kbar,
-            'traffic': traffic_bytes, 'traffic_source': TRAFFIC_SOURCE if traffic_bytes else None}
+            'traffic': traffic_bytes, 'traffic_source': TRAFFIC_SOURCE if traffic_bytes else None})
 
 
 def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True):
@@ -584,7 +617,10 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
         roof['achieved'] = tb / avg_s / 1e9
         roof['frac'] = roof['achieved'] / roof['peak']
         roof['cache_served'] = bool(roof.get('algorithmic_bytes_per_launch', 0) > tb)
-    return {'dt': dt, 'median': med, 'per_class': per_class, 'dominant': dominant, 'roofline': roof, 'kbar': kbar,
+    if dom_work and dom_work.get('clk_ticks') and 'sclk_mhz_under_load' not in roof:
+        # the clock of the forward kernel's counting launch of the same iteration stands for the workload's
+        roof['sclk_mhz_under_load'] = 100.0 * dom_work['clk_cycles'] / dom_work['clk_ticks']
+    return {'dt': dt, 'median': med, 'per_class': per_class, 'dominant': dominant, 'roofline': ordered(roof), 'kbar': kbar,
             'B': B, 's0': s0, 'dens': dens, 'attr': attr, 'acts': acts, 'step': step}
 
 
@@ -634,19 +670,20 @@ def run_sweep(rig, fence):
                 roof['traffic'] = tb
         batches = more_batches(step, fence, steps, dt, SWEEP_MIN_GPU_S)
         med, best = float(np.median(batches)), float(min(batches))
-        out.append({'name': name, 'workload': label, 'n_particles': N, 'rows': B, 'n_look_ahead': H, 'steps': steps, 'warmup': warm,
-                    'batches': len(batches), 'gpu_active_s': round(float(sum(batches)), 3),
-                    'ms_per_step': med / steps * 1e3, 'value': B * N * H * steps / med, 'unit': 'particle-steps/s',
-                    'ms_per_step_min': best / steps * 1e3, 'value_max': B * N * H * steps / best,
-                    'ms_per_step_first_batch': dt / steps * 1e3,
-                    'mean_in_degree': kbar, 'dominant_kernel': roof['kernel'], 'avg_launch_ms': roof['avg_launch_ms'],
+        out.append({'name': name, 'value': B * N * H * steps / med, 'ms_per_step': med / steps * 1e3, 'frac': roof['frac'],
+                    'dominant_kernel': roof['kernel'], 'avg_launch_ms': roof['avg_launch_ms'], 'traffic': roof.get('traffic'),
+                    'frac_executed_16bit': roof.get('frac_executed_16bit'), 'mfma_pipe_busy_est': roof.get('mfma_pipe_busy_est'),
+                    'hbm_algorithmic_frac': roof.get('hbm_algorithmic_frac'),
+                    'sclk_mhz_under_load': roof.get('sclk_mhz_under_load'), 'frac_at_measured_clock': roof.get('frac_at_measured_clock'),
                     'bound': roof['bound'], 'achieved': roof['achieved'], 'peak': roof['peak'], 'roofline_unit': roof['unit'],
-                    'frac': roof['frac'], 'peak_basis': roof.get('peak_basis'), 'frac_executed_16bit': roof.get('frac_executed_16bit'),
-                    'mfma_pipe_busy_est': roof.get('mfma_pipe_busy_est'), 'hbm_algorithmic_frac': roof.get('hbm_algorithmic_frac'),
-                    'executed_per_launch': roof.get('executed_per_launch'),
-                    'traffic': roof.get('traffic'),
+                    'unit': 'particle-steps/s', 'n_particles': N, 'rows': B, 'n_look_ahead': H, 'steps': steps, 'warmup': warm,
+                    'batches': len(batches), 'gpu_active_s': round(float(sum(batches)), 3),
+                    'ms_per_step_min': best / steps * 1e3, 'value_max': B * N * H * steps / best,
+                    'ms_per_step_first_batch': dt / steps * 1e3, 'mean_in_degree': kbar,
+                    'wall_s': round(time.perf_counter() - t_wall, 2),
                     'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items() if v[1] > 0},
-                    'wall_s': round(time.perf_counter() - t_wall, 2)})
+                    'executed_per_launch': roof.get('executed_per_launch'),
+                    'workload': label, 'peak_basis': roof.get('peak_basis')})
     return out
 
 
@@ -814,6 +851,15 @@ def run_rank(args):
             if len(set(v for v, _ in seen)) != 1:
                 sys.stderr.write('bench.py: the ranks bound different RCCL versions: %r\n' % (seen,))
                 return EXIT_WORLD_MISMATCH
+    # what EVERY rank's communicator says of itself (ncclCommCount, the library's version and file), for the line
+    rccl_ranks = None
+    if comm_info:
+        mine = {'rank': rank, 'local_rank': local_rank, 'comm_count': comm_info['n_ranks'], 'version': comm_info['version_str'],
+                'library': comm_info['path']}
+        rccl_ranks = [mine]
+        if world > 1:
+            rccl_ranks = [None] * world
+            dist.all_gather_object(rccl_ranks, mine)
 
     def fence():
         eng.sync()
@@ -933,6 +979,7 @@ def run_rank(args):
             tb = tj.get(engine, {}).get(tkey, {}).get('hbm_bytes_per_launch')
             if tb:
                 roof['traffic'], roof['traffic_source'] = tb, TRAFFIC_SOURCE
+            roof = ordered(roof)
             comm_label = None
             if use_rccl:
                 comm_label = 'rccl, %d rank%s' % (world, '' if world == 1 else 's')
@@ -951,7 +998,7 @@ def run_rank(args):
                            'n_look_ahead': H, 'engine': engine, 'gpus_requested': args.gpus, 'world_size': world,
                            'communicator': comm_label,
                            'rccl': ({'comm_count': comm_info['n_ranks'], 'version': comm_info['version_str'],
-                                     'library': comm_info['path']} if comm_info else None),
+                                     'library': comm_info['path'], 'ranks': rccl_ranks} if comm_info else None),
                            'rendezvous': 'gloo (id broadcast, barrier, timing reductions)' if world > 1 else None,
                            'mean_in_degree': m['kbar'], 'parallelism': 'samples sharded x%d' % world,
                            'update': 'softmax mean (optimize_action)' if args.update == 'mppi' else 'mean of the %d best (elite)' % args.elite},

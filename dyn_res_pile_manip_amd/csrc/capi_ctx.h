@@ -28,6 +28,7 @@ enum DispatchVariant {
     DV_REWARD = DV_ROLLOUT + 12, DV_BWD_REWARD, DV_REV_256, DV_REV_1024, DV_BWD_ROWS, DV_BWD_STEP, DV_BWD_STAGES_MFMA,
     DV_BWD_STAGES_VALU, DV_BWD_EDGE_MFMA, DV_BWD_EDGE_VALU, DV_TRAIN_NODE_FUSED, DV_TRAIN_NODE_FUSED_COOP, DV_TRAIN_NODE_MFMA, DV_TRAIN_NODE_VALU, DV_WGRAD_MFMA, DV_WGRAD_VALU,
     DV_WGRAD_DEFERRED, DV_MPPI_SOFTMAX, DV_ELITE_SORT, DV_ELITE_ROUNDS, DV_FPS_REG, DV_FPS_MEM, DV_DT_CV5, DV_DT_EXACT,
+    DV_TRAIN_BARRIER_RETRY,
     DV_COUNT
 };
 // name of variant `id`; *by_default = reachable without an environment switch (DRP_NO_* / drp_probe_begin("prop+work"))
@@ -92,6 +93,7 @@ void dv_name(int id, char* buf, size_t n, bool* by_default) {
         case DV_FPS_MEM: s = "k_fps"; break;
         case DV_DT_CV5: s = "k_dt_cv5"; break;
         case DV_DT_EXACT: s = "k_edt"; break;
+        case DV_TRAIN_BARRIER_RETRY: s = "train:barrier gave up, step re-run with one workgroup per group"; dflt = false; break;   // a shared / masked device
         default: break;
         }
         snprintf(buf, n, "%s", s);
@@ -279,6 +281,8 @@ struct drp_ctx {
     // history buffer over the whole batch and are not split: their cache covers the whole batch, which pays up to
     // ecache_tape_max_n = 40 particles at the planner's 1 500 rows (50 particles: 0.398 ms per iteration recomputing, 0.42 cached).
     int ecache_max_mb = 192;
+    int ecache_hard_max_mb = 4096;  // a cached launch that cannot be split (the tape's: 1 500 x 40 rows are 150 MB) and would need more recomputes:
+                                    // 1.6 million rows -- no caller of the reference comes near; the one place where the batch decides the kernel
     int ecache_max_n = 128, ecache_full_n = 225, ecache_tape_max_n = 40;
     DevBuf ecache;
     // how many float4 a workgroup of `rows` receivers needs

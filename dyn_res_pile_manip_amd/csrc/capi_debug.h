@@ -64,7 +64,12 @@ int drp_probe_work(drp_ctx* c, unsigned long long out[8]) {
     // the matrix instructions those units are made of (k_mlp_split.h: the chain of an edge slot, the node layers of a tile)
     out[5] = (unsigned long long)PROP_MFMA_CHAIN * w[PROP_WORK_CHAIN_SLOTS] + (unsigned long long)PROP_MFMA_NODE * w[PROP_WORK_TILES] +
              (unsigned long long)PROP_MFMA_NODE_LAST * w[PROP_WORK_TILES_LAST] + (unsigned long long)PROP_MFMA_ENC * w[PROP_WORK_ENC_TILES];
+    // shader-clock cycles and 100 MHz ticks between entry and exit, summed over the workgroups of the counted launches
     out[6] = 0; out[7] = 0;
+    for (int q = 0; q < PROP_WORK_SHARDS; ++q) {
+        out[6] += sh[(size_t)q * PROP_WORK_STRIDE + PROP_WORK_CLK_CYCLES];
+        out[7] += sh[(size_t)q * PROP_WORK_STRIDE + PROP_WORK_CLK_TICKS];
+    }
     return DRP_OK;
 }
 

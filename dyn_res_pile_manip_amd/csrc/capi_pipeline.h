@@ -427,7 +427,7 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             // cached or recomputing: by the pile size alone (drp_ctx::ec_shape).  A cached batch too large for one launch of
             // at most ec_rows_cap rows per workgroup goes out as several launches over consecutive blocks of samples, the same
             // cache buffer under each; the tape's launches (one history buffer over the whole batch) take a larger buffer instead
-            const bool ec = c->ec_shape(N, tape);
+            bool ec = c->ec_shape(N, tape);
             long chunk = B;
             if (ec && !tape) {
                 long unit = 1;
@@ -437,9 +437,13 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                 const long cap = c->ec_chunk(N, unit);
                 if (ok && cap > 0 && cap < B) chunk = cap;
             }
-            {
+            if (ec) {
+                // a launch that cannot be split (the tape's; batch columns no block is a multiple of) takes a cache over the whole
+                // batch, 2.5 KB per row: beyond ecache_hard_max_mb it recomputes instead of failing for memory
                 const long B0 = std::min((long)B, chunk), spw0 = (B0 + c->n_cu - 1) / c->n_cu;
-                if (ec) CHK(ensure(c, c->ecache, (size_t)((B0 + spw0 - 1) / spw0) * drp_ctx::ecache_stride(spw0 * N, false) * 16));
+                const size_t need = (size_t)((B0 + spw0 - 1) / spw0) * drp_ctx::ecache_stride(spw0 * N, false) * 16;
+                if (need > ((size_t)c->ecache_hard_max_mb << 20)) { ec = false; chunk = B; }
+                else CHK(ensure(c, c->ecache, need));
             }
             note_degrees(c, spw, N, B);
             unsigned long long* const wk = c->work_ptr();    // not null: the counting instantiations (drp_probe_begin("prop+work"))

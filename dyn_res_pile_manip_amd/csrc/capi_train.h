@@ -433,10 +433,13 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     const bool backward = mode != DRP_TRAIN_EVAL;
     // the batch in one copy: packed into pinned staging in the caller's layouts, unpacked by one launch (kt_unpack_inputs)
     const TrArena lay = tr_layout(B, H, N);
-    if (c->tr_pin_cap < lay.bytes) {
+    // behind the batch: what comes BACK after the one wait -- the loss terms [H][B] and the give-up flag of kmb_step_bwd's
+    // barrier (pinned: the copies are asynchronous, nothing on the way touches pageable memory or this frame)
+    const size_t back_off = lay.bytes, back_bytes = (size_t)H * B * sizeof(double) + 16;
+    if (c->tr_pin_cap < lay.bytes + back_bytes) {
         if (c->tr_pin) { (void)hipHostFree(c->tr_pin); c->tr_pin = nullptr; c->tr_pin_cap = 0; }
-        HIPCHK(c, hipHostMalloc(&c->tr_pin, lay.bytes, hipHostMallocDefault));
-        c->tr_pin_cap = lay.bytes;
+        HIPCHK(c, hipHostMalloc(&c->tr_pin, lay.bytes + back_bytes, hipHostMallocDefault));
+        c->tr_pin_cap = lay.bytes + back_bytes;
     }
     {
         char* pin = static_cast<char*>(c->tr_pin);
@@ -494,42 +497,56 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     }
     CHK(ensure(c, c->tr_loss, (size_t)H * B * sizeof(double)));
     c->lastH = H;
-    CHK(train_forward_backward(c, B, N, backward));
-    std::vector<double> parts((size_t)H * B);
-    if (loss_out) CHK(d2h(c, parts.data(), c->tr_loss.p, parts.size() * sizeof(double)));
-    if (grad_out && backward) CHK(d2h(c, grad_out, c->tr_grad.p, (size_t)W_TOTAL * sizeof(float)));
-    bool repacked = false;
-    unsigned gave_up = 0;                       // kmb_step_bwd's barrier among workgroups (the flag sits behind its counters)
-    if (backward) {
+    double* const parts = reinterpret_cast<double*>(static_cast<char*>(c->tr_pin) + back_off);
+    unsigned* const gave_up = reinterpret_cast<unsigned*>(parts + (size_t)H * B);
+    // kmb_step_bwd's barrier among the workgroups of a group gives up after two seconds (k_backward_mfma.h) and sets a flag
+    // behind its counters; the gradient of such a pass is partial.  The optimiser step reads the flag ON THE DEVICE and moves
+    // nothing when it is set (k_adam's `skip`), the iteration count advances only once the flag has come back clear, and the
+    // step runs again with one workgroup per group (no barrier to wait at) -- for the rest of the context's life.
+    for (int attempt = 0; ; ++attempt) {
+        CHK(train_forward_backward(c, B, N, backward));
         const int f_spw = (B + c->n_cu - 1) / c->n_cu, f_groups = (B + f_spw - 1) / f_spw;
-        CHK(d2h(c, &gave_up, ptr<float>(c->tr_grad) + TR_GRAD_PAD + (size_t)H * f_groups, sizeof(unsigned)));
-    }
-    if (mode == DRP_TRAIN_UPDATE) {
-        c->tr_iter += 1;
-        const double bc1 = 1.0 - pow(c->tr_beta1, (double)c->tr_iter), bc2 = 1.0 - pow(0.999, (double)c->tr_iter);
-        const float inf = __builtin_inff();
-        hipLaunchKernelGGL(k_adam, dim3((W_TOTAL + 255) / 256), dim3(256), 0, c->stream, ptr<float>(c->w_raw),
-                           ptr<float>(c->tr_grad), ptr<float>(c->tr_m), ptr<float>(c->tr_v), (int)W_TOTAL,
-                           (float)(c->tr_lr / bc1), (float)sqrt(bc2), make_float4(-inf, -inf, -inf, -inf),
-                           make_float4(inf, inf, inf, inf), (float)c->tr_beta1);
-        HIPCHK(c, hipGetLastError());
-        // the engines read packed copies of the weights: rebuild them from the updated blob
-        if (c->repack_device) {
-            CHK(repack_on_device(c));
-            repacked = true;
-        } else {
-            std::vector<float> blob((size_t)W_TOTAL);
-            CHK(d2h(c, blob.data(), c->w_raw.p, (size_t)W_TOTAL * sizeof(float)));
-            CHK(guarded_wait(c, nullptr));
-            CHK(install_weights(c, blob));
+        const unsigned* const flag_dev = reinterpret_cast<const unsigned*>(ptr<float>(c->tr_grad) + TR_GRAD_PAD + (size_t)H * f_groups);
+        *gave_up = 0;
+        if (loss_out) CHK(d2h(c, parts, c->tr_loss.p, (size_t)H * B * sizeof(double)));
+        if (grad_out && backward) CHK(d2h(c, grad_out, c->tr_grad.p, (size_t)W_TOTAL * sizeof(float)));
+        if (backward) CHK(d2h(c, gave_up, flag_dev, sizeof(unsigned)));
+        bool repacked = false;
+        if (mode == DRP_TRAIN_UPDATE) {
+            const long iter = c->tr_iter + 1;
+            const double bc1 = 1.0 - pow(c->tr_beta1, (double)iter), bc2 = 1.0 - pow(0.999, (double)iter);
+            const float inf = __builtin_inff();
+            hipLaunchKernelGGL(k_adam, dim3((W_TOTAL + 255) / 256), dim3(256), 0, c->stream, ptr<float>(c->w_raw),
+                               ptr<float>(c->tr_grad), ptr<float>(c->tr_m), ptr<float>(c->tr_v), (int)W_TOTAL,
+                               (float)(c->tr_lr / bc1), (float)sqrt(bc2), make_float4(-inf, -inf, -inf, -inf),
+                               make_float4(inf, inf, inf, inf), (float)c->tr_beta1, (float*)nullptr, flag_dev);
+            if (hipGetLastError() != hipSuccess) { (void)drp_sync(c); return fail(c, DRP_EHIP, "k_adam launch"); }
+            // the engines read packed copies of the weights: rebuild them from the blob (unchanged if the step was skipped)
+            if (c->repack_device) {
+                const int rc = repack_on_device(c);
+                if (rc != DRP_OK) { (void)drp_sync(c); return rc; }
+                repacked = true;
+            } else {
+                std::vector<float> blob((size_t)W_TOTAL);
+                CHK(d2h(c, blob.data(), c->w_raw.p, (size_t)W_TOTAL * sizeof(float)));
+                CHK(guarded_wait(c, nullptr));
+                CHK(install_weights(c, blob));
+            }
         }
+        CHK(drp_sync(c));
+        if (repacked) CHK(finish_repack(c));
+        if (!*gave_up) {
+            if (mode == DRP_TRAIN_UPDATE) c->tr_iter += 1;
+            break;
+        }
+        if (attempt > 0 || c->train_parts == 1)
+            return fail(c, DRP_EHIP, "kmb_step_bwd: a workgroup waited two seconds for the others of its group, with one workgroup per group too");
+        c->train_parts = 1;                     // the device is shared or masked: the groups' workgroups are not all resident
+        c->dv(DV_TRAIN_BARRIER_RETRY);
     }
-    CHK(drp_sync(c));
-    if (repacked) CHK(finish_repack(c));
-    if (gave_up) return fail(c, DRP_EHIP, "kmb_step_bwd: a workgroup waited two seconds for the others of its group (DRP_TRAIN_PARTS=1 runs a group on one workgroup)");
     if (loss_out) {
         double total = 0.0;                     // fixed order: step-major, then sample
-        for (double v : parts) total += v;
+        for (size_t q = 0; q < (size_t)H * B; ++q) total += parts[q];
         *loss_out = total;
     }
     return DRP_OK;

@@ -735,9 +735,11 @@ kb_gather_pos(const float* __restrict__ gpos_edge, const int* __restrict__ rev_o
 // the same step as a launch of its own (the trainer's weights; a planner row whose gradient needs no kb_sdelta launch)
 __global__ void k_adam(float* __restrict__ act, const float* __restrict__ grad, float* __restrict__ m,
                        float* __restrict__ v, int n, float step_size, float bc2_sqrt, float4 lo, float4 hi,
-                       float b1 = 0.9f, float* __restrict__ act_copy = nullptr /* pinned host memory: the updated values once more */) {
+                       float b1 = 0.9f, float* __restrict__ act_copy = nullptr /* pinned host memory: the updated values once more */,
+                       const unsigned* __restrict__ skip = nullptr /* not null and set: the gradient is not to be trusted, nothing moves */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (skip != nullptr && *skip != 0u) return;
     const int c = i & 3;
     const float l = (c == 0) ? lo.x : (c == 1) ? lo.y : (c == 2) ? lo.z : lo.w;
     const float h = (c == 0) ? hi.x : (c == 1) ? hi.y : (c == 2) ? hi.z : hi.w;

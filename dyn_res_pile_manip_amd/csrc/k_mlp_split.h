@@ -593,6 +593,24 @@ enum {
 __device__ __forceinline__ unsigned long long* prop_work_shard(unsigned long long* work) {
     return work + (size_t)(blockIdx.x % PROP_WORK_SHARDS) * PROP_WORK_STRIDE;
 }
+// ... and in words 5 / 6 of its copy the shader-clock cycles (s_memtime) and the 100 MHz ticks (s_memrealtime) the workgroup's
+// first thread saw between the launch's entry and its exit: their ratio over all workgroups is the clock the kernel ran at
+// (bench.py's sclk_mhz_under_load; tools/clock_probe.hip is the same pair on a spin loop)
+#define PROP_WORK_CLK_CYCLES 5
+#define PROP_WORK_CLK_TICKS 6
+struct WorkClock { unsigned long long c0, r0; };
+__device__ __forceinline__ WorkClock work_clock_begin() {
+    WorkClock w;
+    w.c0 = __builtin_amdgcn_s_memtime();
+    w.r0 = __builtin_amdgcn_s_memrealtime();
+    return w;
+}
+__device__ __forceinline__ void work_clock_end(const WorkClock& w, unsigned long long* work) {
+    if (threadIdx.x == 0 && work) {
+        atomicAdd(prop_work_shard(work) + PROP_WORK_CLK_CYCLES, (unsigned long long)(__builtin_amdgcn_s_memtime() - w.c0));
+        atomicAdd(prop_work_shard(work) + PROP_WORK_CLK_TICKS, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - w.r0));
+    }
+}
 #define PROP_MFMA_CHAIN 78
 #define PROP_MFMA_NODE 144
 #define PROP_MFMA_NODE_LAST 96
@@ -1134,6 +1152,8 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
         float re_scale, float re_inv, int spread /* few tiles: one per workgroup first (see decode) */,
         unsigned long long* __restrict__ work /* WORK: PROP_WORK_* counters */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    WorkClock wclk;
+    if constexpr (WORK) wclk = work_clock_begin();
 #ifdef PROP_STAMPS
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1204,6 +1224,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
     };
     HeadCarry hc_none;
     prop_tiles<LAST, TAPE, PAIR, false, 0, WORK, false>(A, L, [&]() { return decode(wave); }, decode, row_of, lane, hc_none PROP_STAMPS_ARG);
+    if constexpr (WORK) work_clock_end(wclk, work);
 #ifdef PROP_STAMPS
     st_sum[6] = st_k1 - st_k0;                               // entry -> weights in LDS
     st_sum[7] = __builtin_amdgcn_s_memtime() - st_k1;        // all tiles of this wave
@@ -1575,12 +1596,15 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    WorkClock wclk;
+    if constexpr (WORK) wclk = work_clock_begin();
     const Prop3Lds P = prop3_lds(lds);
     prop3_fill_resident(P, sw, sw6, mw);
     prop3_step<TAPE, PAIR, PAIR && !TAPE /* the tape's kernel has no register to spare for the carried head; the big kernel's
                                             allocation is not to move (with it: 256 VGPRs) */, ECACHE, WORK, ONE>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
                      eff, N, B, spw, s_delta, s_out, out_stride, cself, cself_ok, mask_hist, agg_hist, re_scale, re_inv, order_rows,
                      (int)threadIdx.x, ECACHE ? ecache + (size_t)blockIdx.x * ec_stride : nullptr, work PROP_STAMPS_ARG);
+    if constexpr (WORK) work_clock_end(wclk, work);
 #ifdef PROP_STAMPS
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

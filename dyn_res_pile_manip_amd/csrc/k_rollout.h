@@ -55,6 +55,8 @@ km_rollout(const RolloutArgs* __restrict__ args) {
 #ifdef PROP_STAMPS
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    WorkClock wclk;
+    if constexpr (WORK) wclk = work_clock_begin();
     const Prop3Lds P = prop3_lds(lds);
     prop3_fill_resident(P, args->sw, args->sw6, args->mw);   // stays for all H steps; the first barrier of step 0 publishes it
     float4* p4 = reinterpret_cast<float4*>(P.wsp_f);         // displaced positions of the workgroup's rows, between two steps
@@ -174,6 +176,7 @@ km_rollout(const RolloutArgs* __restrict__ args) {
         if (roll_on) atomicAdd(&g_roll_stamps[15], 1ull);
 #endif
     }
+    if constexpr (WORK) work_clock_end(wclk, args->work);
 }
 #define KM_ROLLOUT_LDS KM_PROP3_LDS
 

@@ -95,8 +95,9 @@ class Engine(object):
             import warnings
             warnings.warn('the split-fp16 engine refused the call (%s): continuing on the fp32 matrix engine' % e,
                           RuntimeWarning, stacklevel=3)
+            self._engine_before_auto = self.engine_id   # restored by the next load_weights: the refusal belongs to these weights / inputs
             self.set_engine(L.ENGINE_MFMA)
-            self._auto_switched = True                # undone by the next load_weights: the refusal belongs to these weights / inputs
+            self._auto_switched = True
             return self._ck(call())
 
     # ---- constants ----------------------------------------------------------------
@@ -116,8 +117,8 @@ class Engine(object):
         self._weights_owner = None                    # whoever believed its weights were resident no longer is right
         self._ck(self.lib.drp_load_weights(self.h, _fp(blob), blob.size, float(adj_thresh)))
         if self.auto_engine and self.engine_id == L.ENGINE_MFMA and getattr(self, '_auto_switched', False):
-            # the fallback was for the OTHER weights: these get the fused engine's chance again
-            self.set_engine(L.ENGINE_FUSED)
+            # the fallback was for the OTHER weights: these get the chance of the engine the caller had chosen again
+            self.set_engine(getattr(self, '_engine_before_auto', L.ENGINE_FUSED))
             self._auto_switched = False
 
     def set_camera(self, m34, global_scale, intr):
@@ -527,7 +528,7 @@ class Engine(object):
         """What the propagation kernels executed since probe_begin('prop'), counted by the kernels (include/drp.h)."""
         out = (ctypes.c_ulonglong * 8)()
         self._ck(self.lib.drp_probe_work(self.h, out))
-        keys = ('chain_slots', 'cached_slots', 'tiles', 'tiles_last', 'encoder_tiles', 'mfmas')
+        keys = ('chain_slots', 'cached_slots', 'tiles', 'tiles_last', 'encoder_tiles', 'mfmas', 'clk_cycles', 'clk_ticks')
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def dispatch_reset(self):

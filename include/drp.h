@@ -342,7 +342,9 @@ int drp_probe_read(drp_ctx* ctx, double* total_ms, long* launches);
  * timed region runs under the plain "prop" probe and the counters over an iteration of their own): out[0] slot iterations that ran the relation
  * encoder's chain (78 16-bit MFMAs each), [1] slot iterations served by the edge-chain cache (none), [2] / [3] tiles of
  * propagation steps that are not / are the last (144 / 96), [4] particle-encoder tiles inside the launch (204),
- * [5] the 16-bit MFMAs (32x32x16, 32 768 FLOP each) those add up to; [6], [7] zero.  bench.py's roofline numerator. */
+ * [5] the 16-bit MFMAs (32x32x16, 32 768 FLOP each) those add up to; [6] shader-clock cycles (s_memtime) and [7] 100 MHz
+ * ticks (s_memrealtime) between entry and exit of the counted launches, summed over their workgroups: 100 * [6] / [7] is the
+ * shader clock in MHz the kernel ran at.  bench.py's roofline numerator and its sclk_mhz_under_load. */
 int drp_probe_work(drp_ctx* ctx, unsigned long long out[8]);
 /* Which kernel variant served the launches since drp_dispatch_reset (or drp_create): graph build (k_graph, k_graph_q4,
  * k_graph_strips_q<128|256>, k_graph_cells, k_graph_rev, inside km_rollout), propagation kernel with its template flags

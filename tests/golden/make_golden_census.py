@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""A parity CENSUS on the trained network: every push sequence, not only the ones that cannot diverge.
+
+`make_golden_trained.py` keeps a 10-step push sequence for its `rollout/` cases only if the reference's whole trajectory
+stays clear of every graph decision (367 candidates for six rows at 300 particles).  Here NOTHING is filtered: per pile
+size (20 / 50 / 100 / 300 particles) the first ROWS candidates of the same generator go through the REFERENCE
+(`PlannerGD.ptcl_model_rollout` + `ptcl_evaluate_traj` on `weights_trained.npz`), and per row and step this file records
+
+  state_pred, next_r     the reference's free-running trajectory and all-step rewards
+  recv_hash              a 32-bit hash of each receiver's sender list, taken from the reference's OWN Rr / Rs of that step
+                         (model/gnn_dyn.py:244-251) -- what the device's lists are compared with, no oracle in between
+  margin                 how far that step's graph is from changing (`decision_margin`: smallest |d - adj_thresh^2| and
+                         smallest gap between a receiver's 10th and 11th sender inside the radius, squared units)
+  twin_*                 the yardstick: the reference AGAIN on the same rows, started ONE ULP away (`torch.nextafter` on
+                         s_cur): its deviation from the first run per row and step, the receivers whose lists differ,
+                         its rewards.  How far the reference drifts from ITSELF once a near-tie is crossed.
+
+and, per size, one MPPI iteration of MPPI_ROWS rows built from census row 0 (the reference's `sample_action_sequences`
+around it): final-step rewards of the reference and of its one-ulp twin, `optimize_action` of both (planners.py:549-561),
+the per-row smallest margin.  Output: tests/golden/census.npz.  Runs ONLY in the build container (about 12 minutes on
+8 cores).  Usage:  python tests/golden/make_golden_census.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import make_golden as mg  # noqa: E402
+
+ROWS = 64
+MPPI_ROWS = 1024
+CHUNK = 64
+H = 10
+SIZES = [('n20', 20), ('n50', 50), ('n100', 100), ('n300', 300)]
+
+
+def fmix32(x):
+    """murmur3's 32-bit finaliser on uint32 arrays (the tests hash the device's lists the same way)."""
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x = (x * np.uint32(0x85ebca6b)).astype(np.uint32)
+    x ^= x >> np.uint32(13)
+    x = (x * np.uint32(0xc2b2ae35)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def recv_hash_from_onehot(Rr, Rs):
+    """Dense one-hot relations [B,E,N] (zero rows pad short samples) -> [B,N] uint32: per receiver the wrapped sum of
+    fmix32(sender + 1) over its in-edges."""
+    Rr, Rs = Rr.numpy(), Rs.numpy()
+    B, E, N = Rr.shape
+    valid = Rr.sum(2) > 0.5
+    recv = Rr.argmax(2)
+    send = Rs.argmax(2)
+    h = np.zeros((B, N), np.uint32)
+    term = np.where(valid, fmix32(send + 1), np.uint32(0)).astype(np.uint32)
+    with np.errstate(over='ignore'):
+        for b in range(B):
+            np.add.at(h[b], recv[b][valid[b]], term[b][valid[b]])
+    return h
+
+
+def decision_margin_rows(pos, thr=np.float32(0.0064)):
+    """make_golden_trained.decision_margin per ROW: [B] float64."""
+    d = ((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(-1)
+    m = np.abs(d - thr).reshape(d.shape[0], -1).min(1).astype(np.float64)
+    if d.shape[1] > 10:
+        ds = np.sort(d, axis=2)
+        gap = np.where(ds[:, :, 9] < thr, np.abs(ds[:, :, 9] - ds[:, :, 10]), np.float32(np.inf)).min(1)
+        m = np.minimum(m, gap.astype(np.float64))
+    return m
+
+
+class StepTap(object):
+    """Records, for every call of the reference's `model.model.forward` (one per rollout step), the receiver hashes of
+    the Rr / Rs it was handed."""
+
+    def __init__(self, model):
+        self.m = model.model
+        self.orig = self.m.forward
+        self.hashes = []
+
+        def wrapped(*args, **kw):
+            self.hashes.append(recv_hash_from_onehot(args[3].detach(), args[4].detach()))
+            return self.orig(*args, **kw)
+        self.m.forward = wrapped
+
+    def take(self):
+        h, self.hashes = self.hashes, []
+        return np.stack(h, 1)                      # [B,H,N]
+
+    def close(self):
+        del self.m.forward
+
+
+def reference_rows(torch, planner, model, tap, s, dens, attr, acts, obs_goal, goal_coor, want_margin=True):
+    """The reference on rows acts [B,H,4] of ONE pile s [1,N,3], in chunks: state_pred [B,H,N,3], next_r [B,H],
+    recv_hash [B,H,N], margin [B,H]."""
+    B, N = acts.shape[0], s.shape[1]
+    sp_all, nr_all, h_all, m_all = [], [], [], []
+    for c in range(0, B, CHUNK):
+        a = np.ascontiguousarray(acts[c:c + CHUNK])
+        with torch.no_grad():
+            ro = planner.ptcl_model_rollout(torch.from_numpy(s), torch.from_numpy(dens), torch.from_numpy(attr), model,
+                                            torch.from_numpy(a))
+            sp = ro['model_rollout']['state_pred']
+            _, nr = planner.ptcl_evaluate_traj(sp.reshape(a.shape[0], H, 1, N, 3), torch.from_numpy(obs_goal),
+                                               torch.from_numpy(goal_coor))
+        sp = sp.numpy()
+        h_all.append(tap.take())
+        sp_all.append(sp)
+        nr_all.append(nr.numpy()[:, :, 0])
+        if want_margin:
+            m = np.empty((a.shape[0], H))
+            prev = np.tile(s, (a.shape[0], 1, 1))
+            for t in range(H):
+                with torch.no_grad():
+                    sd = planner.gen_s_delta(torch.from_numpy(prev), torch.from_numpy(a[:, t])).numpy()
+                m[:, t] = decision_margin_rows((prev + sd).astype(np.float32))
+                prev = sp[:, t]
+            m_all.append(m)
+    return (np.concatenate(sp_all), np.concatenate(nr_all), np.concatenate(h_all),
+            np.concatenate(m_all) if want_margin else None)
+
+
+def main():
+    from dyn_res_pile_manip_amd import synthetic as syn
+    torch, PropNetDiffDenModel, ref_planners, config_reward_ptcl = mg.load_reference()
+    torch.set_num_threads(8)
+    config = syn.default_config()
+    env = syn.SyntheticEnv(config)
+    planner = ref_planners.PlannerGD(config, env)
+    model = PropNetDiffDenModel(config, False)
+    w = np.load(os.path.join(HERE, 'weights_trained.npz'))
+    model.load_state_dict({k[2:]: torch.from_numpy(w[k]) for k in w.files if k.startswith('w/')})
+    model.eval()
+    tap = StepTap(model)
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    out = {}
+    t0 = time.time()
+    for name, N in SIZES:
+        planner.particle_num = N
+        # the pile of make_golden_trained.py's rollout case, batch column 0 (its accepted rows are among these candidates)
+        s, dens, attr = (x[:1] for x in syn.make_pile(N, n_batch=2, seed=170 + N, kind='blob' if N <= 50 else 'uniform'))
+        s_twin = np.nextafter(s, np.float32(np.inf)).astype(np.float32)
+        goal_coor = syn.goal_coor_strided(obs_goal, 5 * N)
+        # the generator of make_golden_trained.py's rollout rows, candidates 0 .. ROWS-1, none rejected
+        acts = np.stack([np.stack([syn.pushes_through(s, seed=1000 * t + N + 7919 * cand)[0] for t in range(H)], 0)
+                         for cand in range(ROWS)], 0).astype(np.float32)
+        sp, nr, hh, margin = reference_rows(torch, planner, model, tap, s, dens, attr, acts, obs_goal, goal_coor)
+        sp2, nr2, hh2, _ = reference_rows(torch, planner, model, tap, s_twin, dens, attr, acts, obs_goal, goal_coor, False)
+        p = 'census/' + name + '/'
+        out[p + 's_cur'], out[p + 'dens'], out[p + 'attr'], out[p + 'goal_coor'] = s, dens, attr, goal_coor
+        out[p + 'act_seqs'] = acts
+        out[p + 'state_pred'], out[p + 'next_r'], out[p + 'recv_hash'], out[p + 'margin'] = sp, nr, hh, margin
+        out[p + 'twin_dev'] = np.abs(sp2 - sp).max((2, 3)).astype(np.float64)          # [ROWS,H]
+        out[p + 'twin_next_r'] = nr2
+        out[p + 'twin_flips'] = (hh2 != hh).sum(2).astype(np.int32)                   # receivers whose list differs
+        sub = margin < 5e-8
+        print('[census] %s: %d rows; rows with a step below 5e-8: %d, below 1e-6: %d; twin: rows with a flipped list %d, '
+              'max dev %.2e (rows without a flip: %.2e), max |d final reward| %.2e   %.0f s' %
+              (name, ROWS, sub.any(1).sum(), (margin < 1e-6).any(1).sum(), (out[p + 'twin_flips'].sum(1) > 0).sum(),
+               out[p + 'twin_dev'].max(),
+               out[p + 'twin_dev'][out[p + 'twin_flips'].sum(1) == 0].max() if (out[p + 'twin_flips'].sum(1) == 0).any() else 0,
+               np.abs(nr2[:, -1] - nr[:, -1]).max(), time.time() - t0), flush=True)
+
+        # one MPPI iteration around census row 0: the reference's sampler, rollout, reward and update -- and its twin's
+        np.random.seed(N)
+        macts = planner.sample_action_sequences(acts[0].astype(np.float64), np.zeros(H), MPPI_ROWS, lo, hi,
+                                                noise_type='normal').astype(np.float32)
+        spm, nrm, hhm, mm = reference_rows(torch, planner, model, tap, s, dens, attr, macts, obs_goal, goal_coor)
+        spm2, nrm2, hhm2, _ = reference_rows(torch, planner, model, tap, s_twin, dens, attr, macts, obs_goal, goal_coor, False)
+        p = 'mppi/' + name + '/'
+        out[p + 'act_seqs'] = macts
+        out[p + 'reward'], out[p + 'twin_reward'] = nrm[:, -1], nrm2[:, -1]
+        out[p + 'min_margin'] = mm.min(1)
+        out[p + 'twin_flip_rows'] = ((hhm2 != hhm).sum((1, 2)) > 0)
+        a4 = macts.astype(np.float64)[:, :, None, :]
+        out[p + 'update'] = planner.optimize_action(a4, nrm[:, -1:].astype(np.float64))[:, 0]
+        out[p + 'twin_update'] = planner.optimize_action(a4, nrm2[:, -1:].astype(np.float64))[:, 0]
+        print('[census] %s mppi: twin rows with a flipped list %d of %d, max |d reward| %.2e, |d update| %.2e, arg-max %d / %d'
+              '   %.0f s' % (name, out[p + 'twin_flip_rows'].sum(), MPPI_ROWS, np.abs(nrm2[:, -1] - nrm[:, -1]).max(),
+                             np.abs(out[p + 'update'] - out[p + 'twin_update']).max(), nrm[:, -1].argmax(),
+                             nrm2[:, -1].argmax(), time.time() - t0), flush=True)
+    tap.close()
+    np.savez_compressed(os.path.join(HERE, 'census.npz'), **out)
+    print('census.npz %8.1f KB' % (os.path.getsize(os.path.join(HERE, 'census.npz')) / 1024.0))
+
+
+if __name__ == '__main__':
+    main()

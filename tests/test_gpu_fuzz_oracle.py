@@ -193,6 +193,10 @@ GD_SHAPES = [
 ]
 
 
+GRAD_BOUND_FUZZ = 4e-5      # a row's gradient against the oracle's autograd, relative to the row's largest entry: 5 x the worst
+                            # observed over the 45 rows (7.2e-6 at 60 x 300, horizon 2, trained weights); round 5 asserted 3e-3
+
+
 @pytest.mark.parametrize('shape', GD_SHAPES, ids=lambda s: 'gd-%dx%d-nb%d-h%d-%s-%s' % s)
 def test_gradient_shape_against_the_oracle(eng, shape, exact_goal_transform):
     B, N, nb, H, which, engine = shape
@@ -214,7 +218,9 @@ def test_gradient_shape_against_the_oracle(eng, shape, exact_goal_transform):
                                          syn.demo_cam_params(), goal_coor, syn.demo_cam_extrinsics(), 24)
         np.testing.assert_allclose(r[row], np.asarray(rr).reshape(-1)[0], rtol=5e-5)
         scale = max(np.abs(gr).max(), 1e-6)
-        assert np.abs(ga[row] - np.asarray(gr)[0]).max() < 3e-3 * scale, (row, np.abs(ga[row] - np.asarray(gr)[0]).max(), scale)
+        err = float(np.abs(ga[row] - np.asarray(gr)[0]).max() / scale)
+        print('[grad-err] fuzz %dx%d nb%d h%d %s %s row %d: %.3e (scale %.3e)' % (B, N, nb, H, which, engine, row, err, scale))
+        assert err < GRAD_BOUND_FUZZ, (row, err, scale)
     eng.set_engine(_lib.ENGINE_FUSED)
 
 

@@ -10,6 +10,11 @@ from dyn_res_pile_manip_amd.gnn_dyn import PropNetDiffDenModel
 from dyn_res_pile_manip_amd.planners import PlannerGD, world2cam_affine
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('exact_goal_transform')]
+# max|gradient - reference's autograd| / max|reference's|: 5 x the worst OBSERVED (round 6) -- d loss / d state
+# 1.6e-6, d loss / d push 5.5e-7 on the seed-0 weights, 7.7e-7 on the stress weights; rounds 2 - 5 asserted 1e-3 / 2e-3
+GRAD_STATE_BOUND = 8e-6
+GRAD_BOUND = 3e-6
+GRAD_BOUND_STRESS = 4e-6
 
 
 @pytest.fixture(scope='module')
@@ -36,9 +41,12 @@ def test_gradients_match_the_reference(ctx, golden, case):
     # (the reference's retained gradient of its in-place-filled state_pred tensor only shows the final
     # step's slice: earlier slices were read through an older version of the tensor)
     assert gs.shape == ref_gs.shape
-    assert np.abs(gs[:, -1] - ref_gs[:, -1]).max() < 1e-3 * np.abs(ref_gs).max()
+    err_s = float(np.abs(gs[:, -1] - ref_gs[:, -1]).max() / np.abs(ref_gs).max())
     # d loss / d push through predictor, 3 propagation steps, particle encoder and gen_s_delta
-    assert np.abs(ga - ref_ga).max() < 2e-3 * np.abs(ref_ga).max()
+    err = float(np.abs(ga - ref_ga).max() / np.abs(ref_ga).max())
+    print('[grad-err] seed0 %s: d/d state %.3e, d/d push %.3e (abs %.3e)' % (case, err_s, err, np.abs(ga - ref_ga).max()))
+    assert err_s < GRAD_STATE_BOUND
+    assert err < GRAD_BOUND
     assert np.abs(ga - ref_ga).max() < 1e-4
     # rows whose push misses the pile have exactly zero gradient in both
     np.testing.assert_array_equal(np.abs(ga).sum((1, 2)) == 0, np.abs(ref_ga).sum((1, 2)) == 0)
@@ -67,7 +75,9 @@ def test_gradients_under_other_weights_match_the_reference(golden, case):
         r, ga, _ = eng.gd_grad()
         want = np.tile(ref_ga, (reps, 1, 1))
         np.testing.assert_allclose(r, np.tile(g[case + '/reward'][:, 0], reps), rtol=2e-5)
-        assert np.abs(ga - want).max() < 2e-3 * np.abs(ref_ga).max(), reps
+        err = float(np.abs(ga - want).max() / np.abs(ref_ga).max())
+        print('[grad-err] stress %s reps=%d: %.3e' % (case, reps, err))
+        assert err < GRAD_BOUND_STRESS, (reps, err)
         assert np.abs(ga).sum((1, 2)).min() > 0
     eng.close()
 

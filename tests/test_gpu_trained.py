@@ -16,6 +16,9 @@ from test_gpu_parity import check_rollout, disp_rel
 pytestmark = pytest.mark.gpu
 SIZES = ['n20', 'n50', 'n100', 'n300']
 ENGINES = ['valu', 'mfma', 'split', 'fused']
+# max|grad - reference's autograd| / max|reference's|, by the engine that wrote the tape: 5 x the worst OBSERVED over the
+# sixteen cases (fused 8.0e-6 at n100_h2, fp32 tape 3.5e-6 at n50_h1; gpurun_out of round 6) -- rounds 2 - 5 asserted 2e-3
+GRAD_BOUND = {'fused': 4e-5, 'mfma': 2e-5}
 
 
 @pytest.fixture(scope='module')
@@ -114,7 +117,9 @@ def test_gradients_match_the_reference(eng, golden, case, tape, exact_goal_trans
         r, ga, _ = eng.gd_grad()
         want = np.tile(ref_ga, (reps, 1, 1))
         np.testing.assert_allclose(r, np.tile(g[p + 'reward'][:, 0], reps), rtol=2e-5)
-        assert np.abs(ga - want).max() < 2e-3 * np.abs(ref_ga).max(), (reps, np.abs(ga - want).max(), np.abs(ref_ga).max())
+        err = float(np.abs(ga - want).max() / np.abs(ref_ga).max())
+        print('[grad-err] trained %s tape=%s reps=%d: max|ga - ref| / max|ref| = %.3e' % (case, tape, reps, err))
+        assert err < GRAD_BOUND[tape], (reps, err)
         np.testing.assert_array_equal(np.abs(ga).sum((1, 2)) == 0, np.abs(want).sum((1, 2)) == 0)
     eng.set_engine(_lib.ENGINE_FUSED)
 

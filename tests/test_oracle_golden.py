@@ -136,6 +136,9 @@ def test_mppi(golden):
     assert (samp.min(0) >= lo - 1e-12).all() and (samp.max(0) <= hi + 1e-12).all()
 
 
+ORACLE_GRAD_BOUND = 1e-6     # oracle's autograd against the reference's, relative to the largest entry (observed: 0)
+
+
 @pytest.mark.parametrize('case', ['h1', 'h2', 'h1_n100'])
 def test_gd_gradients(golden, W, case):
     """Row f1: the oracle differentiated by autograd == the reference differentiated by autograd."""
@@ -145,8 +148,10 @@ def test_gd_gradients(golden, W, case):
                                      g[case + '/act_seqs'], syn.goal_field(obs_goal), syn.demo_cam_params(),
                                      g[case + '/goal_coor'], syn.demo_cam_extrinsics(), 24)
     np.testing.assert_allclose(r, g[case + '/reward'][:, 0], rtol=2e-6)
-    np.testing.assert_allclose(gs, g[case + '/grad_state_pred'], rtol=0, atol=1e-3 * np.abs(g[case + '/grad_state_pred']).max())
-    np.testing.assert_allclose(ga, g[case + '/grad_act'], rtol=0, atol=1e-3 * np.abs(g[case + '/grad_act']).max())
+    # observed in the build container: bit-identical (the oracle runs the reference's torch ops in the reference's order); the
+    # bound leaves room for another host's BLAS kernel selection, not for a lost digit (rounds 2 - 5 asserted 1e-3)
+    np.testing.assert_allclose(gs, g[case + '/grad_state_pred'], rtol=0, atol=ORACLE_GRAD_BOUND * np.abs(g[case + '/grad_state_pred']).max())
+    np.testing.assert_allclose(ga, g[case + '/grad_act'], rtol=0, atol=ORACLE_GRAD_BOUND * np.abs(g[case + '/grad_act']).max())
 
 
 # ---- training (row f4): loss, autograd weight gradients and Adam steps of the reference model ----
@@ -271,4 +276,4 @@ def test_gd_gradients_under_other_weights(golden, case):
                                     g[case + '/act_seqs'], syn.goal_field(obs_goal), syn.demo_cam_params(),
                                     g[case + '/goal_coor'], syn.demo_cam_extrinsics(), 24)
     np.testing.assert_allclose(r, g[case + '/reward'][:, 0], rtol=2e-6)
-    np.testing.assert_allclose(ga, g[case + '/grad_act'], rtol=0, atol=1e-3 * np.abs(g[case + '/grad_act']).max())
+    np.testing.assert_allclose(ga, g[case + '/grad_act'], rtol=0, atol=ORACLE_GRAD_BOUND * np.abs(g[case + '/grad_act']).max())

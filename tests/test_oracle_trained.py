@@ -103,7 +103,7 @@ def test_gradients_of_the_planner_loss(golden, W, case):
     ref = g[p + 'grad_act']
     assert np.abs(ref).max() > 0
     np.testing.assert_allclose(np.asarray(rew).reshape(-1), g[p + 'reward'].reshape(-1), rtol=1e-5)
-    assert np.abs(np.asarray(ga) - ref).max() < 1e-4 * np.abs(ref).max() + 1e-7
+    assert np.abs(np.asarray(ga) - ref).max() < 1e-6 * np.abs(ref).max()       # observed: bit-identical (round 5 asserted 1e-4)
 
 
 def test_the_training_loop_body_follows_the_reference(golden):
