@@ -7,21 +7,29 @@ Every quantity is per ROW (one unfiltered 10-step push sequence) and STEP:
               reference's Rr / Rs in the fixture; the device's lists from its own previous state through drp_gen_s_delta +
               drp_build_graph, the kernels the rollout's lists are bit-equal to)
   dev         max |device - reference| over the row's particles
-  twin_*      the same three for the reference's second run, started one ulp away
+  twin_*      the same three for the reference's own second and third runs, started one ulp up / one ulp down ([2, B, H])
+
+TAU: a step is NEAR A TIE when `margin` is below it.  5e-8 -- the margin make_golden_trained.py demands of every step of the
+rows it KEEPS at 300 particles -- is a hundred ulps of adj_thresh^2 = 0.0064 in fp32 (4.66e-10 each): the decisions of
+model/gnn_dyn.py:231-237 (`topk` on fp32 squared distances, `dis - thr < 0`) that rounding-level differences of the positions
+decide.  Observed: the reference's own twins change lists at margins up to 2.7e-9, the device up to 6.5e-9 on the census rows
+and 2.8e-8 on one of the 4 096 MPPI rows (late in the rollout, where ten steps of a chaotic map have grown the deviation to 1e-5).
 """
 import numpy as np
 
 SIZES = ['n20', 'n50', 'n100', 'n300']
+TAU = 5e-8
 
 
 def fmix32(x):
     """murmur3's 32-bit finaliser (make_golden_census.fmix32)."""
-    x = np.asarray(x).astype(np.uint32)
-    x ^= x >> np.uint32(16)
-    x = (x * np.uint32(0x85ebca6b)).astype(np.uint32)
-    x ^= x >> np.uint32(13)
-    x = (x * np.uint32(0xc2b2ae35)).astype(np.uint32)
-    x ^= x >> np.uint32(16)
+    x = np.atleast_1d(np.asarray(x)).astype(np.uint32)
+    with np.errstate(over='ignore'):
+        x ^= x >> np.uint32(16)
+        x = (x * np.uint32(0x85ebca6b)).astype(np.uint32)
+        x ^= x >> np.uint32(13)
+        x = (x * np.uint32(0xc2b2ae35)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
     return x
 
 
@@ -32,23 +40,32 @@ def list_hash(idx, cnt):
     return term.sum(2, dtype=np.uint32)
 
 
-def device_rows(eng, g, p, acts=None):
-    """Roll the census rows of group p out on the device -> states [B,H,N,3], rewards [B,H], flips_dev [B,H] (None when the
-    group has no recv_hash), dev [B,H]."""
+def row_hash(recv_hash):
+    """[..., N] receiver hashes -> [...] uint32: one word for a whole row's lists (make_golden_census.row_hash)."""
+    n = recv_hash.shape[-1]
+    salt = fmix32(np.arange(1, n + 1))
+    return fmix32(recv_hash ^ salt).sum(-1, dtype=np.uint32)
+
+
+def device_rows(eng, g, p, acts=None, row_hashes=None):
+    """Roll the census rows of group p out on the device -> states [B,H,N,3], rewards [B,H], flips_dev [B,H] (receivers
+    whose list differs from the reference's; with `row_hashes` [B,H] -- the MPPI population, other pushes on the group's pile
+    -- 0 / 1 per row and step), dev [B,H] (None for the MPPI population: no reference states in the fixture)."""
     s0, attr, dens = g[p + 's_cur'], g[p + 'attr'], g[p + 'dens']
     own = acts is None                     # other push sequences on the group's pile (the MPPI population): no lists, no states to compare
     acts = g[p + 'act_seqs'] if own else acts
     states, rew = eng.rollout(s0, attr, dens, acts, want_reward=True)
     B, H = acts.shape[:2]
     flips = None
-    if own and (p + 'recv_hash') in g.files:
-        ref_h = g[p + 'recv_hash']
+    if own or row_hashes is not None:
+        ref_h = g[p + 'recv_hash'] if own else None
         flips = np.zeros((B, H), np.int64)
         prev = np.tile(s0, (B, 1, 1))
         for t in range(H):
             sd = eng.gen_s_delta(prev, acts[:, t])
             idx, cnt = eng.build_graph(prev, sd)
-            flips[:, t] = (list_hash(idx, cnt) != ref_h[:, t]).sum(1)
+            h = list_hash(idx, cnt)
+            flips[:, t] = (h != ref_h[:, t]).sum(1) if own else (row_hash(h) != row_hashes[:, t])
             prev = states[:, t]
     dev = None
     if own and (p + 'state_pred') in g.files:

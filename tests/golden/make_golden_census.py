@@ -11,14 +11,17 @@ size (20 / 50 / 100 / 300 particles) the first ROWS candidates of the same gener
                          (model/gnn_dyn.py:244-251) -- what the device's lists are compared with, no oracle in between
   margin                 how far that step's graph is from changing (`decision_margin`: smallest |d - adj_thresh^2| and
                          smallest gap between a receiver's 10th and 11th sender inside the radius, squared units)
-  twin_*                 the yardstick: the reference AGAIN on the same rows, started ONE ULP away (`torch.nextafter` on
-                         s_cur): its deviation from the first run per row and step, the receivers whose lists differ,
-                         its rewards.  How far the reference drifts from ITSELF once a near-tie is crossed.
+  mask_margin            how far the push band's hard mask (planners.py:248, 0 < u < L) is from changing for any particle
+  twin_*                 the yardstick: the reference AGAIN on the same rows, started ONE ULP away (`nextafter` on s_cur, once
+                         towards +inf and once towards -inf: two twins): deviation from the first run per row and step, the
+                         receivers whose lists differ, the rewards.  How far the reference drifts from ITSELF once a
+                         near-tie is crossed.
 
 and, per size, one MPPI iteration of MPPI_ROWS rows built from census row 0 (the reference's `sample_action_sequences`
-around it): final-step rewards of the reference and of its one-ulp twin, `optimize_action` of both (planners.py:549-561),
-the per-row smallest margin.  Output: tests/golden/census.npz.  Runs ONLY in the build container (about 12 minutes on
-8 cores).  Usage:  python tests/golden/make_golden_census.py
+around it): final-step rewards of the reference and of its one-ulp twins, `optimize_action` of each (planners.py:549-561),
+per row and step a hash of the whole row's lists (so the device's flipped rows can be counted on 1 024 rows too) and which
+steps of the twins' lists differ, the per-row smallest margin.  Output: tests/golden/census.npz.  Runs ONLY in the build
+container (about 17 minutes on 8 cores).  Usage:  python tests/golden/make_golden_census.py
 """
 import os
 import sys
@@ -42,12 +45,13 @@ SIZES = [('n20', 20), ('n50', 50), ('n100', 100), ('n300', 300)]
 
 def fmix32(x):
     """murmur3's 32-bit finaliser on uint32 arrays (the tests hash the device's lists the same way)."""
-    x = x.astype(np.uint32)
-    x ^= x >> np.uint32(16)
-    x = (x * np.uint32(0x85ebca6b)).astype(np.uint32)
-    x ^= x >> np.uint32(13)
-    x = (x * np.uint32(0xc2b2ae35)).astype(np.uint32)
-    x ^= x >> np.uint32(16)
+    x = np.atleast_1d(np.asarray(x)).astype(np.uint32)
+    with np.errstate(over='ignore'):
+        x ^= x >> np.uint32(16)
+        x = (x * np.uint32(0x85ebca6b)).astype(np.uint32)
+        x ^= x >> np.uint32(13)
+        x = (x * np.uint32(0xc2b2ae35)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
     return x
 
 
@@ -65,6 +69,26 @@ def recv_hash_from_onehot(Rr, Rs):
         for b in range(B):
             np.add.at(h[b], recv[b][valid[b]], term[b][valid[b]])
     return h
+
+
+def row_hash(recv_hash):
+    """[..., N] receiver hashes -> [...] uint32: one word for the whole row's lists (position-dependent)."""
+    n = recv_hash.shape[-1]
+    salt = fmix32(np.arange(1, n + 1))
+    return fmix32(recv_hash ^ salt).sum(-1, dtype=np.uint32)
+
+
+def mask_margin_rows(pos, act, M34, gs=24.0):
+    """planners.py:231-248 in float64: u = (p - s) . dir, L = |e - s|; min over particles of min(|u|, |L - u|): [B]."""
+    def to_cam(x, z):
+        p = np.stack([x, np.zeros_like(x), z, np.ones_like(x)], 1)
+        return (p @ M34.astype(np.float64).T) / gs
+    a = act.astype(np.float64)
+    sc, ec = to_cam(a[:, 0], -a[:, 1]), to_cam(a[:, 2], -a[:, 3])
+    dv = ec - sc
+    L = np.sqrt((dv * dv).sum(1))
+    u = ((pos.astype(np.float64) - sc[:, None, :]) * (dv / L[:, None])[:, None, :]).sum(-1)
+    return np.minimum(np.abs(u), np.abs(L[:, None] - u)).min(1)
 
 
 def decision_margin_rows(pos, thr=np.float32(0.0064)):
@@ -100,11 +124,11 @@ class StepTap(object):
         del self.m.forward
 
 
-def reference_rows(torch, planner, model, tap, s, dens, attr, acts, obs_goal, goal_coor, want_margin=True):
+def reference_rows(torch, planner, model, tap, s, dens, attr, acts, obs_goal, goal_coor, want_margin=True, M34=None):
     """The reference on rows acts [B,H,4] of ONE pile s [1,N,3], in chunks: state_pred [B,H,N,3], next_r [B,H],
     recv_hash [B,H,N], margin [B,H]."""
     B, N = acts.shape[0], s.shape[1]
-    sp_all, nr_all, h_all, m_all = [], [], [], []
+    sp_all, nr_all, h_all, m_all, mm_all = [], [], [], [], []
     for c in range(0, B, CHUNK):
         a = np.ascontiguousarray(acts[c:c + CHUNK])
         with torch.no_grad():
@@ -118,16 +142,18 @@ def reference_rows(torch, planner, model, tap, s, dens, attr, acts, obs_goal, go
         sp_all.append(sp)
         nr_all.append(nr.numpy()[:, :, 0])
         if want_margin:
-            m = np.empty((a.shape[0], H))
+            m, mm = np.empty((a.shape[0], H)), np.empty((a.shape[0], H))
             prev = np.tile(s, (a.shape[0], 1, 1))
             for t in range(H):
                 with torch.no_grad():
                     sd = planner.gen_s_delta(torch.from_numpy(prev), torch.from_numpy(a[:, t])).numpy()
                 m[:, t] = decision_margin_rows((prev + sd).astype(np.float32))
+                mm[:, t] = mask_margin_rows(prev, a[:, t], M34)
                 prev = sp[:, t]
             m_all.append(m)
+            mm_all.append(mm)
     return (np.concatenate(sp_all), np.concatenate(nr_all), np.concatenate(h_all),
-            np.concatenate(m_all) if want_margin else None)
+            (np.concatenate(m_all), np.concatenate(mm_all)) if want_margin else None)
 
 
 def main():
@@ -144,52 +170,61 @@ def main():
     tap = StepTap(model)
     obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
     lo, hi = syn.action_limits()
+    from oracle import propnet_sparse as osp           # only the camera affine of the mask-margin diagnostic
+    M34 = osp.world2cam_affine(syn.demo_cam_extrinsics(), 24)
     out = {}
     t0 = time.time()
     for name, N in SIZES:
         planner.particle_num = N
         # the pile of make_golden_trained.py's rollout case, batch column 0 (its accepted rows are among these candidates)
         s, dens, attr = (x[:1] for x in syn.make_pile(N, n_batch=2, seed=170 + N, kind='blob' if N <= 50 else 'uniform'))
-        s_twin = np.nextafter(s, np.float32(np.inf)).astype(np.float32)
+        s_twins = [np.nextafter(s, np.float32(np.inf)).astype(np.float32), np.nextafter(s, np.float32(-np.inf)).astype(np.float32)]
         goal_coor = syn.goal_coor_strided(obs_goal, 5 * N)
         # the generator of make_golden_trained.py's rollout rows, candidates 0 .. ROWS-1, none rejected
         acts = np.stack([np.stack([syn.pushes_through(s, seed=1000 * t + N + 7919 * cand)[0] for t in range(H)], 0)
                          for cand in range(ROWS)], 0).astype(np.float32)
-        sp, nr, hh, margin = reference_rows(torch, planner, model, tap, s, dens, attr, acts, obs_goal, goal_coor)
-        sp2, nr2, hh2, _ = reference_rows(torch, planner, model, tap, s_twin, dens, attr, acts, obs_goal, goal_coor, False)
+        sp, nr, hh, (margin, mmargin) = reference_rows(torch, planner, model, tap, s, dens, attr, acts, obs_goal, goal_coor, True, M34)
+        tw = [reference_rows(torch, planner, model, tap, st, dens, attr, acts, obs_goal, goal_coor, False) for st in s_twins]
         p = 'census/' + name + '/'
         out[p + 's_cur'], out[p + 'dens'], out[p + 'attr'], out[p + 'goal_coor'] = s, dens, attr, goal_coor
         out[p + 'act_seqs'] = acts
-        out[p + 'state_pred'], out[p + 'next_r'], out[p + 'recv_hash'], out[p + 'margin'] = sp, nr, hh, margin
-        out[p + 'twin_dev'] = np.abs(sp2 - sp).max((2, 3)).astype(np.float64)          # [ROWS,H]
-        out[p + 'twin_next_r'] = nr2
-        out[p + 'twin_flips'] = (hh2 != hh).sum(2).astype(np.int32)                   # receivers whose list differs
-        sub = margin < 5e-8
-        print('[census] %s: %d rows; rows with a step below 5e-8: %d, below 1e-6: %d; twin: rows with a flipped list %d, '
-              'max dev %.2e (rows without a flip: %.2e), max |d final reward| %.2e   %.0f s' %
-              (name, ROWS, sub.any(1).sum(), (margin < 1e-6).any(1).sum(), (out[p + 'twin_flips'].sum(1) > 0).sum(),
-               out[p + 'twin_dev'].max(),
-               out[p + 'twin_dev'][out[p + 'twin_flips'].sum(1) == 0].max() if (out[p + 'twin_flips'].sum(1) == 0).any() else 0,
-               np.abs(nr2[:, -1] - nr[:, -1]).max(), time.time() - t0), flush=True)
+        out[p + 'state_pred'], out[p + 'next_r'], out[p + 'recv_hash'] = sp, nr, hh
+        out[p + 'margin'], out[p + 'mask_margin'] = margin, mmargin
+        out[p + 'twin_dev'] = np.stack([np.abs(x[0] - sp).max((2, 3)) for x in tw]).astype(np.float64)     # [2,ROWS,H]
+        out[p + 'twin_next_r'] = np.stack([x[1] for x in tw])
+        out[p + 'twin_flips'] = np.stack([(x[2] != hh).sum(2) for x in tw]).astype(np.int32)               # receivers whose list differs
+        tf = out[p + 'twin_flips'].sum(2) > 0
+        print('[census] %s: %d rows; rows with a step below 1e-8: %d, below 5e-8: %d, below 1e-6: %d; smallest mask margin %.1e; twins: '
+              'rows with a flipped list %s, max dev %s, max |d final reward| %s   %.0f s' %
+              (name, ROWS, (margin < 1e-8).any(1).sum(), (margin < 5e-8).any(1).sum(), (margin < 1e-6).any(1).sum(), mmargin.min(),
+               tf.sum(1), ['%.2e' % v for v in out[p + 'twin_dev'].max((1, 2))],
+               ['%.2e' % np.abs(x[1][:, -1] - nr[:, -1]).max() for x in tw], time.time() - t0), flush=True)
 
-        # one MPPI iteration around census row 0: the reference's sampler, rollout, reward and update -- and its twin's
+        # one MPPI iteration around census row 0: the reference's sampler, rollout, reward and update -- and its twins'
         np.random.seed(N)
         macts = planner.sample_action_sequences(acts[0].astype(np.float64), np.zeros(H), MPPI_ROWS, lo, hi,
                                                 noise_type='normal').astype(np.float32)
-        spm, nrm, hhm, mm = reference_rows(torch, planner, model, tap, s, dens, attr, macts, obs_goal, goal_coor)
-        spm2, nrm2, hhm2, _ = reference_rows(torch, planner, model, tap, s_twin, dens, attr, macts, obs_goal, goal_coor, False)
+        spm, nrm, hhm, (mm, mmm) = reference_rows(torch, planner, model, tap, s, dens, attr, macts, obs_goal, goal_coor, True, M34)
+        del spm
+        twm = []
+        for st in s_twins:
+            x = reference_rows(torch, planner, model, tap, st, dens, attr, macts, obs_goal, goal_coor, False)
+            twm.append((x[1], row_hash(x[2])))
+            del x
         p = 'mppi/' + name + '/'
         out[p + 'act_seqs'] = macts
-        out[p + 'reward'], out[p + 'twin_reward'] = nrm[:, -1], nrm2[:, -1]
-        out[p + 'min_margin'] = mm.min(1)
-        out[p + 'twin_flip_rows'] = ((hhm2 != hhm).sum((1, 2)) > 0)
+        out[p + 'reward'] = nrm[:, -1]
+        out[p + 'twin_reward'] = np.stack([x[0][:, -1] for x in twm])
+        out[p + 'row_hash'] = row_hash(hhm)                                                    # [MPPI_ROWS,H] uint32
+        out[p + 'twin_flip_steps'] = np.stack([x[1] != out[p + 'row_hash'] for x in twm])      # [2,MPPI_ROWS,H] bool
+        out[p + 'min_margin'], out[p + 'min_mask_margin'] = mm.min(1), mmm.min(1)
         a4 = macts.astype(np.float64)[:, :, None, :]
         out[p + 'update'] = planner.optimize_action(a4, nrm[:, -1:].astype(np.float64))[:, 0]
-        out[p + 'twin_update'] = planner.optimize_action(a4, nrm2[:, -1:].astype(np.float64))[:, 0]
-        print('[census] %s mppi: twin rows with a flipped list %d of %d, max |d reward| %.2e, |d update| %.2e, arg-max %d / %d'
-              '   %.0f s' % (name, out[p + 'twin_flip_rows'].sum(), MPPI_ROWS, np.abs(nrm2[:, -1] - nrm[:, -1]).max(),
-                             np.abs(out[p + 'update'] - out[p + 'twin_update']).max(), nrm[:, -1].argmax(),
-                             nrm2[:, -1].argmax(), time.time() - t0), flush=True)
+        out[p + 'twin_update'] = np.stack([planner.optimize_action(a4, x[0][:, -1:].astype(np.float64))[:, 0] for x in twm])
+        print('[census] %s mppi: twin rows with a flipped list %s of %d, max |d reward| %s, |d update| %s, arg-max %d / %s   %.0f s' %
+              (name, out[p + 'twin_flip_steps'].any(2).sum(1), MPPI_ROWS, ['%.2e' % np.abs(r - nrm[:, -1]).max() for r in out[p + 'twin_reward']],
+               ['%.2e' % np.abs(u - out[p + 'update']).max() for u in out[p + 'twin_update']], nrm[:, -1].argmax(),
+               [int(r.argmax()) for r in out[p + 'twin_reward']], time.time() - t0), flush=True)
     tap.close()
     np.savez_compressed(os.path.join(HERE, 'census.npz'), **out)
     print('census.npz %8.1f KB' % (os.path.getsize(os.path.join(HERE, 'census.npz')) / 1024.0))

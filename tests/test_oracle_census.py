@@ -1,0 +1,52 @@
+"""CPU: the census fixture (tests/golden/census.npz, make_golden_census.py) against the sparse oracle -- the fixture's hashes,
+margins and twins are consistent with a second fp32 restatement of the path, under the rule tests/test_gpu_census.py holds the
+device to: lists identical up to a row's first near-tie, deviation within 4 x the reference's own twins."""
+import numpy as np
+import pytest
+
+import _census as C
+from dyn_res_pile_manip_amd import synthetic as syn
+from oracle import propnet_sparse as osp
+
+
+@pytest.mark.parametrize('case', C.SIZES)
+def test_the_sparse_oracle_on_the_census_rows(golden, case):
+    g = golden.census
+    p = 'census/' + case + '/'
+    W = osp.weights_np(golden.weights_trained)
+    M34 = osp.world2cam_affine(syn.demo_cam_extrinsics(), 24)
+    s0, attr, dens, acts = g[p + 's_cur'], g[p + 'attr'], g[p + 'dens'], g[p + 'act_seqs']
+    rows = slice(0, 64 if s0.shape[1] <= 100 else 16)                  # 300 particles: a quarter of the rows (seconds, not a minute)
+    acts = acts[rows]
+    taps = {}
+    states = osp.rollout(W, s0, dens, attr, acts, M34, 24.0, taps=taps)
+    ref, margin, tw = g[p + 'state_pred'][rows], g[p + 'margin'][rows], g[p + 'twin_dev'][:, rows]
+    B, H = margin.shape
+    flips = np.stack([(C.list_hash(taps['nbr_idx'][t], taps['nbr_cnt'][t]) != g[p + 'recv_hash'][rows][:, t]).sum(1) for t in range(H)], 1)
+    dev = np.abs(states - ref).max((2, 3))
+    first = C.first_true(margin < C.TAU)
+    pre = np.arange(H)[None, :] < first[:, None]
+    assert (flips[pre] == 0).all()
+    disp_b = C.displacement(g, p)[rows].max(0)
+    assert dev[:, 0].max() < 1e-4 * disp_b[0]
+    for t in range(H):
+        if pre[:, t].any():
+            assert dev[pre[:, t], t].max() <= max(1e-4 * disp_b[t], 4 * tw[:, pre[:, t], t].max()), t
+    # the fixture's own consistency: a twin's lists differ only in rows that reach a near-tie, and only from that step on
+    tf = g[p + 'twin_flips'][:, rows]
+    assert (tf[:, pre] == 0).all()
+    assert g[p + 'mask_margin'].min() > 1e-7                            # no particle within rounding of the push band's ends
+
+
+def test_census_hash_helpers():
+    idx = -np.ones((1, 3, 10), np.int16)
+    cnt = np.array([[2, 0, 1]], np.uint8)
+    idx[0, 0, :2] = [1, 2]
+    idx[0, 2, :1] = [0]
+    h = C.list_hash(idx, cnt)
+    assert h[0, 1] == 0 and h[0, 0] == np.uint32((int(C.fmix32(2)[0]) + int(C.fmix32(3)[0])) % 2 ** 32) and h[0, 2] == C.fmix32(1)[0]
+    idx2 = idx.copy()
+    idx2[0, 0, :2] = [2, 1]                                             # a set, not a sequence
+    assert (C.list_hash(idx2, cnt) == h).all()
+    assert C.row_hash(h)[0] != C.row_hash(h[:, ::-1])[0]               # ... but receiver i's list is receiver i's
+    assert (C.first_true(np.array([[0, 1, 1], [0, 0, 0]], bool)) == [1, 3]).all()
