@@ -617,10 +617,28 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
         roof['achieved'] = tb / avg_s / 1e9
         roof['frac'] = roof['achieved'] / roof['peak']
         roof['cache_served'] = bool(roof.get('algorithmic_bytes_per_launch', 0) > tb)
+    # the backward launch (kmb_rows_bwd up to 256 particles, kmb_step_bwd above) beside the forward's, whichever dominates:
+    # HBM side from the counters on file, matrix side from the algorithmic FLOPs of reverse mode WITHOUT weight gradients at
+    # horizon 1 (no gradient into the relation encoder: its inputs are the given state): predictor 2 x (192 + 4096), per propagation
+    # step W_agg^T, W_r^T, W_s^T (3 x 4096 MAC) and 128 adds per edge, node constant and particle encoder 4096 + 4096 + 320 MAC
+    roof_bwd = None
+    if per_class.get('bwd_node', (0, 0))[1] > 0 and per_class['bwd_edge'][1] == 0 and H == 1:
+        b_s = per_class['bwd_node'][0] / per_class['bwd_node'][1] * 1e-3
+        per_node_b = (256 + 12 + 3 * 256) + 3 * (2 * 256 + 8 * kbar + kbar * (4 + 8 + 256)) + 2 * (256 + 2 * 256 + 2 * 256) + (2 * 256 + 24)
+        flop_b = B * N * (99328.0 + 384.0 * kbar)
+        tbb = traffic.get('step_bwd', {}).get('hbm_bytes_per_launch')
+        roof_bwd = ordered({'kernel': 'bwd_node (kmb_rows_bwd / kmb_step_bwd: the whole reverse pass of a rollout step in one launch)',
+                            'avg_launch_ms': b_s * 1e3, 'launches': per_class['bwd_node'][1], 'traffic': tbb,
+                            'bound': 'neither roof: a chain of gathers from LDS / L2 between fp32 matrix layers',
+                            'frac': (tbb / b_s / 1e9 / PEAK_HBM_GBS) if tbb else None, 'frac_basis': 'counter bytes over time against 8 TB/s',
+                            'achieved': (tbb / b_s / 1e9) if tbb else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                            'algorithmic_bytes_per_launch': B * N * per_node_b, 'algorithmic_gbs': B * N * per_node_b / b_s / 1e9,
+                            'mfma_f32_frac_algorithmic': flop_b / b_s / 1e12 / PEAK_F32_TFLOPS, 'algorithmic_tflops': flop_b / b_s / 1e12,
+                            'flop_model': 'F_bwd(K) = 99328 + 384 K per particle (K = %.2f): reverse mode without weight gradients, horizon 1' % kbar})
     if dom_work and dom_work.get('clk_ticks') and 'sclk_mhz_under_load' not in roof:
         # the clock of the forward kernel's counting launch of the same iteration stands for the workload's
         roof['sclk_mhz_under_load'] = 100.0 * dom_work['clk_cycles'] / dom_work['clk_ticks']
-    return {'dt': dt, 'median': med, 'per_class': per_class, 'dominant': dominant, 'roofline': ordered(roof), 'kbar': kbar,
+    return {'dt': dt, 'median': med, 'per_class': per_class, 'dominant': dominant, 'roofline': ordered(roof), 'roofline_backward': roof_bwd, 'kbar': kbar,
             'B': B, 's0': s0, 'dens': dens, 'attr': attr, 'acts': acts, 'step': step}
 
 
@@ -653,16 +671,18 @@ def run_sweep(rig, fence):
         N, ns, H, _, label = CONFIGS[name]
         steps, warm = 20, 5
         t_wall = time.perf_counter()
+        roof_bwd = None
         if name == 'gd-demo':
             g = bench_gd(rig, N, ns // 30, 30, H, steps, warm, fence, want_median=False)
             B, roof, per_class, dt = g['B'], g['roofline'], g['per_class'], g['dt']
             kbar, step = g['kbar'], g['step']
+            roof_bwd = g['roofline_backward']
         else:
             m = bench_mppi(rig, N, ns, H, 0, steps, warm, lambda e: e.mpc_update_device(), fence,
                            ['graph', 'node_encode', 'prop', 'reward', 'mppi'], want_median=False)
             B, roof, per_class, dt, kbar = ns, mppi_roofline(rig, m, N, ns, H, steps), m['per_class'], m['dt'], m['kbar']
             step = m['step']
-            # HBM-side bytes per launch of the dominant kernel, where a PMC pass of this preset is on file (tools/profile_r05.sh)
+            # HBM-side bytes per launch of the dominant kernel, where a PMC pass of this preset is on file (tools/profile_r06.sh)
             tkey = ('rollout' if roof.get('graph_build_in_launch') else
                     'prop3' if roof.get('propagation_steps_per_launch', 0) >= 3 else m['dominant'])
             tb = load_traffic().get(name, {}).get(tkey, {}).get('hbm_bytes_per_launch')
@@ -684,6 +704,8 @@ def run_sweep(rig, fence):
                     'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in per_class.items() if v[1] > 0},
                     'executed_per_launch': roof.get('executed_per_launch'),
                     'workload': label, 'peak_basis': roof.get('peak_basis')})
+        if roof_bwd:
+            out[-1]['roofline_backward'] = roof_bwd
     return out
 
 
@@ -907,7 +929,8 @@ def run_rank(args):
                               'n_batch': nb, 'rows_per_gpu': B, 'n_look_ahead': H, 'engine': 'fused', 'mean_in_degree': g['kbar'],
                               'parallelism': 'trajectories sharded x%d, no collective' % world,
                               'reference_time_model_ms': particle_num_to_iter_time(N)},     # planners.py:25-28, batch 300 on its GPU
-                   'roofline': g['roofline'], 'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in g['per_class'].items()},
+                   'roofline': g['roofline'], 'roofline_backward': g['roofline_backward'],
+                   'kernel_ms_per_iteration': {k: round(v[0], 4) for k, v in g['per_class'].items()},
                    'cpu_baseline': None}
             if world == 1 and not args.no_cpu_baseline:
                 from oracle import propnet_dense as od

@@ -426,10 +426,11 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
             const dim3 pblk(64 * PROP_WAVES);
             // cached or recomputing: by the pile size alone (drp_ctx::ec_shape).  A cached batch too large for one launch of
             // at most ec_rows_cap rows per workgroup goes out as several launches over consecutive blocks of samples, the same
-            // cache buffer under each; the tape's launches (one history buffer over the whole batch) take a larger buffer instead
+            // cache buffer under each -- the tape's launches too: the history buffers are laid out for the whole batch, a block
+            // starts `ro` rows into every slot and the kernel takes the slots' stride as an argument (hist_rows)
             bool ec = c->ec_shape(N, tape);
             long chunk = B;
-            if (ec && !tape) {
+            if (ec) {
                 long unit = 1;
                 bool ok = true;
                 for (int mod : {a.prev_mod, a.attr_mod, a.dens_mod})
@@ -460,9 +461,10 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                 const int attr_mod_c = a.attr_mod >= B ? Bc : a.attr_mod;
                 const float* dens_c = a.dens_mod >= B ? a.dens + b_off : a.dens;
                 const int dens_mod_c = a.dens_mod >= B ? Bc : a.dens_mod;
-                float* eff_base = (tape ? a.eff_hist : ptr<float>(c->eff)) + ro * 64;       // (the tape's launch is never split: ro = 0)
-                unsigned* mask_hist = tape ? a.mask_hist : nullptr;
-                float* agg_hist = tape ? a.agg_hist : nullptr;
+                float* eff_base = (tape ? a.eff_hist : ptr<float>(c->eff)) + ro * 64;
+                unsigned* mask_hist = tape ? a.mask_hist + ro * DRP_K * 2 : nullptr;
+                float* agg_hist = (tape && a.agg_hist) ? a.agg_hist + ro * 64 : nullptr;
+                const size_t hist_rows = tape ? (size_t)B * N : 0;
                 const float* sd_c = phase_e ? (const float*)(ptr<float>(c->s_delta) + ro * 3) : (const float*)nullptr;
                 const float* cself_c = a.cself ? a.cself + (size_t)b_off * 64 : nullptr;
                 const uint8_t* cself_ok_c = a.cself_ok ? a.cself_ok + b_off : nullptr;
@@ -477,8 +479,8 @@ int run_step_mfma(drp_ctx* c, const StepArgs& a) {
                 const bool one = ec && (pair ? ((long)spw_c * N + 15) / 16 : ((long)spw_c * N + 31) / 32) <= PROP_WAVES;
                 if (ec && (size_t)grid.x * ec_stride * 16 > c->ecache.cap) CHK(ensure(c, c->ecache, (size_t)grid.x * ec_stride * 16));
 #define PROP3_LAUNCH_W(TAPE_, PAIR_, EC_, ONE_) do { \
-                    if (wk) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, EC_, true, ONE_>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ptr<float4>(c->ecache), ec_stride, wk); \
-                    else hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, EC_, false, ONE_>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ptr<float4>(c->ecache), ec_stride, wk); } while (0)
+                    if (wk) hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, EC_, true, ONE_>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ptr<float4>(c->ecache), ec_stride, wk, hist_rows); \
+                    else hipLaunchKernelGGL((km_prop3<TAPE_, PAIR_, EC_, false, ONE_>), grid, pblk, KM_PROP3_LDS, st, PROP3_ARGS, ptr<float4>(c->ecache), ec_stride, wk, hist_rows); } while (0)
 #define PROP3_LAUNCH(TAPE_, PAIR_) do { \
                     if (one) PROP3_LAUNCH_W(TAPE_, PAIR_, true, true); else if (ec) PROP3_LAUNCH_W(TAPE_, PAIR_, true, false); \
                     else PROP3_LAUNCH_W(TAPE_, PAIR_, false, false); } while (0)

@@ -466,12 +466,14 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     CHK(ensure(c, c->g_state, (size_t)H * bn * 3 * sizeof(float)));
     c->wg_defer_now = false;
     c->wg_jobs.clear();
+    bool defer_batch = false;               // re-armed before every pass of the step (flush_wgrad_all clears wg_defer_now)
     if (backward) {
         // deferred weight gradients keep every job's operands until the end of the backward pass: H copies of the node-level
         // dumps (3 H + 1 of g_eff, 3 H of g_proj) and of the relation encoder's dumps -- 0.24 GB per rollout step at 32 x 300
         const size_t keep_bytes = (size_t)H * (16 * bn64 + 7 * bnk * 64 + bnk * 8 + bn * 8) * sizeof(float);
         const bool defer = c->wgrad_defer && (long)B * ((N + 31) / 32) >= KMB_MIN_TILES && !c->bwd_valu_stages && keep_bytes <= ((size_t)8 << 30);
         c->wg_defer_now = defer;
+        defer_batch = defer;
         const size_t kt = defer ? (size_t)H : 1;
         CHK(ensure(c, c->eff_hist, (size_t)H * 4 * bn64 * sizeof(float)));
         CHK(ensure(c, c->agg_hist, (size_t)H * 3 * bn64 * sizeof(float)));
@@ -504,10 +506,16 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     // nothing when it is set (k_adam's `skip`), the iteration count advances only once the flag has come back clear, and the
     // step runs again with one workgroup per group (no barrier to wait at) -- for the rest of the context's life.
     for (int attempt = 0; ; ++attempt) {
+        c->wg_defer_now = defer_batch;
+        c->wg_jobs.clear();
         CHK(train_forward_backward(c, B, N, backward));
         const int f_spw = (B + c->n_cu - 1) / c->n_cu, f_groups = (B + f_spw - 1) / f_spw;
         const unsigned* const flag_dev = reinterpret_cast<const unsigned*>(ptr<float>(c->tr_grad) + TR_GRAD_PAD + (size_t)H * f_groups);
         *gave_up = 0;
+        if (c->debug_force_giveup && attempt == 0 && backward) {        // tests: the flag as a timed-out barrier would leave it, once
+            HIPCHK(c, hipMemsetAsync(const_cast<unsigned*>(flag_dev), 1, sizeof(unsigned), c->stream));
+            c->debug_force_giveup = false;
+        }
         if (loss_out) CHK(d2h(c, parts, c->tr_loss.p, (size_t)H * B * sizeof(double)));
         if (grad_out && backward) CHK(d2h(c, grad_out, c->tr_grad.p, (size_t)W_TOTAL * sizeof(float)));
         if (backward) CHK(d2h(c, gave_up, flag_dev, sizeof(unsigned)));

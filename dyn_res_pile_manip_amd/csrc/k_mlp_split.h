@@ -1315,6 +1315,8 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
                                            , unsigned long long (&st_sum)[8]
 #endif
                                            , Aux aux = Aux()
+                                           , size_t hist_rows = 0 /* TAPE: rows (samples x particles) of the WHOLE batch the history buffers
+                                                                     are laid out for -- a launch may cover a block of its samples */
 ) {
     float* wsp_f = P.wsp_f;
     float* w6_f = P.w6_f;
@@ -1517,7 +1519,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
         lr.b = b0 + m;
         return lr;
     };
-    const size_t bn64 = (size_t)B * N * 64;
+    const size_t bn64 = (TAPE && hist_rows != 0 ? hist_rows : (size_t)B * N) * 64;      // stride between the history's slots
     PropArgs A = {mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, c_node, eff, eff,
                   N, B, proj_b, s_out, out_stride, cself, cself_ok, nullptr, nullptr, re_scale, re_inv, ecache, WORK ? work : nullptr};
     PropLds L = {reinterpret_cast<const f16x8*>(wsp_f), reinterpret_cast<const bf16x8*>(w6_f),
@@ -1543,7 +1545,7 @@ __device__ __forceinline__ void prop3_step(const Prop3Lds& P, const uint16_t* __
         if (TAPE) { \
             A.eff_in = eff + (size_t)(p_) * bn64; \
             A.eff = eff + (size_t)((p_) + 1) * bn64; \
-            A.mask_out = mask_hist + (size_t)(p_) * B * N * DRP_K * 2; \
+            A.mask_out = mask_hist + (size_t)(p_) * (bn64 / 64) * DRP_K * 2; \
             A.agg_out = agg_hist ? agg_hist + (size_t)(p_) * bn64 : nullptr; \
         } \
         if (ECACHE && (p_) == 0) { \
@@ -1590,7 +1592,8 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
          unsigned* __restrict__ mask_hist /* TAPE: [3][B*N*10][2] */, float* __restrict__ agg_hist /* TAPE, nullable: [3][B*N,64] */,
          float re_scale, float re_inv, int order_rows,
          float4* __restrict__ ecache /* ECACHE: [workgroup][ec_stride] */, size_t ec_stride,
-         unsigned long long* __restrict__ work /* WORK: PROP_WORK_* counters */) {
+         unsigned long long* __restrict__ work /* WORK: PROP_WORK_* counters */,
+         size_t hist_rows /* TAPE: rows of the whole batch behind the history buffers (0: this launch's B * N) */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef PROP_STAMPS
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_w0 = __builtin_amdgcn_s_memrealtime();
@@ -1603,7 +1606,7 @@ km_prop3(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, cons
     prop3_step<TAPE, PAIR, PAIR && !TAPE /* the tape's kernel has no register to spare for the carried head; the big kernel's
                                             allocation is not to move (with it: 256 VGPRs) */, ECACHE, WORK, ONE>(P, sw, sw6, mw, s_cur, s_mod, s_stride, attr, attr_mod, dens, dens_mod, nbr_idx, nbr_cnt, proj_a, proj_b, c_node,
                      eff, N, B, spw, s_delta, s_out, out_stride, cself, cself_ok, mask_hist, agg_hist, re_scale, re_inv, order_rows,
-                     (int)threadIdx.x, ECACHE ? ecache + (size_t)blockIdx.x * ec_stride : nullptr, work PROP_STAMPS_ARG);
+                     (int)threadIdx.x, ECACHE ? ecache + (size_t)blockIdx.x * ec_stride : nullptr, work PROP_STAMPS_ARG, 0, TAPE ? hist_rows : 0);
     if constexpr (WORK) work_clock_end(wclk, work);
 #ifdef PROP_STAMPS
     {

@@ -12,7 +12,7 @@
 #define KM_PROP3_SIG(T, P, E, W, O) __global__ void km_prop3<T, P, E, W, O>( \
     const uint16_t*, const uint16_t*, const float*, const float*, int, size_t, const float*, int, const float*, int, const int16_t*, \
     const uint8_t*, float*, float*, float*, float*, int, int, int, const float*, float*, size_t, const float*, const uint8_t*, \
-    unsigned*, float*, float, float, int, float4*, size_t, unsigned long long*)
+    unsigned*, float*, float, float, int, float4*, size_t, unsigned long long*, size_t)
 #define KM_ROLLOUT_SIG(P, E, W, O) __global__ void km_rollout<P, E, W, O>(const RolloutArgs*)
 
 // X(last, tape, pair, work)

@@ -1,5 +1,5 @@
 """The parity census (tests/golden/make_golden_census.py -> census.npz) on the device: helpers shared by
-tests/test_gpu_census.py and tools/census_report.py.
+tests/test_gpu_census.py and tests/test_oracle_census.py.
 
 Every quantity is per ROW (one unfiltered 10-step push sequence) and STEP:
   margin      the reference trajectory's distance from a graph decision changing (fixture)

@@ -309,3 +309,35 @@ def test_the_one_launch_backward_pass_of_the_trainer(golden, monkeypatch, case):
         scale = max(np.abs(np.asarray(a[k])).max(), 1e-8)
         assert np.abs(np.asarray(a[k]) - np.asarray(b[k])).max() < 2e-5 * scale, k
     np.testing.assert_allclose(runs['default'][2], runs['stages'][2], rtol=1e-4)
+
+
+def test_a_timed_out_barrier_of_the_backward_pass_moves_nothing_and_the_step_runs_again(golden, monkeypatch):
+    """kmb_step_bwd's barrier among the workgroups of a group gives up after two seconds (a shared or masked device: its
+    workgroups are not all resident) and leaves a flag; the gradient of that pass is partial.  The optimiser step reads the flag
+    on the device and moves neither the weights nor the moments, the iteration count stays, and drp_train_step runs the step
+    again with one workgroup per group.  Forced here (DRP_DEBUG_FORCE_GIVEUP=1 sets the flag after the first pass):
+    losses, gradient and weights are the bits of a context whose barrier never gave up running with DRP_TRAIN_PARTS=1 from the
+    start -- three update iterations in, Adam's bias correction included."""
+    g = golden.train
+    case = 'b4_r3'
+    batch = _batch(g, case)
+    lr, beta1 = g[case + '/lr_beta1']
+    runs = {}
+    for name, env in (('retry', {'DRP_DEBUG_FORCE_GIVEUP': '1'}), ('one', {'DRP_TRAIN_PARTS': '1'})):
+        for k in ('DRP_DEBUG_FORCE_GIVEUP', 'DRP_TRAIN_PARTS'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model = _model(golden)
+        eng = model.engine
+        eng.train_begin(batch[0].shape[1] - 1, float(lr), float(beta1))
+        eng.dispatch_reset()
+        loss, grad = eng.train_step(*batch, mode='grad', want_grad=True)
+        losses = [eng.train_step(*batch, mode='update')[0] for _ in range(3)]
+        runs[name] = (loss, grad, losses, eng.get_weights(), eng.last_dispatch())
+        eng.close()
+    assert any('barrier gave up' in v for v in runs['retry'][4]), runs['retry'][4]
+    assert not any('barrier gave up' in v for v in runs['one'][4])
+    assert runs['retry'][0] == runs['one'][0] and runs['retry'][2] == runs['one'][2]
+    np.testing.assert_array_equal(runs['retry'][1], runs['one'][1])
+    np.testing.assert_array_equal(runs['retry'][3], runs['one'][3])

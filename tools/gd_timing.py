@@ -16,13 +16,13 @@ for N in ([int(a) for a in sys.argv[1:]] or (20, 50, 100, 300)):
     s0, dens, attr = syn.make_pile(N, 30, seed=N)
     acts = np.repeat(np.stack([syn.nominal_pushes(1, seed=i) for i in range(50)]), 30, axis=0).astype(np.float32)
     eng.gd_begin(s0, attr, dens, acts, 0.05, lo, hi)
-    for _ in range(3):
-        eng.gd_step()
-    eng.sync()
-    t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(30):
         eng.lib.drp_gd_step(eng.h, None)
     eng.sync()
-    ms = (time.perf_counter() - t0) / 20 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(200):
+        eng.lib.drp_gd_step(eng.h, None)
+    eng.sync()
+    ms = (time.perf_counter() - t0) / 200 * 1e3
     print('N=%3d B=1500: %.3f ms per GD iteration (rollout+reward+backward+Adam+clip); reference time model '
           '(its GPU, batch 300): %d ms' % (N, ms, particle_num_to_iter_time(N)))
