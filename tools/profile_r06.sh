@@ -77,6 +77,8 @@ if [ -f tools/bin/libdrp_ts.so ]; then
   DRP_LIB=tools/bin/libdrp_ts.so python3 tools/rollout_stamps.py 50 > $O/summ/r06_rollout_stamps_50.txt 2>&1
 fi
 python3 tools/prep_timing.py > $O/summ/r06_prep_timing.txt 2>&1
+# the parity census as the test prints it (tests/test_gpu_census.py)
+python3 -m pytest tests/test_gpu_census.py -q -s 2>&1 | grep -v "^\.$" | grep "census\|before it\|after it\|deviation after\|final reward\|passed\|failed" | cut -c1-700 > $O/summ/r06_census.txt
 python3 tools/gd_timing.py 5 10 20 30 40 50 100 > $O/summ/r06_gd_timing.txt 2>&1
 python3 tools/planner_timing.py > $O/summ/r06_planner_timing.txt 2>&1
 # the bench lines of this build on this box
