@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Round 4: every `frac` of the driver line's sweep block against the counters on file.  The bench line's numerator is what
+"""Round 5: every `frac` of the driver line's sweep block against the counters on file.  The bench line's numerator is what
 the kernels counted themselves (drp_probe_work); here the same quantity comes from the SQ pass of the same preset:
 (SQ_INSTS_VALU_MFMA_MOPS_F16 + _BF16) / 64 = 16-bit MFMA instructions per launch of the dominant kernel.
-usage: python3 profiles/check_r04.py   (reads profiles/r04_bench_default.json and profiles/r04_<preset>_pmc_sq_per_kernel.csv)"""
+usage: python3 profiles/check_r06.py   (reads profiles/r06_bench_default.json and profiles/r06_<preset>_pmc_sq_per_kernel.csv)"""
 import csv
 import json
 import os
@@ -24,7 +24,7 @@ def counts_work(name):
 
 def mfmas_from_sq(tag, prefixes):
     best = None
-    for r in csv.DictReader(open(os.path.join(HERE, 'r04_%s_pmc_sq_per_kernel.csv' % tag))):
+    for r in csv.DictReader(open(os.path.join(HERE, 'r06_%s_pmc_sq_per_kernel.csv' % tag))):
         name = r['Kernel_Name']
         if not name.startswith(prefixes) or counts_work(name) or not r['Counter_Name'].startswith('SQ_INSTS_VALU_MFMA_MOPS'):
             continue
@@ -34,7 +34,7 @@ def mfmas_from_sq(tag, prefixes):
     return best
 
 
-line = [json.loads(l) for l in open(os.path.join(HERE, 'r04_bench_default.json')) if l.startswith('{')][0]
+line = [json.loads(l) for l in open(os.path.join(HERE, 'r06_bench_default.json')) if l.startswith('{')][0]
 rows = [('fused', line['roofline'], ('km_prop3',))]
 for e in line['sweep']:
     if e['name'] == 'gd-demo':
