@@ -45,6 +45,7 @@ int drp_create(int device, drp_ctx** out) {
     c->bwd_valu_stages = getenv("DRP_BWD_VALU_STAGES") != nullptr;
     if (const char* e = getenv("DRP_TRAIN_PARTS")) c->train_parts = atoi(e);
     c->debug_force_giveup = getenv("DRP_DEBUG_FORCE_GIVEUP") != nullptr;
+    c->train_copy_upload = getenv("DRP_TRAIN_COPY_UPLOAD") != nullptr;
     if (const char* e = getenv("DRP_TRAIN_COOP")) c->train_coop = atoi(e);
     c->graph_encode = getenv("DRP_NO_GRAPH_ENCODE") == nullptr;
     if (const char* e = getenv("DRP_TRAIN_FUSED")) c->train_fused = atoi(e);

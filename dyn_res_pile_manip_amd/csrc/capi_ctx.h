@@ -230,6 +230,8 @@ struct drp_ctx {
     bool graph_encode = true;       // DRP_NO_GRAPH_ENCODE=1: k_graph_q4 and km_node_encode_split as two launches where they could be one (km_graph_q4_encode)
     int train_fused = -1;           // DRP_TRAIN_FUSED=0/1: the trainer's node stages as one launch per rollout step (kmb_step_bwd<dump>) never / for any batch (-1: up to n_cu / 4 tiles)
     int train_coop = -1;            // DRP_TRAIN_COOP=0/1: the workgroup-wide gather of the edge terms off / on whatever the tile count (-1: by tiles per workgroup)
+    double* tr_loss_host = nullptr; // drp_train_step: pinned host memory the loss kernel stores its terms to (null: c->tr_loss)
+    bool train_copy_upload = false; // DRP_TRAIN_COPY_UPLOAD=1: the training batch goes up by a copy on the stream instead of inside kt_unpack_inputs
     bool debug_force_giveup = false; // DRP_DEBUG_FORCE_GIVEUP=1 (tests): drp_train_step's first pass ends as if kmb_step_bwd's barrier had timed out
     int train_parts = 0;            // DRP_TRAIN_PARTS=n: workgroups per group of samples in the trainer's kmb_step_bwd (0: as many as there are CUs for)
     bool bwd_valu_stages = false;   // DRP_BWD_VALU_STAGES=1: the reverse-mode node stages on the VALU row kernels (kb_predict ... kb_node_encode; cross-check)

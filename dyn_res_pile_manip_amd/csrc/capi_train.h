@@ -38,7 +38,7 @@ int train_forward_backward(drp_ctx* c, int B, int N, bool backward) {
     unsigned* mh = ptr<unsigned>(c->tape_mask);
     float* ah = ptr<float>(c->agg_hist);
     float* g_state = ptr<float>(c->g_state);
-    double* loss = ptr<double>(c->tr_loss);
+    double* loss = c->tr_loss_host ? c->tr_loss_host : ptr<double>(c->tr_loss);      // pinned host memory: the terms land where the caller reads them
     const float scale = 1.0f / (float)(H * B);
     const int saved_engine = c->engine;
     c->engine = c->tr_engine;
@@ -350,7 +350,7 @@ int ensure_repack_maps(drp_ctx* c) {
 }
 
 // launches only: the caller's final wait brings the blob and the device's shift back (finish_repack)
-int repack_on_device(drp_ctx* c) {
+int repack_on_device(drp_ctx* c, bool blob_in_pin = false /* k_adam has written the updated blob to w_pin already */) {
     CHK(ensure_repack_maps(c));
     CHK(ensure(c, c->re_shift_dev, sizeof(int)));
     hipStream_t st = c->stream;
@@ -364,9 +364,12 @@ int repack_on_device(drp_ctx* c) {
     hipLaunchKernelGGL(kt_repack_all, dim3(KT_REPACK_ALL_BLOCKS((int)V_TOTAL, (int)M_TOTAL, (int)MB_TOTAL)), dim3(256), 0, st, w, a);
     // the relation encoder's range shift depends on the new weights: the launch above derived it; the blob itself comes
     // back too (it is the host copy drp_get_weights serves, and the host's own range for the calls to come)
-    hipLaunchKernelGGL(kt_repack_split, dim3(4 * 16), dim3(256), 0, st, w, 0, ptr<uint16_t>(c->w_split), ptr<int>(c->re_shift_dev));
-    HIPCHK(c, hipMemcpyAsync(c->w_pin, c->w_raw.p, (size_t)W_TOTAL * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(c->w_pin + W_TOTAL, c->re_shift_dev.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(kt_repack_split, dim3(4 * 16), dim3(256), 0, st, w, 0, ptr<uint16_t>(c->w_split), ptr<int>(c->re_shift_dev),
+                       blob_in_pin ? reinterpret_cast<int*>(c->w_pin + W_TOTAL) : (int*)nullptr);
+    if (!blob_in_pin) {
+        HIPCHK(c, hipMemcpyAsync(c->w_pin, c->w_raw.p, (size_t)W_TOTAL * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(c->w_pin + W_TOTAL, c->re_shift_dev.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(c, hipGetLastError());
     return DRP_OK;
 }
@@ -449,17 +452,22 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         memcpy(pin + lay.dens, particle_dens, (size_t)B * sizeof(float));
         memcpy(pin + lay.nums, particle_nums, (size_t)B * sizeof(int));
     }
-    CHK(h2d(c, c->tr_arena, c->tr_pin, lay.bytes));
+    CHK(ensure(c, c->tr_arena, lay.bytes));
     CHK(ensure(c, c->attr, bn * sizeof(float)));
     CHK(ensure(c, c->dens, (size_t)B * sizeof(float)));
     CHK(ensure(c, c->tape_sdelta, (size_t)H * bn * 3 * sizeof(float)));
     {
-        const char* ar = static_cast<const char*>(c->tr_arena.p);
+        // the unpacking launch IS the upload: it reads the staged batch from the pinned host buffer (device-visible) and leaves
+        // the arena copy for the kernels that read the given states; DRP_TRAIN_COPY_UPLOAD=1: a copy on the stream first
+        const bool by_kernel = !c->train_copy_upload;
+        if (!by_kernel) CHK(h2d(c, c->tr_arena, c->tr_pin, lay.bytes));
+        const char* ar = by_kernel ? static_cast<const char*>(c->tr_pin) : static_cast<const char*>(c->tr_arena.p);
         const size_t total = (size_t)H * bn * 3;
         hipLaunchKernelGGL(kt_unpack_inputs, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1024)), dim3(256), 0, c->stream,
                            reinterpret_cast<const float*>(ar + lay.sdelta), reinterpret_cast<const float*>(ar + lay.attrs),
                            reinterpret_cast<const float*>(ar + lay.dens), B, H, N, ptr<float>(c->tape_sdelta), ptr<float>(c->attr),
-                           ptr<float>(c->dens));
+                           ptr<float>(c->dens), by_kernel ? reinterpret_cast<const float4*>(c->tr_pin) : (const float4*)nullptr,
+                           by_kernel ? static_cast<float4*>(c->tr_arena.p) : (float4*)nullptr, by_kernel ? lay.bytes / 16 : (size_t)0);
     }
     CHK(ensure_step_ws(c, B, N, c->tr_engine));
     CHK(ensure(c, c->states, (size_t)H * bn * 3 * sizeof(float)));
@@ -505,6 +513,8 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     // behind its counters; the gradient of such a pass is partial.  The optimiser step reads the flag ON THE DEVICE and moves
     // nothing when it is set (k_adam's `skip`), the iteration count advances only once the flag has come back clear, and the
     // step runs again with one workgroup per group (no barrier to wait at) -- for the rest of the context's life.
+    c->tr_loss_host = (loss_out && !c->train_copy_upload) ? parts : nullptr;
+    struct LossHostReset { drp_ctx* c; ~LossHostReset() { c->tr_loss_host = nullptr; } } loss_host_reset{c};
     for (int attempt = 0; ; ++attempt) {
         c->wg_defer_now = defer_batch;
         c->wg_jobs.clear();
@@ -512,26 +522,32 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
         const int f_spw = (B + c->n_cu - 1) / c->n_cu, f_groups = (B + f_spw - 1) / f_spw;
         const unsigned* const flag_dev = reinterpret_cast<const unsigned*>(ptr<float>(c->tr_grad) + TR_GRAD_PAD + (size_t)H * f_groups);
         *gave_up = 0;
+        // update iterations end WITHOUT a copy on the stream: the loss terms are stored to pinned host memory by the loss kernel,
+        // the optimiser step writes the updated blob and the barrier's flag there, kt_repack_split the range shift -- a copy
+        // engine's transfer between kernels costs tens of microseconds of hand-over (tools/train_trace.sh)
+        const bool direct = mode == DRP_TRAIN_UPDATE && c->repack_device && !c->train_copy_upload;
         if (c->debug_force_giveup && attempt == 0 && backward) {        // tests: the flag as a timed-out barrier would leave it, once
             HIPCHK(c, hipMemsetAsync(const_cast<unsigned*>(flag_dev), 1, sizeof(unsigned), c->stream));
             c->debug_force_giveup = false;
         }
-        if (loss_out) CHK(d2h(c, parts, c->tr_loss.p, (size_t)H * B * sizeof(double)));
+        if (loss_out && !c->tr_loss_host) CHK(d2h(c, parts, c->tr_loss.p, (size_t)H * B * sizeof(double)));
         if (grad_out && backward) CHK(d2h(c, grad_out, c->tr_grad.p, (size_t)W_TOTAL * sizeof(float)));
-        if (backward) CHK(d2h(c, gave_up, flag_dev, sizeof(unsigned)));
+        if (backward && !direct) CHK(d2h(c, gave_up, flag_dev, sizeof(unsigned)));
         bool repacked = false;
         if (mode == DRP_TRAIN_UPDATE) {
             const long iter = c->tr_iter + 1;
             const double bc1 = 1.0 - pow(c->tr_beta1, (double)iter), bc2 = 1.0 - pow(0.999, (double)iter);
             const float inf = __builtin_inff();
+            if (direct) CHK(ensure_repack_maps(c));          // (allocates w_pin)
             hipLaunchKernelGGL(k_adam, dim3((W_TOTAL + 255) / 256), dim3(256), 0, c->stream, ptr<float>(c->w_raw),
                                ptr<float>(c->tr_grad), ptr<float>(c->tr_m), ptr<float>(c->tr_v), (int)W_TOTAL,
                                (float)(c->tr_lr / bc1), (float)sqrt(bc2), make_float4(-inf, -inf, -inf, -inf),
-                               make_float4(inf, inf, inf, inf), (float)c->tr_beta1, (float*)nullptr, flag_dev);
+                               make_float4(inf, inf, inf, inf), (float)c->tr_beta1, direct ? c->w_pin : (float*)nullptr, flag_dev,
+                               direct ? gave_up : (unsigned*)nullptr);
             if (hipGetLastError() != hipSuccess) { (void)drp_sync(c); return fail(c, DRP_EHIP, "k_adam launch"); }
             // the engines read packed copies of the weights: rebuild them from the blob (unchanged if the step was skipped)
             if (c->repack_device) {
-                const int rc = repack_on_device(c);
+                const int rc = repack_on_device(c, direct);
                 if (rc != DRP_OK) { (void)drp_sync(c); return rc; }
                 repacked = true;
             } else {
@@ -542,7 +558,7 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
             }
         }
         CHK(drp_sync(c));
-        if (repacked) CHK(finish_repack(c));
+        if (repacked && !*gave_up) CHK(finish_repack(c));      // (a skipped step wrote no blob: the weights are what they were)
         if (!*gave_up) {
             if (mode == DRP_TRAIN_UPDATE) c->tr_iter += 1;
             break;

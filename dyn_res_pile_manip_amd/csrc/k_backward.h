@@ -736,8 +736,10 @@ kb_gather_pos(const float* __restrict__ gpos_edge, const int* __restrict__ rev_o
 __global__ void k_adam(float* __restrict__ act, const float* __restrict__ grad, float* __restrict__ m,
                        float* __restrict__ v, int n, float step_size, float bc2_sqrt, float4 lo, float4 hi,
                        float b1 = 0.9f, float* __restrict__ act_copy = nullptr /* pinned host memory: the updated values once more */,
-                       const unsigned* __restrict__ skip = nullptr /* not null and set: the gradient is not to be trusted, nothing moves */) {
+                       const unsigned* __restrict__ skip = nullptr /* not null and set: the gradient is not to be trusted, nothing moves */,
+                       unsigned* __restrict__ skip_copy = nullptr /* pinned host memory: what `skip` held */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && skip != nullptr && skip_copy != nullptr) *skip_copy = *skip;
     if (i >= n) return;
     if (skip != nullptr && *skip != 0u) return;
     const int c = i & 3;

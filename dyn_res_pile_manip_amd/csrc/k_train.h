@@ -53,7 +53,14 @@ kt_mse_grad(const float* __restrict__ s_pred, size_t pred_stride, const float* _
 __global__ void __launch_bounds__(256)
 kt_unpack_inputs(const float* __restrict__ sdelta_in /* [B][H][N][3] */, const float* __restrict__ attrs_in /* [B][H+1][N] */,
                  const float* __restrict__ dens_in, int B, int H, int N, float* __restrict__ sdelta_out /* [H][B][N][3] */,
-                 float* __restrict__ attr_out /* [B][N] */, float* __restrict__ dens_out) {
+                 float* __restrict__ attr_out /* [B][N] */, float* __restrict__ dens_out,
+                 const float4* __restrict__ arena_src = nullptr /* not null: the whole staged batch (pinned HOST memory the device
+                                                                   reads over the bus: the inputs above point into it too) ... */,
+                 float4* __restrict__ arena_dst = nullptr /* ... copied to the device arena the later kernels read, n16 float4 */,
+                 size_t n16 = 0) {
+    // the upload as part of this launch: a copy engine's transfer in front of it costs ~80 us of hand-over between the engines
+    // on a stream that is otherwise kernels (tools/train_trace.sh), for 90 KB
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n16; e += (size_t)gridDim.x * 256) arena_dst[e] = arena_src[e];
     const size_t n3 = (size_t)N * 3, total = (size_t)B * H * n3;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const size_t bt = e / n3, r = e - bt * n3;
@@ -461,8 +468,10 @@ __device__ __forceinline__ int dev_split_feature(int s, int h, int jj) {
 // one thread per (ob, s, lane, jj) of a 64x64 matrix (4096), per (ob, lane, jj) of the first layer (1024)
 __global__ void __launch_bounds__(256)
 kt_repack_split(const float* __restrict__ w, int shift, uint16_t* __restrict__ out,
-                const int* __restrict__ shift_dev = nullptr /* nullable: the shift kt_repack_all derived from these weights */) {
+                const int* __restrict__ shift_dev = nullptr /* nullable: the shift kt_repack_all derived from these weights */,
+                int* __restrict__ shift_copy = nullptr /* pinned host memory: the shift used */) {
     if (shift_dev != nullptr) shift = *shift_dev;
+    if (shift_copy != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *shift_copy = shift;
     const int job = blockIdx.x >> 4, e = (blockIdx.x & 15) * 256 + threadIdx.x;
     if (job == 0) {
         if (e < 1024) {
