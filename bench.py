@@ -463,6 +463,7 @@ def bench_mppi(rig, N, ns, H, s_lo, steps, warmup, step_extra, fence, classes, w
     dominant = max(per_class, key=lambda k: per_class[k][0])
     cnt_last = eng.debug_fetch('nbr_cnt', (ns, N), np.uint8)
     eng.probe_begin(dominant)
+    eng.dispatch_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -471,6 +472,7 @@ def bench_mppi(rig, N, ns, H, s_lo, steps, warmup, step_extra, fence, classes, w
     dt = time.perf_counter() - t0
     dom_ms, dom_n = eng.probe_read()
     eng.probe_begin(None)
+    ran = eng.last_dispatch()            # the kernel variants the timed iterations launched (drp_last_dispatch)
     med = None
     if want_median:
         # per-iteration times (each iteration synchronised; SURVEY.md 8d asks for the median): a second pass, so the
@@ -483,7 +485,7 @@ def bench_mppi(rig, N, ns, H, s_lo, steps, warmup, step_extra, fence, classes, w
             per_iter.append(time.perf_counter() - t1)
         fence()
         med = float(np.median(per_iter))
-    return {'dt': dt, 'median': med, 'per_class': per_class, 'dominant': dominant, 'dom_ms': dom_ms, 'dom_n': dom_n,
+    return {'dt': dt, 'median': med, 'per_class': per_class, 'dominant': dominant, 'dom_ms': dom_ms, 'dom_n': dom_n, 'ran': ran,
             'cnt': cnt_last, 'kbar': float(cnt_last.mean()), 'step': step, 's0': s0, 'dens': dens, 'attr': attr, 'work': dom_work}
 
 
@@ -508,7 +510,9 @@ def mppi_roofline(rig, m, N, ns, H, steps):
     else:
         roof = {'bound': 'hbm', 'achieved': 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
     roof['frac'] = roof['achieved'] / roof['peak']
-    roof['kernel'] = dominant
+    # the class the HIP-event probe timed, and the variant(s) of it the timed iterations launched
+    names = [v for v in m.get('ran', []) if v.startswith('km_')] if dominant == 'prop' else []
+    roof['kernel'] = '%s: %s' % (dominant, ', '.join(names)) if names else dominant
     roof['avg_launch_ms'] = avg_s * 1e3
     roof['launches'] = m['dom_n']
     roof['work_per_launch'] = work
@@ -564,6 +568,7 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
     cnt = eng.debug_fetch('nbr_cnt', (B, N), np.uint8)
     kbar = float(cnt.mean())
     eng.probe_begin(dominant)
+    eng.dispatch_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -572,6 +577,7 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
     dt = time.perf_counter() - t0
     dom_ms, dom_n = eng.probe_read()
     eng.probe_begin(None)
+    ran = eng.last_dispatch()
     med = None
     if want_median:
         per_iter = []
@@ -609,7 +615,9 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
     else:
         roof = {'bound': 'hbm', 'achieved': 0.0, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
     tb = traffic.get(tkey, {}).get('hbm_bytes_per_launch') if tkey else None
-    roof.update({'frac': roof['achieved'] / roof['peak'], 'kernel': dominant, 'avg_launch_ms': avg_s * 1e3,
+    names = [v for v in ran if v.startswith('km_')] if dominant == 'prop' else [v for v in ran if v.startswith('bwd:')]
+    roof.update({'frac': roof['achieved'] / roof['peak'], 'kernel': '%s: %s' % (dominant, ', '.join(names)) if names else dominant,
+                 'avg_launch_ms': avg_s * 1e3,
                  'launches': dom_n, 'traffic': tb, 'traffic_source': TRAFFIC_SOURCE if tb else None})
     if tb and roof['bound'] == 'hbm':
         # the HBM fraction proper: counter bytes over time (the algorithmic figure above counts L2-served gathers)
@@ -691,7 +699,7 @@ def run_sweep(rig, fence):
         batches = more_batches(step, fence, steps, dt, SWEEP_MIN_GPU_S)
         med, best = float(np.median(batches)), float(min(batches))
         out.append({'name': name, 'value': B * N * H * steps / med, 'ms_per_step': med / steps * 1e3, 'frac': roof['frac'],
-                    'dominant_kernel': roof['kernel'], 'avg_launch_ms': roof['avg_launch_ms'], 'traffic': roof.get('traffic'),
+                    'dominant_kernel': roof['kernel'].split(':')[0], 'kernel': roof['kernel'], 'avg_launch_ms': roof['avg_launch_ms'], 'traffic': roof.get('traffic'),
                     'frac_executed_16bit': roof.get('frac_executed_16bit'), 'mfma_pipe_busy_est': roof.get('mfma_pipe_busy_est'),
                     'hbm_algorithmic_frac': roof.get('hbm_algorithmic_frac'),
                     'sclk_mhz_under_load': roof.get('sclk_mhz_under_load'), 'frac_at_measured_clock': roof.get('frac_at_measured_clock'),

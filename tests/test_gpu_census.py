@@ -27,7 +27,7 @@ from dyn_res_pile_manip_amd import synthetic as syn, weights, _lib
 from dyn_res_pile_manip_amd.planners import world2cam_affine
 
 pytestmark = pytest.mark.gpu
-ENGINES = ['fused', 'mfma']
+ENGINES = ['fused', 'mfma', 'split', 'valu']
 K = 4.0            # "a small multiple of the reference's deviation from itself": the rule of test_the_device_trainer_follows...
 
 
