@@ -354,8 +354,11 @@ __device__ __forceinline__ void gagg_lds_write(float* gl, int r, int h, const Fr
 // is shared by `parts` workgroups (tiles dealt statically: part + wave * parts, stride parts * waves) and the phases are
 // separated by a barrier among those workgroups -- a counter in memory per group (`bar`, zeroed by the host; every wave's
 // stores are performed at device scope before its workgroup arrives, every wave invalidates its L1 after the wait).  The
-// host keeps the grid at or below the number of CUs (all workgroups resident); a wait that lasts two seconds gives up and
-// sets bar_err instead of hanging the device.
+// host keeps the grid at or below the number of CUs (all workgroups resident -- each needs KMB_COOP_LDS, one per CU -- which
+// ASSUMES the process has the device to itself: under a CU mask, or beside another process's LDS-heavy kernel, a group's
+// workgroups may not all be resident); a wait that lasts two seconds gives up and sets bar_err instead of hanging the device.
+// drp_train_step then moves nothing (k_adam reads the flag on the device) and runs the step again with one workgroup per
+// group, for the rest of the context's life (capi_train.h).
 struct KmbDump {
     float* hact; float* gh;          // predictor: relu(hidden), hidden pre-activation gradient        [rows][64]
     float* ge[3];                    // pre-activation gradient of propagation steps 2, 1, 0           [rows][64]
