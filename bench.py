@@ -595,7 +595,7 @@ def bench_gd(rig, N, traj, nb, H, steps, warmup, fence, rank=0, want_median=True
         roof, _ = prop_roofline(dom_work, kbar, True, B, N, avg_s, H, rig.n_cu)
         tkey = 'prop3_tape'
     elif dominant == 'bwd_node' and per_class['bwd_edge'][1] == 0:
-        # kmb_rows_bwd / kmb_step_bwd (the whole node / edge backward of a rollout step in one launch): algorithmic
+        # kmb_rows_bwd / kmb_step_bwd (the whole node / edge backward of a rollout step in one launch, DESIGN.md 8 and DESIGN_NOTES.md 7b): algorithmic
         # bytes per node -- phase P: effect row + reward gradient in, g_eff / g_cnode / g_agg rows out; per
         # propagation step: own g_agg and g_eff rows, own masks, one (list entry, mask, g_agg row) per edge the
         # node feeds; steps 2 and 1 also the effect row in, g_eff / g_agg rows out and g_cnode in and out; step 0

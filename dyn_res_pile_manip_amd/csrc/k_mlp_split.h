@@ -1241,7 +1241,7 @@ km_prop(const uint16_t* __restrict__ sw, const uint16_t* __restrict__ sw6, const
 // W_s eff rows of the SAME sample only, so a workgroup that owns whole samples needs no chip-wide barrier
 // between steps: __syncthreads() (workgroup-scope release / acquire: the waves of a workgroup share their CU's
 // L1) orders its own stores and gathers.  Saves two launches per rollout step, each with its refill of the
-// packed weights (5 us), its launch and its end-of-launch imbalance (tools/prop_stamps.py).
+// packed weights (5 us), its launch and its end-of-launch imbalance (tools/prop_stamps.py, DESIGN_NOTES.md 5b).
 // All four node matrices stay in LDS (153.6 KB).  grid = ceil(B / spw) workgroups, spw = samples per
 // workgroup; the host uses it when every CU gets at least one sample and a workgroup at least PROP_WAVES
 // tiles per step, and the one-step kernels otherwise (small batches spread by tiles, not by samples).

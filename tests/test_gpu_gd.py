@@ -10,7 +10,7 @@ from dyn_res_pile_manip_amd.gnn_dyn import PropNetDiffDenModel
 from dyn_res_pile_manip_amd.planners import PlannerGD, world2cam_affine
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('exact_goal_transform')]
-# max|gradient - reference's autograd| / max|reference's|: 5 x the worst OBSERVED (round 6; DESIGN.md 6) -- d loss / d state
+# max|gradient - reference's autograd| / max|reference's|: 5 x the worst OBSERVED (round 6; DESIGN.md 2) -- d loss / d state
 # 1.6e-6, d loss / d push 5.5e-7 on the seed-0 weights, 7.7e-7 on the stress weights; rounds 2 - 5 asserted 1e-3 / 2e-3
 GRAD_STATE_BOUND = 8e-6
 GRAD_BOUND = 3e-6

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 SIZES = ['n20', 'n50', 'n100', 'n300']
 ENGINES = ['valu', 'mfma', 'split', 'fused']
 # max|grad - reference's autograd| / max|reference's|, by the engine that wrote the tape: 5 x the worst OBSERVED over the
-# sixteen cases (fused 8.0e-6 at n100_h2, fp32 tape 3.5e-6 at n50_h1; gpurun_out of round 6) -- rounds 2 - 5 asserted 2e-3
+# sixteen cases (fused 8.0e-6 at n100_h2, fp32 tape 3.5e-6 at n50_h1; round 6) -- rounds 2 - 5 asserted 2e-3
 GRAD_BOUND = {'fused': 4e-5, 'mfma': 2e-5}
 
 
