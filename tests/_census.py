@@ -17,8 +17,15 @@ and 2.8e-8 on one of the 4 096 MPPI rows (late in the rollout, where ten steps o
 """
 import numpy as np
 
-SIZES = ['n20', 'n50', 'n100', 'n300']
+SIZES = ['n20', 'n50', 'n100', 'n300', 'n600']
 TAU = 5e-8
+TAU_MASK = 1e-6      # camera-frame units: a particle this close to an end of the push band (planners.py:248, 0 < u < L) -- the other
+                     # discontinuity of a step; the smallest such distance in the fixture is 5.6e-8 (600 particles), no run flipped one
+
+
+def near_tie(g, p):
+    """[B,H] bool: the step's graph (margin) or push mask (mask_margin) is within rounding-level reach of changing."""
+    return (g[p + 'margin'] < TAU) | (g[p + 'mask_margin'] < TAU_MASK)
 
 
 def fmix32(x):

@@ -3,7 +3,7 @@
 
 `make_golden_trained.py` keeps a 10-step push sequence for its `rollout/` cases only if the reference's whole trajectory
 stays clear of every graph decision (367 candidates for six rows at 300 particles).  Here NOTHING is filtered: per pile
-size (20 / 50 / 100 / 300 particles) the first ROWS candidates of the same generator go through the REFERENCE
+size (20 / 50 / 100 / 300 / 600 particles) the first 64 (600: 32) candidates of the same generator go through the REFERENCE
 (`PlannerGD.ptcl_model_rollout` + `ptcl_evaluate_traj` on `weights_trained.npz`), and per row and step this file records
 
   state_pred, next_r     the reference's free-running trajectory and all-step rewards
@@ -17,11 +17,11 @@ size (20 / 50 / 100 / 300 particles) the first ROWS candidates of the same gener
                          receivers whose lists differ, the rewards.  How far the reference drifts from ITSELF once a
                          near-tie is crossed.
 
-and, per size, one MPPI iteration of MPPI_ROWS rows built from census row 0 (the reference's `sample_action_sequences`
+and, per size, one MPPI iteration of 1 024 (600 particles: 128) rows built from census row 0 (the reference's `sample_action_sequences`
 around it): final-step rewards of the reference and of its one-ulp twins, `optimize_action` of each (planners.py:549-561),
 per row and step a hash of the whole row's lists (so the device's flipped rows can be counted on 1 024 rows too) and which
 steps of the twins' lists differ, the per-row smallest margin.  Output: tests/golden/census.npz.  Runs ONLY in the build
-container (about 17 minutes on 8 cores).  Usage:  python tests/golden/make_golden_census.py
+container (about 35 minutes on 8 cores).  Usage:  python tests/golden/make_golden_census.py
 """
 import os
 import sys
@@ -36,11 +36,11 @@ sys.path.insert(0, HERE)
 
 import make_golden as mg  # noqa: E402
 
-ROWS = 64
-MPPI_ROWS = 1024
 CHUNK = 64
 H = 10
-SIZES = [('n20', 20), ('n50', 50), ('n100', 100), ('n300', 300)]
+# (name, particles, census rows, rows of the MPPI population); 600 particles: the two-dimensional cell build of the neighbour
+# lists (k_graph_cells, from 400 particles) under the same census -- fewer rows, the reference takes 0.16 s per row and step there
+SIZES = [('n20', 20, 64, 1024), ('n50', 50, 64, 1024), ('n100', 100, 64, 1024), ('n300', 300, 64, 1024), ('n600', 600, 32, 128)]
 
 
 def fmix32(x):
@@ -174,7 +174,7 @@ def main():
     M34 = osp.world2cam_affine(syn.demo_cam_extrinsics(), 24)
     out = {}
     t0 = time.time()
-    for name, N in SIZES:
+    for name, N, ROWS, MPPI_ROWS in SIZES:
         planner.particle_num = N
         # the pile of make_golden_trained.py's rollout case, batch column 0 (its accepted rows are among these candidates)
         s, dens, attr = (x[:1] for x in syn.make_pile(N, n_batch=2, seed=170 + N, kind='blob' if N <= 50 else 'uniform'))

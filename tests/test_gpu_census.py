@@ -1,7 +1,7 @@
 """GPU: the parity CENSUS on the trained network -- every push sequence, not the ones that cannot diverge.
 
-tests/golden/census.npz (make_golden_census.py) holds, per pile size, 64 UNFILTERED 10-step push sequences and one 1 024-row
-MPPI population as the REFERENCE rolled them out on weights_trained.npz: trajectory, all-step rewards, a hash of every
+tests/golden/census.npz (make_golden_census.py) holds, per pile size (20 / 50 / 100 / 300 / 600 particles), 64 UNFILTERED 10-step
+push sequences and one 1 024-row MPPI population (600 particles: 32 and 128) as the REFERENCE rolled them out on weights_trained.npz: trajectory, all-step rewards, a hash of every
 receiver's sender list taken from the reference's own Rr / Rs, the distance of every step's graph from a decision changing
 (`margin`), and the same rows through the reference twice more, started one ulp up and one ulp down (the `twin_*` arrays): how
 far the reference drifts from ITSELF.  A free-running rollout is a chaotic map with discontinuities (model/gnn_dyn.py:231-237:
@@ -57,7 +57,7 @@ def test_census_rows(eng, golden, case, engine):
     margin, disp = g[p + 'margin'], C.displacement(g, p)
     tw_dev, tw_flips = g[p + 'twin_dev'], g[p + 'twin_flips']                # [2,B,H]
     B, H = margin.shape
-    first = C.first_true(margin < C.TAU)                                    # the row's first step near a tie (H: none)
+    first = C.first_true(C.near_tie(g, p))                                  # the row's first step near a tie (H: none)
     pre = np.arange(H)[None, :] < first[:, None]
     disp_b = disp.max(0)                                                    # the batch's displacement per step
 
@@ -109,7 +109,8 @@ def test_census_mppi_iteration(eng, golden, case, engine):
     acts = g[m + 'act_seqs']
     _, rew, flips, _ = C.device_rows(eng, g, p, acts, g[m + 'row_hash'])
     r_dev, r_ref, r_tw = rew[:, -1], g[m + 'reward'], g[m + 'twin_reward']
-    first = C.first_true(np.repeat((g[m + 'min_margin'] < C.TAU)[:, None], acts.shape[1], 1))       # rows that meet a near-tie at all
+    meets = (g[m + 'min_margin'] < C.TAU) | (g[m + 'min_mask_margin'] < C.TAU_MASK)
+    first = C.first_true(np.repeat(meets[:, None], acts.shape[1], 1))       # rows that meet a near-tie at all
     crossed = first < acts.shape[1]
     dev_rows, tw_rows = (flips > 0).any(1), g[m + 'twin_flip_steps'].any(2)
     # (b) on 1 024 rows: who flips, and by how much the final reward moves
@@ -140,9 +141,9 @@ def test_census_mppi_iteration(eng, golden, case, engine):
     assert np.abs(nominal - g[m + 'update']).max() <= K * max(tw_upd, 1e-7)
     assert eng.mpc_stats()['argmax'] == int(r_ref.argmax())
     print('\n[census mppi %s %s] smallest margin of the rows whose lists differ: device %s' % (case, engine, fmt(np.sort(g[m + 'min_margin'][dev_rows])[-6:])))
-    print('[census mppi %s %s] 1024 rows, %d meet a near-tie; rows with a flipped list: device %d, twins %d / %d; |d final reward| '
+    print('[census mppi %s %s] %d rows, %d meet a near-tie; rows with a flipped list: device %d, twins %d / %d; |d final reward| '
           '50 / 90 / 99 %% / max: device %s  twins %s; |d update| device %.2e (kernel %.2e), twins %.2e; arg-max row %d = the reference\'s; '
-          'rewards span %.1f' % (case, engine, crossed.sum(), dev_rows.sum(), tw_rows[0].sum(), tw_rows[1].sum(),
+          'rewards span %.1f' % (case, engine, acts.shape[0], crossed.sum(), dev_rows.sum(), tw_rows[0].sum(), tw_rows[1].sum(),
                                  fmt(np.append(q_dev, d_dev.max())), fmt(np.append(q_tw, d_tw.max())), d_upd,
                                  np.abs(nominal - g[m + 'update']).max(), tw_upd, r_dev.argmax(), r_ref.max() - r_ref.min()))
     eng.set_engine(_lib.ENGINE_FUSED)
