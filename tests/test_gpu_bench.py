@@ -56,6 +56,16 @@ def test_single_gpu_line_has_the_contract_fields():
     assert abs(r['frac_executed_16bit'] - ex['mfmas'] * 32768.0 / (r['avg_launch_ms'] * 1e-3) / 1e12 / 2500.0) < 1e-6
     assert 0 < r['frac_executed_16bit'] < 1 and 0 < r['mfma_pipe_busy_est'] < 1 and r['hbm_algorithmic_frac'] > 0
     assert r['executed_over_algorithmic'] > 1
+    # what a reader -- or a driver that keeps the first keys of a block -- needs comes FIRST: the fraction, the
+    # kernel by name, its launch time, the counters' bytes, the executed-work pair, and the shader clock the counting launches
+    # saw (s_memtime over s_memrealtime inside the kernels) with the fraction at that clock
+    assert list(r)[:10] == ['frac', 'kernel', 'avg_launch_ms', 'launches', 'traffic', 'frac_executed_16bit', 'mfma_pipe_busy_est',
+                            'hbm_algorithmic_frac', 'sclk_mhz_under_load', 'frac_at_measured_clock'], list(r)[:10]
+    assert isinstance(r[list(r)[-1]], (str, dict, type(None)))          # explanatory strings last
+    assert r['kernel'].startswith('prop: km_prop')
+    assert 1500.0 < r['sclk_mhz_under_load'] < 2600.0
+    assert abs(r['frac_at_measured_clock'] - r['frac'] * 2400.0 / r['sclk_mhz_under_load']) < 1e-9
+    assert set(c['seconds_by_threads']) == set(c['value_by_threads']) and c['cores'] == int(min(c['seconds_by_threads'], key=lambda k: c['seconds_by_threads'][k]))
 
 
 def test_the_propagation_kernels_count_what_they_execute():
