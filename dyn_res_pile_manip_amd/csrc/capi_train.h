@@ -440,7 +440,12 @@ int drp_train_step(drp_ctx* c, const float* states, const float* states_delta, c
     // barrier (pinned: the copies are asynchronous, nothing on the way touches pageable memory or this frame)
     const size_t back_off = lay.bytes, back_bytes = (size_t)H * B * sizeof(double) + 16;
     if (c->tr_pin_cap < lay.bytes + back_bytes) {
-        if (c->tr_pin) { (void)hipHostFree(c->tr_pin); c->tr_pin = nullptr; c->tr_pin_cap = 0; }
+        if (c->tr_pin) {
+            // kernels read and write this buffer directly: nothing of an earlier call (one that returned on an error before its
+            // wait, say) may still be in flight when it goes
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipHostFree(c->tr_pin); c->tr_pin = nullptr; c->tr_pin_cap = 0;
+        }
         HIPCHK(c, hipHostMalloc(&c->tr_pin, lay.bytes + back_bytes, hipHostMallocDefault));
         c->tr_pin_cap = lay.bytes + back_bytes;
     }
