@@ -20,8 +20,11 @@ size (20 / 50 / 100 / 300 / 600 particles) the first 64 (600: 32) candidates of 
 and, per size, one MPPI iteration of 1 024 (600 particles: 128) rows built from census row 0 (the reference's `sample_action_sequences`
 around it): final-step rewards of the reference and of its one-ulp twins, `optimize_action` of each (planners.py:549-561),
 per row and step a hash of the whole row's lists (so the device's flipped rows can be counted on 1 024 rows too) and which
-steps of the twins' lists differ, the per-row smallest margin.  Output: tests/golden/census.npz.  Runs ONLY in the build
-container (about 35 minutes on 8 cores).  Usage:  python tests/golden/make_golden_census.py
+steps of the twins' lists differ, the per-row smallest margin.  And `gdplan/<n20|n50|n100>`: the reference's LIVE planner
+(`trajectory_optimization_ptcl_multi_traj`, `mpc_type 'GD'`, planners.py:661-871) at a TEN-step horizon -- Adam iterations through
+free-running rollouts, the per-column best and the final vote (:721-727, :773-781) -- with the dicts of its two one-ulp twins: does
+the planner's choice survive a near-tie?  Output: tests/golden/census.npz.  Runs ONLY in the build
+container (about 15 minutes on 8 cores; two full runs and the --only-gdplan path gave the same bytes).  Usage:  python tests/golden/make_golden_census.py
 """
 import os
 import sys
@@ -156,6 +159,34 @@ def reference_rows(torch, planner, model, tap, s, dens, attr, acts, obs_goal, go
             (np.concatenate(m_all), np.concatenate(mm_all)) if want_margin else None)
 
 
+GD_KEYS = ('action_sequence', 'action_full', 'reward_full', 'observation_sequence', 'reward', 'next_r', 'rew_mean', 'rew_std')
+
+
+def gd_planner_cases(torch, planner, model, syn, obs_goal, lo, hi, out, t0):
+    """The reference's GD planner at horizon H on 6 trajectories x 3 batch columns, 5 Adam iterations, and its one-ulp twins."""
+    for name, N in (('n20', 20), ('n50', 50), ('n100', 100)):
+        nb, traj, n_it = 3, 6, 5
+        planner.particle_num = N
+        s, dens, attr = syn.make_pile(N, n_batch=nb, seed=570 + N, kind='blob' if N <= 50 else 'uniform')
+        act_seq = np.stack([syn.pushes_through(np.tile(s[:1], (traj, 1, 1)), seed=5000 + 100 * t + N) for t in range(H)], 0).astype(np.float64)
+        p = 'gdplan/' + name + '/'
+        out[p + 's_cur'], out[p + 'dens'], out[p + 'attr'], out[p + 'act_seq'] = s, dens, attr, act_seq
+        out[p + 'n_update_iter'] = np.array(n_it)
+        starts = [s, np.nextafter(s, np.float32(np.inf)).astype(np.float32), np.nextafter(s, np.float32(-np.inf)).astype(np.float32)]
+        for q, st in enumerate(starts):
+            res = planner.trajectory_optimization_ptcl_multi_traj(
+                st, dens, attr, obs_goal, model, act_seq.copy(), np.zeros(H), n_sample=traj, n_look_ahead=H, n_update_iter=n_it,
+                action_lower_lim=lo, action_upper_lim=hi, use_gpu=False, time_lim=1e9)
+            pre = p + ('out/' if q == 0 else 'twin%d/' % q)
+            for k in GD_KEYS:
+                out[pre + k] = np.asarray(res[k])
+            out[pre + 'iter_num'] = np.array(res['iter_num'])
+        d = [np.abs(out[p + 'twin%d/action_sequence' % q] - out[p + 'out/action_sequence']).max() for q in (1, 2)]
+        print('[census] %s GD planner, horizon %d: reward %.4f (twins %.4f, %.4f); |d action_sequence| of the twins %.2e, %.2e   %.0f s' %
+              (name, H, float(np.asarray(out[p + 'out/reward']).ravel()[-1]), float(np.asarray(out[p + 'twin1/reward']).ravel()[-1]),
+               float(np.asarray(out[p + 'twin2/reward']).ravel()[-1]), d[0], d[1], time.time() - t0), flush=True)
+
+
 def main():
     from dyn_res_pile_manip_amd import synthetic as syn
     torch, PropNetDiffDenModel, ref_planners, config_reward_ptcl = mg.load_reference()
@@ -174,6 +205,15 @@ def main():
     M34 = osp.world2cam_affine(syn.demo_cam_extrinsics(), 24)
     out = {}
     t0 = time.time()
+    if '--only-gdplan' in sys.argv:
+        # development shortcut: the committed file's other groups as they are, only the planner group made again (the default
+        # path makes everything and gives the same bytes)
+        old = np.load(os.path.join(HERE, 'census.npz'))
+        out = {k: old[k] for k in old.files if not k.startswith('gdplan/')}
+        gd_planner_cases(torch, planner, model, syn, obs_goal, lo, hi, out, t0)
+        tap.close()
+        np.savez_compressed(os.path.join(HERE, 'census.npz'), **out)
+        return
     for name, N, ROWS, MPPI_ROWS in SIZES:
         planner.particle_num = N
         # the pile of make_golden_trained.py's rollout case, batch column 0 (its accepted rows are among these candidates)
@@ -225,6 +265,7 @@ def main():
               (name, out[p + 'twin_flip_steps'].any(2).sum(1), MPPI_ROWS, ['%.2e' % np.abs(r - nrm[:, -1]).max() for r in out[p + 'twin_reward']],
                ['%.2e' % np.abs(u - out[p + 'update']).max() for u in out[p + 'twin_update']], nrm[:, -1].argmax(),
                [int(r.argmax()) for r in out[p + 'twin_reward']], time.time() - t0), flush=True)
+    gd_planner_cases(torch, planner, model, syn, obs_goal, lo, hi, out, t0)
     tap.close()
     np.savez_compressed(os.path.join(HERE, 'census.npz'), **out)
     print('census.npz %8.1f KB' % (os.path.getsize(os.path.join(HERE, 'census.npz')) / 1024.0))

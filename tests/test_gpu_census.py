@@ -147,3 +147,48 @@ def test_census_mppi_iteration(eng, golden, case, engine):
                                  fmt(np.append(q_dev, d_dev.max())), fmt(np.append(q_tw, d_tw.max())), d_upd,
                                  np.abs(nominal - g[m + 'update']).max(), tw_upd, r_dev.argmax(), r_ref.max() - r_ref.min()))
     eng.set_engine(_lib.ENGINE_FUSED)
+
+
+@pytest.mark.parametrize('case', ['n20', 'n50', 'n100'])
+def test_census_gd_planner_at_a_ten_step_horizon(golden, case, exact_goal_transform):
+    """Does the planner's CHOICE survive free-running rollouts?  The reference's live planner (`mpc_type 'GD'`,
+    planners.py:661-871) at n_look_ahead = 10: five Adam iterations whose gradients run back through ten free-running steps, the
+    per-column best (:721-727) and the final vote (:773-781), on 6 trajectories x 3 batch columns of the trained network -- as the
+    reference ran it, as its two one-ulp twins ran it, and here.  Held to K x the twins' own spread (floors: the horizon-1
+    tolerances of tests/test_gpu_trained.py)."""
+    import torch
+    from dyn_res_pile_manip_amd.gnn_dyn import PropNetDiffDenModel
+    from dyn_res_pile_manip_amd.planners import PlannerGD
+    g = golden.census
+    p = 'gdplan/' + case + '/'
+    config = syn.default_config()
+    config['mpc']['mpc_type'] = 'GD'
+    model = PropNetDiffDenModel(config, True)
+    w = golden.weights_trained
+    model.load_state_dict({k[2:]: torch.from_numpy(np.asarray(w[k])) for k in w.files if k.startswith('w/')}, strict=False)
+    planner = PlannerGD(config, syn.SyntheticEnv(config))
+    obs_goal = syn.goal_distance_image(syn.goal_mask('I'))
+    lo, hi = syn.action_limits()
+    act_seq = g[p + 'act_seq']
+    H, traj = act_seq.shape[:2]
+    res = planner.trajectory_optimization_ptcl_multi_traj(
+        g[p + 's_cur'], g[p + 'dens'], g[p + 'attr'], obs_goal, model, act_seq.copy(), np.zeros(H), n_sample=traj, n_look_ahead=H,
+        n_update_iter=int(g[p + 'n_update_iter']), action_lower_lim=lo, action_upper_lim=hi, use_gpu=True, time_lim=1e9)
+    model.engine.close()
+
+    def spread(key):
+        ref = np.asarray(g[p + 'out/' + key], np.float64)
+        dev = np.abs(np.asarray(res[key], np.float64).reshape(ref.shape) - ref).max()
+        tw = max(np.abs(np.asarray(g[p + 'twin%d/' % q + key], np.float64) - ref).max() for q in (1, 2))
+        return dev, tw, np.abs(ref).max()
+    line = []
+    for key, floor_abs, floor_rel in (('action_sequence', 2e-3, 0.0), ('action_full', 2e-3, 0.0), ('reward', 0.0, 1e-4),
+                                      ('reward_full', 0.0, 1e-4), ('rew_mean', 0.0, 1e-4), ('next_r', 0.0, 1e-4),
+                                      ('observation_sequence', 5e-6, 0.0)):
+        dev, tw, scale = spread(key)
+        line.append('%s %.1e (twins %.1e)' % (key, dev, tw))
+        assert dev <= K * max(tw, floor_abs, floor_rel * scale), (key, dev, tw)
+    assert int(res['iter_num']) == int(g[p + 'out/iter_num'])
+    # the choice itself: the voted trajectory's pushes are the reference's (which row won shows in action_sequence: two
+    # candidates differ by whole push lengths, the bound above is 8e-3 of a workspace of +-5)
+    print('\n[census gd planner %s, horizon %d] %s' % (case, H, '; '.join(line)))

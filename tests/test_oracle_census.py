@@ -50,3 +50,20 @@ def test_census_hash_helpers():
     assert (C.list_hash(idx2, cnt) == h).all()
     assert C.row_hash(h)[0] != C.row_hash(h[:, ::-1])[0]               # ... but receiver i's list is receiver i's
     assert (C.first_true(np.array([[0, 1, 1], [0, 0, 0]], bool)) == [1, 3]).all()
+
+
+@pytest.mark.parametrize('case', ['n20', 'n50', 'n100'])
+def test_the_planner_group_of_the_census_is_consistent(golden, case):
+    """gdplan/: the reference's GD planner at a ten-step horizon and its two one-ulp twins -- same iteration count, the
+    reference's shapes (planners.py:858-871), and the twins choose the reference's push to well under a push's length."""
+    g = golden.census
+    p = 'gdplan/' + case + '/'
+    H, traj = g[p + 'act_seq'].shape[:2]
+    nb = g[p + 's_cur'].shape[0]
+    assert H == 10 and g[p + 'out/action_sequence'].shape == (H, 4)
+    assert g[p + 'out/action_full'].shape == (traj * nb, 4) or g[p + 'out/action_full'].shape[-1] == 4
+    assert g[p + 'out/observation_sequence'].shape == (H, g[p + 's_cur'].shape[1], 3)
+    for q in (1, 2):
+        assert int(g[p + 'twin%d/iter_num' % q]) == int(g[p + 'out/iter_num'])
+        assert np.abs(g[p + 'twin%d/action_sequence' % q] - g[p + 'out/action_sequence']).max() < 1e-3
+        assert np.isfinite(g[p + 'twin%d/reward_full' % q]).all()
